@@ -1,0 +1,141 @@
+/*
+ * oracle.h -- TEST INFRASTRUCTURE ONLY.
+ *
+ * Plain-C CPU restatement of the reference algorithms on the hot path
+ *  and of the container around it.  Only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may link or call
+ * anything in oracle/.  The product (xz_amd/csrc) never does.
+ *
+ * Pinning (tests/test_oracle_*.py, CPU-only):
+ *   - container pieces: byte-compared against the real reference library
+ *     (oracle/_ref/liblzma_ref.so) and the reference's own KATs
+ *     (tests/test_vli.c:20-46, tests/test_check.c:69-139);
+ *   - LZMA2 decoder: decodes the reference's tests/files/good-*.xz fixtures
+ *     (copied as data into tests/golden/) and everything liblzma_ref produces;
+ *   - fast-mode encoder (HC3/HC4 + optimum_fast + range coder + LZMA2
+ *     chunking): output is BYTE-IDENTICAL to the reference's raw LZMA2
+ *     encoder for presets 0-3 on every test corpus.
+ * Reference citations are file:line relative to /root/reference.
+ */
+#ifndef XZ_AMD_ORACLE_H
+#define XZ_AMD_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------ */
+/* Container (src/liblzma/common, src/liblzma/check)                    */
+/* ------------------------------------------------------------------ */
+uint32_t orc_crc32(const uint8_t *buf, size_t n, uint32_t crc);
+uint64_t orc_crc64(const uint8_t *buf, size_t n, uint64_t crc);
+/* CRC64 of a concatenation from the parts' CRCs (used to check the GPU's
+ * piecewise CRC): crc(A||B) from crc(A), crc(B), len(B). */
+uint64_t orc_crc64_combine(uint64_t crc_a, uint64_t crc_b, uint64_t len_b);
+
+uint32_t orc_vli_size(uint64_t v);
+uint32_t orc_vli_encode(uint64_t v, uint8_t *out);
+
+#define ORC_CHECK_NONE 0
+#define ORC_CHECK_CRC32 1
+#define ORC_CHECK_CRC64 4
+uint32_t orc_check_size(int check);
+
+void orc_stream_header(uint8_t out[12], int check);
+void orc_stream_footer(uint8_t out[12], uint64_t index_size, int check);
+uint8_t orc_lzma2_dict_byte(uint32_t dict_size);
+uint64_t orc_block_bound(uint64_t uncompressed_size);
+/* Header size as lzma_block_header_size() computes it for one LZMA2 filter
+ * (+ optional x86 BCJ filter without start offset). */
+uint32_t orc_block_header_size(uint64_t csize, uint64_t usize, int with_x86);
+void orc_block_header_encode(uint8_t *out, uint32_t header_size,
+		uint64_t csize, uint64_t usize, uint8_t dict_byte, int with_x86);
+/* Index field. Returns its size (multiple of 4). out may be NULL. */
+uint64_t orc_index_encode(uint8_t *out, uint64_t nblocks,
+		const uint64_t *unpadded, const uint64_t *uncompressed);
+/* Whole-Block uncompressed fallback (block_buffer_encoder.c:88-162). Writes
+ * header + chunks + 0x00 + padding + check; returns total bytes, sets
+ * *unpadded. */
+uint64_t orc_block_uncomp_encode(const uint8_t *in, uint64_t n, int check,
+		uint8_t *out, uint64_t *unpadded);
+
+/* Assemble a whole .xz Stream the way stream_encoder_mt does from per-Block
+ * raw LZMA2 payloads (each already ending with the 0x00 end marker).
+ * block_size = the lzma_mt.block_size the header sizes are derived from. */
+uint64_t orc_xz_frame(const uint8_t *const *payloads, const uint64_t *payload_sizes,
+		const uint8_t *const *inputs, const uint64_t *input_sizes,
+		uint64_t nblocks, uint64_t block_size, uint32_t dict_size,
+		int check, uint8_t *out, uint64_t out_cap);
+
+/* ------------------------------------------------------------------ */
+/* Decoder (verifier)                                                   */
+/* ------------------------------------------------------------------ */
+typedef struct {
+	uint32_t pos;   /* uncompressed offset in the Block */
+	uint32_t back;  /* 0..3 rep index, dist+4, or 0xFFFFFFFF literal */
+	uint32_t len;
+} orc_symbol;
+
+typedef struct {
+	orc_symbol *sym;     /* optional, capacity sym_cap */
+	uint64_t sym_cap;
+	uint64_t sym_count;  /* total symbols seen (may exceed cap) */
+	uint64_t chunks_lzma, chunks_uncompressed, state_resets, prop_resets, dict_resets;
+} orc_trace;
+
+/* Raw LZMA2 decode. Returns 0 on success (end marker seen, all input used). */
+int orc_lzma2_decode(const uint8_t *in, uint64_t in_size, uint32_t dict_size,
+		uint8_t *out, uint64_t out_cap, uint64_t *out_size, orc_trace *trace);
+/* Full .xz single-stream decode with all CRC/size/index checks.
+ * Returns 0 on success; negative codes identify the failing check.
+ * nblocks_out (optional) receives the number of Blocks. */
+int orc_xz_decode(const uint8_t *in, uint64_t in_size,
+		uint8_t *out, uint64_t out_cap, uint64_t *out_size,
+		uint64_t *nblocks_out);
+
+/* ------------------------------------------------------------------ */
+/* Fast-mode encoder (HC3/HC4, optimum_fast, rc, LZMA2 chunker)         */
+/* ------------------------------------------------------------------ */
+typedef struct {
+	uint32_t dict_size;
+	uint32_t lc, lp, pb;
+	uint32_t nice_len;
+	uint32_t mf;        /* 3 = HC3, 4 = HC4 */
+	uint32_t depth;     /* 0 = reference default (4 + nice_len/4) */
+	uint32_t span_size; /* 0 = whole Block is one span (== reference);
+	                       else independent state-reset spans (GPU mode) */
+} orc_enc_params;
+
+int orc_preset(uint32_t preset, orc_enc_params *p, uint32_t *mode_normal);
+
+/* Encode one Block's raw LZMA2 payload (incl. 0x00 end marker).
+ * Returns 0 on success. trace optional. */
+int orc_lzma2_encode_block(const uint8_t *in, uint32_t n, const orc_enc_params *p,
+		uint8_t *out, uint64_t out_cap, uint64_t *out_size, orc_trace *trace);
+
+/* Match-finder dump: for every position pos_list[i] report what
+ * lzma_mf_find() would return there when positions are consumed one at a
+ * time (lz_encoder_mf.c:22-79).  `end` = exclusive end used for avail
+ * (Block end, or span end in span mode).  Output: for each i,
+ * counts[i] pairs stored at pairs[i*max_pairs*2 ...] as (len,dist), and
+ * longest[i] = the (possibly extended) longest length. */
+int orc_mf_dump(const uint8_t *in, uint32_t n, const orc_enc_params *p,
+		const uint32_t *pos_list, const uint32_t *end_list, uint32_t npos,
+		uint32_t max_pairs, uint32_t *counts, uint32_t *pairs, uint32_t *longest);
+
+/* ------------------------------------------------------------------ */
+/* Synthetic corpora                                     */
+/* ------------------------------------------------------------------ */
+/* lorem-LCG: tests/create_compress_files.c:110-152 continued to n bytes. */
+void orc_corpus_lorem(uint8_t *out, uint64_t n);
+/* tests/create_compress_files.c:82-105 */
+void orc_corpus_abc(uint8_t *out, uint64_t n);
+void orc_corpus_random(uint8_t *out, uint64_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

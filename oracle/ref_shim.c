@@ -1,0 +1,226 @@
+/*
+ * ref_shim.c -- TEST INFRASTRUCTURE ONLY (never linked into the product).
+ *
+ * Thin flat-C wrappers around the REAL reference liblzma (built by
+ * oracle/Makefile from the sources under /root/reference into
+ * oracle/_ref/liblzma_ref.so).  They let the Python tests and bench.py's
+ * cpu_baseline leg drive the reference through plain (pointer,size) calls
+ * instead of re-declaring lzma_stream in ctypes.
+ *
+ * Compiled against the reference's own public header (api/lzma.h) where it
+ * lies; nothing from the reference is copied into this repository.
+ */
+#include <lzma.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* lzma_stream_encoder_mt + lzma_code(FINISH) over one in-memory buffer.
+ * Mirrors doc/examples/04_compress_easy_mt.c:29-82 but with one big buffer.
+ * preset may carry LZMA_PRESET_EXTREME.  block_size 0 = library default.
+ * Returns lzma_ret (1 = LZMA_STREAM_END on success). */
+int ref_encode_mt(const uint8_t *in, size_t in_size, uint32_t preset,
+		uint32_t threads, uint64_t block_size, int check,
+		uint8_t *out, size_t out_cap, size_t *out_size)
+{
+	lzma_stream strm = LZMA_STREAM_INIT;
+	lzma_mt mt;
+	memset(&mt, 0, sizeof(mt));
+	mt.threads = threads;
+	mt.block_size = block_size;
+	mt.preset = preset;
+	mt.check = (lzma_check)check;
+	lzma_ret r = lzma_stream_encoder_mt(&strm, &mt);
+	if (r != LZMA_OK)
+		return (int)r;
+	strm.next_in = in;
+	strm.avail_in = in_size;
+	strm.next_out = out;
+	strm.avail_out = out_cap;
+	do {
+		r = lzma_code(&strm, LZMA_FINISH);
+	} while (r == LZMA_OK && strm.avail_out > 0);
+	*out_size = out_cap - strm.avail_out;
+	lzma_end(&strm);
+	return (int)r;
+}
+
+/* Same, but with an explicit LZMA2 option set (filters[] = {LZMA2}). */
+int ref_encode_mt_opts(const uint8_t *in, size_t in_size,
+		uint32_t dict_size, uint32_t lc, uint32_t lp, uint32_t pb,
+		int mode, uint32_t nice_len, int mf, uint32_t depth,
+		uint32_t threads, uint64_t block_size, int check,
+		uint8_t *out, size_t out_cap, size_t *out_size)
+{
+	lzma_options_lzma opt;
+	memset(&opt, 0, sizeof(opt));
+	opt.dict_size = dict_size;
+	opt.lc = lc; opt.lp = lp; opt.pb = pb;
+	opt.mode = (lzma_mode)mode;
+	opt.nice_len = nice_len;
+	opt.mf = (lzma_match_finder)mf;
+	opt.depth = depth;
+	lzma_filter f[2] = { { LZMA_FILTER_LZMA2, &opt }, { LZMA_VLI_UNKNOWN, NULL } };
+	lzma_stream strm = LZMA_STREAM_INIT;
+	lzma_mt mt;
+	memset(&mt, 0, sizeof(mt));
+	mt.threads = threads;
+	mt.block_size = block_size;
+	mt.filters = f;
+	mt.check = (lzma_check)check;
+	lzma_ret r = lzma_stream_encoder_mt(&strm, &mt);
+	if (r != LZMA_OK)
+		return (int)r;
+	strm.next_in = in;
+	strm.avail_in = in_size;
+	strm.next_out = out;
+	strm.avail_out = out_cap;
+	do {
+		r = lzma_code(&strm, LZMA_FINISH);
+	} while (r == LZMA_OK && strm.avail_out > 0);
+	*out_size = out_cap - strm.avail_out;
+	lzma_end(&strm);
+	return (int)r;
+}
+
+/* Raw LZMA2 encode of one buffer (what one worker's filter chain produces
+ * for one Block: stream_encoder_mt.c:219-298 minus header/padding/check). */
+int ref_raw_lzma2_encode(const uint8_t *in, size_t in_size,
+		uint32_t dict_size, uint32_t lc, uint32_t lp, uint32_t pb,
+		int mode, uint32_t nice_len, int mf, uint32_t depth,
+		uint8_t *out, size_t out_cap, size_t *out_size)
+{
+	lzma_options_lzma opt;
+	memset(&opt, 0, sizeof(opt));
+	opt.dict_size = dict_size;
+	opt.lc = lc; opt.lp = lp; opt.pb = pb;
+	opt.mode = (lzma_mode)mode;
+	opt.nice_len = nice_len;
+	opt.mf = (lzma_match_finder)mf;
+	opt.depth = depth;
+	lzma_filter f[2] = { { LZMA_FILTER_LZMA2, &opt }, { LZMA_VLI_UNKNOWN, NULL } };
+	lzma_stream strm = LZMA_STREAM_INIT;
+	lzma_ret r = lzma_raw_encoder(&strm, f);
+	if (r != LZMA_OK)
+		return (int)r;
+	/* Feed in 16 KiB pieces exactly like worker_encode()
+	 * (stream_encoder_mt.c:284-296); output is independent of the piece
+	 * size, this merely keeps the call pattern identical. */
+	size_t pos = 0;
+	strm.next_out = out;
+	strm.avail_out = out_cap;
+	for (;;) {
+		size_t n = in_size - pos;
+		lzma_action a = LZMA_FINISH;
+		if (n > 16384) { n = 16384; a = LZMA_RUN; }
+		strm.next_in = in + pos;
+		strm.avail_in = n;
+		r = lzma_code(&strm, a);
+		pos += n - strm.avail_in;
+		if (r != LZMA_OK || strm.avail_out == 0)
+			break;
+	}
+	*out_size = out_cap - strm.avail_out;
+	lzma_end(&strm);
+	return (int)r;
+}
+
+/* lzma_stream_decoder over one buffer (the verifier: what `xz -dc` runs). */
+int ref_decode(const uint8_t *in, size_t in_size,
+		uint8_t *out, size_t out_cap, size_t *out_size)
+{
+	lzma_stream strm = LZMA_STREAM_INIT;
+	lzma_ret r = lzma_stream_decoder(&strm, UINT64_MAX, 0);
+	if (r != LZMA_OK)
+		return (int)r;
+	strm.next_in = in;
+	strm.avail_in = in_size;
+	strm.next_out = out;
+	strm.avail_out = out_cap;
+	do {
+		r = lzma_code(&strm, LZMA_FINISH);
+	} while (r == LZMA_OK && strm.avail_out > 0 );
+	*out_size = out_cap - strm.avail_out;
+	if (r == LZMA_STREAM_END && strm.avail_in != 0)
+		r = LZMA_DATA_ERROR;
+	lzma_end(&strm);
+	return (int)r;
+}
+
+/* Raw LZMA2 decode (dict_size from the caller). */
+int ref_raw_lzma2_decode(const uint8_t *in, size_t in_size, uint32_t dict_size,
+		uint8_t *out, size_t out_cap, size_t *out_size)
+{
+	lzma_options_lzma opt;
+	memset(&opt, 0, sizeof(opt));
+	opt.dict_size = dict_size;
+	lzma_filter f[2] = { { LZMA_FILTER_LZMA2, &opt }, { LZMA_VLI_UNKNOWN, NULL } };
+	lzma_stream strm = LZMA_STREAM_INIT;
+	lzma_ret r = lzma_raw_decoder(&strm, f);
+	if (r != LZMA_OK)
+		return (int)r;
+	strm.next_in = in;
+	strm.avail_in = in_size;
+	strm.next_out = out;
+	strm.avail_out = out_cap;
+	do {
+		r = lzma_code(&strm, LZMA_FINISH);
+	} while (r == LZMA_OK && strm.avail_out > 0);
+	*out_size = out_cap - strm.avail_out;
+	if (r == LZMA_STREAM_END && strm.avail_in != 0)
+		r = LZMA_DATA_ERROR;
+	lzma_end(&strm);
+	return (int)r;
+}
+
+uint32_t ref_crc32(const uint8_t *buf, size_t n, uint32_t crc) { return lzma_crc32(buf, n, crc); }
+uint64_t ref_crc64(const uint8_t *buf, size_t n, uint64_t crc) { return lzma_crc64(buf, n, crc); }
+
+int ref_vli_encode(uint64_t v, uint8_t *out, size_t cap, size_t *n)
+{
+	*n = 0;
+	return (int)lzma_vli_encode(v, NULL, out, n, cap);
+}
+
+uint64_t ref_block_buffer_bound(uint64_t n) { return lzma_block_buffer_bound((size_t)n); }
+uint64_t ref_mt_block_size_preset(uint32_t preset)
+{
+	lzma_options_lzma opt;
+	if (lzma_lzma_preset(&opt, preset))
+		return 0;
+	lzma_filter f[2] = { { LZMA_FILTER_LZMA2, &opt }, { LZMA_VLI_UNKNOWN, NULL } };
+	return lzma_mt_block_size(f);
+}
+
+/* Preset table query (lzma_encoder_presets.c:17-63). out[8] =
+ * dict_size, lc, lp, pb, mode, nice_len, mf, depth. */
+int ref_preset(uint32_t preset, uint32_t *out)
+{
+	lzma_options_lzma opt;
+	if (lzma_lzma_preset(&opt, preset))
+		return 1;
+	out[0] = opt.dict_size; out[1] = opt.lc; out[2] = opt.lp; out[3] = opt.pb;
+	out[4] = (uint32_t)opt.mode; out[5] = opt.nice_len; out[6] = (uint32_t)opt.mf;
+	out[7] = opt.depth;
+	return 0;
+}
+
+/* Whole-Block uncompressed fallback writer (block_buffer_encoder.c:88-162,
+ * public entry :345-354), as used by worker_encode (stream_encoder_mt.c:316-344). */
+int ref_block_uncomp_encode(const uint8_t *in, size_t in_size, int check,
+		uint8_t *out, size_t out_cap, size_t *out_size,
+		uint64_t *unpadded_size)
+{
+	lzma_block b;
+	memset(&b, 0, sizeof(b));
+	b.version = 0;
+	b.check = (lzma_check)check;
+	size_t pos = 0;
+	lzma_ret r = lzma_block_uncomp_encode(&b, in, in_size, out, &pos, out_cap);
+	*out_size = pos;
+	*unpadded_size = lzma_block_unpadded_size(&b);
+	return (int)r;
+}
+
+const char *ref_version(void) { return lzma_version_string(); }
+uint32_t ref_cputhreads(void) { return lzma_cputhreads(); }

@@ -1,0 +1,312 @@
+"""ctypes bindings for the test infrastructure under oracle/ (NOT product code).
+
+* ``liboracle.so``      -- our plain-C restatements (container, LZMA2 decoder,
+                            fast-mode encoder); always buildable with gcc.
+* ``_ref/libref_shim.so`` -- flat wrappers around the REAL reference liblzma
+                            5.8.3 compiled from /root/reference by oracle/Makefile
+                            (prebuilt file travels to the GPU box).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+
+u8p = C.POINTER(C.c_uint8)
+u32p = C.POINTER(C.c_uint32)
+u64p = C.POINTER(C.c_uint64)
+
+
+def _ptr(a, typ=u8p):
+    return a.ctypes.data_as(typ)
+
+
+def build_oracle():
+    """(Re)build liboracle.so; builds oracle/_ref too when the reference tree is here."""
+    subprocess.run(["make", "-s", "-C", ORACLE_DIR, "all"], check=True,
+                   stdout=subprocess.DEVNULL)
+
+
+def _load(path):
+    if not os.path.exists(path):
+        build_oracle()
+    return C.CDLL(path)
+
+
+class OrcParams(C.Structure):
+    _fields_ = [("dict_size", C.c_uint32), ("lc", C.c_uint32), ("lp", C.c_uint32),
+                ("pb", C.c_uint32), ("nice_len", C.c_uint32), ("mf", C.c_uint32),
+                ("depth", C.c_uint32), ("span_size", C.c_uint32)]
+
+
+class OrcSymbol(C.Structure):
+    _fields_ = [("pos", C.c_uint32), ("back", C.c_uint32), ("len", C.c_uint32)]
+
+
+class OrcTrace(C.Structure):
+    _fields_ = [("sym", C.POINTER(OrcSymbol)), ("sym_cap", C.c_uint64),
+                ("sym_count", C.c_uint64), ("chunks_lzma", C.c_uint64),
+                ("chunks_uncompressed", C.c_uint64), ("state_resets", C.c_uint64),
+                ("prop_resets", C.c_uint64), ("dict_resets", C.c_uint64)]
+
+
+_orc = None
+_ref = None
+
+
+def orc():
+    global _orc
+    if _orc is None:
+        lib = _load(os.path.join(ORACLE_DIR, "liboracle.so"))
+        lib.orc_crc32.restype = C.c_uint32
+        lib.orc_crc32.argtypes = [u8p, C.c_size_t, C.c_uint32]
+        lib.orc_crc64.restype = C.c_uint64
+        lib.orc_crc64.argtypes = [u8p, C.c_size_t, C.c_uint64]
+        lib.orc_crc64_combine.restype = C.c_uint64
+        lib.orc_crc64_combine.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64]
+        lib.orc_vli_encode.restype = C.c_uint32
+        lib.orc_vli_encode.argtypes = [C.c_uint64, u8p]
+        lib.orc_block_bound.restype = C.c_uint64
+        lib.orc_block_bound.argtypes = [C.c_uint64]
+        lib.orc_lzma2_dict_byte.restype = C.c_uint8
+        lib.orc_lzma2_dict_byte.argtypes = [C.c_uint32]
+        lib.orc_block_uncomp_encode.restype = C.c_uint64
+        lib.orc_block_uncomp_encode.argtypes = [u8p, C.c_uint64, C.c_int, u8p, u64p]
+        lib.orc_xz_frame.restype = C.c_uint64
+        lib.orc_lzma2_decode.restype = C.c_int
+        lib.orc_lzma2_decode.argtypes = [u8p, C.c_uint64, C.c_uint32, u8p, C.c_uint64, u64p,
+                                         C.POINTER(OrcTrace)]
+        lib.orc_xz_decode.restype = C.c_int
+        lib.orc_xz_decode.argtypes = [u8p, C.c_uint64, u8p, C.c_uint64, u64p, u64p]
+        lib.orc_lzma2_encode_block.restype = C.c_int
+        lib.orc_lzma2_encode_block.argtypes = [u8p, C.c_uint32, C.POINTER(OrcParams), u8p,
+                                               C.c_uint64, u64p, C.POINTER(OrcTrace)]
+        lib.orc_mf_dump.restype = C.c_int
+        lib.orc_mf_dump.argtypes = [u8p, C.c_uint32, C.POINTER(OrcParams), u32p, u32p,
+                                    C.c_uint32, C.c_uint32, u32p, u32p, u32p]
+        lib.orc_preset.restype = C.c_int
+        lib.orc_preset.argtypes = [C.c_uint32, C.POINTER(OrcParams), u32p]
+        _orc = lib
+    return _orc
+
+
+def have_ref():
+    p = os.path.join(ORACLE_DIR, "_ref", "libref_shim.so")
+    if not os.path.exists(p) and os.path.exists("/root/reference/src/liblzma/api/lzma.h"):
+        build_oracle()
+    return os.path.exists(p)
+
+
+def ref():
+    global _ref
+    if _ref is None:
+        lib = C.CDLL(os.path.join(ORACLE_DIR, "_ref", "libref_shim.so"))
+        lib.ref_encode_mt.restype = C.c_int
+        lib.ref_encode_mt.argtypes = [u8p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint64,
+                                      C.c_int, u8p, C.c_size_t, C.POINTER(C.c_size_t)]
+        lib.ref_encode_mt_opts.restype = C.c_int
+        lib.ref_encode_mt_opts.argtypes = [u8p, C.c_size_t] + [C.c_uint32] * 4 + [C.c_int, C.c_uint32, C.c_int, C.c_uint32,
+                                           C.c_uint32, C.c_uint64, C.c_int, u8p, C.c_size_t, C.POINTER(C.c_size_t)]
+        lib.ref_raw_lzma2_encode.restype = C.c_int
+        lib.ref_raw_lzma2_encode.argtypes = [u8p, C.c_size_t] + [C.c_uint32] * 4 + [C.c_int, C.c_uint32, C.c_int, C.c_uint32,
+                                             u8p, C.c_size_t, C.POINTER(C.c_size_t)]
+        lib.ref_decode.restype = C.c_int
+        lib.ref_decode.argtypes = [u8p, C.c_size_t, u8p, C.c_size_t, C.POINTER(C.c_size_t)]
+        lib.ref_raw_lzma2_decode.restype = C.c_int
+        lib.ref_raw_lzma2_decode.argtypes = [u8p, C.c_size_t, C.c_uint32, u8p, C.c_size_t,
+                                             C.POINTER(C.c_size_t)]
+        lib.ref_crc32.restype = C.c_uint32
+        lib.ref_crc32.argtypes = [u8p, C.c_size_t, C.c_uint32]
+        lib.ref_crc64.restype = C.c_uint64
+        lib.ref_crc64.argtypes = [u8p, C.c_size_t, C.c_uint64]
+        lib.ref_vli_encode.restype = C.c_int
+        lib.ref_vli_encode.argtypes = [C.c_uint64, u8p, C.c_size_t, C.POINTER(C.c_size_t)]
+        lib.ref_block_buffer_bound.restype = C.c_uint64
+        lib.ref_block_buffer_bound.argtypes = [C.c_uint64]
+        lib.ref_mt_block_size_preset.restype = C.c_uint64
+        lib.ref_mt_block_size_preset.argtypes = [C.c_uint32]
+        lib.ref_preset.restype = C.c_int
+        lib.ref_preset.argtypes = [C.c_uint32, u32p]
+        lib.ref_block_uncomp_encode.restype = C.c_int
+        lib.ref_block_uncomp_encode.argtypes = [u8p, C.c_size_t, C.c_int, u8p, C.c_size_t,
+                                                C.POINTER(C.c_size_t), u64p]
+        lib.ref_version.restype = C.c_char_p
+        lib.ref_cputhreads.restype = C.c_uint32
+        _ref = lib
+    return _ref
+
+
+# ---------------------------------------------------------------- helpers
+def as_u8(data):
+    if isinstance(data, (bytes, bytearray)):
+        return np.frombuffer(bytes(data), dtype=np.uint8).copy()
+    return np.ascontiguousarray(data, dtype=np.uint8)
+
+
+def params_for_preset(preset, span_size=0):
+    p = OrcParams()
+    normal = C.c_uint32(0)
+    assert orc().orc_preset(preset, C.byref(p), C.byref(normal)) == 0
+    p.span_size = span_size
+    return p, bool(normal.value)
+
+
+def orc_encode_block(data, prm, want_trace=False):
+    data = as_u8(data)
+    cap = len(data) + len(data) // 8 + 4096
+    out = np.empty(cap, dtype=np.uint8)
+    n = C.c_uint64(0)
+    tr = None
+    syms = None
+    if want_trace:
+        tr = OrcTrace()
+        syms = (OrcSymbol * (len(data) + 16))()
+        tr.sym = C.cast(syms, C.POINTER(OrcSymbol))
+        tr.sym_cap = len(data) + 16
+    r = orc().orc_lzma2_encode_block(_ptr(data), len(data), C.byref(prm), _ptr(out), cap,
+                                     C.byref(n), C.byref(tr) if tr else None)
+    assert r == 0, r
+    res = out[: n.value].tobytes()
+    if want_trace:
+        s = np.frombuffer(syms, dtype=np.uint32).reshape(-1, 3)[: tr.sym_count].copy()
+        return res, s, tr
+    return res
+
+
+def orc_decode_raw(payload, dict_size, out_cap, want_trace=False):
+    payload = as_u8(payload)
+    out = np.empty(max(out_cap, 1), dtype=np.uint8)
+    n = C.c_uint64(0)
+    tr = None
+    syms = None
+    if want_trace:
+        tr = OrcTrace()
+        syms = (OrcSymbol * (out_cap + 16))()
+        tr.sym = C.cast(syms, C.POINTER(OrcSymbol))
+        tr.sym_cap = out_cap + 16
+    r = orc().orc_lzma2_decode(_ptr(payload), len(payload), dict_size, _ptr(out), out_cap,
+                               C.byref(n), C.byref(tr) if tr else None)
+    res = out[: n.value].tobytes()
+    if want_trace:
+        s = np.frombuffer(syms, dtype=np.uint32).reshape(-1, 3)[: min(tr.sym_count, tr.sym_cap)].copy()
+        return r, res, s, tr
+    return r, res
+
+
+def orc_xz_decode(stream, out_cap):
+    stream = as_u8(stream)
+    out = np.empty(max(out_cap, 1), dtype=np.uint8)
+    n = C.c_uint64(0)
+    nb = C.c_uint64(0)
+    r = orc().orc_xz_decode(_ptr(stream), len(stream), _ptr(out), out_cap, C.byref(n), C.byref(nb))
+    return r, out[: n.value].tobytes(), nb.value
+
+
+def ref_raw_encode(data, prm, mode=1):
+    """Reference raw LZMA2 encoder with explicit options (mode 1 = fast, 2 = normal)."""
+    data = as_u8(data)
+    cap = len(data) + len(data) // 8 + 4096
+    out = np.empty(cap, dtype=np.uint8)
+    n = C.c_size_t(0)
+    mf = {3: 0x03, 4: 0x04}.get(prm.mf, prm.mf)
+    r = ref().ref_raw_lzma2_encode(_ptr(data), len(data), prm.dict_size, prm.lc, prm.lp, prm.pb,
+                                   mode, prm.nice_len, mf, prm.depth, _ptr(out), cap, C.byref(n))
+    assert r == 1, r
+    return out[: n.value].tobytes()
+
+
+def ref_encode_mt(data, preset, threads=1, block_size=0, check=4):
+    data = as_u8(data)
+    cap = len(data) + len(data) // 4 + 65536
+    out = np.empty(cap, dtype=np.uint8)
+    n = C.c_size_t(0)
+    r = ref().ref_encode_mt(_ptr(data), len(data), preset, threads, block_size, check,
+                            _ptr(out), cap, C.byref(n))
+    assert r == 1, r
+    return out[: n.value].tobytes()
+
+
+def ref_decode(stream, out_cap):
+    stream = as_u8(stream)
+    out = np.empty(max(out_cap, 1), dtype=np.uint8)
+    n = C.c_size_t(0)
+    r = ref().ref_decode(_ptr(stream), len(stream), _ptr(out), out_cap, C.byref(n))
+    return r, out[: n.value].tobytes()
+
+
+# ---------------------------------------------------------------- corpora
+_LOREM = ("Lorem ipsum dolor sit amet, consectetur adipisicing elit, sed do eiusmod tempor "
+          "incididunt ut labore et dolore magna aliqua. Ut enim ad minim veniam, quis nostrud "
+          "exercitation ullamco laboris nisi ut aliquip ex ea commodo consequat. Duis aute irure "
+          "dolor in reprehenderit in voluptate velit esse cillum dolore eu fugiat nulla pariatur. "
+          "Excepteur sint occaecat cupidatat non proident, sunt in culpa qui officia deserunt "
+          "mollit anim id est laborum.").split(" ")
+
+
+def corpus_lorem(n):
+    """tests/create_compress_files.c:110-152 (write_text) continued until n bytes."""
+    assert len(_LOREM) == 69
+    parts = []
+    total = 0
+    for w, word in enumerate(_LOREM):
+        parts.append(word + " ")
+        if w % 7 == 6:
+            parts.append("\n")
+    total = sum(len(p) for p in parts)
+    x = 29
+    while total < n:
+        parts.append("\n\n")
+        total += 2
+        for w in range(69):
+            x = (101771 * x + 71777) & 0xFFFFFFFF
+            s = _LOREM[x % 69] + " "
+            if w % 7 == 6:
+                s += "\n"
+            parts.append(s)
+            total += len(s)
+    return "".join(parts).encode("ascii")[:n]
+
+
+def corpus_abc(n=49380):
+    """tests/create_compress_files.c:82-88"""
+    return (b"abc\n" * ((n + 3) // 4))[:n]
+
+
+def corpus_random(n=493824):
+    """tests/create_compress_files.c:93-105 (LCG, seed 5)"""
+    k = (n + 3) // 4
+    out = np.empty(k, dtype=np.uint32)
+    x = 5
+    for i in range(k):
+        x = (101771 * x + 71777) & 0xFFFFFFFF
+        out[i] = x
+    return out.astype("<u4").tobytes()[:n]
+
+
+def corpus_mixed(n, seed=1):
+    """Seeded mix of text, repeats, binary-ish and random segments (edge-case stress)."""
+    rng = np.random.default_rng(seed)
+    lorem = corpus_lorem(min(n, 1 << 16))
+    parts = []
+    total = 0
+    while total < n:
+        kind = rng.integers(0, 5)
+        ln = int(rng.integers(1, 5000))
+        if kind == 0:
+            off = int(rng.integers(0, max(1, len(lorem) - ln)))
+            seg = lorem[off:off + ln]
+        elif kind == 1:
+            seg = bytes(rng.integers(0, 256, size=ln, dtype=np.uint8))
+        elif kind == 2:
+            seg = bytes([int(rng.integers(0, 256))]) * ln
+        elif kind == 3:
+            unit = bytes(rng.integers(0, 256, size=int(rng.integers(1, 9)), dtype=np.uint8))
+            seg = (unit * (ln // len(unit) + 1))[:ln]
+        else:
+            seg = bytes(rng.integers(0, 4, size=ln, dtype=np.uint8) + 97)
+        parts.append(seg)
+        total += len(seg)
+    return b"".join(parts)[:n]
