@@ -1,0 +1,163 @@
+/*
+ * xz_amd.h -- public C ABI of the MI355X-native LZMA2 Block encoder (libxz_amd.so).
+ *
+ * Plain C: pointers and sizes only, no HIP or torch types in any signature.
+ * `stream` arguments are a hipStream_t passed as void* (NULL = the library's
+ * own stream).
+ *
+ * Two levels, both replacing reference interfaces (paths relative to the
+ * XZ Utils 5.8.3 tree):
+ *
+ *  (1) Device-resident batch encode -- what every worker thread of the
+ *      reference does for one Block, done here for all Blocks at once:
+ *        worker_encode()            src/liblzma/common/stream_encoder_mt.c:219-361
+ *        block_encode()             src/liblzma/common/block_encoder.c:47-135
+ *        lzma2_encode()             src/liblzma/lzma/lzma2_encoder.c:135-259
+ *        lzma_lzma_encode()         src/liblzma/lzma/lzma_encoder.c:313-436
+ *        lzma_mf_hc3/hc4_find/skip  src/liblzma/lz/lz_encoder_mf.c:305-441
+ *      -> xzamd_stream_encode_device()
+ *
+ *  (2) The liblzma streaming API itself (declared in xz_amd_lzma.h):
+ *        lzma_stream_encoder_mt()   stream_encoder_mt.c:1196
+ *        lzma_code()/lzma_end()     common/common.c:203,379
+ *        lzma_get_progress()        common/common.c:406
+ */
+#ifndef XZ_AMD_H
+#define XZ_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct xzamd_ctx xzamd_ctx;
+
+/* Return codes: the lzma_ret values of api/lzma/base.h:55-271 (same numbers). */
+#define XZAMD_OK              0
+#define XZAMD_STREAM_END      1
+#define XZAMD_UNSUPPORTED_CHECK 3
+#define XZAMD_MEM_ERROR       5
+#define XZAMD_OPTIONS_ERROR   8
+#define XZAMD_DATA_ERROR      9
+#define XZAMD_BUF_ERROR      10
+#define XZAMD_PROG_ERROR     11
+/* HIP runtime / kernel failure (mapped to LZMA_PROG_ERROR at the lzma_* level). */
+#define XZAMD_DEVICE_ERROR  100
+
+#define XZAMD_CHECK_NONE   0
+#define XZAMD_CHECK_CRC32  1
+#define XZAMD_CHECK_CRC64  4
+
+#define XZAMD_MF_HC3 0x03   /* lzma_match_finder values, api/lzma/lzma12.h:58-112 */
+#define XZAMD_MF_HC4 0x04
+#define XZAMD_MF_BT4 0x14
+
+#define XZAMD_MODE_FAST   1 /* lzma_mode, api/lzma/lzma12.h:138-157 */
+#define XZAMD_MODE_NORMAL 2
+
+#define XZAMD_PRESET_EXTREME 0x80000000u
+
+/* One span per Block: output is byte-identical to the reference MT encoder
+ * for fast-mode HC3/HC4 chains (presets 0-3). */
+#define XZAMD_SPAN_WHOLE_BLOCK 0xFFFFFFFFu
+#define XZAMD_SPAN_DEFAULT 0u
+
+/* LZMA2 options: the encoder-relevant subset of lzma_options_lzma
+ * (api/lzma/lzma12.h:216-525) plus the GPU span size. */
+typedef struct {
+	uint32_t dict_size;
+	uint32_t lc, lp, pb;
+	uint32_t mode;       /* as requested by the preset (informational) */
+	uint32_t nice_len;
+	uint32_t mf;         /* requested match finder */
+	uint32_t depth;      /* 0 = reference default (lz_encoder.c:359-365) */
+	/* --- what the device path actually runs --- */
+	uint32_t gpu_mf;     /* XZAMD_MF_HC3 / XZAMD_MF_HC4 */
+	uint32_t gpu_nice_len;
+	uint32_t gpu_depth;  /* 1..56 */
+	uint32_t span_size;  /* bytes per independently coded span; XZAMD_SPAN_* */
+} xzamd_lzma_options;
+
+/* lzma_lzma_preset() (lzma/lzma_encoder_presets.c:17-63) + the device mapping.
+ * Returns nonzero for an invalid preset. */
+int xzamd_lzma_preset(xzamd_lzma_options *opt, uint32_t preset);
+/* lzma_mt_block_size() for a plain LZMA2 chain (lzma2_encoder.c:403-413). */
+uint64_t xzamd_mt_block_size(const xzamd_lzma_options *opt);
+/* lzma_block_buffer_bound64() (common/block_buffer_encoder.c:55-69). */
+uint64_t xzamd_block_buffer_bound(uint64_t uncompressed_size);
+/* Upper bound for the whole .xz Stream produced from in_size bytes. */
+uint64_t xzamd_stream_buffer_bound(uint64_t in_size, uint64_t block_size);
+
+/* Context = one GPU (device ordinal, -1 = current) + its work buffers. */
+int xzamd_ctx_create(xzamd_ctx **ctx, int device);
+void xzamd_ctx_destroy(xzamd_ctx *ctx);
+/* Bytes of input processed per device batch (default 1 GiB, < 2 GiB). */
+int xzamd_ctx_set_batch_bytes(xzamd_ctx *ctx, uint64_t bytes);
+const char *xzamd_last_error(const xzamd_ctx *ctx);
+
+typedef struct {
+	uint64_t in_bytes, out_bytes;
+	uint64_t blocks, spans, batches;
+	uint64_t blocks_stored;      /* Blocks that took the uncompressed fallback */
+	/* HIP-event time per stage, summed over batches (milliseconds) */
+	float ms_chains;             /* hash keys + radix sorts + link kernels */
+	float ms_encode;             /* k_span_encode (the dominant kernel) */
+	float ms_crc;
+	float ms_assemble;
+	float ms_total;              /* first launch -> last kernel done */
+	uint32_t encode_launches;
+} xzamd_stats;
+void xzamd_get_stats(const xzamd_ctx *ctx, xzamd_stats *out);
+
+/* Encode in_size bytes resident in device memory (d_in) into a complete,
+ * standards-conformant .xz Stream in device memory (d_out): Stream Header,
+ * one Block per block_size bytes (Block Header with both sizes, LZMA2 data,
+ * padding, Check), Index, Stream Footer -- exactly the layout
+ * lzma_stream_encoder_mt produces (stream_encoder_mt.c:717-883).
+ *
+ * flags: XZAMD_F_BLOCKS_ONLY emits only the Blocks (no header/index/footer)
+ * and reports per-Block sizes through `binfo` so several GPUs can each encode
+ * a shard and one of them frames the Stream.
+ *
+ * block_size 0 = xzamd_mt_block_size(opt). check = XZAMD_CHECK_*.
+ * Returns XZAMD_OK or an error code. */
+#define XZAMD_F_BLOCKS_ONLY 1u
+
+typedef struct {
+	uint64_t unpadded_size;      /* Index record field 1 (block_util.c:45-76) */
+	uint64_t uncompressed_size;  /* Index record field 2 */
+	uint64_t out_offset;         /* where the Block starts in d_out */
+	uint64_t total_size;         /* header + data + padding + check */
+} xzamd_block_info;
+
+int xzamd_stream_encode_device(xzamd_ctx *ctx,
+		const void *d_in, uint64_t in_size, uint64_t block_size,
+		const xzamd_lzma_options *opt, int check, uint32_t flags,
+		void *d_out, uint64_t out_cap, uint64_t *out_size,
+		xzamd_block_info *binfo, uint64_t binfo_cap, uint64_t *nblocks,
+		void *stream);
+
+/* Host-side framing helpers for the multi-GPU path: Stream Header (12 bytes),
+ * Index + Stream Footer from gathered Block records. Return bytes written. */
+uint64_t xzamd_frame_header(uint8_t *out, int check);
+uint64_t xzamd_frame_index_footer(uint8_t *out, uint64_t out_cap, int check,
+		const uint64_t *unpadded, const uint64_t *uncompressed, uint64_t nblocks);
+
+/* Debug hook for the parity tests: when set, the next encode records every
+ * LZMA symbol (span, pos, back, len as 4 x u32) into a device buffer of
+ * `cap` symbols; xzamd_trace_read copies it out. Not for production use. */
+int xzamd_trace_enable(xzamd_ctx *ctx, uint32_t cap);
+int xzamd_trace_read(xzamd_ctx *ctx, uint32_t *out, uint32_t cap, uint32_t *count);
+
+/* Seeded synthetic corpora used by bench.py and the tests (host memory). */
+void xzamd_corpus_lorem(uint8_t *out, uint64_t n);                 /* tests/create_compress_files.c:110-152 continued */
+void xzamd_corpus_text(uint8_t *out, uint64_t n, uint64_t seed, int threads);   /* Zipf/Markov "enwik-style" */
+
+const char *xzamd_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,80 @@
+/* kernels_api.h -- internal ABI between the plain-C host layer (xzamd_host.c) and the HIP
+ * translation unit (lzma_kernels.hip).  Plain C types only; not part of the public C ABI
+ * (that is include/xz_amd.h). */
+#ifndef XZAMD_KERNELS_API_H
+#define XZAMD_KERNELS_API_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Arguments of the span encoder (one wavefront per span). All offsets are byte offsets into
+ * the batch input `in` (n < 2^31). */
+typedef struct {
+	const uint8_t *in;
+	const uint32_t *rank;        /* rank[pos]   = slot of pos in the sorted bucket order */
+	const uint32_t *sorted_pos;  /* slot -> pos | first_of_bucket << 31 */
+	const uint32_t *prev2;       /* distance to previous position with equal hash2, 0 = none */
+	const uint32_t *prev3;       /* same for hash3 (HC4 only) */
+	uint8_t *scratch;            /* span s writes at scratch + s * span_cap */
+	uint64_t span_cap;
+	uint32_t *span_bytes;        /* out: bytes produced per span */
+	uint32_t *trace;             /* optional debug: 4 x u32 per symbol (span,pos,back,len) */
+	uint32_t *trace_count;
+	uint32_t trace_cap;
+	uint32_t n;
+	uint32_t block_size;
+	uint32_t span_size;
+	uint32_t spans_per_block;
+	uint32_t dict_size, nice_len, depth, hash_bytes;
+	uint32_t lc, lp, pb;
+} xzamd_span_args;
+
+/* One gather segment of the final assembly. kind 0: src is an offset into the span scratch,
+ * 1: into the literal-bytes buffer prepared by the host, 2: into the batch input (raw). */
+typedef struct {
+	uint64_t src;
+	uint64_t dst;
+	uint64_t len;
+	uint32_t kind;
+	uint32_t pad_;
+} xzamd_copy_seg;
+
+int xzk_sort_temp_bytes(uint32_t n, uint32_t end_bit, uint64_t *bytes);
+int xzk_build_chains(const uint8_t *d_in, uint32_t n, uint32_t block_size, uint32_t nblocks,
+		uint32_t hash_bytes, uint32_t hash_mask, uint32_t hash_bits,
+		uint32_t *keys_a, uint32_t *keys_b, uint32_t *vals_a, uint32_t *vals_b,
+		void *sort_tmp, uint64_t sort_tmp_bytes,
+		uint32_t *rank, uint32_t *sorted_pos, uint32_t *prev2, uint32_t *prev3, void *stream);
+int xzk_span_encode(const xzamd_span_args *a, uint32_t nspans, void *stream);
+int xzk_crc64_blocks(const uint8_t *d_in, uint32_t n, uint32_t block_size, uint32_t nblocks,
+		uint32_t strip, uint64_t *d_strip_crc, uint64_t *d_block_crc, void *stream);
+int xzk_assemble(const xzamd_copy_seg *d_segs, uint32_t nsegs, const uint8_t *d_scratch,
+		const uint8_t *d_lits, const uint8_t *d_in, uint8_t *d_out, void *stream);
+
+int xzk_malloc(void **p, uint64_t bytes);
+int xzk_free(void *p);
+int xzk_host_alloc(void **p, uint64_t bytes);
+int xzk_host_free(void *p);
+int xzk_h2d(void *d, const void *h, uint64_t bytes, void *stream);
+int xzk_d2h(void *h, const void *d, uint64_t bytes, void *stream);
+int xzk_memset(void *d, int v, uint64_t bytes, void *stream);
+int xzk_sync(void *stream);
+int xzk_set_device(int dev);
+int xzk_get_device(int *dev);
+int xzk_device_count(int *n);
+int xzk_stream_create(void **stream);
+int xzk_stream_destroy(void *stream);
+int xzk_event_create(void **ev);
+int xzk_event_destroy(void *ev);
+int xzk_event_record(void *ev, void *stream);
+int xzk_event_elapsed_ms(void *a, void *b, float *ms);
+const char *xzk_error_string(int e);
+int xzk_mem_info(uint64_t *free_b, uint64_t *total_b);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,947 @@
+// lzma_kernels.hip -- MI355X (gfx950 / CDNA4) device side of the LZMA2 Block encoder.
+//
+// Replaces, for a whole batch of .xz Blocks resident in HBM, what one worker
+// thread of the reference runs per Block (stream_encoder_mt.c:219-298):
+//
+//   lz/lz_encoder_mf.c      HC3/HC4 match finder      -> k_hash_keys + radix sort + k_link_*
+//                                                       (Block-global "sorted bucket" chains)
+//                                                       + wave-parallel candidate evaluation
+//   lzma/lzma_encoder_optimum_fast.c  parser           -> optimum_fast() below (wave-uniform)
+//   lzma/lzma_encoder.c     symbol coder               -> encode_symbol()
+//   rangecoder/range_encoder.h  range coder            -> struct RC
+//   lzma/lzma2_encoder.c    chunk framing              -> k_span_encode epilogue
+//   check/crc64_fast.c      CRC64 of the Block         -> k_crc64_strips / k_crc64_fold
+//   block_encoder.c / stream_encoder_mt.c assembly     -> k_assemble (gather of span outputs)
+//
+// Design: the sequential insert-then-search hash chain of the
+// reference is replaced by a parse-independent structure built in parallel:
+// every position's masked hash is radix-sorted (key = block<<hash_bits | hash,
+// stable, so positions ascend inside a bucket).  rank4[pos] gives the slot of
+// a position in that order; the `depth` slots before it ARE the hash chain the
+// reference would walk (same candidates, same order, collisions included), so
+// one coalesced read fetches the whole chain and 64 lanes evaluate all
+// candidates at once.  hash2/hash3 "head" tables become prev2/prev3 link
+// arrays built the same way.  The LZMA state machine + range coder is serial
+// by construction; parallelism there comes from cutting each Block into spans
+// that are entropy-coded independently (LZMA2 state-reset chunks), one
+// wavefront per span, probability model in LDS.
+//
+// No MFMA: there is no dense contraction anywhere on this path.
+
+#include <hip/hip_runtime.h>
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
+#include <stdint.h>
+#include "kernels_api.h"
+
+namespace {
+
+constexpr uint32_t MATCH_LEN_MAX = 273;
+constexpr uint32_t LITERAL = 0xFFFFFFFFu;
+constexpr uint32_t NO_DELTA = 0xFFFFFFFFu;
+
+// Probability model layout (u16 each), 7990 entries at lc+lp<=... we size for lc+lp <= 3
+// (8 literal coders = 6144) which covers every preset (lc=3, lp=0).  Same order as the oracle.
+enum : uint32_t {
+    P_IS_MATCH = 0,
+    P_IS_REP = P_IS_MATCH + 12 * 16,
+    P_IS_REP0 = P_IS_REP + 12,
+    P_IS_REP1 = P_IS_REP0 + 12,
+    P_IS_REP2 = P_IS_REP1 + 12,
+    P_IS_REP0_LONG = P_IS_REP2 + 12,
+    P_DIST_SLOT = P_IS_REP0_LONG + 12 * 16,
+    P_DIST_SPECIAL = P_DIST_SLOT + 4 * 64,
+    P_DIST_ALIGN = P_DIST_SPECIAL + 114,
+    P_MATCH_LEN = P_DIST_ALIGN + 16,
+    LEN_CHOICE = 0, LEN_CHOICE2 = 1, LEN_LOW = 2, LEN_MID = 2 + 16 * 8, LEN_HIGH = 2 + 32 * 8,
+    LEN_CODER_SIZE = 2 + 32 * 8 + 256,
+    P_REP_LEN = P_MATCH_LEN + LEN_CODER_SIZE,
+    P_LITERAL = P_REP_LEN + LEN_CODER_SIZE,       // 1846
+    P_TOTAL = P_LITERAL + (0x300 << 3)            // 7990
+};
+static_assert(P_TOTAL <= 8192, "model must fit the 16 KiB LDS slice");
+
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ uint32_t lane_of(uint32_t v, uint32_t l) { return __builtin_amdgcn_readlane(v, uni(l)); }
+
+// CRC32 table[0] entry for one byte (lz_encoder_hash.h:31-39 uses lzma_crc32_table[0]).
+__device__ __forceinline__ uint32_t crc_t0(uint32_t b)
+{
+    uint32_t r = b;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) r = (r >> 1) ^ ((r & 1) ? 0xEDB88320u : 0u);
+    return r;
+}
+
+// ------------------------------------------------------------------------------------------
+// Match-finder structure build
+// ------------------------------------------------------------------------------------------
+
+// One thread per input byte: one of the hash keys of lz_encoder_hash.h:55-75 (which = 2: hash2,
+// 3: hash3 of HC4, 0: the main chain hash), prefixed with the Block number so one sort serves
+// every Block of the batch.  Positions with fewer than hash_bytes left in their Block are never
+// inserted by the reference (lz_encoder_mf.c:190-201 "pending"): they get the sentinel bucket
+// `nblocks`.  vals = iota (the position itself).
+__global__ __launch_bounds__(256) void k_hash_keys(const uint8_t* __restrict__ in, uint32_t n,
+        uint32_t block_size, uint32_t nblocks, uint32_t hash_bytes, uint32_t hash_mask, uint32_t hash_bits,
+        uint32_t which, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals)
+{
+    __shared__ uint32_t T[256];
+    T[threadIdx.x] = crc_t0(threadIdx.x);
+    __syncthreads();
+    const uint32_t kbits = which == 2 ? 10u : (which == 3 ? 16u : hash_bits);
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < n; g += stride) {
+        const uint32_t b = g / block_size;
+        const uint32_t bend = min(n, (b + 1) * block_size);   // n < 2^31, no overflow
+        const uint32_t avail = bend - g;
+        uint32_t key = nblocks << kbits;
+        if (avail >= hash_bytes) {
+            const uint32_t c0 = in[g], c1 = in[g + 1], c2 = in[g + 2];
+            const uint32_t temp = T[c0] ^ c1;
+            uint32_t h;
+            if (which == 2) h = temp & 0x3FF;
+            else if (which == 3) h = (temp ^ (c2 << 8)) & 0xFFFF;
+            else if (hash_bytes == 3) h = (temp ^ (c2 << 8)) & hash_mask;
+            else h = (temp ^ (c2 << 8) ^ (T[in[g + 3]] << 5)) & hash_mask;
+            key = (b << kbits) | h;
+        }
+        keys[g] = key;
+        vals[g] = g;
+    }
+}
+
+// After the stable sort by key_main: publish the bucket order.
+//   sorted_pos[i] = position | (first-of-bucket << 31)      rank[position] = i
+__global__ __launch_bounds__(256) void k_link_main(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals,
+        uint32_t n, uint32_t* __restrict__ sorted_pos, uint32_t* __restrict__ rank)
+{
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint32_t p = vals[i];
+        const uint32_t first = (i == 0 || keys[i - 1] != keys[i]) ? 0x80000000u : 0u;
+        sorted_pos[i] = p | first;
+        rank[p] = i;
+    }
+}
+
+// After the stable sort by key2 / key3: prev[position] = distance to the previous position of
+// the same bucket (the value the reference's hash2/hash3 head table holds when `position` is
+// reached, expressed as delta), 0 = none.
+__global__ __launch_bounds__(256) void k_link_prev(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals,
+        uint32_t n, uint32_t* __restrict__ prev)
+{
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint32_t p = vals[i];
+        uint32_t d = 0;
+        if (i > 0 && keys[i - 1] == keys[i]) d = p - vals[i - 1];
+        prev[p] = d;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Range coder (rangecoder/range_encoder.h:136-263), coding directly instead of queueing.
+// All members are wave-uniform.
+// ------------------------------------------------------------------------------------------
+struct RC {
+    uint64_t low;
+    uint32_t range;
+    uint32_t cache_size;
+    uint32_t cache;
+    uint32_t cpos;      // payload bytes written for the current chunk
+    uint8_t* out;       // payload base of the current chunk
+
+    __device__ __forceinline__ void reset()
+    {
+        low = 0; range = 0xFFFFFFFFu; cache_size = 1; cache = 0;
+    }
+    __device__ __forceinline__ void shift_low()
+    {
+        if ((uint32_t)low < 0xFF000000u || (uint32_t)(low >> 32) != 0) {
+            const uint32_t carry = (uint32_t)(low >> 32);
+            const uint32_t lane = threadIdx.x;
+            // byte 0 = cache + carry, then cache_size-1 bytes of 0xFF + carry
+            for (uint32_t i = lane; i < cache_size; i += 64)
+                out[cpos + i] = (uint8_t)((i == 0 ? cache : 0xFFu) + carry);
+            cpos += cache_size;
+            cache_size = 0;
+            cache = (uint32_t)(low >> 24) & 0xFF;
+        }
+        ++cache_size;
+        low = (low & 0x00FFFFFFu) << 8;
+    }
+    __device__ __forceinline__ void normalize()
+    {
+        if (range < (1u << 24)) { shift_low(); range <<= 8; }
+    }
+    __device__ __forceinline__ void bit(uint16_t* probs, uint32_t idx, uint32_t b)
+    {
+        normalize();
+        uint32_t p = uni(probs[idx]);
+        const uint32_t bound = (range >> 11) * p;
+        if (!b) { range = bound; p += (2048 - p) >> 5; }
+        else { low += bound; range -= bound; p -= p >> 5; }
+        probs[idx] = (uint16_t)p;
+    }
+    __device__ __forceinline__ void tree(uint16_t* probs, uint32_t base, uint32_t nbits, uint32_t sym)
+    {
+        uint32_t m = 1;
+        do {
+            const uint32_t b = (sym >> --nbits) & 1;
+            bit(probs, base + m, b);
+            m = (m << 1) + b;
+        } while (nbits);
+    }
+    __device__ __forceinline__ void tree_rev(uint16_t* probs, uint32_t base, uint32_t nbits, uint32_t sym)
+    {
+        uint32_t m = 1;
+        do {
+            const uint32_t b = sym & 1;
+            sym >>= 1;
+            bit(probs, base + m, b);
+            m = (m << 1) + b;
+        } while (--nbits);
+    }
+    __device__ __forceinline__ void direct(uint32_t value, uint32_t nbits)
+    {
+        do {
+            normalize();
+            range >>= 1;
+            if ((value >> --nbits) & 1) low += range;
+        } while (nbits);
+    }
+    __device__ __forceinline__ void flush()
+    {
+        normalize();                     // the queue loop normalizes before the first RC_FLUSH
+        for (int i = 0; i < 5; ++i) shift_low();
+        reset();
+    }
+};
+
+// ------------------------------------------------------------------------------------------
+// Wave-cooperative byte comparison
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t ld64(const uint8_t* p)
+{
+    uint64_t v;
+    __builtin_memcpy(&v, p, 8);
+    return v;
+}
+
+// Per-lane: length of the common prefix of in[q..] and in[x..], at most lim.  Lanes diverge.
+__device__ __forceinline__ uint32_t lane_cmplen(const uint8_t* __restrict__ in, uint32_t q, uint32_t x, uint32_t lim)
+{
+    uint32_t len = 0;
+    while (len + 8 <= lim) {
+        const uint64_t d = ld64(in + q + len) ^ ld64(in + x + len);
+        if (d) return len + (uint32_t)(__builtin_ctzll(d) >> 3);
+        len += 8;
+    }
+    while (len < lim && in[q + len] == in[x + len]) ++len;
+    return len;
+}
+
+// Whole wave: extend a known common prefix `len` of in[a..], in[b..] up to lim (64 bytes/step).
+__device__ __forceinline__ uint32_t wave_cmplen(const uint8_t* __restrict__ in, uint32_t a, uint32_t b,
+        uint32_t len, uint32_t lim)
+{
+    const uint32_t lane = threadIdx.x;
+    while (len < lim) {
+        const uint32_t off = len + lane;
+        const bool mism = off >= lim || in[a + off] != in[b + off];
+        const uint64_t m = __ballot(mism);
+        if (m) { len += (uint32_t)__builtin_ctzll(m); break; }
+        len += 64;
+    }
+    return len < lim ? len : lim;
+}
+
+__device__ __forceinline__ uint32_t prefix_max_incl(uint32_t v)
+{
+    const uint32_t lane = threadIdx.x;
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1) {
+        const uint32_t o = __shfl_up(v, s);
+        if (lane >= (uint32_t)s) v = max(v, o);
+    }
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------
+// One "round": everything lzma_mf_find() would report at position x (lz_encoder_mf.c:22-79,
+// HC3 :305-335, HC4 :366-413, chain walk :250-287) plus the four rep-match lengths at x.
+// Lane roles: 0 = hash2 candidate, 1 = hash3 candidate, 2 = own slot (bucket flag only),
+// 3..2+depth = chain candidates in chain order, 60..63 = rep0..rep3.
+// ------------------------------------------------------------------------------------------
+struct Round {
+    uint64_t mask;      // recorded matches, in matches[] order (ascending lane)
+    uint32_t L;         // per lane: recorded length (lanes 0..58), rep length (60..63)
+    uint32_t D;         // per lane: distance (zero based)
+    uint32_t longest;   // lzma_mf_find() return value (incl. the > nice_len extension)
+};
+
+struct Env {
+    const uint8_t* __restrict__ in;
+    const uint32_t* __restrict__ rank;
+    const uint32_t* __restrict__ sorted_pos;
+    const uint32_t* __restrict__ prev2;
+    const uint32_t* __restrict__ prev3;
+    uint32_t nice, depth, hb, cyclic;
+};
+
+__device__ __forceinline__ void do_round(const Env& e, uint32_t x, uint32_t end,
+        uint32_t r0, uint32_t r1, uint32_t r2, uint32_t r3, Round& R)
+{
+    const uint32_t lane = threadIdx.x;
+    const uint32_t avail = end - x;
+    const uint32_t buf_avail = avail < MATCH_LEN_MAX ? avail : MATCH_LEN_MAX;
+    uint32_t len_limit = avail;
+    bool mf_ok = true;
+    if (e.nice <= len_limit) len_limit = e.nice;
+    else if (len_limit < e.hb) mf_ok = false;            // "pending": no matches reported
+
+    uint32_t q = 0, lim = 0;
+    bool chain_valid = false;
+    if (mf_ok) {
+        const uint32_t rk = e.rank[x];
+        const uint32_t d2 = e.prev2[x];
+        const uint32_t d3 = e.hb == 4 ? e.prev3[x] : 0;
+        if (lane == 0) {
+            if (d2 != 0 && d2 < e.cyclic) { q = x - d2; lim = len_limit; }
+        } else if (lane == 1) {
+            if (d3 != 0 && d3 != d2 && d3 < e.cyclic) { q = x - d3; lim = len_limit; }
+        }
+        uint32_t ent = 0x80000000u;                      // treat out-of-range as "bucket start"
+        const bool in_chain = lane >= 2 && lane <= 2 + e.depth;
+        if (in_chain && rk >= lane - 2) ent = e.sorted_pos[rk - (lane - 2)];
+        const uint64_t flags = __ballot(in_chain && (ent >> 31)) >> 2;   // bit j = flag of slot rank-j
+        if (lane >= 3 && in_chain) {
+            const uint32_t j = lane - 2;                 // candidate number 1..depth
+            const bool same_bucket = (flags & ((1ull << j) - 1)) == 0;
+            const uint32_t qp = ent & 0x7FFFFFFFu;
+            if (same_bucket && x - qp < e.cyclic) { chain_valid = true; q = qp; lim = len_limit; }
+        }
+    }
+    if (lane >= 60) {
+        const uint32_t rep = lane == 60 ? r0 : lane == 61 ? r1 : lane == 62 ? r2 : r3;
+        q = x - rep - 1;
+        lim = buf_avail;
+    }
+
+    uint32_t L = lane_cmplen(e.in, q, x, lim);
+    const uint32_t D = x - q - 1;
+
+    const uint32_t L0 = lane_of(L, 0), L1 = lane_of(L, 1);
+    const bool has2 = L0 >= 1;              // first byte equal => (by the hash) >= 2 bytes equal
+    const bool has3 = L1 >= 1;              // lane 1 only active for HC4
+    uint32_t best;
+    bool done;
+    if (e.hb == 4) {
+        best = has3 ? L1 : (has2 ? L0 : 1);
+        done = (has2 || has3) && best == len_limit;
+        if (best < 3) best = 3;
+    } else {
+        best = has2 ? L0 : 2;
+        done = has2 && best == len_limit;
+    }
+    const uint32_t X = chain_valid ? L : 0;
+    const uint32_t incl = prefix_max_incl(X);
+    uint32_t excl = __shfl_up(incl, 1);
+    if (lane == 0) excl = 0;
+    bool rec = chain_valid && !done && X > max(best, excl);
+    if (lane == 0) { rec = has2; if (has2 && has3) L = 2; }
+    if (lane == 1) rec = has3;
+    R.mask = mf_ok ? __ballot(rec) : 0ull;
+    R.L = L;
+    R.D = D;
+    uint32_t longest = 0;
+    if (R.mask) {
+        const uint32_t top = 63 - (uint32_t)__builtin_clzll(R.mask);
+        longest = lane_of(L, top);
+        if (longest == e.nice) {
+            const uint32_t dist = lane_of(D, top);
+            longest = wave_cmplen(e.in, x, x - dist - 1, longest, buf_avail);
+        }
+    }
+    R.longest = longest;
+}
+
+// ------------------------------------------------------------------------------------------
+// LZMA symbol coder (lzma/lzma_encoder.c:23-263)
+// ------------------------------------------------------------------------------------------
+struct Lz {
+    uint32_t state;
+    uint32_t rep0, rep1, rep2, rep3;
+    uint32_t lc, lp, pb;
+};
+
+__device__ __forceinline__ uint32_t dist_slot_of(uint32_t d)
+{
+    if (d <= 4) return d;
+    const uint32_t i = 31 - __builtin_clz(d);
+    return (i + i) + ((d >> (i - 1)) & 1);
+}
+
+__device__ __forceinline__ void enc_length(RC& rc, uint16_t* probs, uint32_t base, uint32_t ps, uint32_t len)
+{
+    len -= 2;
+    if (len < 8) {
+        rc.bit(probs, base + LEN_CHOICE, 0);
+        rc.tree(probs, base + LEN_LOW + ps * 8, 3, len);
+    } else {
+        rc.bit(probs, base + LEN_CHOICE, 1);
+        len -= 8;
+        if (len < 8) {
+            rc.bit(probs, base + LEN_CHOICE2, 0);
+            rc.tree(probs, base + LEN_MID + ps * 8, 3, len);
+        } else {
+            rc.bit(probs, base + LEN_CHOICE2, 1);
+            rc.tree(probs, base + LEN_HIGH, 8, len - 8);
+        }
+    }
+}
+
+// g = global offset of the byte, upos = its offset inside the Block
+__device__ __forceinline__ void enc_literal(RC& rc, uint16_t* probs, Lz& z, const uint8_t* __restrict__ in,
+        uint32_t g, uint32_t upos)
+{
+    const uint32_t cur = uni(in[g]);
+    const uint32_t prev = upos ? uni(in[g - 1]) : 0;
+    const uint32_t mask = (0x100u << z.lp) - (0x100u >> z.lc);
+    const uint32_t sub = P_LITERAL + 3u * ((((upos << 8) + prev) & mask) << z.lc);
+    if (z.state < 7) {
+        z.state = z.state <= 3 ? 0 : z.state - 3;
+        rc.tree(probs, sub, 8, cur);
+    } else {
+        z.state = z.state <= 9 ? z.state - 3 : z.state - 6;
+        uint32_t mb = uni(in[g - z.rep0 - 1]);
+        uint32_t off = 0x100, sym = 0x100u + cur;
+        do {
+            mb <<= 1;
+            const uint32_t mbit = mb & off;
+            const uint32_t idx = off + mbit + (sym >> 8);
+            const uint32_t b = (sym >> 7) & 1;
+            rc.bit(probs, sub + idx, b);
+            sym <<= 1;
+            off &= ~(mb ^ sym);
+        } while (sym < 0x10000);
+    }
+}
+
+__device__ __forceinline__ void encode_symbol(RC& rc, uint16_t* probs, Lz& z, const uint8_t* __restrict__ in,
+        uint32_t g, uint32_t upos, uint32_t back, uint32_t len)
+{
+    const uint32_t ps = upos & ((1u << z.pb) - 1);
+    if (back == LITERAL) {
+        rc.bit(probs, P_IS_MATCH + z.state * 16 + ps, 0);
+        enc_literal(rc, probs, z, in, g, upos);
+        return;
+    }
+    rc.bit(probs, P_IS_MATCH + z.state * 16 + ps, 1);
+    if (back < 4) {
+        rc.bit(probs, P_IS_REP + z.state, 1);
+        if (back == 0) {
+            rc.bit(probs, P_IS_REP0 + z.state, 0);
+            rc.bit(probs, P_IS_REP0_LONG + z.state * 16 + ps, len != 1);
+        } else {
+            rc.bit(probs, P_IS_REP0 + z.state, 1);
+            uint32_t dist;
+            if (back == 1) {
+                rc.bit(probs, P_IS_REP1 + z.state, 0);
+                dist = z.rep1;
+            } else {
+                rc.bit(probs, P_IS_REP1 + z.state, 1);
+                rc.bit(probs, P_IS_REP2 + z.state, back - 2);
+                if (back == 3) { dist = z.rep3; z.rep3 = z.rep2; }
+                else dist = z.rep2;
+                z.rep2 = z.rep1;
+            }
+            z.rep1 = z.rep0;
+            z.rep0 = dist;
+        }
+        if (len == 1) {
+            z.state = z.state < 7 ? 9 : 11;
+        } else {
+            enc_length(rc, probs, P_REP_LEN, ps, len);
+            z.state = z.state < 7 ? 8 : 11;
+        }
+        return;
+    }
+    rc.bit(probs, P_IS_REP + z.state, 0);
+    const uint32_t dist = back - 4;
+    z.state = z.state < 7 ? 7 : 10;
+    enc_length(rc, probs, P_MATCH_LEN, ps, len);
+    const uint32_t slot = dist_slot_of(dist);
+    const uint32_t ds = len < 6 ? len - 2 : 3;
+    rc.tree(probs, P_DIST_SLOT + ds * 64, 6, slot);
+    if (slot >= 4) {
+        const uint32_t fb = (slot >> 1) - 1;
+        const uint32_t base = (2 | (slot & 1)) << fb;
+        const uint32_t red = dist - base;
+        if (slot < 14) {
+            rc.tree_rev(probs, P_DIST_SPECIAL + base - slot - 1, fb, red);
+        } else {
+            rc.direct(red >> 4, fb - 4);
+            rc.tree_rev(probs, P_DIST_ALIGN, 4, red & 15);
+        }
+    }
+    z.rep3 = z.rep2; z.rep2 = z.rep1; z.rep1 = z.rep0; z.rep0 = dist;
+}
+
+__device__ __forceinline__ bool change_pair(uint32_t small_dist, uint32_t big_dist)
+{
+    return (big_dist >> 7) > small_dist;
+}
+
+// ------------------------------------------------------------------------------------------
+// Span encoder: one wavefront per span.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_span_encode(xzamd_span_args a)
+{
+    __shared__ uint16_t probs[8192];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t span = blockIdx.x;
+    const uint32_t blk = span / a.spans_per_block;
+    const uint32_t k = span - blk * a.spans_per_block;
+    const uint32_t block_start = blk * a.block_size;
+    const uint32_t block_end = min(a.n, block_start + a.block_size);
+    const uint32_t span_start = block_start + k * a.span_size;
+    if (span_start >= block_end) {
+        if (lane == 0) a.span_bytes[span] = 0;
+        return;
+    }
+    const uint32_t span_end = min(block_end, span_start + a.span_size);
+    uint8_t* const outp = a.scratch + (uint64_t)span * a.span_cap;
+    const uint8_t* __restrict__ in = a.in;
+
+    Env e;
+    e.in = in; e.rank = a.rank; e.sorted_pos = a.sorted_pos; e.prev2 = a.prev2; e.prev3 = a.prev3;
+    e.nice = a.nice_len; e.depth = a.depth; e.hb = a.hash_bytes; e.cyclic = a.dict_size + 1;
+
+    Lz z;
+    z.lc = a.lc; z.lp = a.lp; z.pb = a.pb;
+    RC rc;
+    rc.cpos = 0; rc.out = outp; rc.reset();
+
+    bool need_props = true, need_dict_reset = (k == 0), need_state_reset = true;
+    bool initialized = (k != 0);
+    uint32_t cur = span_start;
+    uint32_t read_ahead = 0;
+    uint32_t out_off = 0;
+    Round R;            // cached find at `cur` when read_ahead == 1
+    R.mask = 0; R.L = 0; R.D = 0; R.longest = 0;
+
+    while (cur < span_end) {
+        if (need_state_reset) {
+            // lzma_lzma_encoder_reset (lzma_encoder.c:529-598)
+            uint32_t* p32 = reinterpret_cast<uint32_t*>(probs);
+            for (uint32_t i = lane; i < 4096; i += 64) p32[i] = 0x04000400u;
+            z.state = 0; z.rep0 = z.rep1 = z.rep2 = z.rep3 = 0;
+            // the flag stays set until an LZMA chunk header has announced the reset
+        }
+        const uint32_t chunk_start = cur;
+        const uint32_t hl = need_props ? 6 : 5;
+        rc.out = outp + out_off + hl;
+        rc.cpos = 0;
+        rc.reset();
+
+        if (!initialized) {
+            // encode_init (lzma_encoder.c:267-293)
+            rc.bit(probs, P_IS_MATCH, 0);
+            rc.tree(probs, P_LITERAL, 8, uni(in[block_start]));
+            cur = block_start + 1;
+            initialized = true;
+        }
+
+        for (;;) {
+            // lzma_encoder.c:346-351 (limit from lzma2_encoder.c:167-181)
+            if (cur - chunk_start >= (1u << 21) - MATCH_LEN_MAX
+                    || rc.cpos + rc.cache_size + 4 >= 65536 - 4097)
+                break;
+            if (cur >= span_end)
+                break;
+
+            // ---------------- lzma_lzma_optimum_fast (optimum_fast.c:20-169) ----------------
+            uint32_t back = LITERAL, len = 1;
+            if (read_ahead == 0) {
+                do_round(e, cur, span_end, z.rep0, z.rep1, z.rep2, z.rep3, R);
+                read_ahead = 1;
+            }
+            {
+                const uint32_t rem = span_end - cur;
+                const uint32_t buf_avail = rem < MATCH_LEN_MAX ? rem : MATCH_LEN_MAX;
+                uint32_t len_main = R.longest;
+                uint64_t m = R.mask;
+                bool decided = false;
+                if (buf_avail < 2) decided = true;          // literal
+
+                uint32_t rep_len = 0, rep_index = 0;
+                if (!decided) {
+                    for (uint32_t i = 0; i < 4; ++i) {
+                        const uint32_t rl = lane_of(R.L, 60 + i);
+                        if (rl < 2) continue;
+                        if (rl >= e.nice) {
+                            back = i; len = rl; read_ahead += rl - 1; decided = true;
+                            break;
+                        }
+                        if (rl > rep_len) { rep_index = i; rep_len = rl; }
+                    }
+                }
+                if (!decided && len_main >= e.nice) {
+                    const uint32_t top = 63 - (uint32_t)__builtin_clzll(m);
+                    back = lane_of(R.D, top) + 4; len = len_main; read_ahead += len_main - 1;
+                    decided = true;
+                }
+                uint32_t back_main = 0;
+                if (!decided) {
+                    if (len_main >= 2) {
+                        uint32_t top = 63 - (uint32_t)__builtin_clzll(m);
+                        back_main = lane_of(R.D, top);
+                        while (__builtin_popcountll(m) > 1) {
+                            const uint64_t m2 = m & ~(1ull << top);
+                            const uint32_t t2 = 63 - (uint32_t)__builtin_clzll(m2);
+                            const uint32_t l2 = lane_of(R.L, t2);
+                            if (len_main != l2 + 1) break;
+                            const uint32_t d2 = lane_of(R.D, t2);
+                            if (!change_pair(d2, back_main)) break;
+                            m = m2; top = t2; len_main = l2; back_main = d2;
+                        }
+                        if (len_main == 2 && back_main >= 0x80) len_main = 1;
+                    }
+                    if (rep_len >= 2) {
+                        if (rep_len + 1 >= len_main
+                                || (rep_len + 2 >= len_main && back_main > (1u << 9))
+                                || (rep_len + 3 >= len_main && back_main > (1u << 15))) {
+                            back = rep_index; len = rep_len; read_ahead += rep_len - 1;
+                            decided = true;
+                        }
+                    }
+                }
+                if (!decided && (len_main < 2 || buf_avail <= 2)) decided = true;   // literal
+                if (!decided) {
+                    // lookahead: matches (and rep lengths) of the next byte
+                    do_round(e, cur + 1, span_end, z.rep0, z.rep1, z.rep2, z.rep3, R);
+                    ++read_ahead;
+                    const uint32_t nl = R.longest;
+                    bool lit = false;
+                    if (nl >= 2) {
+                        const uint32_t top = 63 - (uint32_t)__builtin_clzll(R.mask);
+                        const uint32_t new_dist = lane_of(R.D, top);
+                        if ((nl >= len_main && new_dist < back_main)
+                                || (nl == len_main + 1 && !change_pair(back_main, new_dist))
+                                || (nl > len_main + 1)
+                                || (nl + 1 >= len_main && len_main >= 3 && change_pair(new_dist, back_main)))
+                            lit = true;
+                    }
+                    if (!lit) {
+                        const uint32_t limit = len_main - 1 > 2 ? len_main - 1 : 2;
+                        for (uint32_t i = 0; i < 4; ++i)
+                            if (lane_of(R.L, 60 + i) >= limit) lit = true;
+                    }
+                    if (!lit) { back = back_main + 4; len = len_main; read_ahead += len_main - 2; }
+                }
+            }
+            // ------------------------------------------------------------------------------
+            encode_symbol(rc, probs, z, in, cur, cur - block_start, back, len);
+            if (a.trace && lane == 0) {
+                // debug only: symbol stream for the parity tests (compared with the oracle's parse)
+                const uint32_t ti = atomicAdd(a.trace_count, 1u);
+                if (ti < a.trace_cap) {
+                    a.trace[4 * ti] = span;
+                    a.trace[4 * ti + 1] = cur - block_start;
+                    a.trace[4 * ti + 2] = back;
+                    a.trace[4 * ti + 3] = len;
+                }
+            }
+            read_ahead -= len;
+            cur += len;
+        }
+        rc.flush();
+
+        uint32_t usize = cur - chunk_start;
+        const uint32_t csize = rc.cpos;
+        uint8_t* const hdr = outp + out_off;
+        if (csize >= usize) {
+            // lzma2_encoder.c:205-214: store the chunk raw, including the lookahead byte
+            usize += read_ahead;
+            cur += read_ahead;
+            read_ahead = 0;
+            // the discarded range-coder bytes were stored by lane 0; make sure they have landed
+            // before other lanes overwrite the same addresses
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            for (uint32_t i = lane; i < usize; i += 64) hdr[3 + i] = in[chunk_start + i];
+            if (lane == 0) {
+                hdr[0] = need_dict_reset ? 1 : 2;
+                hdr[1] = (uint8_t)((usize - 1) >> 8);
+                hdr[2] = (uint8_t)(usize - 1);
+            }
+            need_dict_reset = false;
+            need_state_reset = true;
+            out_off += 3 + usize;
+            continue;
+        }
+        // lzma2_header_lzma (lzma2_encoder.c:54-106)
+        if (lane == 0) {
+            uint32_t c;
+            if (need_props) c = need_dict_reset ? 0xE0 : 0xC0;
+            else c = need_state_reset ? 0xA0 : 0x80;
+            hdr[0] = (uint8_t)(c + ((usize - 1) >> 16));
+            hdr[1] = (uint8_t)((usize - 1) >> 8);
+            hdr[2] = (uint8_t)(usize - 1);
+            hdr[3] = (uint8_t)((csize - 1) >> 8);
+            hdr[4] = (uint8_t)(csize - 1);
+            if (need_props) hdr[5] = (uint8_t)((a.pb * 5 + a.lp) * 9 + a.lc);
+        }
+        need_props = false; need_dict_reset = false; need_state_reset = false;
+        out_off += hl + csize;
+    }
+    if (lane == 0) a.span_bytes[span] = out_off;
+}
+
+// ------------------------------------------------------------------------------------------
+// CRC64 (check/crc64_fast.c; ECMA-182 reflected, poly 0xC96C5795D7870F42)
+// ------------------------------------------------------------------------------------------
+constexpr uint64_t CRC64_POLY = 0xC96C5795D7870F42ull;
+
+__device__ __forceinline__ uint64_t gf_mul(uint64_t a, uint64_t b)
+{
+    uint64_t r = 0;
+    for (int i = 0; i < 64; ++i) {
+        if (a & 0x8000000000000000ull) r ^= b;
+        a <<= 1;
+        b = (b >> 1) ^ ((b & 1) ? CRC64_POLY : 0ull);
+    }
+    return r;
+}
+
+__device__ __forceinline__ uint64_t gf_xpow8(uint64_t nbytes)
+{
+    uint64_t base = 0x8000000000000000ull >> 8;     // x^8
+    uint64_t acc = 0x8000000000000000ull;           // 1
+    while (nbytes) {
+        if (nbytes & 1) acc = gf_mul(acc, base);
+        base = gf_mul(base, base);
+        nbytes >>= 1;
+    }
+    return acc;
+}
+
+// Standard CRC64 (init ~0, final ~) of each strip of `strip` bytes; strips never straddle Blocks.
+__global__ __launch_bounds__(256) void k_crc64_strips(const uint8_t* __restrict__ in, uint32_t n,
+        uint32_t block_size, uint32_t strip, uint32_t strips_per_block, uint32_t nstrips,
+        uint64_t* __restrict__ out)
+{
+    __shared__ uint64_t T[256];
+    {
+        uint64_t r = threadIdx.x;
+        for (int k = 0; k < 8; ++k) r = (r >> 1) ^ ((r & 1) ? CRC64_POLY : 0ull);
+        T[threadIdx.x] = r;
+    }
+    __syncthreads();
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= nstrips) return;
+    const uint32_t b = s / strips_per_block;
+    const uint32_t bstart = b * block_size;
+    const uint32_t bend = min(n, bstart + block_size);
+    const uint32_t beg = bstart + (s - b * strips_per_block) * strip;
+    uint64_t crc = ~0ull;
+    if (beg < bend) {
+        const uint32_t end = min(bend, beg + strip);
+        for (uint32_t i = beg; i < end; ++i)
+            crc = T[(crc ^ in[i]) & 0xFF] ^ (crc >> 8);
+    }
+    out[s] = ~crc;
+}
+
+// One wave per Block: fold the strip CRCs left to right: crc(A||B) = crc(A)*x^(8|B|) ^ crc(B).
+__global__ __launch_bounds__(64) void k_crc64_fold(const uint64_t* __restrict__ strips, uint32_t n,
+        uint32_t block_size, uint32_t strip, uint32_t strips_per_block, uint64_t* __restrict__ block_crc)
+{
+    const uint32_t b = blockIdx.x;
+    const uint32_t lane = threadIdx.x;
+    const uint32_t bstart = b * block_size;
+    const uint32_t bend = min(n, bstart + block_size);
+    const uint32_t blen = bend - bstart;
+    const uint32_t ns = (blen + strip - 1) / strip;          // strips actually used
+    const uint32_t per = (ns + 63) / 64;
+    const uint32_t s0 = min(ns, lane * per), s1 = min(ns, s0 + per);
+    const uint64_t xs = gf_xpow8(strip);
+    // lane-local fold over its contiguous strips
+    uint64_t acc = 0;       // crc of the empty string is 0 and is the identity of the fold
+    uint64_t bytes = 0;
+    for (uint32_t s = s0; s < s1; ++s) {
+        const uint32_t len = min(strip, blen - s * strip);
+        const uint64_t c = strips[(uint64_t)b * strips_per_block + s];
+        acc = gf_mul(acc, len == strip ? xs : gf_xpow8(len)) ^ c;
+        bytes += len;
+    }
+    // sequential combine across lanes (64 steps, once per Block)
+    uint64_t total = 0;
+    for (uint32_t l = 0; l < 64; ++l) {
+        const uint64_t cl = __shfl(acc, l);
+        const uint64_t bl = __shfl(bytes, l);
+        if (bl) total = gf_mul(total, gf_xpow8(bl)) ^ cl;
+    }
+    if (lane == 0) block_crc[b] = total;
+}
+
+// ------------------------------------------------------------------------------------------
+// Assembly: gather span outputs (and small literal pieces prepared by the host: headers,
+// end markers, padding, checks, index, footer) into the final stream buffer.
+// One workgroup per copy segment.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_assemble(const xzamd_copy_seg* __restrict__ segs, uint32_t nsegs,
+        const uint8_t* __restrict__ scratch, const uint8_t* __restrict__ lits, const uint8_t* __restrict__ in,
+        uint8_t* __restrict__ out)
+{
+    const uint32_t s = blockIdx.x;
+    if (s >= nsegs) return;
+    const xzamd_copy_seg sg = segs[s];
+    const uint8_t* src = sg.kind == 0 ? scratch + sg.src : (sg.kind == 1 ? lits + sg.src : in + sg.src);
+    uint8_t* dst = out + sg.dst;
+    uint64_t len = sg.len;
+    // byte-granular head to 16-byte destination alignment, then 16-byte body when the source
+    // happens to be co-aligned, else dword/bytes.
+    const uint32_t t = threadIdx.x;
+    const uint64_t head = min<uint64_t>(len, (16 - ((uintptr_t)dst & 15)) & 15);
+    if (t < head) dst[t] = src[t];
+    src += head; dst += head; len -= head;
+    if ((((uintptr_t)src) & 15) == 0) {
+        const uint64_t nv = len / 16;
+        const uint4* s4 = reinterpret_cast<const uint4*>(src);
+        uint4* d4 = reinterpret_cast<uint4*>(dst);
+        for (uint64_t i = t; i < nv; i += 256) d4[i] = s4[i];
+        const uint64_t done = nv * 16;
+        for (uint64_t i = done + t; i < len; i += 256) dst[i] = src[i];
+    } else {
+        const uint64_t nv = len / 16;
+        uint4* d4 = reinterpret_cast<uint4*>(dst);
+        for (uint64_t i = t; i < nv; i += 256) {
+            uint4 v;
+            __builtin_memcpy(&v, src + i * 16, 16);
+            d4[i] = v;
+        }
+        const uint64_t done = nv * 16;
+        for (uint64_t i = done + t; i < len; i += 256) dst[i] = src[i];
+    }
+}
+
+inline uint32_t grid_for(uint64_t n, uint32_t threads, uint32_t cap)
+{
+    uint64_t g = (n + threads - 1) / threads;
+    if (g > cap) g = cap;
+    if (g == 0) g = 1;
+    return (uint32_t)g;
+}
+
+} // namespace
+
+// ==========================================================================================
+// extern "C" launch wrappers (internal ABI between the plain-C host layer and the kernels)
+// ==========================================================================================
+extern "C" {
+
+int xzk_sort_temp_bytes(uint32_t n, uint32_t end_bit, uint64_t* bytes)
+{
+    size_t sz = 0;
+    rocprim::double_buffer<uint32_t> k(nullptr, nullptr), v(nullptr, nullptr);
+    hipError_t e = rocprim::radix_sort_pairs(nullptr, sz, k, v, (size_t)n, 0u, end_bit, (hipStream_t)0);
+    *bytes = sz;
+    return (int)e;
+}
+
+// Builds rank/sorted_pos/prev2/prev3 for a batch.  keys_a/keys_b/vals_a/vals_b: n u32 each.
+int xzk_build_chains(const uint8_t* d_in, uint32_t n, uint32_t block_size, uint32_t nblocks,
+        uint32_t hash_bytes, uint32_t hash_mask, uint32_t hash_bits,
+        uint32_t* keys_a, uint32_t* keys_b, uint32_t* vals_a, uint32_t* vals_b,
+        void* sort_tmp, uint64_t sort_tmp_bytes,
+        uint32_t* rank, uint32_t* sorted_pos, uint32_t* prev2, uint32_t* prev3, void* stream_)
+{
+    hipStream_t st = (hipStream_t)stream_;
+    const uint32_t g = grid_for(n, 256, 256 * 16);
+    uint32_t bb = 0;
+    while ((1u << bb) < nblocks + 1) ++bb;
+    size_t tb = sort_tmp_bytes;
+    const uint32_t which_list[3] = { 2u, 3u, 0u };
+    for (int w = 0; w < 3; ++w) {
+        const uint32_t which = which_list[w];
+        if (which == 3 && hash_bytes != 4) continue;
+        const uint32_t kbits = which == 2 ? 10u : (which == 3 ? 16u : hash_bits);
+        hipLaunchKernelGGL(k_hash_keys, dim3(g), dim3(256), 0, st, d_in, n, block_size, nblocks, hash_bytes,
+                hash_mask, hash_bits, which, keys_a, vals_a);
+        rocprim::double_buffer<uint32_t> kb(keys_a, keys_b);
+        rocprim::double_buffer<uint32_t> vb(vals_a, vals_b);
+        size_t need = 0;
+        hipError_t e = rocprim::radix_sort_pairs(nullptr, need, kb, vb, (size_t)n, 0u, kbits + bb, st);
+        if (e != hipSuccess) return (int)e;
+        if (need > tb) return (int)hipErrorOutOfMemory;
+        e = rocprim::radix_sort_pairs(sort_tmp, tb, kb, vb, (size_t)n, 0u, kbits + bb, st);
+        if (e != hipSuccess) return (int)e;
+        if (which == 2)
+            hipLaunchKernelGGL(k_link_prev, dim3(g), dim3(256), 0, st, kb.current(), vb.current(), n, prev2);
+        else if (which == 3)
+            hipLaunchKernelGGL(k_link_prev, dim3(g), dim3(256), 0, st, kb.current(), vb.current(), n, prev3);
+        else
+            hipLaunchKernelGGL(k_link_main, dim3(g), dim3(256), 0, st, kb.current(), vb.current(), n, sorted_pos, rank);
+    }
+    return (int)hipGetLastError();
+}
+
+int xzk_span_encode(const xzamd_span_args* a, uint32_t nspans, void* stream_)
+{
+    hipStream_t st = (hipStream_t)stream_;
+    hipLaunchKernelGGL(k_span_encode, dim3(nspans), dim3(64), 0, st, *a);
+    return (int)hipGetLastError();
+}
+
+int xzk_crc64_blocks(const uint8_t* d_in, uint32_t n, uint32_t block_size, uint32_t nblocks,
+        uint32_t strip, uint64_t* d_strip_crc, uint64_t* d_block_crc, void* stream_)
+{
+    hipStream_t st = (hipStream_t)stream_;
+    const uint32_t spb = (block_size + strip - 1) / strip;
+    const uint32_t ns = spb * nblocks;
+    hipLaunchKernelGGL(k_crc64_strips, dim3((ns + 255) / 256), dim3(256), 0, st, d_in, n, block_size, strip, spb, ns,
+            d_strip_crc);
+    hipLaunchKernelGGL(k_crc64_fold, dim3(nblocks), dim3(64), 0, st, d_strip_crc, n, block_size, strip, spb,
+            d_block_crc);
+    return (int)hipGetLastError();
+}
+
+int xzk_assemble(const xzamd_copy_seg* d_segs, uint32_t nsegs, const uint8_t* d_scratch, const uint8_t* d_lits,
+        const uint8_t* d_in, uint8_t* d_out, void* stream_)
+{
+    hipStream_t st = (hipStream_t)stream_;
+    if (nsegs == 0) return 0;
+    hipLaunchKernelGGL(k_assemble, dim3(nsegs), dim3(256), 0, st, d_segs, nsegs, d_scratch, d_lits, d_in, d_out);
+    return (int)hipGetLastError();
+}
+
+// --- thin runtime shims so the plain-C host layer needs no HIP headers ---------------------
+int xzk_malloc(void** p, uint64_t bytes) { return (int)hipMalloc(p, bytes); }
+int xzk_free(void* p) { return (int)hipFree(p); }
+int xzk_host_alloc(void** p, uint64_t bytes) { return (int)hipHostMalloc(p, bytes, hipHostMallocDefault); }
+int xzk_host_free(void* p) { return (int)hipHostFree(p); }
+int xzk_h2d(void* d, const void* h, uint64_t bytes, void* st) { return (int)hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, (hipStream_t)st); }
+int xzk_d2h(void* h, const void* d, uint64_t bytes, void* st) { return (int)hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, (hipStream_t)st); }
+int xzk_memset(void* d, int v, uint64_t bytes, void* st) { return (int)hipMemsetAsync(d, v, bytes, (hipStream_t)st); }
+int xzk_sync(void* st) { return (int)hipStreamSynchronize((hipStream_t)st); }
+int xzk_set_device(int dev) { return (int)hipSetDevice(dev); }
+int xzk_get_device(int* dev) { return (int)hipGetDevice(dev); }
+int xzk_device_count(int* n) { return (int)hipGetDeviceCount(n); }
+int xzk_stream_create(void** st) { return (int)hipStreamCreateWithFlags((hipStream_t*)st, hipStreamNonBlocking); }
+int xzk_stream_destroy(void* st) { return (int)hipStreamDestroy((hipStream_t)st); }
+int xzk_event_create(void** ev) { return (int)hipEventCreate((hipEvent_t*)ev); }
+int xzk_event_destroy(void* ev) { return (int)hipEventDestroy((hipEvent_t)ev); }
+int xzk_event_record(void* ev, void* st) { return (int)hipEventRecord((hipEvent_t)ev, (hipStream_t)st); }
+int xzk_event_elapsed_ms(void* a, void* b, float* ms) { return (int)hipEventElapsedTime(ms, (hipEvent_t)a, (hipEvent_t)b); }
+const char* xzk_error_string(int e) { return hipGetErrorString((hipError_t)e); }
+int xzk_mem_info(uint64_t* free_b, uint64_t* total_b)
+{
+    size_t f = 0, t = 0;
+    hipError_t e = hipMemGetInfo(&f, &t);
+    *free_b = f; *total_b = t;
+    return (int)e;
+}
+
+} // extern "C"

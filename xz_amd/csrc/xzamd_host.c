@@ -1,0 +1,700 @@
+/*
+ * xzamd_host.c -- plain-C host layer of libxz_amd: splits the input into
+ * independent .xz Blocks, drives the HIP kernels over device-resident batches
+ * of Blocks and reassembles a standards-conformant .xz Stream.
+ *
+ * Mirrors the scheduler/container half of the reference MT encoder
+ *   src/liblzma/common/stream_encoder_mt.c   (stream_encode_mt :717, worker_encode :219)
+ *   src/liblzma/common/block_header_encoder.c, block_buffer_encoder.c,
+ *   index_encoder.c, stream_flags_encoder.c, vli_encoder.c
+ * with threads replaced by one device batch: all Blocks of a batch are
+ * encoded by one grid, the ordered output queue (outqueue.c) becomes a prefix
+ * sum over span sizes, and the copy-out becomes one gather kernel.
+ */
+#include "../../include/xz_amd.h"
+#include "kernels_api.h"
+
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define DEFAULT_SPAN (64u * 1024u)
+#define DEFAULT_BATCH (1ull << 30)
+#define CRC_STRIP 4096u
+
+/* ------------------------------------------------------------------ */
+/* container primitives (doc/xz-file-format.txt)                        */
+/* ------------------------------------------------------------------ */
+static uint32_t crc32_tab[256];
+static int crc32_ready;
+
+static uint32_t crc32_buf(const uint8_t *p, size_t n)
+{
+	if (!crc32_ready) {
+		for (uint32_t i = 0; i < 256; ++i) {
+			uint32_t r = i;
+			for (int k = 0; k < 8; ++k)
+				r = (r >> 1) ^ (0xEDB88320u & (0u - (r & 1)));
+			crc32_tab[i] = r;
+		}
+		crc32_ready = 1;
+	}
+	uint32_t c = 0xFFFFFFFFu;
+	while (n--)
+		c = crc32_tab[(c ^ *p++) & 0xFF] ^ (c >> 8);
+	return ~c;
+}
+
+static void le32(uint8_t *p, uint32_t v)
+{
+	p[0] = (uint8_t)v; p[1] = (uint8_t)(v >> 8); p[2] = (uint8_t)(v >> 16); p[3] = (uint8_t)(v >> 24);
+}
+
+static uint32_t vli_len(uint64_t v)
+{
+	uint32_t n = 0;
+	do { ++n; v >>= 7; } while (v);
+	return n;
+}
+
+static uint32_t vli_put(uint8_t *out, uint64_t v)
+{
+	uint32_t n = 0;
+	for (; v >= 0x80; v >>= 7)
+		out[n++] = (uint8_t)(v | 0x80);
+	out[n++] = (uint8_t)v;
+	return n;
+}
+
+static uint32_t check_bytes(int check)
+{
+	switch (check) {
+	case XZAMD_CHECK_NONE: return 0;
+	case XZAMD_CHECK_CRC32: return 4;
+	case XZAMD_CHECK_CRC64: return 8;
+	default: return 0xFFFFFFFFu;
+	}
+}
+
+uint64_t xzamd_frame_header(uint8_t *out, int check)
+{
+	/* stream_flags_encoder.c:29-52 */
+	static const uint8_t magic[6] = { 0xFD, 0x37, 0x7A, 0x58, 0x5A, 0x00 };
+	memcpy(out, magic, 6);
+	out[6] = 0;
+	out[7] = (uint8_t)check;
+	le32(out + 8, crc32_buf(out + 6, 2));
+	return 12;
+}
+
+uint64_t xzamd_frame_index_footer(uint8_t *out, uint64_t cap, int check,
+		const uint64_t *unpadded, const uint64_t *uncompressed, uint64_t nblocks)
+{
+	/* index_encoder.c:43-164, stream_flags_encoder.c:56-85 */
+	uint64_t need = 1 + vli_len(nblocks);
+	for (uint64_t i = 0; i < nblocks; ++i)
+		need += vli_len(unpadded[i]) + vli_len(uncompressed[i]);
+	const uint64_t padded = (need + 3) & ~3ull;
+	if (cap < padded + 4 + 12)
+		return 0;
+	uint64_t pos = 0;
+	out[pos++] = 0x00;
+	pos += vli_put(out + pos, nblocks);
+	for (uint64_t i = 0; i < nblocks; ++i) {
+		pos += vli_put(out + pos, unpadded[i]);
+		pos += vli_put(out + pos, uncompressed[i]);
+	}
+	while (pos < padded)
+		out[pos++] = 0;
+	le32(out + pos, crc32_buf(out, pos));
+	pos += 4;
+	uint8_t *f = out + pos;
+	le32(f + 4, (uint32_t)(pos / 4 - 1));
+	f[8] = 0;
+	f[9] = (uint8_t)check;
+	le32(f, crc32_buf(f + 4, 6));
+	f[10] = 0x59;
+	f[11] = 0x5A;
+	return pos + 12;
+}
+
+static uint8_t dict_size_byte(uint32_t d)
+{
+	/* lzma2_encoder.c:376-400 */
+	if (d < 4096) d = 4096;
+	--d;
+	d |= d >> 2; d |= d >> 3; d |= d >> 4; d |= d >> 8; d |= d >> 16;
+	if (d == 0xFFFFFFFFu)
+		return 40;
+	++d;
+	uint32_t top = 31;
+	while (!(d >> top)) --top;
+	return (uint8_t)(2 * top + ((d >> (top - 1)) & 1) - 24);
+}
+
+uint64_t xzamd_block_buffer_bound(uint64_t u)
+{
+	/* block_buffer_encoder.c:20-69 */
+	const uint64_t headers = (1 + 1 + 2 * 9 + 3 + 4 + 64 + 3) & ~3ull;
+	const uint64_t lz2 = u + ((u + 65535) / 65536) * 3 + 1;
+	return headers + ((lz2 + 3) & ~3ull);
+}
+
+static uint32_t block_header_size(uint64_t csize, uint64_t usize)
+{
+	/* block_header_encoder.c:17-70 for the chain {LZMA2} */
+	uint32_t s = 1 + 1 + 4 + vli_len(csize) + vli_len(usize) + 3;
+	return (s + 3) & ~3u;
+}
+
+static void block_header_put(uint8_t *out, uint32_t hs, uint64_t csize, uint64_t usize, uint8_t dict_byte)
+{
+	/* block_header_encoder.c:73-131 */
+	const uint32_t body = hs - 4;
+	memset(out, 0, body);
+	out[0] = (uint8_t)(body / 4);
+	out[1] = 0xC0;   /* both sizes present, one filter */
+	uint32_t p = 2;
+	p += vli_put(out + p, csize);
+	p += vli_put(out + p, usize);
+	out[p++] = 0x21;
+	out[p++] = 0x01;
+	out[p++] = dict_byte;
+	le32(out + body, crc32_buf(out, body));
+}
+
+uint64_t xzamd_stream_buffer_bound(uint64_t in_size, uint64_t block_size)
+{
+	if (block_size == 0)
+		return 0;
+	const uint64_t nb = (in_size + block_size - 1) / block_size;
+	uint64_t tot = 12 + 12;
+	tot += nb * xzamd_block_buffer_bound(block_size < in_size ? block_size : in_size);
+	tot += 1 + 9 + nb * 18 + 3 + 4;
+	return (tot + 15) & ~15ull;
+}
+
+/* ------------------------------------------------------------------ */
+/* presets                                                              */
+/* ------------------------------------------------------------------ */
+int xzamd_lzma_preset(xzamd_lzma_options *o, uint32_t preset)
+{
+	/* lzma/lzma_encoder_presets.c:17-63 */
+	const uint32_t level = preset & 0x1F;
+	const uint32_t flags = preset & ~0x1Fu;
+	if (level > 9 || (flags & ~XZAMD_PRESET_EXTREME))
+		return 1;
+	static const uint8_t dict_log2[10] = { 18, 20, 21, 22, 22, 23, 23, 24, 25, 26 };
+	memset(o, 0, sizeof(*o));
+	o->dict_size = 1u << dict_log2[level];
+	o->lc = 3; o->lp = 0; o->pb = 2;
+	if (level <= 3) {
+		static const uint8_t depths[4] = { 4, 8, 24, 48 };
+		o->mode = XZAMD_MODE_FAST;
+		o->mf = level == 0 ? XZAMD_MF_HC3 : XZAMD_MF_HC4;
+		o->nice_len = level <= 1 ? 128 : 273;
+		o->depth = depths[level];
+	} else {
+		o->mode = XZAMD_MODE_NORMAL;
+		o->mf = XZAMD_MF_BT4;
+		o->nice_len = level == 4 ? 16 : (level == 5 ? 32 : 64);
+		o->depth = 0;
+	}
+	if (flags & XZAMD_PRESET_EXTREME) {
+		o->mode = XZAMD_MODE_NORMAL;
+		o->mf = XZAMD_MF_BT4;
+		if (level == 3 || level == 5) { o->nice_len = 192; o->depth = 0; }
+		else { o->nice_len = 273; o->depth = 512; }
+	}
+	/* Device mapping.  Fast-mode HC3/HC4 chains run exactly as requested.
+	 * BT4/normal chains (presets 4-9, -e) have no parallel equivalent: the
+	 * device runs its hash-chain successor with the deepest chain one
+	 * wavefront evaluates in a single round and the lazy parser (DESIGN.md
+	 * "what differs from the reference"). */
+	if (o->mf == XZAMD_MF_HC3 || o->mf == XZAMD_MF_HC4) {
+		o->gpu_mf = o->mf;
+		o->gpu_nice_len = o->nice_len;
+		o->gpu_depth = o->depth;
+	} else {
+		o->gpu_mf = XZAMD_MF_HC4;
+		o->gpu_nice_len = 273;
+		o->gpu_depth = 56;
+	}
+	o->span_size = XZAMD_SPAN_DEFAULT;
+	return 0;
+}
+
+uint64_t xzamd_mt_block_size(const xzamd_lzma_options *o)
+{
+	const uint64_t b = (uint64_t)o->dict_size * 3;
+	return b > (1u << 20) ? b : (1u << 20);
+}
+
+/* ------------------------------------------------------------------ */
+/* context                                                              */
+/* ------------------------------------------------------------------ */
+typedef struct {
+	void *p;
+	uint64_t cap;
+} dbuf;
+
+struct xzamd_ctx {
+	int device;
+	void *own_stream;
+	uint64_t batch_bytes;
+	char err[256];
+	/* device buffers */
+	dbuf keys_a, keys_b, vals_a, vals_b, rank, sorted_pos, prev2, prev3, sort_tmp;
+	dbuf scratch, span_bytes, strip_crc, block_crc, segs, lits, trace;
+	/* pinned host buffers */
+	dbuf h_span_bytes, h_block_crc, h_segs, h_lits;
+	void *ev[10];
+	uint32_t trace_cap;
+	int trace_on;
+	xzamd_stats stats;
+};
+
+static int fail(xzamd_ctx *c, int code, const char *what, int hip_err)
+{
+	if (hip_err)
+		snprintf(c->err, sizeof(c->err), "%s: %s (%d)", what, xzk_error_string(hip_err), hip_err);
+	else
+		snprintf(c->err, sizeof(c->err), "%s", what);
+	return code;
+}
+
+static int dgrow(xzamd_ctx *c, dbuf *b, uint64_t bytes, int host)
+{
+	if (b->cap >= bytes)
+		return 0;
+	if (b->p) {
+		if (host) xzk_host_free(b->p); else xzk_free(b->p);
+		b->p = NULL;
+		b->cap = 0;
+	}
+	bytes = (bytes + 255) & ~255ull;
+	int e = host ? xzk_host_alloc(&b->p, bytes) : xzk_malloc(&b->p, bytes);
+	if (e)
+		return fail(c, XZAMD_MEM_ERROR, host ? "hipHostMalloc" : "hipMalloc", e);
+	b->cap = bytes;
+	return 0;
+}
+
+int xzamd_ctx_create(xzamd_ctx **out, int device)
+{
+	*out = NULL;
+	int ndev = 0;
+	if (xzk_device_count(&ndev) || ndev <= 0)
+		return XZAMD_DEVICE_ERROR;    /* no GPU: the product path never falls back to the CPU */
+	xzamd_ctx *c = (xzamd_ctx *)calloc(1, sizeof(*c));
+	if (!c)
+		return XZAMD_MEM_ERROR;
+	if (device < 0) {
+		if (xzk_get_device(&device)) { free(c); return XZAMD_DEVICE_ERROR; }
+	}
+	if (device >= ndev || xzk_set_device(device)) { free(c); return XZAMD_DEVICE_ERROR; }
+	c->device = device;
+	if (xzk_stream_create(&c->own_stream)) { free(c); return XZAMD_DEVICE_ERROR; }
+	for (int i = 0; i < 10; ++i)
+		if (xzk_event_create(&c->ev[i])) { free(c); return XZAMD_DEVICE_ERROR; }
+	c->batch_bytes = DEFAULT_BATCH;
+	const char *env = getenv("XZAMD_BATCH_MIB");
+	if (env && atoll(env) > 0)
+		xzamd_ctx_set_batch_bytes(c, (uint64_t)atoll(env) << 20);
+	*out = c;
+	return XZAMD_OK;
+}
+
+void xzamd_ctx_destroy(xzamd_ctx *c)
+{
+	if (!c)
+		return;
+	xzk_set_device(c->device);
+	dbuf *d[] = { &c->keys_a, &c->keys_b, &c->vals_a, &c->vals_b, &c->rank, &c->sorted_pos,
+		&c->prev2, &c->prev3, &c->sort_tmp, &c->scratch, &c->span_bytes, &c->strip_crc,
+		&c->block_crc, &c->segs, &c->lits, &c->trace };
+	for (size_t i = 0; i < sizeof(d) / sizeof(d[0]); ++i)
+		if (d[i]->p) xzk_free(d[i]->p);
+	dbuf *h[] = { &c->h_span_bytes, &c->h_block_crc, &c->h_segs, &c->h_lits };
+	for (size_t i = 0; i < sizeof(h) / sizeof(h[0]); ++i)
+		if (h[i]->p) xzk_host_free(h[i]->p);
+	for (int i = 0; i < 10; ++i)
+		if (c->ev[i]) xzk_event_destroy(c->ev[i]);
+	if (c->own_stream) xzk_stream_destroy(c->own_stream);
+	free(c);
+}
+
+int xzamd_ctx_set_batch_bytes(xzamd_ctx *c, uint64_t bytes)
+{
+	if (bytes < (1u << 16) || bytes >= (1ull << 31))
+		return XZAMD_OPTIONS_ERROR;
+	c->batch_bytes = bytes;
+	return XZAMD_OK;
+}
+
+const char *xzamd_last_error(const xzamd_ctx *c) { return c ? c->err : "no context"; }
+void xzamd_get_stats(const xzamd_ctx *c, xzamd_stats *out) { *out = c->stats; }
+const char *xzamd_version(void) { return "xz_amd 0.1 (gfx950)"; }
+
+int xzamd_trace_enable(xzamd_ctx *c, uint32_t cap)
+{
+	xzk_set_device(c->device);
+	int r = dgrow(c, &c->trace, 16ull * cap + 16, 0);
+	if (r) return r;
+	c->trace_cap = cap;
+	c->trace_on = 1;
+	if (xzk_memset(c->trace.p, 0, 16, c->own_stream) || xzk_sync(c->own_stream))
+		return XZAMD_DEVICE_ERROR;
+	return XZAMD_OK;
+}
+
+int xzamd_trace_read(xzamd_ctx *c, uint32_t *out, uint32_t cap, uint32_t *count)
+{
+	if (!c->trace.p)
+		return XZAMD_PROG_ERROR;
+	xzk_set_device(c->device);
+	uint32_t cnt = 0;
+	if (xzk_d2h(&cnt, c->trace.p, 4, c->own_stream) || xzk_sync(c->own_stream))
+		return XZAMD_DEVICE_ERROR;
+	*count = cnt;
+	uint32_t n = cnt < cap ? cnt : cap;
+	if (n > c->trace_cap) n = c->trace_cap;
+	if (n && (xzk_d2h(out, (uint8_t *)c->trace.p + 16, 16ull * n, c->own_stream) || xzk_sync(c->own_stream)))
+		return XZAMD_DEVICE_ERROR;
+	c->trace_on = 0;
+	return XZAMD_OK;
+}
+
+/* ------------------------------------------------------------------ */
+/* batch encode                                                         */
+/* ------------------------------------------------------------------ */
+static uint32_t hash_mask_for(uint32_t dict_size, uint32_t hash_bytes)
+{
+	/* lz/lz_encoder.c:306-327 */
+	uint32_t hs = dict_size - 1;
+	hs |= hs >> 1; hs |= hs >> 2; hs |= hs >> 4; hs |= hs >> 8;
+	hs >>= 1;
+	hs |= 0xFFFF;
+	if (hs > (1u << 24)) {
+		if (hash_bytes == 3) hs = (1u << 24) - 1;
+		else hs >>= 1;
+	}
+	return hs;
+}
+
+typedef struct {
+	uint8_t *lits; uint64_t lits_len, lits_cap;
+	xzamd_copy_seg *segs; uint64_t nsegs, segs_cap;
+} plan;
+
+static uint64_t plan_lit(plan *p, const uint8_t *bytes, uint64_t n, uint64_t dst)
+{
+	/* literal pieces are packed back to back; one segment each */
+	memcpy(p->lits + p->lits_len, bytes, n);
+	xzamd_copy_seg *s = &p->segs[p->nsegs++];
+	s->src = p->lits_len; s->dst = dst; s->len = n; s->kind = 1; s->pad_ = 0;
+	p->lits_len += n;
+	return dst + n;
+}
+
+static uint64_t plan_seg(plan *p, uint32_t kind, uint64_t src, uint64_t n, uint64_t dst)
+{
+	if (n == 0)
+		return dst;
+	xzamd_copy_seg *s = &p->segs[p->nsegs++];
+	s->src = src; s->dst = dst; s->len = n; s->kind = kind; s->pad_ = 0;
+	return dst + n;
+}
+
+#define HIPCHK(call, what) do { int e_ = (call); if (e_) return fail(c, XZAMD_DEVICE_ERROR, what, e_); } while (0)
+
+int xzamd_stream_encode_device(xzamd_ctx *c,
+		const void *d_in_, uint64_t in_size, uint64_t block_size,
+		const xzamd_lzma_options *opt, int check, uint32_t flags,
+		void *d_out_, uint64_t out_cap, uint64_t *out_size,
+		xzamd_block_info *binfo, uint64_t binfo_cap, uint64_t *nblocks_out,
+		void *stream)
+{
+	if (!c || !opt || !out_size || (!d_in_ && in_size) || !d_out_)
+		return XZAMD_PROG_ERROR;
+	c->err[0] = 0;
+	const uint32_t cbytes = check_bytes(check);
+	if ((unsigned)check > 15)
+		return fail(c, XZAMD_PROG_ERROR, "check id out of range", 0);
+	if (cbytes == 0xFFFFFFFFu)
+		return fail(c, XZAMD_UNSUPPORTED_CHECK, "only CRC32/CRC64/none are supported", 0);
+	if (check == XZAMD_CHECK_CRC32)
+		return fail(c, XZAMD_UNSUPPORTED_CHECK, "CRC32 Block check not implemented on the device path", 0);
+	if (opt->lc + opt->lp > 3 || opt->pb > 4)
+		return fail(c, XZAMD_OPTIONS_ERROR, "lc+lp <= 3 and pb <= 4 required (LDS model size)", 0);
+	if ((opt->gpu_mf != XZAMD_MF_HC3 && opt->gpu_mf != XZAMD_MF_HC4)
+			|| opt->gpu_depth < 1 || opt->gpu_depth > 56
+			|| opt->gpu_nice_len < opt->gpu_mf || opt->gpu_nice_len > 273
+			|| opt->dict_size < 4096 || opt->dict_size > (1u << 30))
+		return fail(c, XZAMD_OPTIONS_ERROR, "unsupported match finder options for the device path", 0);
+	if (block_size == 0)
+		block_size = xzamd_mt_block_size(opt);
+	if (block_size >= (1ull << 31))
+		return fail(c, XZAMD_OPTIONS_ERROR, "block_size must be < 2 GiB", 0);
+	void *st = stream ? stream : c->own_stream;
+	const uint8_t *d_in = (const uint8_t *)d_in_;
+	uint8_t *d_out = (uint8_t *)d_out_;
+	HIPCHK(xzk_set_device(c->device), "hipSetDevice");
+
+	const uint32_t hb = opt->gpu_mf & 0x0F;
+	const uint32_t hmask = hash_mask_for(opt->dict_size, hb);
+	uint32_t hbits = 0;
+	while ((1ull << hbits) <= hmask) ++hbits;
+	uint32_t span = opt->span_size == XZAMD_SPAN_DEFAULT ? DEFAULT_SPAN : opt->span_size;
+	if (span > block_size) span = (uint32_t)block_size;
+	if (span < 4096)
+		return fail(c, XZAMD_OPTIONS_ERROR, "span_size must be >= 4096", 0);
+	const uint32_t spb = (uint32_t)((block_size + span - 1) / span);
+	const uint64_t span_cap = ((uint64_t)span + (span >> 3) + 4096 + 15) & ~15ull;
+
+	/* batch = whole Blocks, n < 2^31, (nblocks+1) << hbits < 2^32 */
+	uint64_t max_blocks = c->batch_bytes / block_size;
+	if (max_blocks == 0) max_blocks = 1;
+	const uint64_t key_blocks = (1ull << (32 - hbits)) - 2;
+	if (max_blocks > key_blocks) max_blocks = key_blocks;
+	if (max_blocks * block_size >= (1ull << 31))
+		max_blocks = ((1ull << 31) - 1) / block_size;
+	if (max_blocks == 0)
+		return fail(c, XZAMD_OPTIONS_ERROR, "block_size too large for one device batch", 0);
+
+	const uint64_t total_blocks = (in_size + block_size - 1) / block_size;
+	if (nblocks_out) *nblocks_out = total_blocks;
+	const uint64_t bound = xzamd_block_buffer_bound(block_size);
+	const uint32_t hs_fixed = block_header_size(bound, block_size);
+	const uint8_t dbyte = dict_size_byte(opt->dict_size);
+
+	memset(&c->stats, 0, sizeof(c->stats));
+	uint64_t opos = 0;
+	uint8_t small[64];
+	uint64_t *rec_unp = NULL, *rec_unc = NULL;
+	const int whole = !(flags & XZAMD_F_BLOCKS_ONLY);
+	if (whole) {
+		rec_unp = (uint64_t *)malloc(sizeof(uint64_t) * (total_blocks + 1) * 2);
+		if (!rec_unp)
+			return fail(c, XZAMD_MEM_ERROR, "malloc", 0);
+		rec_unc = rec_unp + total_blocks + 1;
+		if (out_cap < 12) { free(rec_unp); return fail(c, XZAMD_BUF_ERROR, "output buffer too small", 0); }
+		xzamd_frame_header(small, check);
+		int e = xzk_h2d(d_out, small, 12, st);
+		if (!e) e = xzk_sync(st);
+		if (e) { free(rec_unp); return fail(c, XZAMD_DEVICE_ERROR, "h2d header", e); }
+		opos = 12;
+	}
+
+	int rc = XZAMD_OK;
+	xzk_event_record(c->ev[8], st);
+	for (uint64_t b0 = 0; b0 < total_blocks && rc == XZAMD_OK; b0 += max_blocks) {
+		const uint64_t nb = total_blocks - b0 < max_blocks ? total_blocks - b0 : max_blocks;
+		const uint64_t in_off = b0 * block_size;
+		const uint64_t n64 = in_size - in_off < nb * block_size ? in_size - in_off : nb * block_size;
+		const uint32_t n = (uint32_t)n64;
+		const uint32_t nspans = (uint32_t)(nb * spb);
+		const uint32_t spb_crc = (uint32_t)((block_size + CRC_STRIP - 1) / CRC_STRIP);
+
+#define GROW(buf, bytes, host) do { int r_ = dgrow(c, &c->buf, (bytes), host); if (r_) { rc = r_; goto done; } } while (0)
+		uint64_t sort_bytes = 0;
+		{
+			uint32_t bb = 0;
+			while ((1u << bb) < nb + 1) ++bb;
+			const uint32_t bits[3] = { 10 + bb, 16 + bb, hbits + bb };
+			for (int i = 0; i < 3; ++i) {
+				uint64_t sbytes = 0;
+				int e = xzk_sort_temp_bytes(n, bits[i], &sbytes);
+				if (e) { rc = fail(c, XZAMD_DEVICE_ERROR, "rocprim temp size", e); goto done; }
+				if (sbytes > sort_bytes) sort_bytes = sbytes;
+			}
+		}
+		GROW(keys_a, 4ull * n, 0); GROW(keys_b, 4ull * n, 0);
+		GROW(vals_a, 4ull * n, 0); GROW(vals_b, 4ull * n, 0);
+		GROW(rank, 4ull * n, 0); GROW(sorted_pos, 4ull * n, 0);
+		GROW(prev2, 4ull * n, 0); GROW(prev3, 4ull * n, 0);
+		GROW(sort_tmp, sort_bytes + 256, 0);
+		GROW(scratch, span_cap * nspans, 0);
+		GROW(span_bytes, 4ull * nspans, 0);
+		GROW(strip_crc, 8ull * spb_crc * nb, 0);
+		GROW(block_crc, 8ull * nb, 0);
+		GROW(h_span_bytes, 4ull * nspans, 1);
+		GROW(h_block_crc, 8ull * nb, 1);
+		/* plan capacity: per Block header + spans + trailer, or the stored form */
+		const uint64_t segs_per_block = spb + 2 + 2 * ((block_size + 65535) / 65536) + 2;
+		const uint64_t max_segs = nb * segs_per_block + 4;
+		const uint64_t max_lits = nb * (64 + 3 * ((block_size + 65535) / 65536) + 32) + 64;
+		GROW(segs, max_segs * sizeof(xzamd_copy_seg), 0);
+		GROW(lits, max_lits, 0);
+		GROW(h_segs, max_segs * sizeof(xzamd_copy_seg), 1);
+		GROW(h_lits, max_lits, 1);
+
+		/* 1. match-finder structure */
+		xzk_event_record(c->ev[0], st);
+		{
+			int e = xzk_build_chains(d_in + in_off, n, (uint32_t)block_size, (uint32_t)nb, hb, hmask, hbits,
+					(uint32_t *)c->keys_a.p, (uint32_t *)c->keys_b.p, (uint32_t *)c->vals_a.p,
+					(uint32_t *)c->vals_b.p, c->sort_tmp.p, sort_bytes,
+					(uint32_t *)c->rank.p, (uint32_t *)c->sorted_pos.p, (uint32_t *)c->prev2.p,
+					(uint32_t *)c->prev3.p, st);
+			if (e) { rc = fail(c, XZAMD_DEVICE_ERROR, "build_chains", e); goto done; }
+		}
+		xzk_event_record(c->ev[1], st);
+		/* 2. span encode */
+		{
+			xzamd_span_args a;
+			memset(&a, 0, sizeof(a));
+			a.in = d_in + in_off;
+			a.rank = (const uint32_t *)c->rank.p;
+			a.sorted_pos = (const uint32_t *)c->sorted_pos.p;
+			a.prev2 = (const uint32_t *)c->prev2.p;
+			a.prev3 = (const uint32_t *)c->prev3.p;
+			a.scratch = (uint8_t *)c->scratch.p;
+			a.span_cap = span_cap;
+			a.span_bytes = (uint32_t *)c->span_bytes.p;
+			if (c->trace_on) {
+				a.trace_count = (uint32_t *)c->trace.p;
+				a.trace = (uint32_t *)((uint8_t *)c->trace.p + 16);
+				a.trace_cap = c->trace_cap;
+			}
+			a.n = n;
+			a.block_size = (uint32_t)block_size;
+			a.span_size = span;
+			a.spans_per_block = spb;
+			a.dict_size = opt->dict_size;
+			a.nice_len = opt->gpu_nice_len;
+			a.depth = opt->gpu_depth;
+			a.hash_bytes = hb;
+			a.lc = opt->lc; a.lp = opt->lp; a.pb = opt->pb;
+			int e = xzk_span_encode(&a, nspans, st);
+			if (e) { rc = fail(c, XZAMD_DEVICE_ERROR, "span_encode launch", e); goto done; }
+		}
+		xzk_event_record(c->ev[2], st);
+		/* 3. Block checks */
+		if (check == XZAMD_CHECK_CRC64) {
+			int e = xzk_crc64_blocks(d_in + in_off, n, (uint32_t)block_size, (uint32_t)nb, CRC_STRIP,
+					(uint64_t *)c->strip_crc.p, (uint64_t *)c->block_crc.p, st);
+			if (e) { rc = fail(c, XZAMD_DEVICE_ERROR, "crc64 launch", e); goto done; }
+			e = xzk_d2h(c->h_block_crc.p, c->block_crc.p, 8ull * nb, st);
+			if (e) { rc = fail(c, XZAMD_DEVICE_ERROR, "d2h crc", e); goto done; }
+		}
+		xzk_event_record(c->ev[3], st);
+		{
+			int e = xzk_d2h(c->h_span_bytes.p, c->span_bytes.p, 4ull * nspans, st);
+			if (!e) e = xzk_sync(st);
+			if (e) { rc = fail(c, XZAMD_DEVICE_ERROR, "span encode / d2h sizes", e); goto done; }
+		}
+
+		/* 4. layout (the ordered output queue of the reference, outqueue.c) */
+		plan pl;
+		pl.lits = (uint8_t *)c->h_lits.p; pl.lits_len = 0; pl.lits_cap = max_lits;
+		pl.segs = (xzamd_copy_seg *)c->h_segs.p; pl.nsegs = 0; pl.segs_cap = max_segs;
+		const uint32_t *sb = (const uint32_t *)c->h_span_bytes.p;
+		const uint64_t *bcrc = (const uint64_t *)c->h_block_crc.p;
+		for (uint64_t b = 0; b < nb; ++b) {
+			const uint64_t boff = b * block_size;                 /* in batch */
+			const uint64_t usize = n64 - boff < block_size ? n64 - boff : block_size;
+			uint64_t payload = 1;                                 /* end marker */
+			for (uint32_t s = 0; s < spb; ++s)
+				payload += sb[b * spb + s];
+			const uint64_t pad = (4 - (payload & 3)) & 3;
+			const uint64_t bstart = opos;
+			uint64_t unp;
+			uint8_t tail[16];
+			uint32_t tl = 0;
+			if (hs_fixed + payload + pad + cbytes > bound) {
+				/* stream_encoder_mt.c:298,316-344 -> block_buffer_encoder.c:88-162 */
+				const uint64_t csz = usize + ((usize + 65535) / 65536) * 3 + 1;
+				const uint32_t hs = block_header_size(csz, usize);
+				if (opos + hs + csz + 3 + cbytes > out_cap) { rc = fail(c, XZAMD_BUF_ERROR, "output buffer too small", 0); goto done; }
+				block_header_put(small, hs, csz, usize, 0x00);
+				opos = plan_lit(&pl, small, hs, opos);
+				uint8_t ctl = 0x01;
+				for (uint64_t ip = 0; ip < usize; ip += 65536) {
+					const uint64_t cs = usize - ip < 65536 ? usize - ip : 65536;
+					uint8_t ch[3] = { ctl, (uint8_t)((cs - 1) >> 8), (uint8_t)(cs - 1) };
+					ctl = 0x02;
+					opos = plan_lit(&pl, ch, 3, opos);
+					opos = plan_seg(&pl, 2, boff + ip, cs, opos);
+				}
+				tail[tl++] = 0x00;
+				while ((csz + (tl - 1)) & 3) tail[tl++] = 0;
+				unp = hs + csz + cbytes;
+				++c->stats.blocks_stored;
+			} else {
+				if (opos + hs_fixed + payload + pad + cbytes > out_cap) { rc = fail(c, XZAMD_BUF_ERROR, "output buffer too small", 0); goto done; }
+				block_header_put(small, hs_fixed, payload, usize, dbyte);
+				opos = plan_lit(&pl, small, hs_fixed, opos);
+				for (uint32_t s = 0; s < spb; ++s)
+					opos = plan_seg(&pl, 0, (uint64_t)(b * spb + s) * span_cap, sb[b * spb + s], opos);
+				tail[tl++] = 0x00;
+				for (uint64_t i = 0; i < pad; ++i) tail[tl++] = 0;
+				unp = hs_fixed + payload + cbytes;
+			}
+			if (check == XZAMD_CHECK_CRC64) {
+				const uint64_t v = bcrc[b];
+				le32(tail + tl, (uint32_t)v);
+				le32(tail + tl + 4, (uint32_t)(v >> 32));
+				tl += 8;
+			}
+			opos = plan_lit(&pl, tail, tl, opos);
+			const uint64_t gi = b0 + b;
+			if (whole) { rec_unp[gi] = unp; rec_unc[gi] = usize; }
+			if (binfo && gi < binfo_cap) {
+				binfo[gi].unpadded_size = unp;
+				binfo[gi].uncompressed_size = usize;
+				binfo[gi].out_offset = bstart;
+				binfo[gi].total_size = opos - bstart;
+			}
+		}
+		if (pl.nsegs > pl.segs_cap || pl.lits_len > pl.lits_cap) { rc = fail(c, XZAMD_PROG_ERROR, "plan overflow", 0); goto done; }
+
+		/* 5. gather */
+		{
+			int e = xzk_h2d(c->segs.p, pl.segs, pl.nsegs * sizeof(xzamd_copy_seg), st);
+			if (!e) e = xzk_h2d(c->lits.p, pl.lits, pl.lits_len ? pl.lits_len : 1, st);
+			if (!e) e = xzk_assemble((const xzamd_copy_seg *)c->segs.p, (uint32_t)pl.nsegs,
+					(const uint8_t *)c->scratch.p, (const uint8_t *)c->lits.p, d_in + in_off, d_out, st);
+			xzk_event_record(c->ev[4], st);
+			if (!e) e = xzk_sync(st);
+			if (e) { rc = fail(c, XZAMD_DEVICE_ERROR, "assemble", e); goto done; }
+		}
+		float ms;
+		if (!xzk_event_elapsed_ms(c->ev[0], c->ev[1], &ms)) c->stats.ms_chains += ms;
+		if (!xzk_event_elapsed_ms(c->ev[1], c->ev[2], &ms)) c->stats.ms_encode += ms;
+		if (!xzk_event_elapsed_ms(c->ev[2], c->ev[3], &ms)) c->stats.ms_crc += ms;
+		if (!xzk_event_elapsed_ms(c->ev[3], c->ev[4], &ms)) c->stats.ms_assemble += ms;
+		c->stats.blocks += nb;
+		c->stats.spans += nspans;
+		c->stats.batches += 1;
+		c->stats.encode_launches += 1;
+	}
+done:
+	if (rc == XZAMD_OK && whole) {
+		const uint64_t isz_cap = 32 + total_blocks * 18 + 16;
+		uint8_t *ib = (uint8_t *)malloc(isz_cap);
+		if (!ib) rc = fail(c, XZAMD_MEM_ERROR, "malloc", 0);
+		else {
+			const uint64_t w = xzamd_frame_index_footer(ib, isz_cap, check, rec_unp, rec_unc, total_blocks);
+			if (w == 0 || opos + w > out_cap) rc = fail(c, XZAMD_BUF_ERROR, "output buffer too small", 0);
+			else {
+				int e = xzk_h2d(d_out + opos, ib, w, st);
+				if (!e) e = xzk_sync(st);
+				if (e) rc = fail(c, XZAMD_DEVICE_ERROR, "h2d index", e);
+				opos += w;
+			}
+			free(ib);
+		}
+	}
+	xzk_event_record(c->ev[9], st);
+	xzk_sync(st);
+	{
+		float ms;
+		if (!xzk_event_elapsed_ms(c->ev[8], c->ev[9], &ms)) c->stats.ms_total = ms;
+	}
+	free(rec_unp);
+	c->stats.in_bytes = in_size;
+	c->stats.out_bytes = opos;
+	*out_size = opos;
+	return rc;
+}
