@@ -280,28 +280,28 @@ static int lzma_chunk(lzma_dec *d, uint8_t *out, uint64_t dict_start, uint64_t *
 	return 0;
 }
 
-int orc_lzma2_decode(const uint8_t *in, uint64_t in_size, uint32_t dict_size,
-		uint8_t *out, uint64_t out_cap, uint64_t *out_size, orc_trace *tr)
+static int lzma2_decode_ex(const uint8_t *in, uint64_t in_size, uint32_t dict_size,
+		uint8_t *out, uint64_t out_cap, uint64_t *out_size, orc_trace *tr,
+		uint64_t *in_used)
 {
 	lzma_dec *d = (lzma_dec *)calloc(1, sizeof(*d));
 	if (!d) return -1;
 	int need_dict_reset = 1, need_props = 1;
-	uint64_t ip = 0, op = 0;
+	uint64_t ip = 0, op = 0, dict_start = 0;
 	int ret = -2;
 	d->in = in;
 	for (;;) {
 		if (ip >= in_size) { ret = -3; break; }
 		uint8_t control = in[ip++];
-		if (control == 0x00) { ret = (ip == in_size) ? 0 : -4; break; }
+		if (control == 0x00) { ret = (in_used || ip == in_size) ? 0 : -4; break; }
 		/* lzma2_decoder.c:67-127 */
 		if (control >= 0xE0 || control == 0x01) {
 			need_props = 1;
 			need_dict_reset = 0;
 			if (tr) ++tr->dict_resets;
-			/* a dictionary reset in the middle of a Block is legal but the
-			 * MT encoder never emits one; this whole-buffer decoder only
-			 * supports it at offset 0. */
-			if (op != 0) { ret = -5; break; }
+			/* lzma2_decoder.c:121-127 -> lz_decoder dict_reset: history is
+			 * dropped and the position counter restarts */
+			dict_start = op;
 		} else if (need_dict_reset) { ret = -6; break; }
 		if (control >= 0x80) {
 			if (in_size - ip < 4) { ret = -3; break; }
@@ -329,7 +329,7 @@ int orc_lzma2_decode(const uint8_t *in, uint64_t in_size, uint32_t dict_size,
 			d->in_pos = ip;
 			d->in_end = ip + csize;
 			d->error = 0;
-			int r = lzma_chunk(d, out, 0, &op, out_cap, usize, dict_size, tr);
+			int r = lzma_chunk(d, out, dict_start, &op, out_cap, usize, dict_size, tr);
 			if (r) { ret = r; break; }
 			if (d->in_pos != d->in_end) { ret = -21; break; }
 			ip += csize;
@@ -347,8 +347,15 @@ int orc_lzma2_decode(const uint8_t *in, uint64_t in_size, uint32_t dict_size,
 		}
 	}
 	*out_size = op;
+	if (in_used) *in_used = ip;
 	free(d);
 	return ret;
+}
+
+int orc_lzma2_decode(const uint8_t *in, uint64_t in_size, uint32_t dict_size,
+		uint8_t *out, uint64_t out_cap, uint64_t *out_size, orc_trace *tr)
+{
+	return lzma2_decode_ex(in, in_size, dict_size, out, out_cap, out_size, tr, NULL);
 }
 
 /* ---- .xz Stream decode with every integrity check ------------------------ */
@@ -412,12 +419,19 @@ int orc_xz_decode(const uint8_t *in, uint64_t n, uint8_t *out, uint64_t out_cap,
 		while (p < pos + hs - 4) if (in[p++] != 0) { ok = 0; break; }
 		if (!ok) { ret = -108; break; }
 		pos += hs;
-		/* find payload extent: need csize; the MT encoder always stores it */
-		if (csize == UINT64_MAX) { ret = -109; break; }
-		if (pos + csize > n) { ret = -110; break; }
 		uint64_t produced = 0;
-		int r = orc_lzma2_decode(in + pos, csize, dict_size, out + op, out_cap - op, &produced, NULL);
-		if (r) { ret = r; break; }
+		if (csize == UINT64_MAX) {
+			/* single-threaded encoder output (stream_encoder.c:68-69): sizes
+			 * absent, the payload ends at its end marker */
+			uint64_t used = 0;
+			int r = lzma2_decode_ex(in + pos, n - pos, dict_size, out + op, out_cap - op, &produced, NULL, &used);
+			if (r) { ret = r; break; }
+			csize = used;
+		} else {
+			if (pos + csize > n) { ret = -110; break; }
+			int r = orc_lzma2_decode(in + pos, csize, dict_size, out + op, out_cap - op, &produced, NULL);
+			if (r) { ret = r; break; }
+		}
 		if (usize != UINT64_MAX && usize != produced) { ret = -111; break; }
 		pos += csize;
 		while (pos & 3) { if (pos >= n || in[pos] != 0) { ok = 0; break; } ++pos; }

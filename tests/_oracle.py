@@ -310,3 +310,48 @@ def corpus_mixed(n, seed=1):
         parts.append(seg)
         total += len(seg)
     return b"".join(parts)[:n]
+
+
+# ---------------------------------------------------------------- stream-level helpers
+def orc_xz_stream(data, prm, block_size, check=4):
+    """Whole .xz Stream in the reference MT layout from the oracle's per-Block payloads."""
+    data = bytes(data)
+    blocks = [data[i:i + block_size] for i in range(0, len(data), block_size)]
+    payloads = [orc_encode_block(b, prm) for b in blocks]
+    nb = len(blocks)
+    pay = [as_u8(p) for p in payloads]
+    inp = [as_u8(b) for b in blocks]
+    PP = (u8p * max(nb, 1))(*[_ptr(a) for a in pay])
+    IP = (u8p * max(nb, 1))(*[_ptr(a) for a in inp])
+    ps = (C.c_uint64 * max(nb, 1))(*[len(p) for p in payloads])
+    isz = (C.c_uint64 * max(nb, 1))(*[len(b) for b in blocks])
+    cap = len(data) + len(data) // 4 + 65536 + nb * 128
+    out = np.empty(cap, dtype=np.uint8)
+    n = orc().orc_xz_frame(PP, ps, IP, isz, C.c_uint64(nb), C.c_uint64(block_size),
+                           C.c_uint32(prm.dict_size), C.c_int(check), _ptr(out), C.c_uint64(cap))
+    return out[:n].tobytes()
+
+
+def params_for_gpu_options(opts, span_size=None):
+    """Oracle parameters equal to what the device path runs for an xz_amd.LzmaOptions."""
+    p = OrcParams()
+    p.dict_size = opts.dict_size
+    p.lc, p.lp, p.pb = opts.lc, opts.lp, opts.pb
+    p.nice_len = opts.gpu_nice_len
+    p.mf = opts.gpu_mf & 0x0F
+    p.depth = opts.gpu_depth
+    sp = opts.span_size if span_size is None else span_size
+    if sp == 0:
+        sp = 65536           # XZAMD DEFAULT_SPAN
+    p.span_size = 0 if sp == 0xFFFFFFFF else sp
+    return p
+
+
+def first_diff(a, b):
+    n = min(len(a), len(b))
+    aa = np.frombuffer(a, dtype=np.uint8, count=n)
+    bb = np.frombuffer(b, dtype=np.uint8, count=n)
+    d = np.nonzero(aa != bb)[0]
+    if len(d):
+        return int(d[0])
+    return -1 if len(a) == len(b) else n

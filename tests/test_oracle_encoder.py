@@ -1,0 +1,95 @@
+"""Oracle fast-mode encoder: byte-identical to the real reference raw LZMA2 encoder (presets 0-3),
+pinned additionally by recorded hashes; span mode decodes with both decoders."""
+import ctypes as C
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+import _oracle as o
+
+MAN = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "manifest.json")))
+needs_ref = pytest.mark.skipif(not o.have_ref(), reason="needs oracle/_ref")
+
+CORPORA = {
+    "text": lambda: o.corpus_lorem(229001),       # tests/create_compress_files.c:110-152
+    "abc": lambda: o.corpus_abc(),                # :82-88
+    "random": lambda: o.corpus_random(),          # :93-105
+}
+
+
+@pytest.mark.parametrize("cname", sorted(CORPORA))
+@pytest.mark.parametrize("preset", [0, 1, 2, 3])
+def test_golden_hash(cname, preset):
+    data = CORPORA[cname]()
+    prm, _ = o.params_for_preset(preset)
+    enc = o.orc_encode_block(data, prm)
+    exp = MAN["encode"][cname]["raw_lzma2"][str(preset)]
+    assert len(enc) == exp["size"] and hashlib.sha256(enc).hexdigest() == exp["sha256"]
+
+
+def _edge_inputs():
+    rng = np.random.default_rng(21)
+    lorem = o.corpus_lorem(1 << 20)
+    rnd = bytes(rng.integers(0, 256, size=300000, dtype=np.uint8))
+    return {
+        "empty": b"", "one": b"x", "two": b"xy", "three": b"aaa", "four": b"abcd", "run": b"\0" * 100000,
+        "period3": b"abc" * 30000, "lorem1M": lorem, "mixed": o.corpus_mixed(700000, 5),
+        "rnd": rnd, "sandwich": lorem[:150000] + rnd[:200000] + lorem[:100000],
+        "long_match": lorem[:5000] * 40, "binaryish": bytes(rng.integers(0, 4, size=200000, dtype=np.uint8)),
+    }
+
+
+@needs_ref
+@pytest.mark.parametrize("preset", [0, 1, 2, 3])
+def test_identical_to_reference_raw_encoder(preset):
+    prm, _ = o.params_for_preset(preset)
+    for name, data in _edge_inputs().items():
+        mine = o.orc_encode_block(data, prm)
+        theirs = o.ref_raw_encode(data, prm, mode=1)
+        assert o.first_diff(mine, theirs) == -1, (name, preset)
+
+
+@needs_ref
+def test_identical_with_custom_options():
+    """Non-preset corners: tiny dictionary (chain cut by cyclic_size), lc/lp/pb variants, depth 1."""
+    data = o.corpus_mixed(500000, 8)
+    for dict_size, lc, lp, pb, nice, mf, depth in [
+            (4096, 3, 0, 2, 32, 4, 0), (65536, 0, 2, 0, 273, 4, 1), (1 << 20, 4, 0, 4, 8, 3, 0),
+            (12345, 2, 2, 1, 64, 4, 100), (1 << 16, 3, 0, 2, 32, 3, 0)]:
+        p = o.OrcParams(dict_size, lc, lp, pb, nice, mf, depth, 0)
+        assert o.orc_encode_block(data, p) == o.ref_raw_encode(data, p, mode=1), (dict_size, lc, lp, pb, nice, mf, depth)
+
+
+@pytest.mark.parametrize("span", [4096, 65536, 100000])
+def test_span_mode_roundtrip(span):
+    for name, data in _edge_inputs().items():
+        prm, _ = o.params_for_preset(1, span_size=span)
+        enc = o.orc_encode_block(data, prm)
+        r, dec, syms, tr = o.orc_decode_raw(enc, prm.dict_size, len(data) + 16, want_trace=True)
+        assert r == 0 and dec == bytes(data), (name, span)
+        if o.have_ref():
+            out = np.empty(len(data) + 16, dtype=np.uint8); n = C.c_size_t(0)
+            pl = o.as_u8(enc)
+            rr = o.ref().ref_raw_lzma2_decode(o._ptr(pl), len(pl), prm.dict_size, o._ptr(out), len(out), C.byref(n))
+            assert rr == 1 and out[:n.value].tobytes() == bytes(data), (name, span)
+
+
+def test_span_cost_is_small():
+    data = o.corpus_lorem(4 << 20)
+    prm0, _ = o.params_for_preset(1)
+    base = len(o.orc_encode_block(data, prm0))
+    prm, _ = o.params_for_preset(1, span_size=65536)
+    assert len(o.orc_encode_block(data, prm)) <= base * 1.03
+
+
+def test_parse_trace_consistency():
+    """Decoder-extracted parse == encoder-emitted parse (ties the two restatements together)."""
+    data = o.corpus_mixed(300000, 4)
+    prm, _ = o.params_for_preset(2)
+    enc, esym, _ = o.orc_encode_block(data, prm, want_trace=True)
+    r, dec, dsym, _ = o.orc_decode_raw(enc, prm.dict_size, len(data) + 16, want_trace=True)
+    assert r == 0 and dec == data
+    assert esym.shape == dsym.shape and (esym == dsym).all()

@@ -21,33 +21,6 @@ import xz_amd  # noqa: E402
 import _oracle as o  # noqa: E402
 
 
-def oracle_stream(data, prm, block_size, check=4):
-    """Reference-layout .xz stream from the oracle's per-Block payloads."""
-    data = bytes(data)
-    blocks = [data[i:i + block_size] for i in range(0, len(data), block_size)]
-    payloads = [o.orc_encode_block(b, prm) for b in blocks]
-    nb = len(blocks)
-    pay_arrs = [o.as_u8(p) for p in payloads]
-    in_arrs = [o.as_u8(b) for b in blocks]
-    PP = (C.POINTER(C.c_uint8) * max(nb, 1))(*[o._ptr(a) for a in pay_arrs])
-    IP = (C.POINTER(C.c_uint8) * max(nb, 1))(*[o._ptr(a) for a in in_arrs])
-    ps = (C.c_uint64 * max(nb, 1))(*[len(p) for p in payloads])
-    isz = (C.c_uint64 * max(nb, 1))(*[len(b) for b in blocks])
-    cap = len(data) + len(data) // 4 + 65536 + nb * 128
-    out = np.empty(cap, dtype=np.uint8)
-    n = o.orc().orc_xz_frame(PP, ps, IP, isz, C.c_uint64(nb), C.c_uint64(block_size),
-                             C.c_uint32(prm.dict_size), C.c_int(check), o._ptr(out), C.c_uint64(cap))
-    return out[:n].tobytes()
-
-
-def first_diff(a, b):
-    n = min(len(a), len(b))
-    aa = np.frombuffer(a, dtype=np.uint8, count=n)
-    bb = np.frombuffer(b, dtype=np.uint8, count=n)
-    d = np.nonzero(aa != bb)[0]
-    return int(d[0]) if len(d) else (n if len(a) != len(b) else -1)
-
-
 def run_case(enc, name, data, preset, block_size, span, trace_on_fail=True):
     data = bytes(data)
     opts = xz_amd.preset_options(preset, span_size=span)
@@ -59,9 +32,9 @@ def run_case(enc, name, data, preset, block_size, span, trace_on_fail=True):
     dt = time.time() - t0
     got = out.cpu().numpy().tobytes()
     st = enc.stats()
-    prm, _ = o.params_for_preset(preset, span_size=0 if span == xz_amd.SPAN_WHOLE_BLOCK else span)
-    want = oracle_stream(data, prm, block_size)
-    fd = first_diff(got, want)
+    prm = o.params_for_gpu_options(opts)
+    want = o.orc_xz_stream(data, prm, block_size)
+    fd = o.first_diff(got, want)
     r, dec, nb = o.orc_xz_decode(got, len(data) + 16)
     rt = (r == 0 and dec == data)
     line = (f"[{name}] preset={preset} n={len(data)} bs={block_size} span={span:#x} out={len(got)} want={len(want)} "
@@ -69,9 +42,9 @@ def run_case(enc, name, data, preset, block_size, span, trace_on_fail=True):
             f"blocks={nb} wall={dt*1e3:.1f}ms enc={st.ms_encode:.2f}ms chains={st.ms_chains:.2f}ms "
             f"crc={st.ms_crc:.2f}ms asm={st.ms_assemble:.2f}ms")
     print(line, flush=True)
-    if span == xz_amd.SPAN_WHOLE_BLOCK and o.have_ref() and block_size >= 4096:
+    if span == xz_amd.SPAN_WHOLE_BLOCK and preset <= 3 and o.have_ref() and block_size >= 4096:
         refs = o.ref_encode_mt(data, preset, threads=2, block_size=block_size)
-        fr = first_diff(got, refs)
+        fr = o.first_diff(got, refs)
         print(f"    vs REAL reference liblzma {o.ref().ref_version().decode()}: "
               f"{'IDENTICAL' if fr < 0 else 'DIFF@%d' % fr} (ref {len(refs)} B)", flush=True)
     ok = fd < 0 and rt
