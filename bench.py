@@ -1,0 +1,204 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X-native LZMA2 Block encoder.
+
+Metric (BASELINE.json): compress MB/s (10^6 uncompressed bytes per wall second) + ratio vs
+`xz -T0 -6`, 4 GiB synthetic enwik-style input per GPU, preset -6 options (8 MiB dictionary,
+24 MiB Blocks).  One "step" = one full pass of the hot path (match-finder build, span encode,
+CRC64, assembly into a complete .xz Stream) over the batch already resident in HBM.
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+N>1: weak scaling -- every rank encodes its own shard of Blocks on its own GPU (no data-path
+collective), then the encoded Blocks are gathered to rank 0 over RCCL (send/recv of
+variable-length byte tensors + the 16-byte Index records) and rank 0 frames the Stream.  The gather
+is inside the timed region.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import xz_amd  # noqa: E402
+from xz_amd import parallel  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def cpu_baseline(sample, preset):
+    """Reference liblzma (oracle/_ref, the real 5.8.3 sources) MT encoder on the host cores, timed on a
+    bounded sample of the same workload.  Test infrastructure used as a reported baseline only."""
+    try:
+        import _oracle as o
+        if not o.have_ref():
+            return None, None
+        cores = int(o.ref().ref_cputhreads())
+        t0 = time.time()
+        enc = o.ref_encode_mt(sample, preset, threads=max(cores, 1), block_size=0)
+        dt = time.time() - t0
+        return {"value": round(len(sample) / dt / 1e6, 2), "unit": "MB/s", "cores": cores, "kind": "reference",
+                "sample": f"first {len(sample) >> 20} MiB of rank 0's input, liblzma 5.8.3 lzma_stream_encoder_mt "
+                          f"preset {preset} threads={cores} default block size, {dt:.1f} s wall",
+                "ratio": round(len(enc) / max(len(sample), 1), 5)}, enc
+    except Exception as e:  # noqa: BLE001
+        return {"value": None, "unit": "MB/s", "cores": 0, "kind": "reference", "sample": f"failed: {e}"}, None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--size-mib", type=int, default=4096, help="input MiB per GPU")
+    ap.add_argument("--preset", type=int, default=6)
+    ap.add_argument("--span-kib", type=int, default=0, help="0 = library default")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    n = args.size_mib << 20
+    opts = xz_amd.preset_options(args.preset)
+    if args.span_kib:
+        opts.span_size = args.span_kib << 10
+    block_size = xz_amd.mt_block_size(opts)
+
+    host = xz_amd.corpus_text(n, seed=1000 + rank)
+    data = torch.from_numpy(host).to(dev)
+    enc = xz_amd.Encoder(local_rank)
+    out_buf = torch.empty(xz_amd.lib().xzamd_stream_buffer_bound(n, block_size) + 64, dtype=torch.uint8, device=dev)
+
+    def step():
+        if world == 1:
+            out, binfo = enc.encode(data, opts=opts, block_size=block_size, out=out_buf)
+            return out, binfo
+        out, binfo = enc.encode(data, opts=opts, block_size=block_size, out=out_buf, blocks_only=True)
+        stream = parallel.gather_stream(out, binfo, check=xz_amd.CHECK_CRC64)
+        return stream, binfo
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    enc_ms = 0.0
+    launches = 0
+    out = None
+    for _ in range(args.steps):
+        out, binfo = step()
+        st = enc.stats()
+        enc_ms += st.ms_encode
+        launches += st.encode_launches
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    st = enc.stats()
+    total_in = n * world * args.steps
+    value = total_in / elapsed / 1e6
+    # roofline of the dominant kernel (k_span_encode): algorithmic bytes = uncompressed in +
+    # compressed out per launch, divided by its HIP-event time on its own stream.
+    alg_bytes = (st.in_bytes + st.out_bytes) * args.steps
+    achieved = alg_bytes / (enc_ms / 1e3) / 1e9 if enc_ms > 0 else 0.0
+
+    if rank == 0:
+        local_out_bytes = int(st.out_bytes)
+        res = {
+            "metric": "compress MB/s + ratio vs xz -T0 -6",
+            "value": round(value, 2),
+            "unit": "MB/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 2),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u8",
+            "data": "synthetic",
+            "config": {
+                "workload": f"preset -{args.preset} options (dict {opts.dict_size >> 20} MiB, {block_size >> 20} MiB Blocks, "
+                            f"CRC64), {args.size_mib} MiB synthetic enwik-style text per GPU, input resident in HBM, "
+                            f"output = complete .xz Stream in HBM",
+                "device_match_finder": f"HC{opts.gpu_mf & 15} depth {opts.gpu_depth} nice {opts.gpu_nice_len} (sort-built chains)",
+                "device_parser": "lzma_lzma_optimum_fast semantics (greedy + 1-byte lazy)",
+                "span_kib": (opts.span_size or 65536) >> 10,
+                "parallelism": f"{world} x (one wavefront per span, {int(st.spans)} spans per GPU)",
+            },
+            "ratio": {"ours": round(local_out_bytes / n, 5)},
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "k_span_encode",
+                "achieved": round(achieved, 3),
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 6),
+                "traffic": None,
+                "avg_launch_ms": round(enc_ms / max(launches, 1), 3),
+                "launches": launches,
+            },
+            "stage_ms_last_step": {"chains": round(st.ms_chains, 2), "encode": round(st.ms_encode, 2),
+                                   "crc": round(st.ms_crc, 2), "assemble": round(st.ms_assemble, 2),
+                                   "total": round(st.ms_total, 2)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                import _oracle as o
+                cores = int(o.ref().ref_cputhreads()) if o.have_ref() else 1
+            except Exception:  # noqa: BLE001
+                cores = 1
+            sample_n = min(n, max(1, cores) * block_size, 2 << 30)
+            cb, ref_enc = cpu_baseline(host[:sample_n], args.preset)
+            if cb is not None:
+                res["cpu_baseline"] = cb
+                # our ratio on the same sample + bit-exact round trip of that output through the
+                # REAL reference decoder (first 64 MiB only: the CPU decoder is the slow side)
+                try:
+                    import _oracle as o
+                    s_out, _ = enc.encode(data[:sample_n], opts=opts, block_size=block_size)
+                    res["ratio"]["ours_on_sample"] = round(s_out.numel() / sample_n, 5)
+                    if cb.get("ratio"):
+                        res["ratio"]["reference_xz_T0_6_on_sample"] = cb["ratio"]
+                        res["ratio"]["size_vs_reference_pct"] = round(100.0 * (s_out.numel() / sample_n / cb["ratio"] - 1), 2)
+                    vn = min(sample_n, 64 << 20)
+                    v_out, _ = enc.encode(data[:vn], opts=opts, block_size=block_size)
+                    rr, dec = o.ref_decode(v_out.cpu().numpy().tobytes(), vn + 16)
+                    res["roundtrip_reference_decoder"] = bool(rr == 1 and dec == host[:vn].tobytes())
+                except Exception as e:  # noqa: BLE001
+                    res["roundtrip_reference_decoder"] = f"failed: {e}"
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,80 @@
+"""CPU-side checks of the product library: it loads without a GPU, exports every symbol the public
+headers declare, and its host-side helpers (presets, sizes, framing) agree with the reference."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import _oracle as o
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions(header):
+    src = open(os.path.join(ROOT, "include", header)).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    names = set(re.findall(r"\b((?:xzamd|lzma)_[a-z0-9_]+)\s*\(", src))
+    return sorted(names)
+
+
+@pytest.mark.parametrize("header", ["xz_amd.h", "xz_amd_lzma.h"])
+def test_exports_every_declared_symbol(product_lib, header):
+    names = declared_functions(header)
+    assert names, header
+    missing = [n for n in names if not hasattr(product_lib, n)]
+    assert not missing, missing
+
+
+def test_presets_match_reference(product_lib):
+    import xz_amd
+    for preset in list(range(10)) + [p | xz_amd.PRESET_EXTREME for p in range(10)]:
+        opt = xz_amd.preset_options(preset)
+        if o.have_ref():
+            r = (C.c_uint32 * 8)()
+            assert o.ref().ref_preset(preset, r) == 0
+            assert [opt.dict_size, opt.lc, opt.lp, opt.pb, opt.mode, opt.nice_len, opt.mf, opt.depth] == list(r), hex(preset)
+            assert xz_amd.mt_block_size(opt) == o.ref().ref_mt_block_size_preset(preset)
+        assert opt.gpu_mf in (xz_amd.MF_HC3, xz_amd.MF_HC4) and 1 <= opt.gpu_depth <= 56
+    with pytest.raises(ValueError):
+        xz_amd.preset_options(10)
+
+
+def test_sizes_and_framing(product_lib):
+    from xz_amd import parallel
+    for u in (0, 1, 65535, 65536, 65537, 1 << 20, 24 << 20):
+        assert product_lib.xzamd_block_buffer_bound(u) == o.orc().orc_block_bound(u)
+    hdr = parallel.frame_header(4).tobytes()
+    want = np.zeros(12, dtype=np.uint8)
+    o.orc().orc_stream_header(o._ptr(want), 4)
+    assert hdr == want.tobytes()
+    # empty stream == header + empty index + footer
+    empty = hdr + parallel.frame_index_footer([], [], 4).tobytes()
+    r, dec, nb = o.orc_xz_decode(empty, 16)
+    assert r == 0 and dec == b"" and nb == 0
+    if o.have_ref():
+        assert empty == o.ref_encode_mt(b"", 6, threads=2)
+
+
+def test_corpus_generators(product_lib):
+    import hashlib
+    import xz_amd
+    a = xz_amd.corpus_lorem(229001).tobytes()
+    assert a == o.corpus_lorem(229001)
+    # sha256 of the reference's generated test file
+    assert hashlib.sha256(a).hexdigest().startswith("0e2490f0")
+    t1 = xz_amd.corpus_text(3 << 20, seed=5, threads=1)
+    t4 = xz_amd.corpus_text(3 << 20, seed=5, threads=4)
+    assert (t1 == t4).all() and not (t1 == xz_amd.corpus_text(3 << 20, seed=6, threads=4)).all()
+
+
+def test_no_gpu_means_error_not_fallback(product_lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    ctx = C.c_void_p()
+    assert product_lib.xzamd_ctx_create(C.byref(ctx), 0) != 0
+    import xz_amd
+    with pytest.raises(xz_amd.XzAmdError):
+        xz_amd.Encoder()
