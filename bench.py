@@ -175,7 +175,7 @@ def main():
                 cores = int(o.ref().ref_cputhreads()) if o.have_ref() else 1
             except Exception:  # noqa: BLE001
                 cores = 1
-            sample_n = min(n, max(1, cores) * block_size, 2 << 30)
+            sample_n = min(n, min(max(1, cores), 32) * block_size)
             cb, ref_enc = cpu_baseline(host[:sample_n], args.preset)
             if cb is not None:
                 res["cpu_baseline"] = cb

@@ -165,12 +165,13 @@ static void block_header_put(uint8_t *out, uint32_t hs, uint64_t csize, uint64_t
 
 uint64_t xzamd_stream_buffer_bound(uint64_t in_size, uint64_t block_size)
 {
+	/* Worst case of the span-parallel layout: every span may add LZMA2 chunk headers of its
+	 * own (<= 6 bytes per chunk, at least one chunk per 4 KiB span), on top of the reference's
+	 * per-Block header/padding/check and the Index.  in/128 covers 6 bytes per 768 input bytes. */
 	if (block_size == 0)
 		return 0;
 	const uint64_t nb = (in_size + block_size - 1) / block_size;
-	uint64_t tot = 12 + 12;
-	tot += nb * xzamd_block_buffer_bound(block_size < in_size ? block_size : in_size);
-	tot += 1 + 9 + nb * 18 + 3 + 4;
+	uint64_t tot = 12 + 12 + in_size + (in_size >> 7) + nb * (128 + 18) + 4096;
 	return (tot + 15) & ~15ull;
 }
 
