@@ -76,8 +76,12 @@ typedef struct {
 	/* --- what the device path actually runs --- */
 	uint32_t gpu_mf;     /* XZAMD_MF_HC3 / XZAMD_MF_HC4 */
 	uint32_t gpu_nice_len;
-	uint32_t gpu_depth;  /* 1..56 */
+	uint32_t gpu_depth;  /* candidates taken from the main (3/4-byte hash) chain */
 	uint32_t span_size;  /* bytes per independently coded span; XZAMD_SPAN_* */
+	uint32_t gpu_depth2; /* 0 = exact HC3/HC4 semantics of the reference; else candidates from the
+	                        second, 8-byte-context chain family (HC4+H8 Pareto finder, the BT4
+	                        successor); gpu_depth + gpu_depth2 <= 56 */
+	uint32_t gpu_parser; /* 0 = lzma_lzma_optimum_fast semantics, 1 = windowed optimal parser */
 } xzamd_lzma_options;
 
 /* lzma_lzma_preset() (lzma/lzma_encoder_presets.c:17-63) + the device mapping.

@@ -1,9 +1,8 @@
 /*
  * lzma_fast_enc.c -- TEST INFRASTRUCTURE ONLY (oracle).
  *
- * CPU restatement of the reference's fast-mode LZMA2 encode path for ONE
- * Block -- the code a worker thread of lzma_stream_encoder_mt runs for
- * presets 0-3:
+ * CPU restatement of the LZMA2 encode path for ONE Block -- the code a worker
+ * thread of lzma_stream_encoder_mt runs:
  *
  *   lz/lz_encoder_mf.c:22-79     lzma_mf_find (longest-match extension)
  *   lz/lz_encoder_mf.c:190-201   header macro (len_limit / pending rule)
@@ -16,21 +15,31 @@
  *   lzma/lzma_encoder.c:23-263   literal/match/rep symbol coding
  *   lzma/lzma_encoder.c:313-436  per-chunk loop and its two cut-off rules
  *   rangecoder/range_encoder.h:136-263       rc_shift_low / rc_encode
+ *   rangecoder/price.h, price_tablegen.c     bit prices (optimal parser)
  *   lzma/lzma2_encoder.c:54-259  chunk headers, uncompressed-chunk fallback
  *
- * It is written for a whole-Block-resident window (positions are absolute
- * offsets in the Block; no sliding, no cyclic buffers) and codes bits
- * directly instead of queueing them -- the same layout the HIP kernels use --
- * but every decision is the reference's, so with span_size == 0 the output is
- * byte-identical to liblzma's raw LZMA2 encoder (pinned in
- * tests/test_oracle_encoder.py).
+ * Layout mirrors the HIP kernels: the whole Block is resident, positions are
+ * absolute offsets, and -- because the reference inserts EVERY position into
+ * its hash tables (find and skip both do) -- the chain links are a pure
+ * function of the data and are precomputed once (prev2/prev3/son arrays)
+ * instead of being maintained while parsing.  Bits are coded directly instead
+ * of being queued.  Every decision on the "exact" path (mf = 3/4, parser 0,
+ * span_size 0) is the reference's, so the output is byte-identical to
+ * liblzma's raw LZMA2 encoder (pinned in tests/test_oracle_encoder.py).
  *
- * span_size != 0 is the GPU production mode: the Block is cut into spans that
- * are parsed and entropy-coded independently (LZMA state reset + properties at
- * each span start, control byte 0xC0; lzma2_decoder.c:84-111 makes that
- * legal) while the dictionary and the hash chains stay Block-global.  Matches
- * may not cross a span end.  This is our definition, not the reference's; the
- * HIP path must reproduce it bit-exactly.
+ * OUR definitions (not the reference's; the HIP path must reproduce them
+ * bit-exactly, tests/test_gpu_parity.py):
+ *   span_size != 0   independent state-reset spans (control 0xC0), matches may
+ *                    not cross a span end, chains stay Block-global;
+ *   depth2 != 0      "HC4+H8" match finder: a second chain family keyed by a
+ *                    22-bit hash of 8 bytes; all candidates (hash2, hash3,
+ *                    <= depth 4-byte-chain, <= depth2 8-byte-chain) are merged
+ *                    by the Pareto rule "closer or longer" -- the GPU successor
+ *                    of BT4 (lz_encoder_mf.c:450-743 is sequential per insert);
+ *   parser == 1      price-based forward dynamic program over a bounded window
+ *                    (the role of lzma_encoder_optimum_normal.c:803-858, not its
+ *                    code): exact current-probability prices, edges literal /
+ *                    short rep / rep0-3 x all lengths / match x all lengths.
  */
 #include "oracle.h"
 #include <stdlib.h>
@@ -38,6 +47,10 @@
 
 #define MATCH_LEN_MAX 273u
 #define LIT 0xFFFFFFFFu
+#define NO_DELTA 0xFFFFFFFFu
+#define H8_BITS 22
+#define WMAX 256u                 /* optimal-parser window (nodes 0..WMAX) */
+#define PRICE_INF (1u << 30)
 
 /* ------------------------------------------------------------------ */
 /* Probability model layout (flat u16 array; HIP kernels share it)      */
@@ -62,22 +75,30 @@ enum {
 };
 
 typedef struct {
+	uint32_t price;
+	uint32_t back;      /* edge arriving here: LIT / rep index / dist + 4 */
+	uint32_t len;       /* its length */
+	uint32_t state;     /* valid once the node has been visited */
+	uint32_t reps[4];
+} node;
+
+typedef struct {
 	const uint8_t *in;
 	uint32_t n;
 	orc_enc_params prm;
 	uint32_t depth, hash_mask, cyclic_size;
-	/* match finder: positions stored +1, 0 = empty
-	 * (EMPTY_HASH_VALUE, lz_encoder_mf.c:82-85) */
-	uint32_t *head2, *head3, *head4, *son;
-	uint32_t mf_pos;            /* next position to insert */
+	/* parse-independent chain links (0 = none) */
+	uint32_t *prev2, *prev3;    /* delta to the previous position with equal hash2 / hash3 */
+	uint32_t *son;              /* main chain: previous position + 1 */
+	uint32_t *son8;             /* 8-byte-context chain: previous position + 1 */
 	uint32_t span_end;          /* exclusive end for avail computations */
-	/* matches of the last find */
-	uint32_t m_len[MATCH_LEN_MAX + 1], m_dist[MATCH_LEN_MAX + 1];
+	/* result of the last find */
+	uint32_t m_len[MATCH_LEN_MAX + 8], m_dist[MATCH_LEN_MAX + 8];
 	uint32_t m_count, m_longest;
+	uint32_t rep_len[4];
 	/* lzma state */
 	uint16_t probs[P_TOTAL_MAX];
 	uint32_t state, reps[4];
-	uint32_t read_ahead;        /* 0/1: lookahead find already done */
 	/* range coder */
 	uint64_t low;
 	uint64_t cache_size;
@@ -85,6 +106,18 @@ typedef struct {
 	uint8_t cache;
 	uint8_t *cbuf;              /* chunk payload buffer */
 	uint32_t cpos;
+	/* optimal parser */
+	node *nodes;
+	uint32_t q_back[WMAX + 1], q_len[WMAX + 1], q_head, q_count;
+	uint8_t price_tab[128];
+	/* cached price tables (role of length_update_prices / fill_dist_prices /
+	 * fill_align_prices), refreshed at window starts by symbol counters */
+	uint16_t lp[2][4][272];     /* [match,rep][pos_state][len-2] */
+	uint16_t dsp[4][64];        /* dist slot price (+ direct bits for slot >= 14) */
+	uint16_t dp[4][128];        /* full price of distances < 128 */
+	uint16_t ap[16];            /* align bits */
+	uint32_t cnt_len, cnt_match, cnt_align;
+	int tables_valid;
 	orc_trace *trace;
 } enc;
 
@@ -105,7 +138,13 @@ static const uint32_t *crc_table0(void)
 	return t;
 }
 
-/* ---- match finder ------------------------------------------------------- */
+static uint32_t hash8_of(const uint8_t *p)
+{
+	uint64_t v;
+	memcpy(&v, p, 8);            /* little-endian hosts only, like the GPU */
+	return (uint32_t)((v * 0x9E3779B185EBCA87ull) >> (64 - H8_BITS));
+}
+
 static uint32_t cmplen(const uint8_t *a, const uint8_t *b, uint32_t len, uint32_t limit)
 {
 	/* common/memcmplen.h:47: first `len` bytes are known equal */
@@ -114,41 +153,51 @@ static uint32_t cmplen(const uint8_t *a, const uint8_t *b, uint32_t len, uint32_
 	return len;
 }
 
-/* Insert position p into the tables without searching (hc3/hc4 skip). */
-static void mf_insert(enc *e, uint32_t p)
+/* ---- chain links: what the reference's hash/son arrays contain when each
+ * position is reached (lz_encoder_mf.c:366-441: find and skip both insert) ---- */
+static int build_links(enc *e)
 {
 	const uint32_t *T = crc_table0();
-	const uint8_t *cur = e->in + p;
 	const uint32_t hb = e->prm.mf;
-	/* lz_encoder_mf.c:419-422 / :331-334: fewer than hash-bytes left in the
-	 * BLOCK -> pending, never inserted.  (nice_len >= hash bytes always,
-	 * lzma_encoder.c:479-480.) */
-	if (e->n - p < hb)
-		return;
-	const uint32_t temp = T[cur[0]] ^ cur[1];
-	const uint32_t h2 = temp & 0x3FF;
-	uint32_t prev;
-	if (hb == 3) {
-		const uint32_t h = (temp ^ ((uint32_t)cur[2] << 8)) & e->hash_mask;
-		prev = e->head3[h];
-		e->head2[h2] = p + 1;
-		e->head3[h] = p + 1;
-	} else {
-		const uint32_t h3 = (temp ^ ((uint32_t)cur[2] << 8)) & 0xFFFF;
-		const uint32_t h = (temp ^ ((uint32_t)cur[2] << 8) ^ (T[cur[3]] << 5)) & e->hash_mask;
-		prev = e->head4[h];
-		e->head2[h2] = p + 1;
-		e->head3[h3] = p + 1;
-		e->head4[h] = p + 1;
+	const uint32_t n = e->n;
+	uint32_t *head2 = (uint32_t *)calloc(1024, 4);
+	uint32_t *head3 = (uint32_t *)calloc(65536, 4);
+	uint32_t *headm = (uint32_t *)calloc((size_t)e->hash_mask + 1, 4);
+	uint32_t *head8 = e->prm.depth2 ? (uint32_t *)calloc((size_t)1 << H8_BITS, 4) : NULL;
+	if (!head2 || !head3 || !headm || (e->prm.depth2 && !head8))
+		return -1;
+	for (uint32_t p = 0; p < n; ++p) {
+		const uint8_t *cur = e->in + p;
+		if (n - p < hb)
+			continue;       /* "pending": never inserted (lz_encoder_mf.c:190-201) */
+		const uint32_t temp = T[cur[0]] ^ cur[1];
+		const uint32_t h2 = temp & 0x3FF;
+		e->prev2[p] = head2[h2] ? p + 1 - head2[h2] : 0;
+		head2[h2] = p + 1;
+		uint32_t h;
+		if (hb == 3) {
+			h = (temp ^ ((uint32_t)cur[2] << 8)) & e->hash_mask;
+		} else {
+			const uint32_t h3 = (temp ^ ((uint32_t)cur[2] << 8)) & 0xFFFF;
+			e->prev3[p] = head3[h3] ? p + 1 - head3[h3] : 0;
+			head3[h3] = p + 1;
+			h = (temp ^ ((uint32_t)cur[2] << 8) ^ (T[cur[3]] << 5)) & e->hash_mask;
+		}
+		e->son[p] = headm[h];
+		headm[h] = p + 1;
+		if (head8 && n - p >= 8) {
+			const uint32_t h8 = hash8_of(cur);
+			e->son8[p] = head8[h8];
+			head8[h8] = p + 1;
+		}
 	}
-	e->son[p] = prev;
+	free(head2); free(head3); free(headm); free(head8);
+	return 0;
 }
 
-/* lzma_mf_find at position p == e->mf_pos. Fills m_*; advances mf_pos. */
-static void mf_find(enc *e)
+/* ---- exact HC3/HC4: what lzma_mf_find() reports at position p ------------- */
+static void find_exact(enc *e, uint32_t p)
 {
-	const uint32_t *T = crc_table0();
-	const uint32_t p = e->mf_pos;
 	const uint8_t *cur = e->in + p;
 	const uint32_t hb = e->prm.mf;
 	const uint32_t nice = e->prm.nice_len;
@@ -156,33 +205,23 @@ static void mf_find(enc *e)
 	uint32_t count = 0;
 	e->m_count = 0;
 	e->m_longest = 0;
-	e->mf_pos = p + 1;
 
 	/* header(): lz_encoder_mf.c:190-201 */
 	uint32_t len_limit = avail;
-	if (nice <= len_limit) {
+	if (nice <= len_limit)
 		len_limit = nice;
-	} else if (len_limit < hb) {
-		/* pending: no matches. In span mode the position may still have
-		 * to enter the Block-global tables. */
-		mf_insert(e, p);
+	else if (len_limit < hb)
 		return;
-	}
 
-	const uint32_t temp = T[cur[0]] ^ cur[1];
-	const uint32_t h2 = temp & 0x3FF;
-	uint32_t cur_match, len_best;
+	uint32_t len_best;
 	int done = 0;
+	/* An empty slot gives delta = pos - 0 >= cyclic_size in the reference
+	 * (positions start at cyclic_size, lz_encoder.c:395). */
+	uint32_t delta2 = e->prev2[p] ? e->prev2[p] : NO_DELTA;
 	if (hb == 3) {
 		/* lz_encoder_mf.c:305-335 */
-		const uint32_t h = (temp ^ ((uint32_t)cur[2] << 8)) & e->hash_mask;
-		const uint32_t s2 = e->head2[h2];
-		cur_match = e->head3[h];
-		e->head2[h2] = p + 1;
-		e->head3[h] = p + 1;
 		len_best = 2;
-		const uint32_t delta2 = p + 1 - s2;
-		if (s2 != 0 && delta2 < e->cyclic_size && cur[-(int64_t)delta2] == cur[0]) {
+		if (delta2 < e->cyclic_size && cur[-(int64_t)delta2] == cur[0]) {
 			len_best = cmplen(cur - delta2, cur, len_best, len_limit);
 			e->m_len[0] = len_best;
 			e->m_dist[0] = delta2 - 1;
@@ -192,17 +231,7 @@ static void mf_find(enc *e)
 		}
 	} else {
 		/* lz_encoder_mf.c:366-413 */
-		const uint32_t h3 = (temp ^ ((uint32_t)cur[2] << 8)) & 0xFFFF;
-		const uint32_t h = (temp ^ ((uint32_t)cur[2] << 8) ^ (T[cur[3]] << 5)) & e->hash_mask;
-		const uint32_t s2 = e->head2[h2], s3 = e->head3[h3];
-		cur_match = e->head4[h];
-		e->head2[h2] = p + 1;
-		e->head3[h3] = p + 1;
-		e->head4[h] = p + 1;
-		/* An empty slot gives delta = pos - 0 >= cyclic_size in the
-		 * reference (positions start at cyclic_size, lz_encoder.c:395). */
-		uint32_t delta2 = s2 ? p + 1 - s2 : 0xFFFFFFFFu;
-		const uint32_t delta3 = s3 ? p + 1 - s3 : 0xFFFFFFFFu;
+		const uint32_t delta3 = e->prev3[p] ? e->prev3[p] : NO_DELTA;
 		len_best = 1;
 		if (delta2 < e->cyclic_size && cur[-(int64_t)delta2] == cur[0]) {
 			len_best = 2;
@@ -224,11 +253,11 @@ static void mf_find(enc *e)
 		if (len_best < 3)
 			len_best = 3;
 	}
-	e->son[p] = cur_match;
 
 	if (!done) {
 		/* hc_find_func: lz_encoder_mf.c:250-287 */
 		uint32_t depth = e->depth;
+		uint32_t cur_match = e->son[p];
 		for (;;) {
 			if (cur_match == 0)
 				break;
@@ -263,12 +292,92 @@ static void mf_find(enc *e)
 	}
 }
 
-static void mf_skip(enc *e, uint32_t amount)
+/* ---- HC4+H8 with Pareto merge (OUR definition, see file header) ----------- */
+static void find_pareto(enc *e, uint32_t p)
 {
-	while (amount--) {
-		mf_insert(e, e->mf_pos);
-		++e->mf_pos;
+	const uint8_t *cur = e->in + p;
+	const uint32_t nice = e->prm.nice_len;
+	const uint32_t avail = e->span_end - p;
+	e->m_count = 0;
+	e->m_longest = 0;
+	uint32_t len_limit = avail;
+	if (nice <= len_limit)
+		len_limit = nice;
+	else if (len_limit < 4)
+		return;
+
+	/* candidates in a fixed order (== GPU lane order): hash2, hash3, 4-byte chain, 8-byte chain */
+	uint32_t cd[64], cl[64], nc = 0;
+	const uint32_t d2 = e->prev2[p], d3 = e->prev3[p];
+	if (d2 && d2 < e->cyclic_size) {
+		uint32_t L = cmplen(cur - d2, cur, 0, len_limit);
+		if (L >= 2) { cd[nc] = d2; cl[nc] = L; ++nc; }
 	}
+	if (d3 && d3 != d2 && d3 < e->cyclic_size) {
+		uint32_t L = cmplen(cur - d3, cur, 0, len_limit);
+		if (L >= 3) { cd[nc] = d3; cl[nc] = L; ++nc; }
+	}
+	uint32_t cm = e->son[p];
+	for (uint32_t k = 0; k < e->depth && cm; ++k) {
+		const uint32_t delta = p + 1 - cm;
+		if (delta >= e->cyclic_size)
+			break;
+		uint32_t L = cmplen(cur - delta, cur, 0, len_limit);
+		if (L >= 4) { cd[nc] = delta; cl[nc] = L; ++nc; }
+		cm = e->son[p - delta];
+	}
+	if (e->n - p >= 8) {
+		cm = e->son8[p];
+		for (uint32_t k = 0; k < e->prm.depth2 && cm; ++k) {
+			const uint32_t delta = p + 1 - cm;
+			if (delta >= e->cyclic_size)
+				break;
+			uint32_t L = cmplen(cur - delta, cur, 0, len_limit);
+			if (L >= 4) { cd[nc] = delta; cl[nc] = L; ++nc; }
+			cm = e->son8[p - delta];
+		}
+	}
+	/* keep candidate i iff L_i > max{ L_j : (delta_j, j) < (delta_i, i) } */
+	uint32_t count = 0;
+	for (uint32_t i = 0; i < nc; ++i) {
+		uint32_t m = 0;
+		for (uint32_t j = 0; j < nc; ++j)
+			if ((cd[j] < cd[i] || (cd[j] == cd[i] && j < i)) && cl[j] > m)
+				m = cl[j];
+		if (cl[i] > m) {
+			/* insert sorted by delta (== sorted by length) */
+			uint32_t k = count++;
+			while (k > 0 && e->m_dist[k - 1] > cd[i] - 1) {
+				e->m_dist[k] = e->m_dist[k - 1];
+				e->m_len[k] = e->m_len[k - 1];
+				--k;
+			}
+			e->m_dist[k] = cd[i] - 1;
+			e->m_len[k] = cl[i];
+		}
+	}
+	e->m_count = count;
+	if (count > 0) {
+		uint32_t lb = e->m_len[count - 1];
+		if (lb == nice) {
+			uint32_t limit = avail < MATCH_LEN_MAX ? avail : MATCH_LEN_MAX;
+			lb = cmplen(cur, cur - e->m_dist[count - 1] - 1, lb, limit);
+		}
+		e->m_longest = lb;
+	}
+}
+
+/* One "round" at position x: matches + the four rep-match lengths with reps r[]. */
+static void do_round(enc *e, uint32_t x, const uint32_t r[4])
+{
+	if (e->prm.depth2)
+		find_pareto(e, x);
+	else
+		find_exact(e, x);
+	const uint32_t rem = e->span_end - x;
+	const uint32_t buf_avail = rem < MATCH_LEN_MAX ? rem : MATCH_LEN_MAX;
+	for (uint32_t i = 0; i < 4; ++i)
+		e->rep_len[i] = cmplen(e->in + x, e->in + x - r[i] - 1, 0, buf_avail);
 }
 
 /* ---- range coder: rangecoder/range_encoder.h:136-263 --------------------- */
@@ -368,6 +477,7 @@ static void lzma_state_reset(enc *e)
 	e->state = 0;
 	e->reps[0] = e->reps[1] = e->reps[2] = e->reps[3] = 0;
 	rc_reset(e);
+	e->tables_valid = 0;
 }
 
 static uint32_t dist_slot_of(uint32_t d)
@@ -400,13 +510,18 @@ static void enc_length(enc *e, uint32_t base, uint32_t ps, uint32_t len)
 	}
 }
 
-static void enc_literal(enc *e, uint32_t pos)
+static uint32_t literal_sub(const enc *e, uint32_t pos)
 {
-	const uint8_t cur = e->in[pos];
 	const uint32_t prev = pos ? e->in[pos - 1] : 0;
 	const uint32_t lc = e->prm.lc;
 	const uint32_t mask = (0x100u << e->prm.lp) - (0x100u >> lc);
-	uint16_t *sub = e->probs + P_LITERAL + 3u * ((((pos << 8) + prev) & mask) << lc);
+	return P_LITERAL + 3u * ((((pos << 8) + prev) & mask) << lc);
+}
+
+static void enc_literal(enc *e, uint32_t pos)
+{
+	const uint8_t cur = e->in[pos];
+	uint16_t *sub = e->probs + literal_sub(e, pos);
 	if (e->state < 7) {
 		e->state = e->state <= 3 ? 0 : e->state - 3;
 		rc_tree(e, sub, 8, cur);
@@ -426,19 +541,23 @@ static void enc_literal(enc *e, uint32_t pos)
 	}
 }
 
+static void trace_sym(enc *e, uint32_t pos, uint32_t back, uint32_t len)
+{
+	orc_trace *t = e->trace;
+	if (!t) return;
+	if (t->sym && t->sym_count < t->sym_cap) {
+		t->sym[t->sym_count].pos = pos;
+		t->sym[t->sym_count].back = back;
+		t->sym[t->sym_count].len = len;
+	}
+	++t->sym_count;
+}
+
 static void enc_symbol(enc *e, uint32_t pos, uint32_t back, uint32_t len)
 {
 	const uint32_t ps = pos & ((1u << e->prm.pb) - 1);
 	uint16_t *P = e->probs;
-	if (e->trace) {
-		orc_trace *t = e->trace;
-		if (t->sym && t->sym_count < t->sym_cap) {
-			t->sym[t->sym_count].pos = pos;
-			t->sym[t->sym_count].back = back;
-			t->sym[t->sym_count].len = len;
-		}
-		++t->sym_count;
-	}
+	trace_sym(e, pos, back, len);
 	if (back == LIT) {
 		rc_bit(e, &P[P_IS_MATCH + e->state * 16 + ps], 0);
 		enc_literal(e, pos);
@@ -470,6 +589,7 @@ static void enc_symbol(enc *e, uint32_t pos, uint32_t back, uint32_t len)
 		} else {
 			enc_length(e, P_REP_LEN, ps, len);
 			e->state = e->state < 7 ? 8 : 11;
+			++e->cnt_len;
 		}
 		return;
 	}
@@ -477,6 +597,8 @@ static void enc_symbol(enc *e, uint32_t pos, uint32_t back, uint32_t len)
 	const uint32_t dist = back - 4;
 	e->state = e->state < 7 ? 7 : 10;
 	enc_length(e, P_MATCH_LEN, ps, len);
+	++e->cnt_len;
+	++e->cnt_match;
 	const uint32_t slot = dist_slot_of(dist);
 	const uint32_t ds = len < 6 ? len - 2 : 3;
 	rc_tree(e, P + P_DIST_SLOT + ds * 64, 6, slot);
@@ -489,6 +611,7 @@ static void enc_symbol(enc *e, uint32_t pos, uint32_t back, uint32_t len)
 		} else {
 			rc_direct(e, red >> 4, fb - 4);
 			rc_tree_rev(e, P + P_DIST_ALIGN, 4, red & 15);
+			++e->cnt_align;
 		}
 	}
 	e->reps[3] = e->reps[2];
@@ -497,39 +620,35 @@ static void enc_symbol(enc *e, uint32_t pos, uint32_t back, uint32_t len)
 	e->reps[0] = dist;
 }
 
-/* ---- parser: lzma/lzma_encoder_optimum_fast.c:20-169 ----------------------- */
+/* ---- fast parser: lzma/lzma_encoder_optimum_fast.c:20-169 -------------------
+ * `cached` = the lookahead round for position `pos` has already been done
+ * (coder->matches / longest_match_length of the reference, plus the rep lengths:
+ * a literal does not change reps, so they are still valid).  Returns the number
+ * of positions the round cache is ahead after the decision (0 or 1). */
 #define change_pair(small, big) (((big) >> 7) > (small))
 
-static void optimum_fast(enc *e, uint32_t pos, uint32_t *back_res, uint32_t *len_res)
+static int optimum_fast(enc *e, uint32_t pos, int cached, uint32_t *back_res, uint32_t *len_res)
 {
 	const uint32_t nice = e->prm.nice_len;
-	uint32_t len_main, count;
-	if (e->read_ahead == 0) {
-		mf_find(e);
-		++e->read_ahead;
-	}
-	len_main = e->m_longest;
-	count = e->m_count;
+	if (!cached)
+		do_round(e, pos, e->reps);
+	uint32_t len_main = e->m_longest;
+	uint32_t count = e->m_count;
 
-	const uint8_t *buf = e->in + pos;
 	const uint32_t rem = e->span_end - pos;
 	const uint32_t buf_avail = rem < MATCH_LEN_MAX ? rem : MATCH_LEN_MAX;
-	if (buf_avail < 2) {
-		*back_res = LIT; *len_res = 1;
-		return;
-	}
+	*back_res = LIT; *len_res = 1;
+	if (buf_avail < 2)
+		return 0;
 
 	uint32_t rep_len = 0, rep_index = 0;
 	for (uint32_t i = 0; i < 4; ++i) {
-		const uint8_t *bb = buf - e->reps[i] - 1;
-		if (buf[0] != bb[0] || buf[1] != bb[1])
+		const uint32_t len = e->rep_len[i];
+		if (len < 2)        /* not_equal_16 */
 			continue;
-		const uint32_t len = cmplen(buf, bb, 2, buf_avail);
 		if (len >= nice) {
 			*back_res = i; *len_res = len;
-			mf_skip(e, len - 1);
-			e->read_ahead += len - 1;
-			return;
+			return 0;
 		}
 		if (len > rep_len) {
 			rep_index = i;
@@ -540,9 +659,7 @@ static void optimum_fast(enc *e, uint32_t pos, uint32_t *back_res, uint32_t *len
 	if (len_main >= nice) {
 		*back_res = e->m_dist[count - 1] + 4;
 		*len_res = len_main;
-		mf_skip(e, len_main - 1);
-		e->read_ahead += len_main - 1;
-		return;
+		return 0;
 	}
 
 	uint32_t back_main = 0;
@@ -564,45 +681,322 @@ static void optimum_fast(enc *e, uint32_t pos, uint32_t *back_res, uint32_t *len
 				|| (rep_len + 2 >= len_main && back_main > (1u << 9))
 				|| (rep_len + 3 >= len_main && back_main > (1u << 15))) {
 			*back_res = rep_index; *len_res = rep_len;
-			mf_skip(e, rep_len - 1);
-			e->read_ahead += rep_len - 1;
-			return;
+			return 0;
 		}
 	}
 
-	if (len_main < 2 || buf_avail <= 2) {
-		*back_res = LIT; *len_res = 1;
-		return;
-	}
+	if (len_main < 2 || buf_avail <= 2)
+		return 0;
 
-	/* lookahead: matches of the next byte */
-	mf_find(e);
-	++e->read_ahead;
+	/* lookahead: matches (and rep lengths) of the next byte */
+	do_round(e, pos + 1, e->reps);
 	if (e->m_longest >= 2) {
 		const uint32_t nl = e->m_longest;
 		const uint32_t new_dist = e->m_dist[e->m_count - 1];
 		if ((nl >= len_main && new_dist < back_main)
 				|| (nl == len_main + 1 && !change_pair(back_main, new_dist))
 				|| (nl > len_main + 1)
-				|| (nl + 1 >= len_main && len_main >= 3 && change_pair(new_dist, back_main))) {
-			*back_res = LIT; *len_res = 1;
-			return;
-		}
+				|| (nl + 1 >= len_main && len_main >= 3 && change_pair(new_dist, back_main)))
+			return 1;
 	}
-
-	++buf;
 	const uint32_t limit = len_main - 1 > 2 ? len_main - 1 : 2;
-	for (uint32_t i = 0; i < 4; ++i) {
-		if (memcmp(buf, buf - e->reps[i] - 1, limit) == 0) {
-			*back_res = LIT; *len_res = 1;
-			return;
-		}
-	}
+	for (uint32_t i = 0; i < 4; ++i)
+		if (e->rep_len[i] >= limit)     /* memcmp(buf+1, buf+1-rep-1, limit) == 0 */
+			return 1;
 
 	*back_res = back_main + 4;
 	*len_res = len_main;
-	mf_skip(e, len_main - 2);
-	e->read_ahead += len_main - 2;
+	return 0;
+}
+
+/* ---- bit prices: rangecoder/price.h:28-92, table from price_tablegen.c:31-58 -- */
+static void price_table_init(enc *e)
+{
+	for (uint32_t i = 8; i < 2048; i += 16) {
+		uint32_t w = i, bit_count = 0;
+		for (uint32_t j = 0; j < 4; ++j) {
+			w *= w;
+			bit_count <<= 1;
+			while (w >= (1u << 16)) {
+				w >>= 1;
+				++bit_count;
+			}
+		}
+		e->price_tab[i >> 4] = (uint8_t)((11 << 4) - 15 - bit_count);
+	}
+}
+
+static inline uint32_t pr_bit(const enc *e, uint32_t idx, uint32_t bit)
+{
+	return e->price_tab[(e->probs[idx] ^ ((0u - bit) & 0x7FF)) >> 4];
+}
+
+static uint32_t pr_tree(const enc *e, uint32_t base, uint32_t nbits, uint32_t sym)
+{
+	uint32_t price = 0;
+	sym += 1u << nbits;
+	do {
+		const uint32_t bit = sym & 1;
+		sym >>= 1;
+		price += pr_bit(e, base + sym, bit);
+	} while (sym != 1);
+	return price;
+}
+
+static uint32_t pr_tree_rev(const enc *e, uint32_t base, uint32_t nbits, uint32_t sym)
+{
+	uint32_t price = 0, m = 1;
+	do {
+		const uint32_t bit = sym & 1;
+		sym >>= 1;
+		price += pr_bit(e, base + m, bit);
+		m = (m << 1) + bit;
+	} while (--nbits);
+	return price;
+}
+
+static uint32_t pr_literal(const enc *e, uint32_t pos, uint32_t state, uint32_t rep0)
+{
+	/* get_literal_price: lzma_encoder_optimum_normal.c:21-53 */
+	const uint32_t sub = literal_sub(e, pos);
+	uint32_t sym = e->in[pos];
+	if (state < 7)
+		return pr_tree(e, sub, 8, sym);
+	uint32_t price = 0, mb = e->in[pos - rep0 - 1], off = 0x100;
+	sym += 0x100;
+	do {
+		mb <<= 1;
+		const uint32_t mbit = mb & off;
+		const uint32_t idx = off + mbit + (sym >> 8);
+		price += pr_bit(e, sub + idx, (sym >> 7) & 1);
+		sym <<= 1;
+		off &= ~(mb ^ sym);
+	} while (sym < 0x10000);
+	return price;
+}
+
+static uint32_t pr_len(const enc *e, uint32_t base, uint32_t ps, uint32_t len)
+{
+	/* length_update_prices: lzma_encoder.c:77-102, evaluated on demand */
+	len -= 2;
+	if (len < 8)
+		return pr_bit(e, base + LEN_CHOICE, 0) + pr_tree(e, base + LEN_LOW + ps * 8, 3, len);
+	len -= 8;
+	if (len < 8)
+		return pr_bit(e, base + LEN_CHOICE, 1) + pr_bit(e, base + LEN_CHOICE2, 0)
+				+ pr_tree(e, base + LEN_MID + ps * 8, 3, len);
+	return pr_bit(e, base + LEN_CHOICE, 1) + pr_bit(e, base + LEN_CHOICE2, 1)
+			+ pr_tree(e, base + LEN_HIGH, 8, len - 8);
+}
+
+static uint32_t pr_dist(const enc *e, uint32_t dist, uint32_t dist_state)
+{
+	/* fill_dist_prices / fill_align_prices: lzma_encoder_optimum_normal.c:132-195 */
+	const uint32_t slot = dist_slot_of(dist);
+	uint32_t price = pr_tree(e, P_DIST_SLOT + dist_state * 64, 6, slot);
+	if (slot >= 4) {
+		const uint32_t fb = (slot >> 1) - 1;
+		const uint32_t base = (2 | (slot & 1)) << fb;
+		const uint32_t red = dist - base;
+		if (slot < 14)
+			price += pr_tree_rev(e, P_DIST_SPECIAL + base - slot - 1, fb, red);
+		else
+			price += ((fb - 4) << 4) + pr_tree_rev(e, P_DIST_ALIGN, 4, red & 15);
+	}
+	return price;
+}
+
+/* Refresh policy (ours; the reference uses per-table countdowns, lzma_encoder.c:129-133,
+ * lzma_encoder_optimum_normal.c:819-826): at a window start, length tables after 64 coded
+ * lengths, distance tables after 128 matches, align table after 16 align-coded matches. */
+static void refresh_tables(enc *e)
+{
+	const uint32_t nps = 1u << e->prm.pb;
+	if (!e->tables_valid || e->cnt_len >= 64) {
+		for (uint32_t c = 0; c < 2; ++c)
+			for (uint32_t ps = 0; ps < nps && ps < 4; ++ps)
+				for (uint32_t l = 2; l <= MATCH_LEN_MAX; ++l)
+					e->lp[c][ps][l - 2] = (uint16_t)pr_len(e, c ? P_REP_LEN : P_MATCH_LEN, ps, l);
+		e->cnt_len = 0;
+	}
+	if (!e->tables_valid || e->cnt_match >= 128) {
+		for (uint32_t ds = 0; ds < 4; ++ds) {
+			for (uint32_t slot = 0; slot < 64; ++slot) {
+				uint32_t pr = pr_tree(e, P_DIST_SLOT + ds * 64, 6, slot);
+				if (slot >= 14)
+					pr += (((slot >> 1) - 1) - 4) << 4;
+				e->dsp[ds][slot] = (uint16_t)pr;
+			}
+			for (uint32_t d = 0; d < 128; ++d)
+				e->dp[ds][d] = (uint16_t)pr_dist(e, d, ds);
+		}
+		e->cnt_match = 0;
+	}
+	if (!e->tables_valid || e->cnt_align >= 16) {
+		for (uint32_t i = 0; i < 16; ++i)
+			e->ap[i] = (uint16_t)pr_tree_rev(e, P_DIST_ALIGN, 4, i);
+		e->cnt_align = 0;
+	}
+	e->tables_valid = 1;
+}
+
+static inline uint32_t tab_dist(const enc *e, uint32_t dist, uint32_t ds)
+{
+	if (dist < 128)
+		return e->dp[ds][dist];
+	return (uint32_t)e->dsp[ds][dist_slot_of(dist)] + e->ap[dist & 15];
+}
+
+static inline uint32_t state_after(uint32_t s, uint32_t back, uint32_t len)
+{
+	if (back == LIT)
+		return s <= 3 ? 0 : (s <= 9 ? s - 3 : s - 6);
+	if (back < 4)
+		return len == 1 ? (s < 7 ? 9 : 11) : (s < 7 ? 8 : 11);
+	return s < 7 ? 7 : 10;
+}
+
+static void reps_after(const uint32_t r[4], uint32_t back, uint32_t out[4])
+{
+	if (back == LIT || back == 0) {
+		out[0] = r[0]; out[1] = r[1]; out[2] = r[2]; out[3] = r[3];
+	} else if (back < 4) {
+		out[0] = r[back];
+		uint32_t k = 1;
+		for (uint32_t i = 0; i < 4; ++i)
+			if (i != back)
+				out[k++] = r[i];
+		/* rep_match(): the chosen rep moves to the front, the others keep their order */
+	} else {
+		out[0] = back - 4; out[1] = r[0]; out[2] = r[1]; out[3] = r[2];
+	}
+}
+
+static inline void relax(node *nd, uint32_t price, uint32_t back, uint32_t len)
+{
+	if (price < nd->price) {
+		nd->price = price;
+		nd->back = back;
+		nd->len = len;
+	}
+}
+
+/* ---- optimal parser (OUR definition).  Parses one window starting at `pos`
+ * with the coder's current state/reps/probabilities, stores the chosen symbols
+ * in the queue.  `cached` as in optimum_fast.  Returns 1 if the round for the
+ * position right after the window has been done (nice-length cut). */
+static int optimum_window(enc *e, uint32_t pos, int cached)
+{
+	const uint32_t nice = e->prm.nice_len;
+	const uint32_t pbm = (1u << e->prm.pb) - 1;
+	node *nd = e->nodes;
+	refresh_tables(e);
+	nd[0].price = 0;
+	nd[0].state = e->state;
+	memcpy(nd[0].reps, e->reps, sizeof(nd[0].reps));
+	uint32_t n_end = 0;
+	int next_cached = 0;
+	uint32_t j = 0;
+	for (;;) {
+		const uint32_t x = pos + j;
+		if (j > 0) {
+			/* the path into node j is final: derive its coder state */
+			const node *pv = &nd[j - nd[j].len];
+			nd[j].state = state_after(pv->state, nd[j].back, nd[j].len);
+			reps_after(pv->reps, nd[j].back, nd[j].reps);
+		}
+		if (!(j == 0 && cached))
+			do_round(e, x, nd[j].reps);
+		const uint32_t rem = e->span_end - x;
+		const uint32_t buf_avail = rem < MATCH_LEN_MAX ? rem : MATCH_LEN_MAX;
+		uint32_t longest = e->m_longest;
+		if (j > 0 && longest >= nice) {
+			/* lzma_encoder_optimum_normal.c:845-849: cut the window here; the long match is
+			 * taken at the start of the next window */
+			next_cached = 1;
+			break;
+		}
+		uint32_t rl[4], rmax = 0;
+		for (uint32_t i = 0; i < 4; ++i) {
+			rl[i] = e->rep_len[i] >= 2 ? e->rep_len[i] : 0;
+			if (rl[i] > rmax) rmax = rl[i];
+		}
+		if (j == 0) {
+			/* helper1 shortcuts (:271-439): a nice-length rep or match is taken at once */
+			for (uint32_t i = 0; i < 4; ++i)
+				if (rl[i] >= nice) {
+					e->q_back[0] = i; e->q_len[0] = rl[i]; e->q_count = 1; e->q_head = 0;
+					return 0;
+				}
+			if (longest >= nice) {
+				e->q_back[0] = e->m_dist[e->m_count - 1] + 4; e->q_len[0] = longest;
+				e->q_count = 1; e->q_head = 0;
+				return 0;
+			}
+		}
+		const uint32_t room = WMAX - j;              /* targets must stay inside the window */
+		if (longest > room) longest = room;
+		for (uint32_t i = 0; i < 4; ++i)
+			if (rl[i] > room) rl[i] = room;
+		if (rmax > room) rmax = room;
+		const uint32_t reach = longest > rmax ? longest : rmax;
+		while (n_end < j + reach || n_end < j + 1)
+			nd[++n_end].price = PRICE_INF;
+		if (buf_avail == 0)
+			break;      /* cannot happen: j < n_end <= span */
+
+		const uint32_t s = nd[j].state, ps = x & pbm, P = nd[j].price;
+		const uint32_t pm1 = P + pr_bit(e, P_IS_MATCH + s * 16 + ps, 1);
+		/* literal */
+		relax(&nd[j + 1], P + pr_bit(e, P_IS_MATCH + s * 16 + ps, 0) + pr_literal(e, x, s, nd[j].reps[0]), LIT, 1);
+		/* short rep */
+		const uint32_t prep = pm1 + pr_bit(e, P_IS_REP + s, 1);
+		if (e->rep_len[0] >= 1)
+			relax(&nd[j + 1], prep + pr_bit(e, P_IS_REP0 + s, 0) + pr_bit(e, P_IS_REP0_LONG + s * 16 + ps, 0), 0, 1);
+		/* reps, every length */
+		for (uint32_t i = 0; i < 4; ++i) {
+			if (rl[i] < 2) continue;
+			uint32_t pure;
+			if (i == 0)
+				pure = pr_bit(e, P_IS_REP0 + s, 0) + pr_bit(e, P_IS_REP0_LONG + s * 16 + ps, 1);
+			else if (i == 1)
+				pure = pr_bit(e, P_IS_REP0 + s, 1) + pr_bit(e, P_IS_REP1 + s, 0);
+			else
+				pure = pr_bit(e, P_IS_REP0 + s, 1) + pr_bit(e, P_IS_REP1 + s, 1) + pr_bit(e, P_IS_REP2 + s, i - 2);
+			for (uint32_t l = 2; l <= rl[i]; ++l)
+				relax(&nd[j + l], prep + pure + e->lp[1][ps & 3][l - 2], i, l);
+		}
+		/* matches, every length: the closest candidate that is long enough */
+		if (longest >= 2) {
+			const uint32_t pmatch = pm1 + pr_bit(e, P_IS_REP + s, 0);
+			uint32_t k = 0;
+			for (uint32_t l = 2; l <= longest; ++l) {
+				while (k + 1 < e->m_count && e->m_len[k] < l)
+					++k;
+				const uint32_t dist = e->m_dist[k];
+				relax(&nd[j + l], pmatch + e->lp[0][ps & 3][l - 2] + tab_dist(e, dist, l < 6 ? l - 2 : 3),
+						dist + 4, l);
+			}
+		}
+		++j;
+		if (j == n_end)
+			break;
+	}
+	/* backtrack from node j */
+	uint32_t cnt = 0, t = j;
+	while (t > 0) {
+		++cnt;
+		t -= nd[t].len;
+	}
+	e->q_count = cnt;
+	e->q_head = 0;
+	t = j;
+	for (uint32_t i = cnt; i-- > 0; ) {
+		e->q_back[i] = nd[t].back;
+		e->q_len[i] = nd[t].len;
+		t -= nd[t].len;
+	}
+	return next_cached;
 }
 
 /* ---- per-span chunk loop: lzma_encoder.c:313-436 + lzma2_encoder.c:135-259 - */
@@ -619,19 +1013,19 @@ static int encode_span(enc *e, uint32_t start, uint32_t end, int first_in_block,
 		uint8_t *out, uint64_t cap, uint64_t *opos)
 {
 	int need_props = 1, need_dict_reset = first_in_block, need_state_reset = 0;
-	uint32_t cur = start;       /* == read_pos - read_ahead */
+	uint32_t cur = start;       /* next position to encode */
+	int cached = 0;             /* round for `cur` already done (read_ahead == 1) */
 	e->span_end = end;
-	e->read_ahead = 0;
+	e->q_count = e->q_head = 0;
 	lzma_state_reset(e);
-	/* catch the match finder up to the span start (Block-global tables) */
-	if (e->mf_pos < start)
-		mf_skip(e, start - e->mf_pos);
 	int initialized = !first_in_block;
 
 	while (cur < end) {
 		/* SEQ_INIT (lzma2_encoder.c:143-162) */
-		if (need_state_reset)
+		if (need_state_reset) {
 			lzma_state_reset(e);
+			e->q_count = e->q_head = 0;
+		}
 		const uint32_t chunk_start = cur;
 		e->cpos = 0;
 
@@ -639,18 +1033,9 @@ static int encode_span(enc *e, uint32_t start, uint32_t end, int first_in_block,
 			/* encode_init (lzma_encoder.c:267-293): first byte of a
 			 * dictionary-reset stream is a literal coded with the
 			 * initial contexts. */
-			mf_skip(e, 1);
 			rc_bit(e, &e->probs[P_IS_MATCH], 0);
 			rc_tree(e, e->probs + P_LITERAL, 8, e->in[0]);
-			if (e->trace) {
-				orc_trace *t = e->trace;
-				if (t->sym && t->sym_count < t->sym_cap) {
-					t->sym[t->sym_count].pos = 0;
-					t->sym[t->sym_count].back = LIT;
-					t->sym[t->sym_count].len = 1;
-				}
-				++t->sym_count;
-			}
+			trace_sym(e, 0, LIT, 1);
 			cur = 1;
 			initialized = 1;
 		}
@@ -660,15 +1045,19 @@ static int encode_span(enc *e, uint32_t start, uint32_t end, int first_in_block,
 			if (cur - chunk_start >= (1u << 21) - MATCH_LEN_MAX
 					|| e->cpos + e->cache_size + 4 >= 65536 - 4097)
 				break;
-			/* lzma_encoder.c:354-360 (finishing) */
-			if (cur >= end && e->read_ahead == 0)
-				break;
 			if (cur >= end)
-				break; /* cannot happen: read_ahead implies cur < end */
+				break;
 			uint32_t back, len;
-			optimum_fast(e, cur, &back, &len);
+			if (e->prm.parser == 0) {
+				cached = optimum_fast(e, cur, cached, &back, &len);
+			} else {
+				if (e->q_head == e->q_count)
+					cached = optimum_window(e, cur, cached);
+				back = e->q_back[e->q_head];
+				len = e->q_len[e->q_head];
+				++e->q_head;
+			}
 			enc_symbol(e, cur, back, len);
-			e->read_ahead -= len;
 			cur += len;
 		}
 		rc_flush(e);
@@ -677,10 +1066,15 @@ static int encode_span(enc *e, uint32_t start, uint32_t end, int first_in_block,
 		const uint32_t csize = e->cpos;
 		uint8_t hdr[6];
 		if (csize >= usize) {
-			/* lzma2_encoder.c:205-214: store raw, incl. the lookahead byte */
-			usize += e->read_ahead;
-			cur += e->read_ahead;
-			e->read_ahead = 0;
+			/* lzma2_encoder.c:205-214: store raw.  Fast parser: incl. the lookahead byte
+			 * (read_ahead).  Optimal parser (ours): pending symbols are dropped and the
+			 * window is re-parsed after the state reset. */
+			if (e->prm.parser == 0 && cached) {
+				usize += 1;
+				cur += 1;
+			}
+			cached = 0;
+			e->q_count = e->q_head = 0;
 			hdr[0] = need_dict_reset ? 1 : 2;
 			need_dict_reset = 0;
 			hdr[1] = (uint8_t)((usize - 1) >> 8);
@@ -728,6 +1122,12 @@ static uint32_t hash_mask_for(uint32_t dict_size, uint32_t hash_bytes)
 	return hs;
 }
 
+static void enc_free(enc *e)
+{
+	if (!e) return;
+	free(e->prev2); free(e->prev3); free(e->son); free(e->son8); free(e->cbuf); free(e->nodes); free(e);
+}
+
 static enc *enc_new(const uint8_t *in, uint32_t n, const orc_enc_params *p)
 {
 	enc *e = (enc *)calloc(1, sizeof(*e));
@@ -740,23 +1140,27 @@ static enc *enc_new(const uint8_t *in, uint32_t n, const orc_enc_params *p)
 	e->depth = p->depth ? p->depth : 4 + e->prm.nice_len / 4; /* lz_encoder.c:359-365 */
 	e->hash_mask = hash_mask_for(p->dict_size, p->mf);
 	e->cyclic_size = p->dict_size + 1;       /* lz_encoder.c:254 */
-	e->head2 = (uint32_t *)calloc(1024, 4);
-	e->head3 = (uint32_t *)calloc(p->mf == 3 ? (size_t)e->hash_mask + 1 : 65536, 4);
-	e->head4 = p->mf == 4 ? (uint32_t *)calloc((size_t)e->hash_mask + 1, 4) : NULL;
+	e->prev2 = (uint32_t *)calloc((size_t)n + 1, 4);
+	e->prev3 = (uint32_t *)calloc((size_t)n + 1, 4);
 	e->son = (uint32_t *)calloc((size_t)n + 1, 4);
+	e->son8 = p->depth2 ? (uint32_t *)calloc((size_t)n + 1, 4) : NULL;
 	e->cbuf = (uint8_t *)malloc(1 << 17);
+	e->nodes = (node *)calloc(WMAX + MATCH_LEN_MAX + 2, sizeof(node));
+	if (!e->prev2 || !e->prev3 || !e->son || (p->depth2 && !e->son8) || !e->cbuf || !e->nodes
+			|| build_links(e)) {
+		enc_free(e);
+		return NULL;
+	}
+	price_table_init(e);
 	return e;
-}
-
-static void enc_free(enc *e)
-{
-	free(e->head2); free(e->head3); free(e->head4); free(e->son); free(e->cbuf); free(e);
 }
 
 int orc_lzma2_encode_block(const uint8_t *in, uint32_t n, const orc_enc_params *p,
 		uint8_t *out, uint64_t cap, uint64_t *out_size, orc_trace *trace)
 {
-	if ((p->mf != 3 && p->mf != 4) || p->lc + p->lp > 4 || p->pb > 4)
+	if ((p->mf != 3 && p->mf != 4) || p->lc + p->lp > 4 || p->pb > 4
+			|| (p->depth2 && (p->mf != 4 || p->depth == 0 || p->depth + p->depth2 > 56))
+			|| p->parser > 1)
 		return -2;
 	enc *e = enc_new(in, n, p);
 	if (!e) return -3;
@@ -783,12 +1187,12 @@ int orc_mf_dump(const uint8_t *in, uint32_t n, const orc_enc_params *p,
 {
 	enc *e = enc_new(in, n, p);
 	if (!e) return -3;
+	static const uint32_t zero_reps[4] = { 0, 0, 0, 0 };
 	for (uint32_t i = 0; i < npos; ++i) {
 		const uint32_t pos = pos_list[i];
-		if (pos < e->mf_pos || pos >= n) { enc_free(e); return -4; }
-		mf_skip(e, pos - e->mf_pos);
+		if (pos >= n || pos == 0) { enc_free(e); return -4; }
 		e->span_end = end_list ? end_list[i] : n;
-		mf_find(e);
+		do_round(e, pos, zero_reps);
 		counts[i] = e->m_count;
 		longest[i] = e->m_longest;
 		for (uint32_t k = 0; k < e->m_count && k < max_pairs; ++k) {

@@ -107,6 +107,9 @@ typedef struct {
 	uint32_t depth;     /* 0 = reference default (4 + nice_len/4) */
 	uint32_t span_size; /* 0 = whole Block is one span (== reference);
 	                       else independent state-reset spans (GPU mode) */
+	uint32_t depth2;    /* 0 = exact HC3/HC4; else HC4+H8 Pareto finder with
+	                       `depth` 4-byte-chain + `depth2` 8-byte-chain candidates */
+	uint32_t parser;    /* 0 = optimum_fast (reference); 1 = windowed optimal parser (ours) */
 } orc_enc_params;
 
 int orc_preset(uint32_t preset, orc_enc_params *p, uint32_t *mode_normal);

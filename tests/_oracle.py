@@ -39,7 +39,8 @@ def _load(path):
 class OrcParams(C.Structure):
     _fields_ = [("dict_size", C.c_uint32), ("lc", C.c_uint32), ("lp", C.c_uint32),
                 ("pb", C.c_uint32), ("nice_len", C.c_uint32), ("mf", C.c_uint32),
-                ("depth", C.c_uint32), ("span_size", C.c_uint32)]
+                ("depth", C.c_uint32), ("span_size", C.c_uint32), ("depth2", C.c_uint32),
+                ("parser", C.c_uint32)]
 
 
 class OrcSymbol(C.Structure):
@@ -344,6 +345,8 @@ def params_for_gpu_options(opts, span_size=None):
     if sp == 0:
         sp = 65536           # XZAMD DEFAULT_SPAN
     p.span_size = 0 if sp == 0xFFFFFFFF else sp
+    p.depth2 = opts.gpu_depth2
+    p.parser = opts.gpu_parser
     return p
 
 

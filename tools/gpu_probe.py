@@ -21,9 +21,15 @@ import xz_amd  # noqa: E402
 import _oracle as o  # noqa: E402
 
 
-def run_case(enc, name, data, preset, block_size, span, trace_on_fail=True):
+def run_case(enc, name, data, preset, block_size, span, trace_on_fail=True, parser=None, depth2=None):
     data = bytes(data)
     opts = xz_amd.preset_options(preset, span_size=span)
+    if parser is not None:
+        opts.gpu_parser = parser
+    if depth2 is not None:
+        opts.gpu_depth2 = depth2
+        if depth2:
+            opts.gpu_depth = min(opts.gpu_depth, 8)
     t = torch.frombuffer(bytearray(data), dtype=torch.uint8).cuda() if data else torch.empty(0, dtype=torch.uint8, device="cuda")
     torch.cuda.synchronize()
     t0 = time.time()
@@ -42,7 +48,7 @@ def run_case(enc, name, data, preset, block_size, span, trace_on_fail=True):
             f"blocks={nb} wall={dt*1e3:.1f}ms enc={st.ms_encode:.2f}ms chains={st.ms_chains:.2f}ms "
             f"crc={st.ms_crc:.2f}ms asm={st.ms_assemble:.2f}ms")
     print(line, flush=True)
-    if span == xz_amd.SPAN_WHOLE_BLOCK and preset <= 3 and o.have_ref() and block_size >= 4096:
+    if span == xz_amd.SPAN_WHOLE_BLOCK and preset <= 3 and parser is None and depth2 is None and o.have_ref() and block_size >= 4096:
         refs = o.ref_encode_mt(data, preset, threads=2, block_size=block_size)
         fr = o.first_diff(got, refs)
         print(f"    vs REAL reference liblzma {o.ref().ref_version().decode()}: "
@@ -96,26 +102,27 @@ def main():
     if not all(results):
         print("EARLY STOP: basic cases failing", flush=True)
         return 1
-    results.append(run_case(enc, "lorem-p0", lorem, 0, 1 << 20, W))
-    results.append(run_case(enc, "lorem-p2", lorem, 2, 1 << 20, W))
-    results.append(run_case(enc, "lorem-p3", lorem, 3, 1 << 20, W))
-    results.append(run_case(enc, "lorem-4blk", lorem, 1, 65536, W))
-    results.append(run_case(enc, "lorem-span16k", lorem, 1, 1 << 20, 16384))
-    results.append(run_case(enc, "lorem-span4k-blk64k", lorem, 1, 65536, 4096))
-    results.append(run_case(enc, "abc", o.corpus_abc(), 1, 1 << 20, W))
-    results.append(run_case(enc, "random", o.corpus_random(), 1, 1 << 20, W))
+    mixed = o.corpus_mixed(400000, 5)
     rng = np.random.default_rng(7)
-    rnd = bytes(rng.integers(0, 256, size=700000, dtype=np.uint8))
-    results.append(run_case(enc, "rnd700k", rnd, 1, 1 << 20, W))
-    results.append(run_case(enc, "rnd700k-span", rnd, 1, 1 << 20, 65536))
-    big = o.corpus_lorem(5 << 20)
-    sandwich = big[:200000] + rnd[:300000] + big[:150000]
-    results.append(run_case(enc, "sandwich", sandwich, 1, 1 << 20, W))
-    results.append(run_case(enc, "sandwich-span", sandwich, 3, 1 << 20, 65536))
-    results.append(run_case(enc, "mixed3M", o.corpus_mixed(3 << 20, 11), 1, 3 << 20, W))
-    results.append(run_case(enc, "mixed3M-p3", o.corpus_mixed(3 << 20, 11), 3, 1 << 20, 65536))
-    results.append(run_case(enc, "lorem5M", big, 1, 3 << 20, W))
-    results.append(run_case(enc, "lorem5M-p6map", big, 6, 24 << 20, 65536))
+    rnd = bytes(rng.integers(0, 256, size=200000, dtype=np.uint8))
+    big = o.corpus_lorem(1 << 20)
+    sandwich = big[:150000] + rnd[:120000] + big[:100000]
+    # new finder (HC4+H8 Pareto) with the fast parser
+    results.append(run_case(enc, "pareto-fast-lorem", lorem, 6, 1 << 20, W, parser=0))
+    results.append(run_case(enc, "pareto-fast-mixed", mixed, 6, 1 << 20, 65536, parser=0))
+    results.append(run_case(enc, "pareto-fast-sandwich", sandwich, 6, 1 << 20, 16384, parser=0))
+    # exact HC4 finder + optimal parser
+    results.append(run_case(enc, "exact-opt-lorem", lorem, 1, 1 << 20, W, parser=1))
+    results.append(run_case(enc, "exact-opt-mixed", mixed, 2, 1 << 20, 65536, parser=1))
+    # preset 6 mapping: Pareto finder + optimal parser
+    results.append(run_case(enc, "p6-lorem-whole", lorem, 6, 1 << 20, W))
+    results.append(run_case(enc, "p6-lorem-span", lorem, 6, 1 << 20, 0))
+    results.append(run_case(enc, "p6-mixed", mixed, 6, 1 << 20, 0))
+    results.append(run_case(enc, "p6-sandwich", sandwich, 6, 200000, 0))
+    results.append(run_case(enc, "p6-rnd", rnd, 6, 1 << 20, 0))
+    results.append(run_case(enc, "p9e-mixed", mixed, 9 | xz_amd.PRESET_EXTREME, 1 << 20, 0))
+    results.append(run_case(enc, "p4-mixed", mixed, 4, 1 << 20, 0))
+    results.append(run_case(enc, "lorem-p3", lorem, 3, 1 << 20, W))
     print("SUMMARY:", sum(results), "/", len(results), "cases OK", flush=True)
 
     # throughput sample

@@ -22,7 +22,7 @@ F_BLOCKS_ONLY = 1
 class LzmaOptions(C.Structure):
     _fields_ = [(n, C.c_uint32) for n in (
         "dict_size", "lc", "lp", "pb", "mode", "nice_len", "mf", "depth",
-        "gpu_mf", "gpu_nice_len", "gpu_depth", "span_size")]
+        "gpu_mf", "gpu_nice_len", "gpu_depth", "span_size", "gpu_depth2", "gpu_parser")]
 
 
 class Stats(C.Structure):

@@ -18,6 +18,8 @@ typedef struct {
 	const uint32_t *sorted_pos;  /* slot -> pos | first_of_bucket << 31 */
 	const uint32_t *prev2;       /* distance to previous position with equal hash2, 0 = none */
 	const uint32_t *prev3;       /* same for hash3 (HC4 only) */
+	const uint32_t *rank8;       /* second chain family (8-byte context), NULL unless depth2 != 0 */
+	const uint32_t *sorted8;
 	uint8_t *scratch;            /* span s writes at scratch + s * span_cap */
 	uint64_t span_cap;
 	uint32_t *span_bytes;        /* out: bytes produced per span */
@@ -30,6 +32,8 @@ typedef struct {
 	uint32_t spans_per_block;
 	uint32_t dict_size, nice_len, depth, hash_bytes;
 	uint32_t lc, lp, pb;
+	uint32_t depth2;             /* 8-byte-chain candidates (0 = exact HC3/HC4 finder) */
+	uint32_t parser;             /* 0 = optimum_fast, 1 = windowed optimal parser */
 } xzamd_span_args;
 
 /* One gather segment of the final assembly. kind 0: src is an offset into the span scratch,
@@ -47,7 +51,8 @@ int xzk_build_chains(const uint8_t *d_in, uint32_t n, uint32_t block_size, uint3
 		uint32_t hash_bytes, uint32_t hash_mask, uint32_t hash_bits,
 		uint32_t *keys_a, uint32_t *keys_b, uint32_t *vals_a, uint32_t *vals_b,
 		void *sort_tmp, uint64_t sort_tmp_bytes,
-		uint32_t *rank, uint32_t *sorted_pos, uint32_t *prev2, uint32_t *prev3, void *stream);
+		uint32_t *rank, uint32_t *sorted_pos, uint32_t *prev2, uint32_t *prev3,
+		uint32_t *rank8, uint32_t *sorted8, void *stream);
 int xzk_span_encode(const xzamd_span_args *a, uint32_t nspans, void *stream);
 int xzk_crc64_blocks(const uint8_t *d_in, uint32_t n, uint32_t block_size, uint32_t nblocks,
 		uint32_t strip, uint64_t *d_strip_crc, uint64_t *d_block_crc, void *stream);

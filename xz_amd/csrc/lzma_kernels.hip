@@ -39,6 +39,7 @@ namespace {
 constexpr uint32_t MATCH_LEN_MAX = 273;
 constexpr uint32_t LITERAL = 0xFFFFFFFFu;
 constexpr uint32_t NO_DELTA = 0xFFFFFFFFu;
+constexpr uint32_t H8_BITS_K = 22;      // key bits of the 8-byte-context chain family
 
 // Probability model layout (u16 each), 7990 entries at lc+lp<=... we size for lc+lp <= 3
 // (8 literal coders = 6144) which covers every preset (lc=3, lp=0).  Same order as the oracle.
@@ -89,18 +90,23 @@ __global__ __launch_bounds__(256) void k_hash_keys(const uint8_t* __restrict__ i
     __shared__ uint32_t T[256];
     T[threadIdx.x] = crc_t0(threadIdx.x);
     __syncthreads();
-    const uint32_t kbits = which == 2 ? 10u : (which == 3 ? 16u : hash_bits);
+    const uint32_t kbits = which == 2 ? 10u : (which == 3 ? 16u : (which == 8 ? H8_BITS_K : hash_bits));
+    const uint32_t need = which == 8 ? 8u : hash_bytes;
     const uint32_t stride = gridDim.x * blockDim.x;
     for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < n; g += stride) {
         const uint32_t b = g / block_size;
         const uint32_t bend = min(n, (b + 1) * block_size);   // n < 2^31, no overflow
         const uint32_t avail = bend - g;
         uint32_t key = nblocks << kbits;
-        if (avail >= hash_bytes) {
+        if (avail >= need) {
             const uint32_t c0 = in[g], c1 = in[g + 1], c2 = in[g + 2];
             const uint32_t temp = T[c0] ^ c1;
             uint32_t h;
-            if (which == 2) h = temp & 0x3FF;
+            if (which == 8) {
+                uint64_t v;
+                __builtin_memcpy(&v, in + g, 8);
+                h = (uint32_t)((v * 0x9E3779B185EBCA87ull) >> (64 - H8_BITS_K));
+            } else if (which == 2) h = temp & 0x3FF;
             else if (which == 3) h = (temp ^ (c2 << 8)) & 0xFFFF;
             else if (hash_bytes == 3) h = (temp ^ (c2 << 8)) & hash_mask;
             else h = (temp ^ (c2 << 8) ^ (T[in[g + 3]] << 5)) & hash_mask;
@@ -287,7 +293,10 @@ struct Env {
     const uint32_t* __restrict__ sorted_pos;
     const uint32_t* __restrict__ prev2;
     const uint32_t* __restrict__ prev3;
+    const uint32_t* __restrict__ rank8;        // second chain family (8-byte context), PARETO only
+    const uint32_t* __restrict__ sorted8;
     uint32_t nice, depth, hb, cyclic;
+    uint32_t depth2, block_end;
 };
 
 __device__ __forceinline__ void do_round(const Env& e, uint32_t x, uint32_t end,
@@ -374,6 +383,7 @@ struct Lz {
     uint32_t state;
     uint32_t rep0, rep1, rep2, rep3;
     uint32_t lc, lp, pb;
+    uint32_t cnt_len, cnt_match, cnt_align;   // coded lengths / matches / align-coded matches since refresh
 };
 
 __device__ __forceinline__ uint32_t dist_slot_of(uint32_t d)
@@ -465,6 +475,7 @@ __device__ __forceinline__ void encode_symbol(RC& rc, uint16_t* probs, Lz& z, co
         } else {
             enc_length(rc, probs, P_REP_LEN, ps, len);
             z.state = z.state < 7 ? 8 : 11;
+            ++z.cnt_len;
         }
         return;
     }
@@ -472,6 +483,8 @@ __device__ __forceinline__ void encode_symbol(RC& rc, uint16_t* probs, Lz& z, co
     const uint32_t dist = back - 4;
     z.state = z.state < 7 ? 7 : 10;
     enc_length(rc, probs, P_MATCH_LEN, ps, len);
+    ++z.cnt_len;
+    ++z.cnt_match;
     const uint32_t slot = dist_slot_of(dist);
     const uint32_t ds = len < 6 ? len - 2 : 3;
     rc.tree(probs, P_DIST_SLOT + ds * 64, 6, slot);
@@ -484,6 +497,7 @@ __device__ __forceinline__ void encode_symbol(RC& rc, uint16_t* probs, Lz& z, co
         } else {
             rc.direct(red >> 4, fb - 4);
             rc.tree_rev(probs, P_DIST_ALIGN, 4, red & 15);
+            ++z.cnt_align;
         }
     }
     z.rep3 = z.rep2; z.rep2 = z.rep1; z.rep1 = z.rep0; z.rep0 = dist;
@@ -495,9 +509,537 @@ __device__ __forceinline__ bool change_pair(uint32_t small_dist, uint32_t big_di
 }
 
 // ------------------------------------------------------------------------------------------
-// Span encoder: one wavefront per span.
+// Second-generation match finder ("HC4+H8", the GPU successor of BT4) and the windowed optimal
+// parser.  Semantics are defined by oracle/lzma_fast_enc.c (find_pareto / optimum_window); the
+// code below is their wave-parallel form and must stay bit-exact with them.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_span_encode(xzamd_span_args a)
+constexpr uint32_t WMAX = 256;            // optimal-parser window: nodes 0..WMAX
+constexpr uint32_t PRICE_INF = 1u << 30;
+constexpr uint32_t H8_BITS = 22;
+
+__device__ __forceinline__ uint32_t wave_max(uint32_t v)
+{
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) v = max(v, (uint32_t)__shfl_xor(v, s));
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v)
+{
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) v += (uint32_t)__shfl_xor(v, s);
+    return v;
+}
+
+// Per-wave LDS carve for the list-based paths.
+struct Work {
+    uint32_t* ml;       // [64] kept matches, ascending length (== ascending distance)
+    uint32_t* md;       // [64] zero-based distances
+    // optimal parser only
+    uint32_t* n_price;  // [WMAX+1] node price; after backtracking: out-edge `back`
+    uint32_t* n_back;   // [WMAX+1] in-edge back
+    uint32_t* n_info;   // [WMAX+1] in-len (9) | state (4) << 9 | out-len (9) << 13
+    uint32_t* n_reps;   // [(WMAX+1)*4]
+    uint16_t* dsp;      // [4*64]  dist-slot price (+ direct bits for slot >= 14)
+    uint16_t* dp;       // [4*128] full price of distances < 128
+    uint16_t* ap;       // [16]    align price
+    uint8_t* ptab;      // [128]   bit price table (price_tablegen.c:31-58)
+};
+
+struct RoundL {
+    uint32_t L;         // per lane; lanes 60..63 = rep lengths
+    uint32_t cnt;       // entries in Work::ml/md
+    uint32_t longest;   // incl. the > nice_len extension
+};
+
+// Compact the exact finder's recorded lanes into the LDS list (already in ascending order).
+__device__ __forceinline__ void list_from_mask(const Work& w, const Round& R, RoundL& out)
+{
+    const uint32_t lane = threadIdx.x;
+    const uint64_t lt = (1ull << lane) - 1;
+    if ((R.mask >> lane) & 1) {
+        const uint32_t idx = (uint32_t)__builtin_popcountll(R.mask & lt);
+        w.ml[idx] = R.L;
+        w.md[idx] = R.D;
+    }
+    __builtin_amdgcn_wave_barrier();
+    out.L = R.L;
+    out.cnt = (uint32_t)__builtin_popcountll(R.mask);
+    out.longest = R.longest;
+}
+
+// find_pareto(): lanes 0 = hash2, 1 = hash3, 2 = own slot of the 4-byte chain, 3..2+d4 = 4-byte
+// chain, A = 3+d4 = own slot of the 8-byte chain, A+1..A+d8 = 8-byte chain, 60..63 = reps.
+__device__ __forceinline__ void do_round_pareto(const Env& e, const Work& w, uint32_t x, uint32_t end,
+        uint32_t r0, uint32_t r1, uint32_t r2, uint32_t r3, RoundL& R)
+{
+    const uint32_t lane = threadIdx.x;
+    const uint32_t avail = end - x;
+    const uint32_t buf_avail = avail < MATCH_LEN_MAX ? avail : MATCH_LEN_MAX;
+    uint32_t len_limit = avail;
+    bool mf_ok = true;
+    if (e.nice <= len_limit) len_limit = e.nice;
+    else if (len_limit < 4) mf_ok = false;
+
+    const uint32_t d4 = e.depth, d8 = e.depth2, A = 3 + d4;
+    uint32_t q = 0, lim = 0, minlen = 4;
+    bool valid = false;
+    if (mf_ok) {
+        const uint32_t rk4 = e.rank[x];
+        const uint32_t d2 = e.prev2[x];
+        const uint32_t d3 = e.prev3[x];
+        const bool have8 = e.block_end - x >= 8;
+        const uint32_t rk8 = have8 ? e.rank8[x] : 0;
+        if (lane == 0) {
+            minlen = 2;
+            if (d2 != 0 && d2 < e.cyclic) { q = x - d2; lim = len_limit; valid = true; }
+        } else if (lane == 1) {
+            minlen = 3;
+            if (d3 != 0 && d3 != d2 && d3 < e.cyclic) { q = x - d3; lim = len_limit; valid = true; }
+        }
+        const bool in4 = lane >= 2 && lane <= 2 + d4;
+        const bool in8 = have8 && lane >= A && lane <= A + d8;
+        uint32_t ent = 0x80000000u;
+        if (in4 && rk4 >= lane - 2) ent = e.sorted_pos[rk4 - (lane - 2)];
+        if (in8 && rk8 >= lane - A) ent = e.sorted8[rk8 - (lane - A)];
+        const uint64_t fl = __ballot((in4 || in8) && (ent >> 31));
+        const uint64_t flags4 = fl >> 2, flags8 = fl >> A;
+        const uint32_t qp = ent & 0x7FFFFFFFu;
+        if (in4 && lane >= 3) {
+            const uint32_t j = lane - 2;
+            if ((flags4 & ((1ull << j) - 1)) == 0 && x - qp < e.cyclic) { valid = true; q = qp; lim = len_limit; }
+        }
+        if (in8 && lane > A) {
+            const uint32_t j = lane - A;
+            if ((flags8 & ((1ull << j) - 1)) == 0 && x - qp < e.cyclic) { valid = true; q = qp; lim = len_limit; }
+        }
+    }
+    if (lane >= 60) {
+        const uint32_t rep = lane == 60 ? r0 : lane == 61 ? r1 : lane == 62 ? r2 : r3;
+        q = x - rep - 1;
+        lim = buf_avail;
+    }
+    const uint32_t L = lane_cmplen(e.in, q, x, lim);
+    R.L = L;
+    R.cnt = 0;
+    R.longest = 0;
+    if (!mf_ok) return;
+
+    const uint32_t dist = x - q;                        // delta (>= 1) for candidate lanes
+    const bool elig = valid && lane < 60 && L >= minlen;
+    const uint32_t Le = elig ? L : 0;
+    // within the 8-byte chain distances ascend strictly: exclusive prefix max
+    const bool lane8 = lane > A && lane <= A + d8;
+    const uint32_t P8 = prefix_max_incl(lane8 ? Le : 0);
+    uint32_t m = 0;
+    if (lane8) m = __shfl_up(P8, 1);                    // lane A holds 0
+    const uint64_t valid8 = __ballot(lane8 && valid);
+    // small set S = hash2, hash3, 4-byte chain: all-pairs against everybody
+    for (uint32_t s = 0; s <= 2 + d4; ++s) {
+        if (s == 2) continue;
+        const uint32_t Ls = lane_of(Le, s);
+        const uint32_t ds = lane_of(dist, s);
+        if (Ls != 0 && lane != s && (ds < dist || (ds == dist && s < lane)) && Ls > m) m = Ls;
+        // what the 8-byte chain contributes to s: its entries closer than s form a prefix
+        const uint32_t k = (uint32_t)__builtin_popcountll(__ballot(lane8 && valid && dist < ds) & valid8);
+        const uint32_t v = k ? lane_of(P8, A + k) : 0;
+        if (lane == s && v > m) m = v;
+    }
+    const bool keep = elig && L > m;
+    const uint64_t kmask = __ballot(keep);
+    const uint32_t cnt = (uint32_t)__builtin_popcountll(kmask);
+    R.cnt = cnt;
+    if (cnt == 0) return;
+    // rank by length (strictly increasing with distance among kept entries)
+    uint32_t rk = 0;
+    for (uint64_t mm = kmask; mm; mm &= mm - 1) {
+        const uint32_t k = (uint32_t)__builtin_ctzll(mm);
+        const uint32_t Lk = lane_of(L, k);
+        rk += (Lk < L) ? 1u : 0u;
+    }
+    if (keep) { w.ml[rk] = L; w.md[rk] = dist - 1; }
+    __builtin_amdgcn_wave_barrier();
+    uint32_t longest = uni(w.ml[cnt - 1]);
+    if (longest == e.nice) {
+        const uint32_t dd = uni(w.md[cnt - 1]);
+        longest = wave_cmplen(e.in, x, x - dd - 1, longest, buf_avail);
+    }
+    R.longest = longest;
+}
+
+// ---- prices (rangecoder/price.h:28-92) ------------------------------------------------------
+__device__ __forceinline__ uint32_t pr_bit(const uint16_t* probs, const uint8_t* ptab, uint32_t idx, uint32_t bit)
+{
+    return ptab[(probs[idx] ^ ((0u - bit) & 0x7FFu)) >> 4];
+}
+__device__ __forceinline__ uint32_t pr_tree(const uint16_t* probs, const uint8_t* ptab, uint32_t base,
+        uint32_t nbits, uint32_t sym)
+{
+    uint32_t price = 0;
+    sym += 1u << nbits;
+    do {
+        const uint32_t bit = sym & 1;
+        sym >>= 1;
+        price += pr_bit(probs, ptab, base + sym, bit);
+    } while (sym != 1);
+    return price;
+}
+__device__ __forceinline__ uint32_t pr_tree_rev(const uint16_t* probs, const uint8_t* ptab, uint32_t base,
+        uint32_t nbits, uint32_t sym)
+{
+    uint32_t price = 0, m = 1;
+    do {
+        const uint32_t bit = sym & 1;
+        sym >>= 1;
+        price += pr_bit(probs, ptab, base + m, bit);
+        m = (m << 1) + bit;
+    } while (--nbits);
+    return price;
+}
+__device__ __forceinline__ uint32_t pr_len(const uint16_t* probs, const uint8_t* ptab, uint32_t base,
+        uint32_t ps, uint32_t len)
+{
+    len -= 2;
+    if (len < 8)
+        return pr_bit(probs, ptab, base + LEN_CHOICE, 0) + pr_tree(probs, ptab, base + LEN_LOW + ps * 8, 3, len);
+    len -= 8;
+    if (len < 8)
+        return pr_bit(probs, ptab, base + LEN_CHOICE, 1) + pr_bit(probs, ptab, base + LEN_CHOICE2, 0)
+                + pr_tree(probs, ptab, base + LEN_MID + ps * 8, 3, len);
+    return pr_bit(probs, ptab, base + LEN_CHOICE, 1) + pr_bit(probs, ptab, base + LEN_CHOICE2, 1)
+            + pr_tree(probs, ptab, base + LEN_HIGH, 8, len - 8);
+}
+__device__ __forceinline__ uint32_t pr_dist_full(const uint16_t* probs, const uint8_t* ptab, uint32_t dist, uint32_t ds)
+{
+    const uint32_t slot = dist_slot_of(dist);
+    uint32_t price = pr_tree(probs, ptab, P_DIST_SLOT + ds * 64, 6, slot);
+    if (slot >= 4) {
+        const uint32_t fb = (slot >> 1) - 1;
+        const uint32_t base = (2 | (slot & 1)) << fb;
+        const uint32_t red = dist - base;
+        if (slot < 14) price += pr_tree_rev(probs, ptab, P_DIST_SPECIAL + base - slot - 1, fb, red);
+        else price += ((fb - 4) << 4) + pr_tree_rev(probs, ptab, P_DIST_ALIGN, 4, red & 15);
+    }
+    return price;
+}
+
+// Length price tables live in registers: lane holds lengths 2 + lane + 64*it, it = 0..4;
+// low 16 bits = match length coder, high 16 = rep length coder.
+struct LenTab { uint32_t v[4][5]; };
+
+__device__ __forceinline__ void refresh_len_tables(const uint16_t* probs, const uint8_t* ptab, LenTab& t, uint32_t nps)
+{
+    const uint32_t lane = threadIdx.x;
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) {
+#pragma unroll
+        for (int it = 0; it < 5; ++it) {
+            const uint32_t len = 2 + lane + 64u * it;
+            uint32_t pm = 0, prr = 0;
+            if (len <= MATCH_LEN_MAX && (uint32_t)ps < nps) {
+                pm = pr_len(probs, ptab, P_MATCH_LEN, ps, len);
+                prr = pr_len(probs, ptab, P_REP_LEN, ps, len);
+            }
+            t.v[ps][it] = pm | (prr << 16);
+        }
+    }
+}
+
+__device__ __forceinline__ void refresh_dist_tables(const uint16_t* probs, const Work& w)
+{
+    const uint32_t lane = threadIdx.x;
+    for (uint32_t i = lane; i < 256; i += 64) {
+        const uint32_t ds = i >> 6, slot = i & 63;
+        uint32_t pr = pr_tree(probs, w.ptab, P_DIST_SLOT + ds * 64, 6, slot);
+        if (slot >= 14) pr += (((slot >> 1) - 1) - 4) << 4;
+        w.dsp[i] = (uint16_t)pr;
+    }
+    for (uint32_t i = lane; i < 512; i += 64)
+        w.dp[i] = (uint16_t)pr_dist_full(probs, w.ptab, i & 127, i >> 7);
+    __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ void refresh_align_table(const uint16_t* probs, const Work& w)
+{
+    const uint32_t lane = threadIdx.x;
+    if (lane < 16) w.ap[lane] = (uint16_t)pr_tree_rev(probs, w.ptab, P_DIST_ALIGN, 4, lane);
+    __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ uint32_t tab_dist(const Work& w, uint32_t dist, uint32_t ds)
+{
+    if (dist < 128) return w.dp[ds * 128 + dist];
+    return (uint32_t)w.dsp[ds * 64 + dist_slot_of(dist)] + w.ap[dist & 15];
+}
+
+// literal price, 8 bits evaluated by lanes 0..7 (get_literal_price, optimum_normal.c:21-53)
+__device__ __forceinline__ uint32_t pr_literal_wave(const uint16_t* probs, const uint8_t* ptab, const Lz& z,
+        const uint8_t* __restrict__ in, uint32_t g, uint32_t upos, uint32_t state, uint32_t rep0)
+{
+    const uint32_t lane = threadIdx.x;
+    const uint32_t cur = uni(in[g]);
+    const uint32_t prev = upos ? uni(in[g - 1]) : 0;
+    const uint32_t mask = (0x100u << z.lp) - (0x100u >> z.lc);
+    const uint32_t sub = P_LITERAL + 3u * ((((upos << 8) + prev) & mask) << z.lc);
+    uint32_t p = 0;
+    if (lane < 8) {
+        const uint32_t k = lane;                         // bit number, MSB first
+        const uint32_t bit = (cur >> (7 - k)) & 1;
+        const uint32_t pre = (0x100u | cur) >> (8 - k);  // 1 followed by the k bits already coded
+        uint32_t idx = pre;
+        if (state >= 7) {
+            const uint32_t mb = uni(in[g - rep0 - 1]);
+            const bool same = (mb >> (8 - k)) == (cur >> (8 - k));   // k leading bits equal
+            if (same) idx = 0x100 + (((mb >> (7 - k)) & 1) << 8) + pre;
+        }
+        p = pr_bit(probs, ptab, sub + idx, bit);
+    }
+    return wave_sum(p);
+}
+
+__device__ __forceinline__ uint32_t state_after(uint32_t s, uint32_t back, uint32_t len)
+{
+    if (back == LITERAL) return s <= 3 ? 0 : (s <= 9 ? s - 3 : s - 6);
+    if (back < 4) return len == 1 ? (s < 7 ? 9u : 11u) : (s < 7 ? 8u : 11u);
+    return s < 7 ? 7u : 10u;
+}
+
+// Relax all rep / match lengths out of node j (lane = length). PS is the compile-time pos_state.
+template <int PS>
+__device__ __forceinline__ void relax_lengths(const Work& w, const LenTab& lt, uint32_t j, uint32_t reach,
+        uint32_t longest, uint32_t cnt, uint32_t rl0, uint32_t rl1, uint32_t rl2, uint32_t rl3,
+        uint32_t prep0, uint32_t prep1, uint32_t prep2, uint32_t prep3, uint32_t pmatch)
+{
+    const uint32_t lane = threadIdx.x;
+#pragma unroll
+    for (int it = 0; it < 5; ++it) {
+        if (2 + 64u * it > reach) break;
+        const uint32_t l = 2 + lane + 64u * it;
+        if (l <= reach) {
+            const uint32_t lpm = lt.v[PS][it] & 0xFFFFu, lpr = lt.v[PS][it] >> 16;
+            uint32_t best = w.n_price[j + l], bb = 0;
+            bool upd = false;
+            if (rl0 >= l && prep0 + lpr < best) { best = prep0 + lpr; bb = 0; upd = true; }
+            if (rl1 >= l && prep1 + lpr < best) { best = prep1 + lpr; bb = 1; upd = true; }
+            if (rl2 >= l && prep2 + lpr < best) { best = prep2 + lpr; bb = 2; upd = true; }
+            if (rl3 >= l && prep3 + lpr < best) { best = prep3 + lpr; bb = 3; upd = true; }
+            if (l <= longest) {
+                uint32_t idx = 0;
+                for (uint32_t k = 0; k + 1 < cnt; ++k) idx += (uni(w.ml[k]) < l) ? 1u : 0u;
+                const uint32_t dist = w.md[idx];
+                const uint32_t pr = pmatch + lpm + tab_dist(w, dist, l < 6 ? l - 2 : 3);
+                if (pr < best) { best = pr; bb = dist + 4; upd = true; }
+            }
+            if (upd) {
+                w.n_price[j + l] = best;
+                w.n_back[j + l] = bb;
+                w.n_info[j + l] = l;
+            }
+        }
+    }
+}
+
+// One window of the optimal parser (oracle: optimum_window).  Returns with the chosen symbol path
+// stored as out-edges: node t -> (n_price[t] = back, out-len in n_info[t]); q_end = last node.
+template <bool PARETO>
+__device__ __forceinline__ bool optimum_window(const Env& e, const Work& w, uint16_t* probs, const Lz& z, LenTab& lt,
+        const uint8_t* __restrict__ in, uint32_t pos, uint32_t block_start, uint32_t span_end, bool cached,
+        RoundL& RL, uint32_t& q_end)
+{
+    const uint32_t lane = threadIdx.x;
+    const uint32_t pbm = (1u << z.pb) - 1;
+    if (lane == 0) {
+        w.n_price[0] = 0;
+        w.n_info[0] = z.state << 9;
+        w.n_reps[0] = z.rep0; w.n_reps[1] = z.rep1; w.n_reps[2] = z.rep2; w.n_reps[3] = z.rep3;
+    }
+    __builtin_amdgcn_wave_barrier();
+    uint32_t n_end = 0, j = 0;
+    bool next_cached = false;
+    for (;;) {
+        const uint32_t x = pos + j;
+        uint32_t s, r0, r1, r2, r3;
+        if (j > 0) {
+            const uint32_t info = uni(w.n_info[j]);
+            const uint32_t ilen = info & 0x1FF;
+            const uint32_t bk = uni(w.n_back[j]);
+            const uint32_t pv = j - ilen;
+            const uint32_t ps_ = (uni(w.n_info[pv]) >> 9) & 15;
+            const uint32_t a0 = uni(w.n_reps[pv * 4]), a1 = uni(w.n_reps[pv * 4 + 1]);
+            const uint32_t a2 = uni(w.n_reps[pv * 4 + 2]), a3 = uni(w.n_reps[pv * 4 + 3]);
+            s = state_after(ps_, bk, ilen);
+            if (bk == LITERAL || bk == 0) { r0 = a0; r1 = a1; r2 = a2; r3 = a3; }
+            else if (bk == 1) { r0 = a1; r1 = a0; r2 = a2; r3 = a3; }
+            else if (bk == 2) { r0 = a2; r1 = a0; r2 = a1; r3 = a3; }
+            else if (bk == 3) { r0 = a3; r1 = a0; r2 = a1; r3 = a2; }
+            else { r0 = bk - 4; r1 = a0; r2 = a1; r3 = a2; }
+            if (lane == 0) {
+                w.n_info[j] = ilen | (s << 9);
+                w.n_reps[j * 4] = r0; w.n_reps[j * 4 + 1] = r1; w.n_reps[j * 4 + 2] = r2; w.n_reps[j * 4 + 3] = r3;
+            }
+            __builtin_amdgcn_wave_barrier();
+        } else {
+            s = z.state; r0 = z.rep0; r1 = z.rep1; r2 = z.rep2; r3 = z.rep3;
+        }
+        if (!(j == 0 && cached)) {
+            if constexpr (PARETO) {
+                do_round_pareto(e, w, x, span_end, r0, r1, r2, r3, RL);
+            } else {
+                Round R;
+                do_round(e, x, span_end, r0, r1, r2, r3, R);
+                list_from_mask(w, R, RL);
+            }
+        }
+        uint32_t longest = RL.longest;
+        if (j > 0 && longest >= e.nice) { next_cached = true; break; }
+        const uint32_t rp0 = lane_of(RL.L, 60), rp1 = lane_of(RL.L, 61), rp2 = lane_of(RL.L, 62), rp3 = lane_of(RL.L, 63);
+        uint32_t rl0 = rp0 >= 2 ? rp0 : 0, rl1 = rp1 >= 2 ? rp1 : 0, rl2 = rp2 >= 2 ? rp2 : 0, rl3 = rp3 >= 2 ? rp3 : 0;
+        if (j == 0) {
+            uint32_t sb = LITERAL, sl = 0;
+            if (rl0 >= e.nice) { sb = 0; sl = rl0; }
+            else if (rl1 >= e.nice) { sb = 1; sl = rl1; }
+            else if (rl2 >= e.nice) { sb = 2; sl = rl2; }
+            else if (rl3 >= e.nice) { sb = 3; sl = rl3; }
+            else if (longest >= e.nice) { sb = uni(w.md[RL.cnt - 1]) + 4; sl = longest; }
+            if (sl) {
+                if (lane == 0) { w.n_price[0] = sb; w.n_info[0] = (w.n_info[0] & 0x1FFF) | (sl << 13); }
+                __builtin_amdgcn_wave_barrier();
+                q_end = sl;
+                return false;
+            }
+        }
+        const uint32_t room = WMAX - j;
+        if (longest > room) longest = room;
+        if (rl0 > room) rl0 = room;
+        if (rl1 > room) rl1 = room;
+        if (rl2 > room) rl2 = room;
+        if (rl3 > room) rl3 = room;
+        const uint32_t rmax = max(max(rl0, rl1), max(rl2, rl3));
+        const uint32_t reach = max(longest, rmax);
+        const uint32_t new_end = max(max(n_end, j + reach), j + 1);
+        for (uint32_t t = n_end + 1 + lane; t <= new_end; t += 64) w.n_price[t] = PRICE_INF;
+        n_end = new_end;
+        __builtin_amdgcn_wave_barrier();
+
+        const uint32_t upos = x - block_start;
+        const uint32_t ps = upos & pbm;
+        const uint32_t P = uni(w.n_price[j]);
+        const uint32_t pm1 = P + pr_bit(probs, w.ptab, P_IS_MATCH + s * 16 + ps, 1);
+        const uint32_t prep = pm1 + pr_bit(probs, w.ptab, P_IS_REP + s, 1);
+        // literal and short rep -> node j+1
+        {
+            const uint32_t plit = P + pr_bit(probs, w.ptab, P_IS_MATCH + s * 16 + ps, 0)
+                    + pr_literal_wave(probs, w.ptab, z, in, x, upos, s, r0);
+            uint32_t best = uni(w.n_price[j + 1]), bb = 0;
+            bool upd = false;
+            if (plit < best) { best = plit; bb = LITERAL; upd = true; }
+            if (rp0 >= 1) {
+                const uint32_t psr = prep + pr_bit(probs, w.ptab, P_IS_REP0 + s, 0)
+                        + pr_bit(probs, w.ptab, P_IS_REP0_LONG + s * 16 + ps, 0);
+                if (psr < best) { best = psr; bb = 0; upd = true; }
+            }
+            if (upd && lane == 0) { w.n_price[j + 1] = best; w.n_back[j + 1] = bb; w.n_info[j + 1] = 1; }
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (reach >= 2) {
+            const uint32_t b0 = pr_bit(probs, w.ptab, P_IS_REP0 + s, 0), b1 = pr_bit(probs, w.ptab, P_IS_REP0 + s, 1);
+            const uint32_t prep0 = prep + b0 + pr_bit(probs, w.ptab, P_IS_REP0_LONG + s * 16 + ps, 1);
+            const uint32_t prep1 = prep + b1 + pr_bit(probs, w.ptab, P_IS_REP1 + s, 0);
+            const uint32_t p11 = prep + b1 + pr_bit(probs, w.ptab, P_IS_REP1 + s, 1);
+            const uint32_t prep2 = p11 + pr_bit(probs, w.ptab, P_IS_REP2 + s, 0);
+            const uint32_t prep3 = p11 + pr_bit(probs, w.ptab, P_IS_REP2 + s, 1);
+            const uint32_t pmatch = pm1 + pr_bit(probs, w.ptab, P_IS_REP + s, 0);
+            switch (ps & 3) {
+            case 0: relax_lengths<0>(w, lt, j, reach, longest, RL.cnt, rl0, rl1, rl2, rl3, prep0, prep1, prep2, prep3, pmatch); break;
+            case 1: relax_lengths<1>(w, lt, j, reach, longest, RL.cnt, rl0, rl1, rl2, rl3, prep0, prep1, prep2, prep3, pmatch); break;
+            case 2: relax_lengths<2>(w, lt, j, reach, longest, RL.cnt, rl0, rl1, rl2, rl3, prep0, prep1, prep2, prep3, pmatch); break;
+            default: relax_lengths<3>(w, lt, j, reach, longest, RL.cnt, rl0, rl1, rl2, rl3, prep0, prep1, prep2, prep3, pmatch); break;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        ++j;
+        if (j == n_end) break;
+    }
+    // backtrack from node j: turn in-edges into out-edges
+    if (lane == 0) {
+        uint32_t t = j;
+        while (t > 0) {
+            const uint32_t ilen = w.n_info[t] & 0x1FF;
+            const uint32_t bk = w.n_back[t];
+            const uint32_t pv = t - ilen;
+            w.n_price[pv] = bk;
+            w.n_info[pv] = (w.n_info[pv] & 0x1FFF) | (ilen << 13);
+            t = pv;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    q_end = j;
+    return next_cached;
+}
+
+// optimum_fast over the LDS match list (oracle: optimum_fast()).  Returns `cached`.
+template <bool PARETO>
+__device__ __forceinline__ bool fast_parse_list(const Env& e, const Work& w, const Lz& z, uint32_t cur,
+        uint32_t span_end, bool cached, RoundL& RL, uint32_t& back, uint32_t& len)
+{
+    if (!cached) {
+        if constexpr (PARETO) do_round_pareto(e, w, cur, span_end, z.rep0, z.rep1, z.rep2, z.rep3, RL);
+    }
+    back = LITERAL; len = 1;
+    const uint32_t rem = span_end - cur;
+    const uint32_t buf_avail = rem < MATCH_LEN_MAX ? rem : MATCH_LEN_MAX;
+    uint32_t len_main = RL.longest;
+    uint32_t count = RL.cnt;
+    if (buf_avail < 2) return false;
+    uint32_t rep_len = 0, rep_index = 0;
+    for (uint32_t i = 0; i < 4; ++i) {
+        const uint32_t rl = lane_of(RL.L, 60 + i);
+        if (rl < 2) continue;
+        if (rl >= e.nice) { back = i; len = rl; return false; }
+        if (rl > rep_len) { rep_index = i; rep_len = rl; }
+    }
+    if (len_main >= e.nice) { back = uni(w.md[count - 1]) + 4; len = len_main; return false; }
+    uint32_t back_main = 0;
+    if (len_main >= 2) {
+        back_main = uni(w.md[count - 1]);
+        while (count > 1) {
+            const uint32_t l2 = uni(w.ml[count - 2]);
+            if (len_main != l2 + 1) break;
+            const uint32_t d2 = uni(w.md[count - 2]);
+            if (!change_pair(d2, back_main)) break;
+            --count; len_main = l2; back_main = d2;
+        }
+        if (len_main == 2 && back_main >= 0x80) len_main = 1;
+    }
+    if (rep_len >= 2) {
+        if (rep_len + 1 >= len_main || (rep_len + 2 >= len_main && back_main > (1u << 9))
+                || (rep_len + 3 >= len_main && back_main > (1u << 15))) {
+            back = rep_index; len = rep_len;
+            return false;
+        }
+    }
+    if (len_main < 2 || buf_avail <= 2) return false;
+    if constexpr (PARETO) do_round_pareto(e, w, cur + 1, span_end, z.rep0, z.rep1, z.rep2, z.rep3, RL);
+    const uint32_t nl = RL.longest;
+    if (nl >= 2) {
+        const uint32_t new_dist = uni(w.md[RL.cnt - 1]);
+        if ((nl >= len_main && new_dist < back_main) || (nl == len_main + 1 && !change_pair(back_main, new_dist))
+                || (nl > len_main + 1) || (nl + 1 >= len_main && len_main >= 3 && change_pair(new_dist, back_main)))
+            return true;
+    }
+    const uint32_t limit = len_main - 1 > 2 ? len_main - 1 : 2;
+    for (uint32_t i = 0; i < 4; ++i)
+        if (lane_of(RL.L, 60 + i) >= limit) return true;
+    back = back_main + 4;
+    len = len_main;
+    return false;
+}
+
+// ------------------------------------------------------------------------------------------
+// Span encoder: one wavefront per span.  PARETO selects the match finder (false = exact HC3/HC4
+// of the reference), OPT the parser (false = optimum_fast of the reference).
+// ------------------------------------------------------------------------------------------
+template <bool PARETO, bool OPT>
+__global__ __launch_bounds__(64) void k_span_encode_t(xzamd_span_args a)
 {
     __shared__ uint16_t probs[8192];
     const uint32_t lane = threadIdx.x;
@@ -517,20 +1059,59 @@ __global__ __launch_bounds__(64) void k_span_encode(xzamd_span_args a)
 
     Env e;
     e.in = in; e.rank = a.rank; e.sorted_pos = a.sorted_pos; e.prev2 = a.prev2; e.prev3 = a.prev3;
+    e.rank8 = a.rank8; e.sorted8 = a.sorted8;
     e.nice = a.nice_len; e.depth = a.depth; e.hb = a.hash_bytes; e.cyclic = a.dict_size + 1;
+    e.depth2 = a.depth2; e.block_end = block_end;
+
+    Work w{};
+    if constexpr (PARETO || OPT) {
+        __shared__ uint32_t s_ml[64];
+        __shared__ uint32_t s_md[64];
+        w.ml = s_ml; w.md = s_md;
+    }
+    if constexpr (OPT) {
+        __shared__ uint32_t s_price[WMAX + 1];
+        __shared__ uint32_t s_back[WMAX + 1];
+        __shared__ uint32_t s_info[WMAX + 1];
+        __shared__ uint32_t s_reps[(WMAX + 1) * 4];
+        __shared__ uint16_t s_dsp[256];
+        __shared__ uint16_t s_dp[512];
+        __shared__ uint16_t s_ap[16];
+        __shared__ uint8_t s_ptab[128];
+        w.n_price = s_price; w.n_back = s_back; w.n_info = s_info; w.n_reps = s_reps;
+        w.dsp = s_dsp; w.dp = s_dp; w.ap = s_ap; w.ptab = s_ptab;
+        // bit price table (price_tablegen.c:31-58)
+        for (uint32_t t = lane; t < 128; t += 64) {
+            uint32_t wv = t * 16 + 8, bit_count = 0;
+            for (int jj = 0; jj < 4; ++jj) {
+                wv *= wv;
+                bit_count <<= 1;
+                while (wv >= (1u << 16)) { wv >>= 1; ++bit_count; }
+            }
+            w.ptab[t] = (uint8_t)((11 << 4) - 15 - bit_count);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
 
     Lz z;
     z.lc = a.lc; z.lp = a.lp; z.pb = a.pb;
+    z.cnt_len = z.cnt_match = z.cnt_align = 0;
     RC rc;
     rc.cpos = 0; rc.out = outp; rc.reset();
 
     bool need_props = true, need_dict_reset = (k == 0), need_state_reset = true;
     bool initialized = (k != 0);
     uint32_t cur = span_start;
-    uint32_t read_ahead = 0;
+    uint32_t read_ahead = 0;        // exact/fast path bookkeeping (as in the reference)
+    bool cached = false;            // list paths: the round for `cur` has been done
     uint32_t out_off = 0;
-    Round R;            // cached find at `cur` when read_ahead == 1
+    Round R;            // exact path: cached find at `cur` when read_ahead == 1
     R.mask = 0; R.L = 0; R.D = 0; R.longest = 0;
+    RoundL RL;
+    RL.L = 0; RL.cnt = 0; RL.longest = 0;
+    LenTab lt;
+    uint32_t q_pos = 0, q_end = 0;  // pending path of the optimal parser (nodes in LDS)
+    bool tables_valid = false;
 
     while (cur < span_end) {
         if (need_state_reset) {
@@ -538,6 +1119,8 @@ __global__ __launch_bounds__(64) void k_span_encode(xzamd_span_args a)
             uint32_t* p32 = reinterpret_cast<uint32_t*>(probs);
             for (uint32_t i = lane; i < 4096; i += 64) p32[i] = 0x04000400u;
             z.state = 0; z.rep0 = z.rep1 = z.rep2 = z.rep3 = 0;
+            tables_valid = false;
+            q_pos = q_end = 0;
             // the flag stays set until an LZMA chunk header has announced the reset
         }
         const uint32_t chunk_start = cur;
@@ -562,8 +1145,24 @@ __global__ __launch_bounds__(64) void k_span_encode(xzamd_span_args a)
             if (cur >= span_end)
                 break;
 
-            // ---------------- lzma_lzma_optimum_fast (optimum_fast.c:20-169) ----------------
             uint32_t back = LITERAL, len = 1;
+            if constexpr (OPT) {
+                if (q_pos == q_end) {
+                    // price-table refresh policy (oracle: refresh_tables)
+                    if (!tables_valid || z.cnt_len >= 64) { refresh_len_tables(probs, w.ptab, lt, 1u << z.pb); z.cnt_len = 0; }
+                    if (!tables_valid || z.cnt_match >= 128) { refresh_dist_tables(probs, w); z.cnt_match = 0; }
+                    if (!tables_valid || z.cnt_align >= 16) { refresh_align_table(probs, w); z.cnt_align = 0; }
+                    tables_valid = true;
+                    cached = optimum_window<PARETO>(e, w, probs, z, lt, in, cur, block_start, span_end, cached, RL, q_end);
+                    q_pos = 0;
+                }
+                back = uni(w.n_price[q_pos]);
+                len = (uni(w.n_info[q_pos]) >> 13) & 0x1FF;
+                q_pos += len;
+            } else if constexpr (PARETO) {
+                cached = fast_parse_list<true>(e, w, z, cur, span_end, cached, RL, back, len);
+            } else {
+            // ---------------- lzma_lzma_optimum_fast (optimum_fast.c:20-169) ----------------
             if (read_ahead == 0) {
                 do_round(e, cur, span_end, z.rep0, z.rep1, z.rep2, z.rep3, R);
                 read_ahead = 1;
@@ -642,7 +1241,9 @@ __global__ __launch_bounds__(64) void k_span_encode(xzamd_span_args a)
                     if (!lit) { back = back_main + 4; len = len_main; read_ahead += len_main - 2; }
                 }
             }
+            read_ahead -= len;
             // ------------------------------------------------------------------------------
+            }
             encode_symbol(rc, probs, z, in, cur, cur - block_start, back, len);
             if (a.trace && lane == 0) {
                 // debug only: symbol stream for the parity tests (compared with the oracle's parse)
@@ -654,7 +1255,6 @@ __global__ __launch_bounds__(64) void k_span_encode(xzamd_span_args a)
                     a.trace[4 * ti + 3] = len;
                 }
             }
-            read_ahead -= len;
             cur += len;
         }
         rc.flush();
@@ -663,10 +1263,16 @@ __global__ __launch_bounds__(64) void k_span_encode(xzamd_span_args a)
         const uint32_t csize = rc.cpos;
         uint8_t* const hdr = outp + out_off;
         if (csize >= usize) {
-            // lzma2_encoder.c:205-214: store the chunk raw, including the lookahead byte
-            usize += read_ahead;
-            cur += read_ahead;
+            // lzma2_encoder.c:205-214: store the chunk raw.  Fast parser: including the lookahead
+            // byte; optimal parser: pending symbols are dropped and re-parsed after the reset.
+            if constexpr (!OPT) {
+                const uint32_t ra = (PARETO ? (cached ? 1u : 0u) : read_ahead);
+                usize += ra;
+                cur += ra;
+            }
             read_ahead = 0;
+            cached = false;
+            q_pos = q_end = 0;
             // the discarded range-coder bytes were stored by lane 0; make sure they have landed
             // before other lanes overwrite the same addresses
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -856,18 +1462,20 @@ int xzk_build_chains(const uint8_t* d_in, uint32_t n, uint32_t block_size, uint3
         uint32_t hash_bytes, uint32_t hash_mask, uint32_t hash_bits,
         uint32_t* keys_a, uint32_t* keys_b, uint32_t* vals_a, uint32_t* vals_b,
         void* sort_tmp, uint64_t sort_tmp_bytes,
-        uint32_t* rank, uint32_t* sorted_pos, uint32_t* prev2, uint32_t* prev3, void* stream_)
+        uint32_t* rank, uint32_t* sorted_pos, uint32_t* prev2, uint32_t* prev3,
+        uint32_t* rank8, uint32_t* sorted8, void* stream_)
 {
     hipStream_t st = (hipStream_t)stream_;
     const uint32_t g = grid_for(n, 256, 256 * 16);
     uint32_t bb = 0;
     while ((1u << bb) < nblocks + 1) ++bb;
     size_t tb = sort_tmp_bytes;
-    const uint32_t which_list[3] = { 2u, 3u, 0u };
-    for (int w = 0; w < 3; ++w) {
+    const uint32_t which_list[4] = { 2u, 3u, 0u, 8u };
+    for (int w = 0; w < 4; ++w) {
         const uint32_t which = which_list[w];
         if (which == 3 && hash_bytes != 4) continue;
-        const uint32_t kbits = which == 2 ? 10u : (which == 3 ? 16u : hash_bits);
+        if (which == 8 && rank8 == nullptr) continue;
+        const uint32_t kbits = which == 2 ? 10u : (which == 3 ? 16u : (which == 8 ? H8_BITS_K : hash_bits));
         hipLaunchKernelGGL(k_hash_keys, dim3(g), dim3(256), 0, st, d_in, n, block_size, nblocks, hash_bytes,
                 hash_mask, hash_bits, which, keys_a, vals_a);
         rocprim::double_buffer<uint32_t> kb(keys_a, keys_b);
@@ -882,6 +1490,8 @@ int xzk_build_chains(const uint8_t* d_in, uint32_t n, uint32_t block_size, uint3
             hipLaunchKernelGGL(k_link_prev, dim3(g), dim3(256), 0, st, kb.current(), vb.current(), n, prev2);
         else if (which == 3)
             hipLaunchKernelGGL(k_link_prev, dim3(g), dim3(256), 0, st, kb.current(), vb.current(), n, prev3);
+        else if (which == 8)
+            hipLaunchKernelGGL(k_link_main, dim3(g), dim3(256), 0, st, kb.current(), vb.current(), n, sorted8, rank8);
         else
             hipLaunchKernelGGL(k_link_main, dim3(g), dim3(256), 0, st, kb.current(), vb.current(), n, sorted_pos, rank);
     }
@@ -891,7 +1501,14 @@ int xzk_build_chains(const uint8_t* d_in, uint32_t n, uint32_t block_size, uint3
 int xzk_span_encode(const xzamd_span_args* a, uint32_t nspans, void* stream_)
 {
     hipStream_t st = (hipStream_t)stream_;
-    hipLaunchKernelGGL(k_span_encode, dim3(nspans), dim3(64), 0, st, *a);
+    if (a->depth2 == 0 && a->parser == 0)
+        hipLaunchKernelGGL((k_span_encode_t<false, false>), dim3(nspans), dim3(64), 0, st, *a);
+    else if (a->depth2 == 0)
+        hipLaunchKernelGGL((k_span_encode_t<false, true>), dim3(nspans), dim3(64), 0, st, *a);
+    else if (a->parser == 0)
+        hipLaunchKernelGGL((k_span_encode_t<true, false>), dim3(nspans), dim3(64), 0, st, *a);
+    else
+        hipLaunchKernelGGL((k_span_encode_t<true, true>), dim3(nspans), dim3(64), 0, st, *a);
     return (int)hipGetLastError();
 }
 

@@ -209,17 +209,21 @@ int xzamd_lzma_preset(xzamd_lzma_options *o, uint32_t preset)
 	}
 	/* Device mapping.  Fast-mode HC3/HC4 chains run exactly as requested.
 	 * BT4/normal chains (presets 4-9, -e) have no parallel equivalent: the
-	 * device runs its hash-chain successor with the deepest chain one
-	 * wavefront evaluates in a single round and the lazy parser (DESIGN.md
-	 * "what differs from the reference"). */
+	 * device runs its two-family hash-chain successor (<= 56 candidates per
+	 * wavefront round) and its own windowed optimal parser (DESIGN.md "what
+	 * differs from the reference"). */
 	if (o->mf == XZAMD_MF_HC3 || o->mf == XZAMD_MF_HC4) {
 		o->gpu_mf = o->mf;
 		o->gpu_nice_len = o->nice_len;
 		o->gpu_depth = o->depth;
 	} else {
+		/* BT4 + normal mode -> HC4+H8 Pareto finder + windowed optimal parser */
+		uint32_t ref_depth = o->depth ? o->depth : 16 + o->nice_len / 2;   /* lz_encoder.c:359-365 */
 		o->gpu_mf = XZAMD_MF_HC4;
-		o->gpu_nice_len = 273;
-		o->gpu_depth = 56;
+		o->gpu_nice_len = o->nice_len;
+		o->gpu_depth = 8;
+		o->gpu_depth2 = ref_depth > 48 ? 48 : ref_depth;
+		o->gpu_parser = 1;
 	}
 	o->span_size = XZAMD_SPAN_DEFAULT;
 	return 0;
@@ -245,7 +249,7 @@ struct xzamd_ctx {
 	uint64_t batch_bytes;
 	char err[256];
 	/* device buffers */
-	dbuf keys_a, keys_b, vals_a, vals_b, rank, sorted_pos, prev2, prev3, sort_tmp;
+	dbuf keys_a, keys_b, vals_a, vals_b, rank, sorted_pos, prev2, prev3, rank8, sorted8, sort_tmp;
 	dbuf scratch, span_bytes, strip_crc, block_crc, segs, lits, trace;
 	/* pinned host buffers */
 	dbuf h_span_bytes, h_block_crc, h_segs, h_lits;
@@ -312,7 +316,7 @@ void xzamd_ctx_destroy(xzamd_ctx *c)
 		return;
 	xzk_set_device(c->device);
 	dbuf *d[] = { &c->keys_a, &c->keys_b, &c->vals_a, &c->vals_b, &c->rank, &c->sorted_pos,
-		&c->prev2, &c->prev3, &c->sort_tmp, &c->scratch, &c->span_bytes, &c->strip_crc,
+		&c->prev2, &c->prev3, &c->rank8, &c->sorted8, &c->sort_tmp, &c->scratch, &c->span_bytes, &c->strip_crc,
 		&c->block_crc, &c->segs, &c->lits, &c->trace };
 	for (size_t i = 0; i < sizeof(d) / sizeof(d[0]); ++i)
 		if (d[i]->p) xzk_free(d[i]->p);
@@ -429,7 +433,8 @@ int xzamd_stream_encode_device(xzamd_ctx *c,
 	if (opt->lc + opt->lp > 3 || opt->pb > 4)
 		return fail(c, XZAMD_OPTIONS_ERROR, "lc+lp <= 3 and pb <= 4 required (LDS model size)", 0);
 	if ((opt->gpu_mf != XZAMD_MF_HC3 && opt->gpu_mf != XZAMD_MF_HC4)
-			|| opt->gpu_depth < 1 || opt->gpu_depth > 56
+			|| opt->gpu_depth < 1 || opt->gpu_depth + opt->gpu_depth2 > 56
+			|| (opt->gpu_depth2 && opt->gpu_mf != XZAMD_MF_HC4) || opt->gpu_parser > 1
 			|| opt->gpu_nice_len < opt->gpu_mf || opt->gpu_nice_len > 273
 			|| opt->dict_size < 4096 || opt->dict_size > (1u << 30))
 		return fail(c, XZAMD_OPTIONS_ERROR, "unsupported match finder options for the device path", 0);
@@ -446,6 +451,7 @@ int xzamd_stream_encode_device(xzamd_ctx *c,
 	const uint32_t hmask = hash_mask_for(opt->dict_size, hb);
 	uint32_t hbits = 0;
 	while ((1ull << hbits) <= hmask) ++hbits;
+	const uint32_t kbits_max = (opt->gpu_depth2 && hbits < 22) ? 22 : hbits;   /* widest sort key family */
 	uint32_t span = opt->span_size == XZAMD_SPAN_DEFAULT ? DEFAULT_SPAN : opt->span_size;
 	if (span > block_size) span = (uint32_t)block_size;
 	if (span < 4096)
@@ -456,7 +462,7 @@ int xzamd_stream_encode_device(xzamd_ctx *c,
 	/* batch = whole Blocks, n < 2^31, (nblocks+1) << hbits < 2^32 */
 	uint64_t max_blocks = c->batch_bytes / block_size;
 	if (max_blocks == 0) max_blocks = 1;
-	const uint64_t key_blocks = (1ull << (32 - hbits)) - 2;
+	const uint64_t key_blocks = (1ull << (32 - kbits_max)) - 2;
 	if (max_blocks > key_blocks) max_blocks = key_blocks;
 	if (max_blocks * block_size >= (1ull << 31))
 		max_blocks = ((1ull << 31) - 1) / block_size;
@@ -502,8 +508,8 @@ int xzamd_stream_encode_device(xzamd_ctx *c,
 		{
 			uint32_t bb = 0;
 			while ((1u << bb) < nb + 1) ++bb;
-			const uint32_t bits[3] = { 10 + bb, 16 + bb, hbits + bb };
-			for (int i = 0; i < 3; ++i) {
+			const uint32_t bits[4] = { 10 + bb, 16 + bb, hbits + bb, 22 + bb };
+			for (int i = 0; i < (opt->gpu_depth2 ? 4 : 3); ++i) {
 				uint64_t sbytes = 0;
 				int e = xzk_sort_temp_bytes(n, bits[i], &sbytes);
 				if (e) { rc = fail(c, XZAMD_DEVICE_ERROR, "rocprim temp size", e); goto done; }
@@ -514,6 +520,7 @@ int xzamd_stream_encode_device(xzamd_ctx *c,
 		GROW(vals_a, 4ull * n, 0); GROW(vals_b, 4ull * n, 0);
 		GROW(rank, 4ull * n, 0); GROW(sorted_pos, 4ull * n, 0);
 		GROW(prev2, 4ull * n, 0); GROW(prev3, 4ull * n, 0);
+		if (opt->gpu_depth2) { GROW(rank8, 4ull * n, 0); GROW(sorted8, 4ull * n, 0); }
 		GROW(sort_tmp, sort_bytes + 256, 0);
 		GROW(scratch, span_cap * nspans, 0);
 		GROW(span_bytes, 4ull * nspans, 0);
@@ -537,7 +544,9 @@ int xzamd_stream_encode_device(xzamd_ctx *c,
 					(uint32_t *)c->keys_a.p, (uint32_t *)c->keys_b.p, (uint32_t *)c->vals_a.p,
 					(uint32_t *)c->vals_b.p, c->sort_tmp.p, sort_bytes,
 					(uint32_t *)c->rank.p, (uint32_t *)c->sorted_pos.p, (uint32_t *)c->prev2.p,
-					(uint32_t *)c->prev3.p, st);
+					(uint32_t *)c->prev3.p,
+					opt->gpu_depth2 ? (uint32_t *)c->rank8.p : NULL,
+					opt->gpu_depth2 ? (uint32_t *)c->sorted8.p : NULL, st);
 			if (e) { rc = fail(c, XZAMD_DEVICE_ERROR, "build_chains", e); goto done; }
 		}
 		xzk_event_record(c->ev[1], st);
@@ -550,6 +559,10 @@ int xzamd_stream_encode_device(xzamd_ctx *c,
 			a.sorted_pos = (const uint32_t *)c->sorted_pos.p;
 			a.prev2 = (const uint32_t *)c->prev2.p;
 			a.prev3 = (const uint32_t *)c->prev3.p;
+			a.rank8 = opt->gpu_depth2 ? (const uint32_t *)c->rank8.p : NULL;
+			a.sorted8 = opt->gpu_depth2 ? (const uint32_t *)c->sorted8.p : NULL;
+			a.depth2 = opt->gpu_depth2;
+			a.parser = opt->gpu_parser;
 			a.scratch = (uint8_t *)c->scratch.p;
 			a.span_cap = span_cap;
 			a.span_bytes = (uint32_t *)c->span_bytes.p;

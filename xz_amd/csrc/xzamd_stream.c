@@ -127,10 +127,14 @@ static lzma_ret parse_options(const lzma_mt *o, xzamd_lzma_options *opt, uint64_
 			opt->gpu_nice_len = l->nice_len < (opt->gpu_mf & 15) ? (opt->gpu_mf & 15) : l->nice_len;
 			uint32_t d = l->depth ? l->depth : 4 + opt->gpu_nice_len / 4;
 			opt->gpu_depth = d > 56 ? 56 : d;
+			opt->gpu_parser = l->mode == LZMA_MODE_NORMAL ? 1 : 0;
 		} else if (l->mf == LZMA_MF_BT2 || l->mf == LZMA_MF_BT3 || l->mf == LZMA_MF_BT4) {
+			uint32_t rd = l->depth ? l->depth : 16 + l->nice_len / 2;
 			opt->gpu_mf = XZAMD_MF_HC4;
-			opt->gpu_nice_len = 273;
-			opt->gpu_depth = 56;
+			opt->gpu_nice_len = l->nice_len < 4 ? 4 : l->nice_len;
+			opt->gpu_depth = 8;
+			opt->gpu_depth2 = rd > 48 ? 48 : rd;
+			opt->gpu_parser = l->mode == LZMA_MODE_NORMAL ? 1 : 0;
 		} else {
 			return LZMA_OPTIONS_ERROR;
 		}
