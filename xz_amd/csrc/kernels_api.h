@@ -26,6 +26,7 @@ typedef struct {
 	uint32_t *trace;             /* optional debug: 4 x u32 per symbol (span,pos,back,len) */
 	uint32_t *trace_count;
 	uint32_t trace_cap;
+	uint32_t *err;               /* 8 x u32: [0] != 0 -> a span hit an internal consistency check */
 	uint32_t n;
 	uint32_t block_size;
 	uint32_t span_size;

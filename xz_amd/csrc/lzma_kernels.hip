@@ -62,6 +62,15 @@ enum : uint32_t {
 };
 static_assert(P_TOTAL <= 8192, "model must fit the 16 KiB LDS slice");
 
+// Make LDS stores of some lanes visible to later LDS loads of other lanes of the same wavefront:
+// compiler-level fence + drain of the LDS queue.
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
+
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ uint32_t lane_of(uint32_t v, uint32_t l) { return __builtin_amdgcn_readlane(v, uni(l)); }
 
@@ -543,6 +552,7 @@ struct Work {
     uint16_t* dp;       // [4*128] full price of distances < 128
     uint16_t* ap;       // [16]    align price
     uint8_t* ptab;      // [128]   bit price table (price_tablegen.c:31-58)
+    uint32_t* err;      // debug/consistency word block (global)
 };
 
 struct RoundL {
@@ -561,7 +571,7 @@ __device__ __forceinline__ void list_from_mask(const Work& w, const Round& R, Ro
         w.ml[idx] = R.L;
         w.md[idx] = R.D;
     }
-    __builtin_amdgcn_wave_barrier();
+    wave_sync();
     out.L = R.L;
     out.cnt = (uint32_t)__builtin_popcountll(R.mask);
     out.longest = R.longest;
@@ -657,7 +667,7 @@ __device__ __forceinline__ void do_round_pareto(const Env& e, const Work& w, uin
         rk += (Lk < L) ? 1u : 0u;
     }
     if (keep) { w.ml[rk] = L; w.md[rk] = dist - 1; }
-    __builtin_amdgcn_wave_barrier();
+    wave_sync();
     uint32_t longest = uni(w.ml[cnt - 1]);
     if (longest == e.nice) {
         const uint32_t dd = uni(w.md[cnt - 1]);
@@ -755,14 +765,14 @@ __device__ __forceinline__ void refresh_dist_tables(const uint16_t* probs, const
     }
     for (uint32_t i = lane; i < 512; i += 64)
         w.dp[i] = (uint16_t)pr_dist_full(probs, w.ptab, i & 127, i >> 7);
-    __builtin_amdgcn_wave_barrier();
+    wave_sync();
 }
 
 __device__ __forceinline__ void refresh_align_table(const uint16_t* probs, const Work& w)
 {
     const uint32_t lane = threadIdx.x;
     if (lane < 16) w.ap[lane] = (uint16_t)pr_tree_rev(probs, w.ptab, P_DIST_ALIGN, 4, lane);
-    __builtin_amdgcn_wave_barrier();
+    wave_sync();
 }
 
 __device__ __forceinline__ uint32_t tab_dist(const Work& w, uint32_t dist, uint32_t ds)
@@ -807,7 +817,7 @@ __device__ __forceinline__ uint32_t state_after(uint32_t s, uint32_t back, uint3
 template <int PS>
 __device__ __forceinline__ void relax_lengths(const Work& w, const LenTab& lt, uint32_t j, uint32_t reach,
         uint32_t longest, uint32_t cnt, uint32_t rl0, uint32_t rl1, uint32_t rl2, uint32_t rl3,
-        uint32_t prep0, uint32_t prep1, uint32_t prep2, uint32_t prep3, uint32_t pmatch)
+        uint32_t prep0, uint32_t prep1, uint32_t prep2, uint32_t prep3, uint32_t pmatch, uint32_t upos_dbg = 0)
 {
     const uint32_t lane = threadIdx.x;
 #pragma unroll
@@ -826,6 +836,11 @@ __device__ __forceinline__ void relax_lengths(const Work& w, const LenTab& lt, u
                 uint32_t idx = 0;
                 for (uint32_t k = 0; k + 1 < cnt; ++k) idx += (uni(w.ml[k]) < l) ? 1u : 0u;
                 const uint32_t dist = w.md[idx];
+#ifdef XZAMD_PARANOID
+                if (dist >= upos_dbg && w.err && atomicCAS(w.err, 0u, 3u) == 0u) {
+                    w.err[1] = upos_dbg; w.err[2] = j; w.err[3] = l; w.err[4] = idx; w.err[5] = cnt; w.err[6] = dist; w.err[7] = longest;
+                }
+#endif
                 const uint32_t pr = pmatch + lpm + tab_dist(w, dist, l < 6 ? l - 2 : 3);
                 if (pr < best) { best = pr; bb = dist + 4; upd = true; }
             }
@@ -852,7 +867,7 @@ __device__ __forceinline__ bool optimum_window(const Env& e, const Work& w, uint
         w.n_info[0] = z.state << 9;
         w.n_reps[0] = z.rep0; w.n_reps[1] = z.rep1; w.n_reps[2] = z.rep2; w.n_reps[3] = z.rep3;
     }
-    __builtin_amdgcn_wave_barrier();
+    wave_sync();
     uint32_t n_end = 0, j = 0;
     bool next_cached = false;
     for (;;) {
@@ -866,6 +881,15 @@ __device__ __forceinline__ bool optimum_window(const Env& e, const Work& w, uint
             const uint32_t ps_ = (uni(w.n_info[pv]) >> 9) & 15;
             const uint32_t a0 = uni(w.n_reps[pv * 4]), a1 = uni(w.n_reps[pv * 4 + 1]);
             const uint32_t a2 = uni(w.n_reps[pv * 4 + 2]), a3 = uni(w.n_reps[pv * 4 + 3]);
+#ifdef XZAMD_PARANOID
+            if (ilen == 0 || ilen > j || (bk != LITERAL && bk >= 4 && bk - 4 >= (pos + pv) - block_start)) {
+                if (lane == 0 && w.err && atomicCAS(w.err, 0u, 4u) == 0u) {
+                    w.err[1] = (pos + j) - block_start; w.err[2] = j; w.err[3] = ilen; w.err[4] = bk; w.err[5] = info; w.err[6] = n_end; w.err[7] = uni(w.n_price[j]);
+                }
+                q_end = 0;
+                return false;
+            }
+#endif
             s = state_after(ps_, bk, ilen);
             if (bk == LITERAL || bk == 0) { r0 = a0; r1 = a1; r2 = a2; r3 = a3; }
             else if (bk == 1) { r0 = a1; r1 = a0; r2 = a2; r3 = a3; }
@@ -876,10 +900,23 @@ __device__ __forceinline__ bool optimum_window(const Env& e, const Work& w, uint
                 w.n_info[j] = ilen | (s << 9);
                 w.n_reps[j * 4] = r0; w.n_reps[j * 4 + 1] = r1; w.n_reps[j * 4 + 2] = r2; w.n_reps[j * 4 + 3] = r3;
             }
-            __builtin_amdgcn_wave_barrier();
+            wave_sync();
         } else {
             s = z.state; r0 = z.rep0; r1 = z.rep1; r2 = z.rep2; r3 = z.rep3;
         }
+#ifdef XZAMD_PARANOID
+        {
+            const uint32_t up = x - block_start;
+            if (r0 >= up || r1 >= up || r2 >= up || r3 >= up) {
+                if (lane == 0 && w.err && atomicCAS(w.err, 0u, 2u) == 0u) {
+                    w.err[1] = up; w.err[2] = j; w.err[3] = r0; w.err[4] = r1; w.err[5] = r2; w.err[6] = r3;
+                    w.err[7] = j ? w.n_back[j] : 0;
+                }
+                q_end = 0;
+                return false;
+            }
+        }
+#endif
         if (!(j == 0 && cached)) {
             if constexpr (PARETO) {
                 do_round_pareto(e, w, x, span_end, r0, r1, r2, r3, RL);
@@ -902,7 +939,7 @@ __device__ __forceinline__ bool optimum_window(const Env& e, const Work& w, uint
             else if (longest >= e.nice) { sb = uni(w.md[RL.cnt - 1]) + 4; sl = longest; }
             if (sl) {
                 if (lane == 0) { w.n_price[0] = sb; w.n_info[0] = (w.n_info[0] & 0x1FFF) | (sl << 13); }
-                __builtin_amdgcn_wave_barrier();
+                wave_sync();
                 q_end = sl;
                 return false;
             }
@@ -918,7 +955,7 @@ __device__ __forceinline__ bool optimum_window(const Env& e, const Work& w, uint
         const uint32_t new_end = max(max(n_end, j + reach), j + 1);
         for (uint32_t t = n_end + 1 + lane; t <= new_end; t += 64) w.n_price[t] = PRICE_INF;
         n_end = new_end;
-        __builtin_amdgcn_wave_barrier();
+        wave_sync();
 
         const uint32_t upos = x - block_start;
         const uint32_t ps = upos & pbm;
@@ -938,7 +975,7 @@ __device__ __forceinline__ bool optimum_window(const Env& e, const Work& w, uint
                 if (psr < best) { best = psr; bb = 0; upd = true; }
             }
             if (upd && lane == 0) { w.n_price[j + 1] = best; w.n_back[j + 1] = bb; w.n_info[j + 1] = 1; }
-            __builtin_amdgcn_wave_barrier();
+            wave_sync();
         }
         if (reach >= 2) {
             const uint32_t b0 = pr_bit(probs, w.ptab, P_IS_REP0 + s, 0), b1 = pr_bit(probs, w.ptab, P_IS_REP0 + s, 1);
@@ -949,12 +986,12 @@ __device__ __forceinline__ bool optimum_window(const Env& e, const Work& w, uint
             const uint32_t prep3 = p11 + pr_bit(probs, w.ptab, P_IS_REP2 + s, 1);
             const uint32_t pmatch = pm1 + pr_bit(probs, w.ptab, P_IS_REP + s, 0);
             switch (ps & 3) {
-            case 0: relax_lengths<0>(w, lt, j, reach, longest, RL.cnt, rl0, rl1, rl2, rl3, prep0, prep1, prep2, prep3, pmatch); break;
-            case 1: relax_lengths<1>(w, lt, j, reach, longest, RL.cnt, rl0, rl1, rl2, rl3, prep0, prep1, prep2, prep3, pmatch); break;
-            case 2: relax_lengths<2>(w, lt, j, reach, longest, RL.cnt, rl0, rl1, rl2, rl3, prep0, prep1, prep2, prep3, pmatch); break;
-            default: relax_lengths<3>(w, lt, j, reach, longest, RL.cnt, rl0, rl1, rl2, rl3, prep0, prep1, prep2, prep3, pmatch); break;
+            case 0: relax_lengths<0>(w, lt, j, reach, longest, RL.cnt, rl0, rl1, rl2, rl3, prep0, prep1, prep2, prep3, pmatch, upos); break;
+            case 1: relax_lengths<1>(w, lt, j, reach, longest, RL.cnt, rl0, rl1, rl2, rl3, prep0, prep1, prep2, prep3, pmatch, upos); break;
+            case 2: relax_lengths<2>(w, lt, j, reach, longest, RL.cnt, rl0, rl1, rl2, rl3, prep0, prep1, prep2, prep3, pmatch, upos); break;
+            default: relax_lengths<3>(w, lt, j, reach, longest, RL.cnt, rl0, rl1, rl2, rl3, prep0, prep1, prep2, prep3, pmatch, upos); break;
             }
-            __builtin_amdgcn_wave_barrier();
+            wave_sync();
         }
         ++j;
         if (j == n_end) break;
@@ -971,7 +1008,7 @@ __device__ __forceinline__ bool optimum_window(const Env& e, const Work& w, uint
             t = pv;
         }
     }
-    __builtin_amdgcn_wave_barrier();
+    wave_sync();
     q_end = j;
     return next_cached;
 }
@@ -1041,7 +1078,13 @@ __device__ __forceinline__ bool fast_parse_list(const Env& e, const Work& w, con
 template <bool PARETO, bool OPT>
 __global__ __launch_bounds__(64) void k_span_encode_t(xzamd_span_args a)
 {
-    __shared__ uint16_t probs[8192];
+    // One LDS pool, carved by hand (a single __shared__ object: no aliasing or ordering surprises).
+    constexpr uint32_t W_PROBS = 4096;                                   // 8192 x u16
+    constexpr uint32_t W_LIST = (PARETO || OPT) ? 128 : 0;               // ml[64], md[64]
+    constexpr uint32_t W_NODES = OPT ? 7 * (WMAX + 1) + 1 : 0;           // price, back, info, reps[4]
+    constexpr uint32_t W_TABS = OPT ? (128 + 256 + 8 + 32) : 0;          // dsp, dp, ap (u16), ptab (u8)
+    __shared__ __attribute__((aligned(16))) uint32_t pool[W_PROBS + W_LIST + W_NODES + W_TABS];
+    uint16_t* const probs = reinterpret_cast<uint16_t*>(pool);
     const uint32_t lane = threadIdx.x;
     const uint32_t span = blockIdx.x;
     const uint32_t blk = span / a.spans_per_block;
@@ -1065,21 +1108,21 @@ __global__ __launch_bounds__(64) void k_span_encode_t(xzamd_span_args a)
 
     Work w{};
     if constexpr (PARETO || OPT) {
-        __shared__ uint32_t s_ml[64];
-        __shared__ uint32_t s_md[64];
-        w.ml = s_ml; w.md = s_md;
+        w.ml = pool + W_PROBS;
+        w.md = pool + W_PROBS + 64;
     }
     if constexpr (OPT) {
-        __shared__ uint32_t s_price[WMAX + 1];
-        __shared__ uint32_t s_back[WMAX + 1];
-        __shared__ uint32_t s_info[WMAX + 1];
-        __shared__ uint32_t s_reps[(WMAX + 1) * 4];
-        __shared__ uint16_t s_dsp[256];
-        __shared__ uint16_t s_dp[512];
-        __shared__ uint16_t s_ap[16];
-        __shared__ uint8_t s_ptab[128];
-        w.n_price = s_price; w.n_back = s_back; w.n_info = s_info; w.n_reps = s_reps;
-        w.dsp = s_dsp; w.dp = s_dp; w.ap = s_ap; w.ptab = s_ptab;
+        uint32_t* nb = pool + W_PROBS + W_LIST;
+        w.n_price = nb;
+        w.n_back = nb + (WMAX + 1);
+        w.n_info = nb + 2 * (WMAX + 1);
+        w.n_reps = nb + 3 * (WMAX + 1);
+        uint32_t* tb = nb + W_NODES;
+        w.dsp = reinterpret_cast<uint16_t*>(tb);            // 256 x u16 = 128 words
+        w.dp = reinterpret_cast<uint16_t*>(tb + 128);       // 512 x u16 = 256 words
+        w.ap = reinterpret_cast<uint16_t*>(tb + 384);       // 16 x u16 = 8 words
+        w.ptab = reinterpret_cast<uint8_t*>(tb + 392);      // 128 x u8 = 32 words
+        w.err = a.err;
         // bit price table (price_tablegen.c:31-58)
         for (uint32_t t = lane; t < 128; t += 64) {
             uint32_t wv = t * 16 + 8, bit_count = 0;
@@ -1090,7 +1133,7 @@ __global__ __launch_bounds__(64) void k_span_encode_t(xzamd_span_args a)
             }
             w.ptab[t] = (uint8_t)((11 << 4) - 15 - bit_count);
         }
-        __builtin_amdgcn_wave_barrier();
+        wave_sync();
     }
 
     Lz z;
@@ -1155,6 +1198,10 @@ __global__ __launch_bounds__(64) void k_span_encode_t(xzamd_span_args a)
                     tables_valid = true;
                     cached = optimum_window<PARETO>(e, w, probs, z, lt, in, cur, block_start, span_end, cached, RL, q_end);
                     q_pos = 0;
+                    if (q_end == 0) {            // consistency failure reported by the parser
+                        if (lane == 0) a.span_bytes[span] = 0;
+                        return;
+                    }
                 }
                 back = uni(w.n_price[q_pos]);
                 len = (uni(w.n_info[q_pos]) >> 13) & 0x1FF;
@@ -1243,6 +1290,19 @@ __global__ __launch_bounds__(64) void k_span_encode_t(xzamd_span_args a)
             }
             read_ahead -= len;
             // ------------------------------------------------------------------------------
+            }
+            if (len == 0 || len > MATCH_LEN_MAX || cur + len > span_end
+                    || (back != LITERAL && back >= 4 && back - 4 >= cur - block_start)
+                    || out_off + hl + rc.cpos + 64 > a.span_cap) {
+                // internal consistency failure: report instead of corrupting memory
+                if (lane == 0 && a.err) {
+                    if (atomicCAS(a.err, 0u, 1u) == 0u) {
+                        a.err[1] = span; a.err[2] = cur - block_start; a.err[3] = back; a.err[4] = len;
+                        a.err[5] = q_pos; a.err[6] = q_end; a.err[7] = out_off + rc.cpos;
+                    }
+                }
+                if (lane == 0) a.span_bytes[span] = 0;
+                return;
             }
             encode_symbol(rc, probs, z, in, cur, cur - block_start, back, len);
             if (a.trace && lane == 0) {

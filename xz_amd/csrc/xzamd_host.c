@@ -248,9 +248,10 @@ struct xzamd_ctx {
 	void *own_stream;
 	uint64_t batch_bytes;
 	char err[256];
+	char err_msg_buf[200];
 	/* device buffers */
 	dbuf keys_a, keys_b, vals_a, vals_b, rank, sorted_pos, prev2, prev3, rank8, sorted8, sort_tmp;
-	dbuf scratch, span_bytes, strip_crc, block_crc, segs, lits, trace;
+	dbuf scratch, span_bytes, strip_crc, block_crc, segs, lits, trace, errw;
 	/* pinned host buffers */
 	dbuf h_span_bytes, h_block_crc, h_segs, h_lits;
 	void *ev[10];
@@ -317,7 +318,7 @@ void xzamd_ctx_destroy(xzamd_ctx *c)
 	xzk_set_device(c->device);
 	dbuf *d[] = { &c->keys_a, &c->keys_b, &c->vals_a, &c->vals_b, &c->rank, &c->sorted_pos,
 		&c->prev2, &c->prev3, &c->rank8, &c->sorted8, &c->sort_tmp, &c->scratch, &c->span_bytes, &c->strip_crc,
-		&c->block_crc, &c->segs, &c->lits, &c->trace };
+		&c->block_crc, &c->segs, &c->lits, &c->trace, &c->errw };
 	for (size_t i = 0; i < sizeof(d) / sizeof(d[0]); ++i)
 		if (d[i]->p) xzk_free(d[i]->p);
 	dbuf *h[] = { &c->h_span_bytes, &c->h_block_crc, &c->h_segs, &c->h_lits };
@@ -526,6 +527,7 @@ int xzamd_stream_encode_device(xzamd_ctx *c,
 		GROW(span_bytes, 4ull * nspans, 0);
 		GROW(strip_crc, 8ull * spb_crc * nb, 0);
 		GROW(block_crc, 8ull * nb, 0);
+		GROW(errw, 64, 0);
 		GROW(h_span_bytes, 4ull * nspans, 1);
 		GROW(h_block_crc, 8ull * nb, 1);
 		/* plan capacity: per Block header + spans + trailer, or the stored form */
@@ -566,6 +568,8 @@ int xzamd_stream_encode_device(xzamd_ctx *c,
 			a.scratch = (uint8_t *)c->scratch.p;
 			a.span_cap = span_cap;
 			a.span_bytes = (uint32_t *)c->span_bytes.p;
+			a.err = (uint32_t *)c->errw.p;
+			if (xzk_memset(c->errw.p, 0, 64, st)) { rc = fail(c, XZAMD_DEVICE_ERROR, "memset", 1); goto done; }
 			if (c->trace_on) {
 				a.trace_count = (uint32_t *)c->trace.p;
 				a.trace = (uint32_t *)((uint8_t *)c->trace.p + 16);
@@ -594,9 +598,18 @@ int xzamd_stream_encode_device(xzamd_ctx *c,
 		}
 		xzk_event_record(c->ev[3], st);
 		{
+			uint32_t herr[8] = { 0 };
 			int e = xzk_d2h(c->h_span_bytes.p, c->span_bytes.p, 4ull * nspans, st);
+			if (!e) e = xzk_d2h(herr, c->errw.p, 32, st);
 			if (!e) e = xzk_sync(st);
 			if (e) { rc = fail(c, XZAMD_DEVICE_ERROR, "span encode / d2h sizes", e); goto done; }
+			if (herr[0]) {
+				snprintf(c->err_msg_buf, sizeof(c->err_msg_buf),
+						"span encoder consistency check %u failed: %u %u %u %u %u %u %u",
+						herr[0], herr[1], herr[2], herr[3], herr[4], herr[5], herr[6], herr[7]);
+				rc = fail(c, XZAMD_PROG_ERROR, c->err_msg_buf, 0);
+				goto done;
+			}
 		}
 
 		/* 4. layout (the ordered output queue of the reference, outqueue.c) */
