@@ -61,6 +61,8 @@ def main():
     ap.add_argument("--size-mib", type=int, default=4096, help="input MiB per GPU")
     ap.add_argument("--preset", type=int, default=6)
     ap.add_argument("--span-kib", type=int, default=0, help="0 = library default")
+    ap.add_argument("--parser", choices=["default", "fast", "optimal"], default="default",
+                    help="device parser override (default: what the preset maps to)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -81,6 +83,8 @@ def main():
     opts = xz_amd.preset_options(args.preset)
     if args.span_kib:
         opts.span_size = args.span_kib << 10
+    if args.parser != "default":
+        opts.gpu_parser = 1 if args.parser == "optimal" else 0
     block_size = xz_amd.mt_block_size(opts)
 
     host = xz_amd.corpus_text(n, seed=1000 + rank)
@@ -148,9 +152,11 @@ def main():
                 "workload": f"preset -{args.preset} options (dict {opts.dict_size >> 20} MiB, {block_size >> 20} MiB Blocks, "
                             f"CRC64), {args.size_mib} MiB synthetic enwik-style text per GPU, input resident in HBM, "
                             f"output = complete .xz Stream in HBM",
-                "device_match_finder": f"HC{opts.gpu_mf & 15} depth {opts.gpu_depth} nice {opts.gpu_nice_len} (sort-built chains)",
-                "device_parser": "lzma_lzma_optimum_fast semantics (greedy + 1-byte lazy)",
-                "span_kib": (opts.span_size or 65536) >> 10,
+                "device_match_finder": (f"HC{opts.gpu_mf & 15} depth {opts.gpu_depth}" + (f" + H8 depth {opts.gpu_depth2} (Pareto merge)" if opts.gpu_depth2 else "")
+                                        + f", nice {opts.gpu_nice_len} (sort-built chains)"),
+                "device_parser": ("windowed optimal parser (256-node DP, exact prices)" if opts.gpu_parser
+                                  else "lzma_lzma_optimum_fast semantics (greedy + 1-byte lazy)"),
+                "span_kib": (opts.span_size or (131072 if opts.gpu_parser else 65536)) >> 10,
                 "parallelism": f"{world} x (one wavefront per span, {int(st.spans)} spans per GPU)",
             },
             "ratio": {"ours": round(local_out_bytes / n, 5)},

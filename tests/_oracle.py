@@ -343,7 +343,7 @@ def params_for_gpu_options(opts, span_size=None):
     p.depth = opts.gpu_depth
     sp = opts.span_size if span_size is None else span_size
     if sp == 0:
-        sp = 65536           # XZAMD DEFAULT_SPAN
+        sp = 131072 if opts.gpu_parser else 65536    # xzamd_host.c DEFAULT_SPAN_OPT / DEFAULT_SPAN
     p.span_size = 0 if sp == 0xFFFFFFFF else sp
     p.depth2 = opts.gpu_depth2
     p.parser = opts.gpu_parser

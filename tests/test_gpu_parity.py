@@ -77,6 +77,34 @@ def test_span_mode_identical_to_oracle(enc, preset, span):
             assert rr == 1 and rdec == bytes(data), ("liblzma decoder", name)
 
 
+@pytest.mark.parametrize("preset,parser,depth2,span", [
+    (6, 0, None, 0),          # HC4+H8 Pareto finder with the fast parser
+    (6, 0, None, 0xFFFFFFFF),
+    (2, 1, None, 65536),      # exact HC4 finder with the windowed optimal parser
+    (1, 1, None, 0xFFFFFFFF),
+    (4, None, None, 0), (5, None, None, 4096), (7, None, None, 0),
+    (3 | 0x80000000, None, None, 0),
+])
+def test_successor_finder_and_optimal_parser_identical_to_oracle(enc, preset, parser, depth2, span):
+    """Presets 4-9 / -e (BT4 + normal mode in the reference) run OUR finder and parser; the bar is
+    bit-exactness with their CPU restatement (oracle find_pareto / optimum_window) plus a bit-exact
+    round trip through the real reference decoder."""
+    import xz_amd
+    opts = xz_amd.preset_options(preset, span_size=span)
+    if parser is not None:
+        opts.gpu_parser = parser
+    prm = o.params_for_gpu_options(opts)
+    for name, data in inputs().items():
+        if len(data) > 420000:
+            data = data[:420000]
+        got, _ = gpu_encode(enc, data, opts, 1 << 20)
+        want = o.orc_xz_stream(data, prm, 1 << 20)
+        assert o.first_diff(got, want) == -1, (name, preset, parser, span)
+        if o.have_ref():
+            rr, rdec = o.ref_decode(got, len(data) + 16)
+            assert rr == 1 and rdec == bytes(data), ("liblzma decoder", name)
+
+
 def test_custom_options_and_small_dictionary(enc):
     import xz_amd
     data = o.corpus_mixed(500000, 8)

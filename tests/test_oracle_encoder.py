@@ -93,3 +93,34 @@ def test_parse_trace_consistency():
     r, dec, dsym, _ = o.orc_decode_raw(enc, prm.dict_size, len(data) + 16, want_trace=True)
     assert r == 0 and dec == data
     assert esym.shape == dsym.shape and (esym == dsym).all()
+
+
+# ---- OUR definitions (GPU successor of BT4 + windowed optimal parser): CPU-side sanity ----------
+@pytest.mark.parametrize("depth2,parser,span", [(48, 0, 0), (48, 1, 0), (0, 1, 65536), (48, 1, 131072), (24, 1, 4096)])
+def test_pareto_and_optimal_parser_roundtrip(depth2, parser, span):
+    for name, data in _edge_inputs().items():
+        if len(data) > 400000:
+            data = data[:400000]
+        p = o.OrcParams(1 << 20, 3, 0, 2, 64, 4, 8 if depth2 else 24, span, depth2, parser)
+        enc = o.orc_encode_block(data, p)
+        r, dec = o.orc_decode_raw(enc, p.dict_size, len(data) + 16)
+        assert r == 0 and dec == bytes(data), (name, depth2, parser, span)
+        if o.have_ref():
+            out = np.empty(len(data) + 16, dtype=np.uint8); n = C.c_size_t(0)
+            pl = o.as_u8(enc)
+            rr = o.ref().ref_raw_lzma2_decode(o._ptr(pl), len(pl), p.dict_size, o._ptr(out), len(out), C.byref(n))
+            assert rr == 1 and out[:n.value].tobytes() == bytes(data), (name, depth2, parser, span)
+
+
+def test_optimal_parser_beats_fast_parser():
+    """The point of the windowed optimal parser and of the second chain family: smaller output."""
+    data = o.corpus_lorem(1 << 20)
+    base = len(o.orc_encode_block(data, o.OrcParams(1 << 23, 3, 0, 2, 273, 4, 56, 0, 0, 0)))
+    h8 = len(o.orc_encode_block(data, o.OrcParams(1 << 23, 3, 0, 2, 273, 4, 8, 0, 48, 0)))
+    opt = len(o.orc_encode_block(data, o.OrcParams(1 << 23, 3, 0, 2, 64, 4, 8, 0, 48, 1)))
+    assert opt < h8 <= base
+    if o.have_ref():
+        import ctypes as C2
+        prm = o.OrcParams(1 << 23, 3, 0, 2, 64, 0x14, 0, 0, 0, 0)
+        ref6 = len(o.ref_raw_encode(data, prm, mode=2))      # liblzma preset-6 options (BT4, normal)
+        assert opt <= ref6 * 1.10                            # stated tolerance for the device parser

@@ -245,9 +245,26 @@ __device__ __forceinline__ uint64_t ld64(const uint8_t* p)
 }
 
 // Per-lane: length of the common prefix of in[q..] and in[x..], at most lim.  Lanes diverge.
+// 32 bytes per trip: every loop iteration is a dependent HBM/L2 round trip, so the trip count
+// (not the byte count) is what a long match costs.
 __device__ __forceinline__ uint32_t lane_cmplen(const uint8_t* __restrict__ in, uint32_t q, uint32_t x, uint32_t lim)
 {
     uint32_t len = 0;
+    while (len + 32 <= lim) {
+        const uint8_t* a = in + q + len;
+        const uint8_t* b = in + x + len;
+        const uint64_t a0 = ld64(a), a1 = ld64(a + 8), a2 = ld64(a + 16), a3 = ld64(a + 24);
+        const uint64_t b0 = ld64(b), b1 = ld64(b + 8), b2 = ld64(b + 16), b3 = ld64(b + 24);
+        uint64_t d = a0 ^ b0;
+        if (d) return len + (uint32_t)(__builtin_ctzll(d) >> 3);
+        d = a1 ^ b1;
+        if (d) return len + 8 + (uint32_t)(__builtin_ctzll(d) >> 3);
+        d = a2 ^ b2;
+        if (d) return len + 16 + (uint32_t)(__builtin_ctzll(d) >> 3);
+        d = a3 ^ b3;
+        if (d) return len + 24 + (uint32_t)(__builtin_ctzll(d) >> 3);
+        len += 32;
+    }
     while (len + 8 <= lim) {
         const uint64_t d = ld64(in + q + len) ^ ld64(in + x + len);
         if (d) return len + (uint32_t)(__builtin_ctzll(d) >> 3);
@@ -306,11 +323,78 @@ struct Env {
     const uint32_t* __restrict__ sorted8;
     uint32_t nice, depth, hb, cyclic;
     uint32_t depth2, block_end;
+    uint32_t n_last;                            // last valid byte offset of the batch (prefetch clamp)
 };
 
-__device__ __forceinline__ void do_round(const Env& e, uint32_t x, uint32_t end,
+// ------------------------------------------------------------------------------------------
+// Software prefetch of the parse-independent per-position data.  Rounds mostly visit consecutive
+// positions (lookahead of the fast parser, every node of an optimal-parser window), so while the
+// wave works on position x the loads for x+1 (chain slots) and x+2 (rank / prev links) are already
+// in flight: two of the three dependent HBM round trips of a round leave the critical path.
+// ------------------------------------------------------------------------------------------
+struct PreA { uint32_t rk, d2, d3, rk8; };
+struct Pre {
+    uint32_t pos;       // position (a, ent) belong to; `an` belongs to pos + 1
+    bool valid;
+    PreA a;
+    uint32_t ent;       // per lane: chain slot entry for this lane's role
+    PreA an;
+};
+
+template <bool PARETO>
+__device__ __forceinline__ PreA load_a(const Env& e, uint32_t x)
+{
+    x = x < e.n_last ? x : e.n_last;
+    PreA a;
+    a.rk = e.rank[x];
+    a.d2 = e.prev2[x];
+    a.d3 = e.hb == 4 ? e.prev3[x] : 0;
+    a.rk8 = PARETO ? e.rank8[x] : 0;
+    return a;
+}
+
+template <bool PARETO>
+__device__ __forceinline__ uint32_t load_ent(const Env& e, const PreA& a)
+{
+    const uint32_t lane = threadIdx.x;
+    uint32_t ent = 0x80000000u;                      // out of range == "bucket start"
+    if constexpr (!PARETO) {
+        const bool in_chain = lane >= 2 && lane <= 2 + e.depth;
+        if (in_chain && a.rk >= lane - 2) ent = e.sorted_pos[a.rk - (lane - 2)];
+    } else {
+        const uint32_t A = 3 + e.depth;
+        const bool in4 = lane >= 2 && lane <= 2 + e.depth;
+        const bool in8 = lane >= A && lane <= A + e.depth2;
+        if (in4 && a.rk >= lane - 2) ent = e.sorted_pos[a.rk - (lane - 2)];
+        if (in8 && a.rk8 >= lane - A) ent = e.sorted8[a.rk8 - (lane - A)];
+    }
+    return ent;
+}
+
+template <bool PARETO>
+__device__ __forceinline__ void fetch(const Env& e, Pre& P, uint32_t x, PreA& a, uint32_t& ent)
+{
+    if (!(P.valid && P.pos == x)) {                  // cold start: two dependent round trips
+        P.a = load_a<PARETO>(e, x);
+        P.ent = load_ent<PARETO>(e, P.a);
+        P.an = load_a<PARETO>(e, x + 1);
+    }
+    a = P.a;
+    ent = P.ent;
+    const PreA an = P.an;                            // issued one round ago
+    P.a = an;
+    P.ent = load_ent<PARETO>(e, an);                 // for x + 1, consumed next round
+    P.an = load_a<PARETO>(e, x + 2);
+    P.pos = x + 1;
+    P.valid = true;
+}
+
+__device__ __forceinline__ void do_round(const Env& e, Pre& P, uint32_t x, uint32_t end,
         uint32_t r0, uint32_t r1, uint32_t r2, uint32_t r3, Round& R)
 {
+    PreA pa;
+    uint32_t pent;
+    fetch<false>(e, P, x, pa, pent);
     const uint32_t lane = threadIdx.x;
     const uint32_t avail = end - x;
     const uint32_t buf_avail = avail < MATCH_LEN_MAX ? avail : MATCH_LEN_MAX;
@@ -322,17 +406,15 @@ __device__ __forceinline__ void do_round(const Env& e, uint32_t x, uint32_t end,
     uint32_t q = 0, lim = 0;
     bool chain_valid = false;
     if (mf_ok) {
-        const uint32_t rk = e.rank[x];
-        const uint32_t d2 = e.prev2[x];
-        const uint32_t d3 = e.hb == 4 ? e.prev3[x] : 0;
+        const uint32_t d2 = pa.d2;
+        const uint32_t d3 = pa.d3;
         if (lane == 0) {
             if (d2 != 0 && d2 < e.cyclic) { q = x - d2; lim = len_limit; }
         } else if (lane == 1) {
             if (d3 != 0 && d3 != d2 && d3 < e.cyclic) { q = x - d3; lim = len_limit; }
         }
-        uint32_t ent = 0x80000000u;                      // treat out-of-range as "bucket start"
+        const uint32_t ent = pent;
         const bool in_chain = lane >= 2 && lane <= 2 + e.depth;
-        if (in_chain && rk >= lane - 2) ent = e.sorted_pos[rk - (lane - 2)];
         const uint64_t flags = __ballot(in_chain && (ent >> 31)) >> 2;   // bit j = flag of slot rank-j
         if (lane >= 3 && in_chain) {
             const uint32_t j = lane - 2;                 // candidate number 1..depth
@@ -402,76 +484,120 @@ __device__ __forceinline__ uint32_t dist_slot_of(uint32_t d)
     return (i + i) + ((d >> (i - 1)) & 1);
 }
 
-__device__ __forceinline__ void enc_length(RC& rc, uint16_t* probs, uint32_t base, uint32_t ps, uint32_t len)
+// ---- wave-parallel symbol coder -------------------------------------------------------------
+// An LZMA symbol is a list of <= 48 (probability, bit) pairs whose probability INDICES are known
+// up front (lzma_encoder.c:23-263 walks them one rc_bit at a time).  Lane k of the wavefront
+// owns pair k: all probabilities are fetched with ONE LDS gather, adapted in parallel (the update
+// depends only on the old value and the bit) and written back with ONE scatter; only the
+// range/low recurrence (range_encoder.h:196-257) runs serially, on scalar registers, through a
+// single copy of the normalise/shift_low code.
+enum : uint32_t { SEG_BIT = 0, SEG_TREE = 1, SEG_REV = 2, SEG_DIRECT = 3, SEG_MATCHED = 4 };
+
+struct SegSel {            // per lane: which segment this lane's pair belongs to
+    uint32_t type, base, sym, i, n;
+    bool hit;
+};
+
+__device__ __forceinline__ void seg_add(SegSel& s, uint32_t& off, uint32_t n, uint32_t type, uint32_t base, uint32_t sym)
 {
-    len -= 2;
-    if (len < 8) {
-        rc.bit(probs, base + LEN_CHOICE, 0);
-        rc.tree(probs, base + LEN_LOW + ps * 8, 3, len);
-    } else {
-        rc.bit(probs, base + LEN_CHOICE, 1);
-        len -= 8;
-        if (len < 8) {
-            rc.bit(probs, base + LEN_CHOICE2, 0);
-            rc.tree(probs, base + LEN_MID + ps * 8, 3, len);
+    const uint32_t k = threadIdx.x;
+    if (k >= off && k < off + n) { s.type = type; s.base = base; s.sym = sym; s.i = k - off; s.n = n; s.hit = true; }
+    off += n;
+}
+
+// serial part: t = p (12 bits) | bit << 12 | direct << 13, one entry per lane 0..n-1
+__device__ __forceinline__ void rc_run(RC& rc, uint32_t packed, uint32_t n)
+{
+    for (uint32_t k = 0; k < n; ++k) {
+        const uint32_t t = lane_of(packed, k);
+        rc.normalize();
+        if (t & 0x2000u) {
+            rc.range >>= 1;
+            if (t & 0x1000u) rc.low += rc.range;
         } else {
-            rc.bit(probs, base + LEN_CHOICE2, 1);
-            rc.tree(probs, base + LEN_HIGH, 8, len - 8);
+            const uint32_t bound = (rc.range >> 11) * (t & 0xFFFu);
+            if (t & 0x1000u) { rc.low += bound; rc.range -= bound; }
+            else rc.range = bound;
         }
     }
 }
 
-// g = global offset of the byte, upos = its offset inside the Block
-__device__ __forceinline__ void enc_literal(RC& rc, uint16_t* probs, Lz& z, const uint8_t* __restrict__ in,
-        uint32_t g, uint32_t upos)
+__device__ __forceinline__ void rc_emit(RC& rc, uint16_t* probs, const SegSel& s, uint32_t total)
 {
-    const uint32_t cur = uni(in[g]);
-    const uint32_t prev = upos ? uni(in[g - 1]) : 0;
-    const uint32_t mask = (0x100u << z.lp) - (0x100u >> z.lc);
-    const uint32_t sub = P_LITERAL + 3u * ((((upos << 8) + prev) & mask) << z.lc);
-    if (z.state < 7) {
-        z.state = z.state <= 3 ? 0 : z.state - 3;
-        rc.tree(probs, sub, 8, cur);
-    } else {
-        z.state = z.state <= 9 ? z.state - 3 : z.state - 6;
-        uint32_t mb = uni(in[g - z.rep0 - 1]);
-        uint32_t off = 0x100, sym = 0x100u + cur;
-        do {
-            mb <<= 1;
-            const uint32_t mbit = mb & off;
-            const uint32_t idx = off + mbit + (sym >> 8);
-            const uint32_t b = (sym >> 7) & 1;
-            rc.bit(probs, sub + idx, b);
-            sym <<= 1;
-            off &= ~(mb ^ sym);
-        } while (sym < 0x10000);
+    uint32_t idx = 0, bit = 0;
+    bool direct = false;
+    if (s.hit) {
+        const uint32_t i = s.i, n = s.n, sym = s.sym;
+        if (s.type == SEG_BIT) {
+            idx = s.base; bit = sym & 1;
+        } else if (s.type == SEG_TREE) {            // rc_bittree: MSB first
+            bit = (sym >> (n - 1 - i)) & 1;
+            idx = s.base + ((1u << i) | (sym >> (n - i)));
+        } else if (s.type == SEG_REV) {             // rc_bittree_reverse: LSB first
+            bit = (sym >> i) & 1;
+            const uint32_t low = sym & ((1u << i) - 1);
+            idx = s.base + ((1u << i) | (__builtin_bitreverse32(low) >> ((32 - i) & 31)));   // i == 0: low == 0
+        } else if (s.type == SEG_DIRECT) {
+            bit = (sym >> (n - 1 - i)) & 1;
+            direct = true;
+        } else {                                    // literal_matched (lzma_encoder.c:23-41)
+            const uint32_t cur = sym & 0xFF, mb = sym >> 8;
+            bit = (cur >> (7 - i)) & 1;
+            const uint32_t pre = (0x100u | cur) >> (8 - i);
+            const bool same = (mb >> (8 - i)) == (cur >> (8 - i));
+            idx = s.base + (same ? 0x100u + (((mb >> (7 - i)) & 1) << 8) + pre : pre);
+        }
     }
+    uint32_t p = 0;
+    if (s.hit && !direct) {
+        p = probs[idx];
+        probs[idx] = (uint16_t)(bit ? p - (p >> 5) : p + ((2048 - p) >> 5));
+    }
+    const uint32_t packed = p | (bit << 12) | (direct ? 0x2000u : 0u);
+    rc_run(rc, packed, total);
 }
 
+// g = global offset of the byte, upos = its offset inside the Block
 __device__ __forceinline__ void encode_symbol(RC& rc, uint16_t* probs, Lz& z, const uint8_t* __restrict__ in,
         uint32_t g, uint32_t upos, uint32_t back, uint32_t len)
 {
     const uint32_t ps = upos & ((1u << z.pb) - 1);
+    SegSel s;
+    s.type = 0; s.base = 0; s.sym = 0; s.i = 0; s.n = 0; s.hit = false;
+    uint32_t off = 0;
     if (back == LITERAL) {
-        rc.bit(probs, P_IS_MATCH + z.state * 16 + ps, 0);
-        enc_literal(rc, probs, z, in, g, upos);
+        seg_add(s, off, 1, SEG_BIT, P_IS_MATCH + z.state * 16 + ps, 0);
+        const uint32_t cur = uni(in[g]);
+        const uint32_t prev = upos ? uni(in[g - 1]) : 0;
+        const uint32_t mask = (0x100u << z.lp) - (0x100u >> z.lc);
+        const uint32_t sub = P_LITERAL + 3u * ((((upos << 8) + prev) & mask) << z.lc);
+        if (z.state < 7) {
+            z.state = z.state <= 3 ? 0 : z.state - 3;
+            seg_add(s, off, 8, SEG_TREE, sub, cur);
+        } else {
+            z.state = z.state <= 9 ? z.state - 3 : z.state - 6;
+            const uint32_t mb = uni(in[g - z.rep0 - 1]);
+            seg_add(s, off, 8, SEG_MATCHED, sub, cur | (mb << 8));
+        }
+        rc_emit(rc, probs, s, off);
         return;
     }
-    rc.bit(probs, P_IS_MATCH + z.state * 16 + ps, 1);
+    seg_add(s, off, 1, SEG_BIT, P_IS_MATCH + z.state * 16 + ps, 1);
+    uint32_t len_base;
     if (back < 4) {
-        rc.bit(probs, P_IS_REP + z.state, 1);
+        seg_add(s, off, 1, SEG_BIT, P_IS_REP + z.state, 1);
         if (back == 0) {
-            rc.bit(probs, P_IS_REP0 + z.state, 0);
-            rc.bit(probs, P_IS_REP0_LONG + z.state * 16 + ps, len != 1);
+            seg_add(s, off, 1, SEG_BIT, P_IS_REP0 + z.state, 0);
+            seg_add(s, off, 1, SEG_BIT, P_IS_REP0_LONG + z.state * 16 + ps, len != 1);
         } else {
-            rc.bit(probs, P_IS_REP0 + z.state, 1);
+            seg_add(s, off, 1, SEG_BIT, P_IS_REP0 + z.state, 1);
             uint32_t dist;
             if (back == 1) {
-                rc.bit(probs, P_IS_REP1 + z.state, 0);
+                seg_add(s, off, 1, SEG_BIT, P_IS_REP1 + z.state, 0);
                 dist = z.rep1;
             } else {
-                rc.bit(probs, P_IS_REP1 + z.state, 1);
-                rc.bit(probs, P_IS_REP2 + z.state, back - 2);
+                seg_add(s, off, 1, SEG_BIT, P_IS_REP1 + z.state, 1);
+                seg_add(s, off, 1, SEG_BIT, P_IS_REP2 + z.state, back - 2);
                 if (back == 3) { dist = z.rep3; z.rep3 = z.rep2; }
                 else dist = z.rep2;
                 z.rep2 = z.rep1;
@@ -481,35 +607,56 @@ __device__ __forceinline__ void encode_symbol(RC& rc, uint16_t* probs, Lz& z, co
         }
         if (len == 1) {
             z.state = z.state < 7 ? 9 : 11;
-        } else {
-            enc_length(rc, probs, P_REP_LEN, ps, len);
-            z.state = z.state < 7 ? 8 : 11;
-            ++z.cnt_len;
+            rc_emit(rc, probs, s, off);
+            return;
         }
-        return;
+        len_base = P_REP_LEN;
+        z.state = z.state < 7 ? 8 : 11;
+        ++z.cnt_len;
+    } else {
+        seg_add(s, off, 1, SEG_BIT, P_IS_REP + z.state, 0);
+        len_base = P_MATCH_LEN;
+        z.state = z.state < 7 ? 7 : 10;
+        ++z.cnt_len;
+        ++z.cnt_match;
     }
-    rc.bit(probs, P_IS_REP + z.state, 0);
-    const uint32_t dist = back - 4;
-    z.state = z.state < 7 ? 7 : 10;
-    enc_length(rc, probs, P_MATCH_LEN, ps, len);
-    ++z.cnt_len;
-    ++z.cnt_match;
-    const uint32_t slot = dist_slot_of(dist);
-    const uint32_t ds = len < 6 ? len - 2 : 3;
-    rc.tree(probs, P_DIST_SLOT + ds * 64, 6, slot);
-    if (slot >= 4) {
-        const uint32_t fb = (slot >> 1) - 1;
-        const uint32_t base = (2 | (slot & 1)) << fb;
-        const uint32_t red = dist - base;
-        if (slot < 14) {
-            rc.tree_rev(probs, P_DIST_SPECIAL + base - slot - 1, fb, red);
+    // length (lzma_encoder.c:106-134)
+    {
+        const uint32_t l = len - 2;
+        if (l < 8) {
+            seg_add(s, off, 1, SEG_BIT, len_base + LEN_CHOICE, 0);
+            seg_add(s, off, 3, SEG_TREE, len_base + LEN_LOW + ps * 8, l);
+        } else if (l < 16) {
+            seg_add(s, off, 1, SEG_BIT, len_base + LEN_CHOICE, 1);
+            seg_add(s, off, 1, SEG_BIT, len_base + LEN_CHOICE2, 0);
+            seg_add(s, off, 3, SEG_TREE, len_base + LEN_MID + ps * 8, l - 8);
         } else {
-            rc.direct(red >> 4, fb - 4);
-            rc.tree_rev(probs, P_DIST_ALIGN, 4, red & 15);
-            ++z.cnt_align;
+            seg_add(s, off, 1, SEG_BIT, len_base + LEN_CHOICE, 1);
+            seg_add(s, off, 1, SEG_BIT, len_base + LEN_CHOICE2, 1);
+            seg_add(s, off, 8, SEG_TREE, len_base + LEN_HIGH, l - 16);
         }
     }
-    z.rep3 = z.rep2; z.rep2 = z.rep1; z.rep1 = z.rep0; z.rep0 = dist;
+    if (back >= 4) {
+        // distance (lzma_encoder.c:142-181)
+        const uint32_t dist = back - 4;
+        const uint32_t slot = dist_slot_of(dist);
+        const uint32_t ds = len < 6 ? len - 2 : 3;
+        seg_add(s, off, 6, SEG_TREE, P_DIST_SLOT + ds * 64, slot);
+        if (slot >= 4) {
+            const uint32_t fb = (slot >> 1) - 1;
+            const uint32_t base = (2 | (slot & 1)) << fb;
+            const uint32_t red = dist - base;
+            if (slot < 14) {
+                seg_add(s, off, fb, SEG_REV, P_DIST_SPECIAL + base - slot - 1, red);
+            } else {
+                seg_add(s, off, fb - 4, SEG_DIRECT, 0, red >> 4);
+                seg_add(s, off, 4, SEG_REV, P_DIST_ALIGN, red & 15);
+                ++z.cnt_align;
+            }
+        }
+        z.rep3 = z.rep2; z.rep2 = z.rep1; z.rep1 = z.rep0; z.rep0 = dist;
+    }
+    rc_emit(rc, probs, s, off);
 }
 
 __device__ __forceinline__ bool change_pair(uint32_t small_dist, uint32_t big_dist)
@@ -553,25 +700,31 @@ struct Work {
     uint16_t* ap;       // [16]    align price
     uint8_t* ptab;      // [128]   bit price table (price_tablegen.c:31-58)
     uint32_t* err;      // debug/consistency word block (global)
+    uint32_t ptv;       // the same price table in registers: lane l (< 32) holds entries 4l..4l+3
 };
 
 struct RoundL {
     uint32_t L;         // per lane; lanes 60..63 = rep lengths
-    uint32_t cnt;       // entries in Work::ml/md
+    uint32_t SL, SD;    // kept matches sorted by length: lane r holds entry r (length, zero-based distance)
+    uint32_t cnt;       // number of entries
     uint32_t longest;   // incl. the > nice_len extension
 };
+
+// lane `dst` receives `v` from this lane (all lanes must execute; unused senders target lane 63)
+__device__ __forceinline__ uint32_t lane_scatter(uint32_t dst, uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_ds_permute((int)(dst << 2), (int)v);
+}
 
 // Compact the exact finder's recorded lanes into the LDS list (already in ascending order).
 __device__ __forceinline__ void list_from_mask(const Work& w, const Round& R, RoundL& out)
 {
     const uint32_t lane = threadIdx.x;
     const uint64_t lt = (1ull << lane) - 1;
-    if ((R.mask >> lane) & 1) {
-        const uint32_t idx = (uint32_t)__builtin_popcountll(R.mask & lt);
-        w.ml[idx] = R.L;
-        w.md[idx] = R.D;
-    }
-    wave_sync();
+    (void)w;
+    const uint32_t dst = ((R.mask >> lane) & 1) ? (uint32_t)__builtin_popcountll(R.mask & lt) : 63u;
+    out.SL = lane_scatter(dst, R.L);
+    out.SD = lane_scatter(dst, R.D);
     out.L = R.L;
     out.cnt = (uint32_t)__builtin_popcountll(R.mask);
     out.longest = R.longest;
@@ -579,9 +732,12 @@ __device__ __forceinline__ void list_from_mask(const Work& w, const Round& R, Ro
 
 // find_pareto(): lanes 0 = hash2, 1 = hash3, 2 = own slot of the 4-byte chain, 3..2+d4 = 4-byte
 // chain, A = 3+d4 = own slot of the 8-byte chain, A+1..A+d8 = 8-byte chain, 60..63 = reps.
-__device__ __forceinline__ void do_round_pareto(const Env& e, const Work& w, uint32_t x, uint32_t end,
+__device__ __forceinline__ void do_round_pareto(const Env& e, const Work& w, Pre& P, uint32_t x, uint32_t end,
         uint32_t r0, uint32_t r1, uint32_t r2, uint32_t r3, RoundL& R)
 {
+    PreA pa;
+    uint32_t pent;
+    fetch<true>(e, P, x, pa, pent);
     const uint32_t lane = threadIdx.x;
     const uint32_t avail = end - x;
     const uint32_t buf_avail = avail < MATCH_LEN_MAX ? avail : MATCH_LEN_MAX;
@@ -594,11 +750,9 @@ __device__ __forceinline__ void do_round_pareto(const Env& e, const Work& w, uin
     uint32_t q = 0, lim = 0, minlen = 4;
     bool valid = false;
     if (mf_ok) {
-        const uint32_t rk4 = e.rank[x];
-        const uint32_t d2 = e.prev2[x];
-        const uint32_t d3 = e.prev3[x];
+        const uint32_t d2 = pa.d2;
+        const uint32_t d3 = pa.d3;
         const bool have8 = e.block_end - x >= 8;
-        const uint32_t rk8 = have8 ? e.rank8[x] : 0;
         if (lane == 0) {
             minlen = 2;
             if (d2 != 0 && d2 < e.cyclic) { q = x - d2; lim = len_limit; valid = true; }
@@ -608,9 +762,8 @@ __device__ __forceinline__ void do_round_pareto(const Env& e, const Work& w, uin
         }
         const bool in4 = lane >= 2 && lane <= 2 + d4;
         const bool in8 = have8 && lane >= A && lane <= A + d8;
-        uint32_t ent = 0x80000000u;
-        if (in4 && rk4 >= lane - 2) ent = e.sorted_pos[rk4 - (lane - 2)];
-        if (in8 && rk8 >= lane - A) ent = e.sorted8[rk8 - (lane - A)];
+        uint32_t ent = pent;
+        if (!have8 && lane >= A) ent = 0x80000000u;
         const uint64_t fl = __ballot((in4 || in8) && (ent >> 31));
         const uint64_t flags4 = fl >> 2, flags8 = fl >> A;
         const uint32_t qp = ent & 0x7FFFFFFFu;
@@ -666,11 +819,13 @@ __device__ __forceinline__ void do_round_pareto(const Env& e, const Work& w, uin
         const uint32_t Lk = lane_of(L, k);
         rk += (Lk < L) ? 1u : 0u;
     }
-    if (keep) { w.ml[rk] = L; w.md[rk] = dist - 1; }
-    wave_sync();
-    uint32_t longest = uni(w.ml[cnt - 1]);
+    (void)w;
+    const uint32_t dst = keep ? rk : 63u;
+    R.SL = lane_scatter(dst, L);
+    R.SD = lane_scatter(dst, dist - 1);
+    uint32_t longest = lane_of(R.SL, cnt - 1);
     if (longest == e.nice) {
-        const uint32_t dd = uni(w.md[cnt - 1]);
+        const uint32_t dd = lane_of(R.SD, cnt - 1);
         longest = wave_cmplen(e.in, x, x - dd - 1, longest, buf_avail);
     }
     R.longest = longest;
@@ -680,6 +835,12 @@ __device__ __forceinline__ void do_round_pareto(const Env& e, const Work& w, uin
 __device__ __forceinline__ uint32_t pr_bit(const uint16_t* probs, const uint8_t* ptab, uint32_t idx, uint32_t bit)
 {
     return ptab[(probs[idx] ^ ((0u - bit) & 0x7FFu)) >> 4];
+}
+// uniform variant: probability index is wave-uniform -> table lookup by readlane, no second LDS trip
+__device__ __forceinline__ uint32_t pr_bit_u(const uint16_t* probs, uint32_t ptv, uint32_t idx, uint32_t bit)
+{
+    const uint32_t t = (uni(probs[idx]) ^ ((0u - bit) & 0x7FFu)) >> 4;
+    return (lane_of(ptv, t >> 2) >> ((t & 3) * 8)) & 0xFFu;
 }
 __device__ __forceinline__ uint32_t pr_tree(const uint16_t* probs, const uint8_t* ptab, uint32_t base,
         uint32_t nbits, uint32_t sym)
@@ -783,11 +944,11 @@ __device__ __forceinline__ uint32_t tab_dist(const Work& w, uint32_t dist, uint3
 
 // literal price, 8 bits evaluated by lanes 0..7 (get_literal_price, optimum_normal.c:21-53)
 __device__ __forceinline__ uint32_t pr_literal_wave(const uint16_t* probs, const uint8_t* ptab, const Lz& z,
-        const uint8_t* __restrict__ in, uint32_t g, uint32_t upos, uint32_t state, uint32_t rep0)
+        uint32_t b_cur, uint32_t b_prev, uint32_t b_mb, uint32_t upos, uint32_t state)
 {
     const uint32_t lane = threadIdx.x;
-    const uint32_t cur = uni(in[g]);
-    const uint32_t prev = upos ? uni(in[g - 1]) : 0;
+    const uint32_t cur = uni(b_cur);
+    const uint32_t prev = upos ? uni(b_prev) : 0;
     const uint32_t mask = (0x100u << z.lp) - (0x100u >> z.lc);
     const uint32_t sub = P_LITERAL + 3u * ((((upos << 8) + prev) & mask) << z.lc);
     uint32_t p = 0;
@@ -797,7 +958,7 @@ __device__ __forceinline__ uint32_t pr_literal_wave(const uint16_t* probs, const
         const uint32_t pre = (0x100u | cur) >> (8 - k);  // 1 followed by the k bits already coded
         uint32_t idx = pre;
         if (state >= 7) {
-            const uint32_t mb = uni(in[g - rep0 - 1]);
+            const uint32_t mb = uni(b_mb);
             const bool same = (mb >> (8 - k)) == (cur >> (8 - k));   // k leading bits equal
             if (same) idx = 0x100 + (((mb >> (7 - k)) & 1) << 8) + pre;
         }
@@ -815,7 +976,7 @@ __device__ __forceinline__ uint32_t state_after(uint32_t s, uint32_t back, uint3
 
 // Relax all rep / match lengths out of node j (lane = length). PS is the compile-time pos_state.
 template <int PS>
-__device__ __forceinline__ void relax_lengths(const Work& w, const LenTab& lt, uint32_t j, uint32_t reach,
+__device__ __forceinline__ void relax_lengths(const Work& w, const LenTab& lt, uint32_t SL, uint32_t SD, uint32_t j, uint32_t reach,
         uint32_t longest, uint32_t cnt, uint32_t rl0, uint32_t rl1, uint32_t rl2, uint32_t rl3,
         uint32_t prep0, uint32_t prep1, uint32_t prep2, uint32_t prep3, uint32_t pmatch, uint32_t upos_dbg = 0)
 {
@@ -824,6 +985,9 @@ __device__ __forceinline__ void relax_lengths(const Work& w, const LenTab& lt, u
     for (int it = 0; it < 5; ++it) {
         if (2 + 64u * it > reach) break;
         const uint32_t l = 2 + lane + 64u * it;
+        uint32_t idx_m = 0;                       // first entry whose length reaches l (or the last one)
+        for (uint32_t k = 0; k + 1 < cnt; ++k) idx_m += (lane_of(SL, k) < l) ? 1u : 0u;
+        const uint32_t dist_m = __shfl(SD, idx_m);
         if (l <= reach) {
             const uint32_t lpm = lt.v[PS][it] & 0xFFFFu, lpr = lt.v[PS][it] >> 16;
             uint32_t best = w.n_price[j + l], bb = 0;
@@ -833,9 +997,7 @@ __device__ __forceinline__ void relax_lengths(const Work& w, const LenTab& lt, u
             if (rl2 >= l && prep2 + lpr < best) { best = prep2 + lpr; bb = 2; upd = true; }
             if (rl3 >= l && prep3 + lpr < best) { best = prep3 + lpr; bb = 3; upd = true; }
             if (l <= longest) {
-                uint32_t idx = 0;
-                for (uint32_t k = 0; k + 1 < cnt; ++k) idx += (uni(w.ml[k]) < l) ? 1u : 0u;
-                const uint32_t dist = w.md[idx];
+                const uint32_t dist = dist_m;
 #ifdef XZAMD_PARANOID
                 if (dist >= upos_dbg && w.err && atomicCAS(w.err, 0u, 3u) == 0u) {
                     w.err[1] = upos_dbg; w.err[2] = j; w.err[3] = l; w.err[4] = idx; w.err[5] = cnt; w.err[6] = dist; w.err[7] = longest;
@@ -856,7 +1018,7 @@ __device__ __forceinline__ void relax_lengths(const Work& w, const LenTab& lt, u
 // One window of the optimal parser (oracle: optimum_window).  Returns with the chosen symbol path
 // stored as out-edges: node t -> (n_price[t] = back, out-len in n_info[t]); q_end = last node.
 template <bool PARETO>
-__device__ __forceinline__ bool optimum_window(const Env& e, const Work& w, uint16_t* probs, const Lz& z, LenTab& lt,
+__device__ __forceinline__ bool optimum_window(const Env& e, const Work& w, Pre& P, uint16_t* probs, const Lz& z, LenTab& lt,
         const uint8_t* __restrict__ in, uint32_t pos, uint32_t block_start, uint32_t span_end, bool cached,
         RoundL& RL, uint32_t& q_end)
 {
@@ -917,12 +1079,16 @@ __device__ __forceinline__ bool optimum_window(const Env& e, const Work& w, uint
             }
         }
 #endif
+        // bytes the literal price needs: issued now, consumed after the round
+        const uint32_t b_cur = in[x];
+        const uint32_t b_prev = x > block_start ? in[x - 1] : 0;
+        const uint32_t b_mb = in[x - r0 - 1];
         if (!(j == 0 && cached)) {
             if constexpr (PARETO) {
-                do_round_pareto(e, w, x, span_end, r0, r1, r2, r3, RL);
+                do_round_pareto(e, w, P, x, span_end, r0, r1, r2, r3, RL);
             } else {
                 Round R;
-                do_round(e, x, span_end, r0, r1, r2, r3, R);
+                do_round(e, P, x, span_end, r0, r1, r2, r3, R);
                 list_from_mask(w, R, RL);
             }
         }
@@ -936,7 +1102,7 @@ __device__ __forceinline__ bool optimum_window(const Env& e, const Work& w, uint
             else if (rl1 >= e.nice) { sb = 1; sl = rl1; }
             else if (rl2 >= e.nice) { sb = 2; sl = rl2; }
             else if (rl3 >= e.nice) { sb = 3; sl = rl3; }
-            else if (longest >= e.nice) { sb = uni(w.md[RL.cnt - 1]) + 4; sl = longest; }
+            else if (longest >= e.nice) { sb = lane_of(RL.SD, RL.cnt - 1) + 4; sl = longest; }
             if (sl) {
                 if (lane == 0) { w.n_price[0] = sb; w.n_info[0] = (w.n_info[0] & 0x1FFF) | (sl << 13); }
                 wave_sync();
@@ -960,36 +1126,36 @@ __device__ __forceinline__ bool optimum_window(const Env& e, const Work& w, uint
         const uint32_t upos = x - block_start;
         const uint32_t ps = upos & pbm;
         const uint32_t P = uni(w.n_price[j]);
-        const uint32_t pm1 = P + pr_bit(probs, w.ptab, P_IS_MATCH + s * 16 + ps, 1);
-        const uint32_t prep = pm1 + pr_bit(probs, w.ptab, P_IS_REP + s, 1);
+        const uint32_t pm1 = P + pr_bit_u(probs, w.ptv, P_IS_MATCH + s * 16 + ps, 1);
+        const uint32_t prep = pm1 + pr_bit_u(probs, w.ptv, P_IS_REP + s, 1);
         // literal and short rep -> node j+1
         {
-            const uint32_t plit = P + pr_bit(probs, w.ptab, P_IS_MATCH + s * 16 + ps, 0)
-                    + pr_literal_wave(probs, w.ptab, z, in, x, upos, s, r0);
+            const uint32_t plit = P + pr_bit_u(probs, w.ptv, P_IS_MATCH + s * 16 + ps, 0)
+                    + pr_literal_wave(probs, w.ptab, z, b_cur, b_prev, b_mb, upos, s);
             uint32_t best = uni(w.n_price[j + 1]), bb = 0;
             bool upd = false;
             if (plit < best) { best = plit; bb = LITERAL; upd = true; }
             if (rp0 >= 1) {
-                const uint32_t psr = prep + pr_bit(probs, w.ptab, P_IS_REP0 + s, 0)
-                        + pr_bit(probs, w.ptab, P_IS_REP0_LONG + s * 16 + ps, 0);
+                const uint32_t psr = prep + pr_bit_u(probs, w.ptv, P_IS_REP0 + s, 0)
+                        + pr_bit_u(probs, w.ptv, P_IS_REP0_LONG + s * 16 + ps, 0);
                 if (psr < best) { best = psr; bb = 0; upd = true; }
             }
             if (upd && lane == 0) { w.n_price[j + 1] = best; w.n_back[j + 1] = bb; w.n_info[j + 1] = 1; }
             wave_sync();
         }
         if (reach >= 2) {
-            const uint32_t b0 = pr_bit(probs, w.ptab, P_IS_REP0 + s, 0), b1 = pr_bit(probs, w.ptab, P_IS_REP0 + s, 1);
-            const uint32_t prep0 = prep + b0 + pr_bit(probs, w.ptab, P_IS_REP0_LONG + s * 16 + ps, 1);
-            const uint32_t prep1 = prep + b1 + pr_bit(probs, w.ptab, P_IS_REP1 + s, 0);
-            const uint32_t p11 = prep + b1 + pr_bit(probs, w.ptab, P_IS_REP1 + s, 1);
-            const uint32_t prep2 = p11 + pr_bit(probs, w.ptab, P_IS_REP2 + s, 0);
-            const uint32_t prep3 = p11 + pr_bit(probs, w.ptab, P_IS_REP2 + s, 1);
-            const uint32_t pmatch = pm1 + pr_bit(probs, w.ptab, P_IS_REP + s, 0);
+            const uint32_t b0 = pr_bit_u(probs, w.ptv, P_IS_REP0 + s, 0), b1 = pr_bit_u(probs, w.ptv, P_IS_REP0 + s, 1);
+            const uint32_t prep0 = prep + b0 + pr_bit_u(probs, w.ptv, P_IS_REP0_LONG + s * 16 + ps, 1);
+            const uint32_t prep1 = prep + b1 + pr_bit_u(probs, w.ptv, P_IS_REP1 + s, 0);
+            const uint32_t p11 = prep + b1 + pr_bit_u(probs, w.ptv, P_IS_REP1 + s, 1);
+            const uint32_t prep2 = p11 + pr_bit_u(probs, w.ptv, P_IS_REP2 + s, 0);
+            const uint32_t prep3 = p11 + pr_bit_u(probs, w.ptv, P_IS_REP2 + s, 1);
+            const uint32_t pmatch = pm1 + pr_bit_u(probs, w.ptv, P_IS_REP + s, 0);
             switch (ps & 3) {
-            case 0: relax_lengths<0>(w, lt, j, reach, longest, RL.cnt, rl0, rl1, rl2, rl3, prep0, prep1, prep2, prep3, pmatch, upos); break;
-            case 1: relax_lengths<1>(w, lt, j, reach, longest, RL.cnt, rl0, rl1, rl2, rl3, prep0, prep1, prep2, prep3, pmatch, upos); break;
-            case 2: relax_lengths<2>(w, lt, j, reach, longest, RL.cnt, rl0, rl1, rl2, rl3, prep0, prep1, prep2, prep3, pmatch, upos); break;
-            default: relax_lengths<3>(w, lt, j, reach, longest, RL.cnt, rl0, rl1, rl2, rl3, prep0, prep1, prep2, prep3, pmatch, upos); break;
+            case 0: relax_lengths<0>(w, lt, RL.SL, RL.SD, j, reach, longest, RL.cnt, rl0, rl1, rl2, rl3, prep0, prep1, prep2, prep3, pmatch, upos); break;
+            case 1: relax_lengths<1>(w, lt, RL.SL, RL.SD, j, reach, longest, RL.cnt, rl0, rl1, rl2, rl3, prep0, prep1, prep2, prep3, pmatch, upos); break;
+            case 2: relax_lengths<2>(w, lt, RL.SL, RL.SD, j, reach, longest, RL.cnt, rl0, rl1, rl2, rl3, prep0, prep1, prep2, prep3, pmatch, upos); break;
+            default: relax_lengths<3>(w, lt, RL.SL, RL.SD, j, reach, longest, RL.cnt, rl0, rl1, rl2, rl3, prep0, prep1, prep2, prep3, pmatch, upos); break;
             }
             wave_sync();
         }
@@ -1015,11 +1181,11 @@ __device__ __forceinline__ bool optimum_window(const Env& e, const Work& w, uint
 
 // optimum_fast over the LDS match list (oracle: optimum_fast()).  Returns `cached`.
 template <bool PARETO>
-__device__ __forceinline__ bool fast_parse_list(const Env& e, const Work& w, const Lz& z, uint32_t cur,
+__device__ __forceinline__ bool fast_parse_list(const Env& e, const Work& w, Pre& P, const Lz& z, uint32_t cur,
         uint32_t span_end, bool cached, RoundL& RL, uint32_t& back, uint32_t& len)
 {
     if (!cached) {
-        if constexpr (PARETO) do_round_pareto(e, w, cur, span_end, z.rep0, z.rep1, z.rep2, z.rep3, RL);
+        if constexpr (PARETO) do_round_pareto(e, w, P, cur, span_end, z.rep0, z.rep1, z.rep2, z.rep3, RL);
     }
     back = LITERAL; len = 1;
     const uint32_t rem = span_end - cur;
@@ -1034,14 +1200,14 @@ __device__ __forceinline__ bool fast_parse_list(const Env& e, const Work& w, con
         if (rl >= e.nice) { back = i; len = rl; return false; }
         if (rl > rep_len) { rep_index = i; rep_len = rl; }
     }
-    if (len_main >= e.nice) { back = uni(w.md[count - 1]) + 4; len = len_main; return false; }
+    if (len_main >= e.nice) { back = lane_of(RL.SD, count - 1) + 4; len = len_main; return false; }
     uint32_t back_main = 0;
     if (len_main >= 2) {
-        back_main = uni(w.md[count - 1]);
+        back_main = lane_of(RL.SD, count - 1);
         while (count > 1) {
-            const uint32_t l2 = uni(w.ml[count - 2]);
+            const uint32_t l2 = lane_of(RL.SL, count - 2);
             if (len_main != l2 + 1) break;
-            const uint32_t d2 = uni(w.md[count - 2]);
+            const uint32_t d2 = lane_of(RL.SD, count - 2);
             if (!change_pair(d2, back_main)) break;
             --count; len_main = l2; back_main = d2;
         }
@@ -1055,10 +1221,10 @@ __device__ __forceinline__ bool fast_parse_list(const Env& e, const Work& w, con
         }
     }
     if (len_main < 2 || buf_avail <= 2) return false;
-    if constexpr (PARETO) do_round_pareto(e, w, cur + 1, span_end, z.rep0, z.rep1, z.rep2, z.rep3, RL);
+    if constexpr (PARETO) do_round_pareto(e, w, P, cur + 1, span_end, z.rep0, z.rep1, z.rep2, z.rep3, RL);
     const uint32_t nl = RL.longest;
     if (nl >= 2) {
-        const uint32_t new_dist = uni(w.md[RL.cnt - 1]);
+        const uint32_t new_dist = lane_of(RL.SD, RL.cnt - 1);
         if ((nl >= len_main && new_dist < back_main) || (nl == len_main + 1 && !change_pair(back_main, new_dist))
                 || (nl > len_main + 1) || (nl + 1 >= len_main && len_main >= 3 && change_pair(new_dist, back_main)))
             return true;
@@ -1104,7 +1270,10 @@ __global__ __launch_bounds__(64) void k_span_encode_t(xzamd_span_args a)
     e.in = in; e.rank = a.rank; e.sorted_pos = a.sorted_pos; e.prev2 = a.prev2; e.prev3 = a.prev3;
     e.rank8 = a.rank8; e.sorted8 = a.sorted8;
     e.nice = a.nice_len; e.depth = a.depth; e.hb = a.hash_bytes; e.cyclic = a.dict_size + 1;
-    e.depth2 = a.depth2; e.block_end = block_end;
+    e.depth2 = a.depth2; e.block_end = block_end; e.n_last = a.n - 1;
+    Pre P;
+    P.valid = false; P.pos = 0; P.ent = 0;
+    P.a.rk = P.a.d2 = P.a.d3 = P.a.rk8 = 0; P.an = P.a;
 
     Work w{};
     if constexpr (PARETO || OPT) {
@@ -1134,6 +1303,7 @@ __global__ __launch_bounds__(64) void k_span_encode_t(xzamd_span_args a)
             w.ptab[t] = (uint8_t)((11 << 4) - 15 - bit_count);
         }
         wave_sync();
+        w.ptv = reinterpret_cast<const uint32_t*>(w.ptab)[lane & 31];
     }
 
     Lz z;
@@ -1151,10 +1321,14 @@ __global__ __launch_bounds__(64) void k_span_encode_t(xzamd_span_args a)
     Round R;            // exact path: cached find at `cur` when read_ahead == 1
     R.mask = 0; R.L = 0; R.D = 0; R.longest = 0;
     RoundL RL;
-    RL.L = 0; RL.cnt = 0; RL.longest = 0;
+    RL.L = 0; RL.SL = 0; RL.SD = 0; RL.cnt = 0; RL.longest = 0;
     LenTab lt;
     uint32_t q_pos = 0, q_end = 0;  // pending path of the optimal parser (nodes in LDS)
     bool tables_valid = false;
+#ifdef XZAMD_TIMING
+    uint64_t tm_round1 = 0, tm_round2 = 0, tm_encode = 0, tm_rounds = 0, tm_syms = 0;
+    const uint64_t tm_start = __builtin_amdgcn_s_memtime();
+#endif
 
     while (cur < span_end) {
         if (need_state_reset) {
@@ -1196,7 +1370,7 @@ __global__ __launch_bounds__(64) void k_span_encode_t(xzamd_span_args a)
                     if (!tables_valid || z.cnt_match >= 128) { refresh_dist_tables(probs, w); z.cnt_match = 0; }
                     if (!tables_valid || z.cnt_align >= 16) { refresh_align_table(probs, w); z.cnt_align = 0; }
                     tables_valid = true;
-                    cached = optimum_window<PARETO>(e, w, probs, z, lt, in, cur, block_start, span_end, cached, RL, q_end);
+                    cached = optimum_window<PARETO>(e, w, P, probs, z, lt, in, cur, block_start, span_end, cached, RL, q_end);
                     q_pos = 0;
                     if (q_end == 0) {            // consistency failure reported by the parser
                         if (lane == 0) a.span_bytes[span] = 0;
@@ -1207,13 +1381,23 @@ __global__ __launch_bounds__(64) void k_span_encode_t(xzamd_span_args a)
                 len = (uni(w.n_info[q_pos]) >> 13) & 0x1FF;
                 q_pos += len;
             } else if constexpr (PARETO) {
-                cached = fast_parse_list<true>(e, w, z, cur, span_end, cached, RL, back, len);
+                cached = fast_parse_list<true>(e, w, P, z, cur, span_end, cached, RL, back, len);
             } else {
             // ---------------- lzma_lzma_optimum_fast (optimum_fast.c:20-169) ----------------
+#ifdef XZAMD_TIMING
+            const uint64_t tt0 = __builtin_amdgcn_s_memtime();
+#endif
             if (read_ahead == 0) {
-                do_round(e, cur, span_end, z.rep0, z.rep1, z.rep2, z.rep3, R);
+                do_round(e, P, cur, span_end, z.rep0, z.rep1, z.rep2, z.rep3, R);
                 read_ahead = 1;
+#ifdef XZAMD_TIMING
+                ++tm_rounds;
+#endif
             }
+#ifdef XZAMD_TIMING
+            const uint64_t tt1 = __builtin_amdgcn_s_memtime();
+            tm_round1 += tt1 - tt0;
+#endif
             {
                 const uint32_t rem = span_end - cur;
                 const uint32_t buf_avail = rem < MATCH_LEN_MAX ? rem : MATCH_LEN_MAX;
@@ -1267,7 +1451,14 @@ __global__ __launch_bounds__(64) void k_span_encode_t(xzamd_span_args a)
                 if (!decided && (len_main < 2 || buf_avail <= 2)) decided = true;   // literal
                 if (!decided) {
                     // lookahead: matches (and rep lengths) of the next byte
-                    do_round(e, cur + 1, span_end, z.rep0, z.rep1, z.rep2, z.rep3, R);
+#ifdef XZAMD_TIMING
+                    const uint64_t tl0 = __builtin_amdgcn_s_memtime();
+#endif
+                    do_round(e, P, cur + 1, span_end, z.rep0, z.rep1, z.rep2, z.rep3, R);
+#ifdef XZAMD_TIMING
+                    tm_round2 += __builtin_amdgcn_s_memtime() - tl0;
+                    ++tm_rounds;
+#endif
                     ++read_ahead;
                     const uint32_t nl = R.longest;
                     bool lit = false;
@@ -1304,7 +1495,14 @@ __global__ __launch_bounds__(64) void k_span_encode_t(xzamd_span_args a)
                 if (lane == 0) a.span_bytes[span] = 0;
                 return;
             }
+#ifdef XZAMD_TIMING
+            const uint64_t te0 = __builtin_amdgcn_s_memtime();
+#endif
             encode_symbol(rc, probs, z, in, cur, cur - block_start, back, len);
+#ifdef XZAMD_TIMING
+            tm_encode += __builtin_amdgcn_s_memtime() - te0;
+            ++tm_syms;
+#endif
             if (a.trace && lane == 0) {
                 // debug only: symbol stream for the parity tests (compared with the oracle's parse)
                 const uint32_t ti = atomicAdd(a.trace_count, 1u);
@@ -1363,6 +1561,13 @@ __global__ __launch_bounds__(64) void k_span_encode_t(xzamd_span_args a)
         out_off += hl + csize;
     }
     if (lane == 0) a.span_bytes[span] = out_off;
+#ifdef XZAMD_TIMING
+    if (lane == 0 && span == 0 && a.err) {
+        const uint64_t tot = __builtin_amdgcn_s_memtime() - tm_start;
+        a.err[8] = (uint32_t)(tot >> 8); a.err[9] = (uint32_t)(tm_round1 >> 8); a.err[10] = (uint32_t)(tm_round2 >> 8);
+        a.err[11] = (uint32_t)(tm_encode >> 8); a.err[12] = (uint32_t)tm_rounds; a.err[13] = (uint32_t)tm_syms;
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------

@@ -18,7 +18,8 @@
 #include <stdlib.h>
 #include <string.h>
 
-#define DEFAULT_SPAN (64u * 1024u)
+#define DEFAULT_SPAN (64u * 1024u)          /* fast parser */
+#define DEFAULT_SPAN_OPT (128u * 1024u)     /* optimal parser: fewer state resets, still >> resident waves */
 #define DEFAULT_BATCH (1ull << 30)
 #define CRC_STRIP 4096u
 
@@ -453,7 +454,7 @@ int xzamd_stream_encode_device(xzamd_ctx *c,
 	uint32_t hbits = 0;
 	while ((1ull << hbits) <= hmask) ++hbits;
 	const uint32_t kbits_max = (opt->gpu_depth2 && hbits < 22) ? 22 : hbits;   /* widest sort key family */
-	uint32_t span = opt->span_size == XZAMD_SPAN_DEFAULT ? DEFAULT_SPAN : opt->span_size;
+	uint32_t span = opt->span_size == XZAMD_SPAN_DEFAULT ? (opt->gpu_parser ? DEFAULT_SPAN_OPT : DEFAULT_SPAN) : opt->span_size;
 	if (span > block_size) span = (uint32_t)block_size;
 	if (span < 4096)
 		return fail(c, XZAMD_OPTIONS_ERROR, "span_size must be >= 4096", 0);
@@ -598,11 +599,14 @@ int xzamd_stream_encode_device(xzamd_ctx *c,
 		}
 		xzk_event_record(c->ev[3], st);
 		{
-			uint32_t herr[8] = { 0 };
+			uint32_t herr[16] = { 0 };
 			int e = xzk_d2h(c->h_span_bytes.p, c->span_bytes.p, 4ull * nspans, st);
-			if (!e) e = xzk_d2h(herr, c->errw.p, 32, st);
+			if (!e) e = xzk_d2h(herr, c->errw.p, 64, st);
 			if (!e) e = xzk_sync(st);
 			if (e) { rc = fail(c, XZAMD_DEVICE_ERROR, "span encode / d2h sizes", e); goto done; }
+			if (getenv("XZAMD_TIMING") && herr[8])
+				fprintf(stderr, "[timing span0] total %u round1 %u round2 %u encode %u (x256 clk) rounds %u symbols %u\n",
+						herr[8], herr[9], herr[10], herr[11], herr[12], herr[13]);
 			if (herr[0]) {
 				snprintf(c->err_msg_buf, sizeof(c->err_msg_buf),
 						"span encoder consistency check %u failed: %u %u %u %u %u %u %u",
