@@ -34,6 +34,24 @@ from xz_amd import parallel  # noqa: E402
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
+def pmc_traffic(opts):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
+    (FETCH_SIZE and WRITE_SIZE in separate passes, tools/prof_bench.sh -> profiles/*pmc_summary.json).
+    PMC counters cannot be collected from inside this process; None when no profile of the same
+    kernel variant is present."""
+    import glob
+    want = "k_span_encode_t<%s, %s>" % ("true" if opts.gpu_depth2 else "false", "true" if opts.gpu_parser else "false")
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_summary.json")), reverse=True):
+        try:
+            d = json.load(open(f))
+        except Exception:  # noqa: BLE001
+            continue
+        for k, e in d.items():
+            if want in k and "hbm_bytes_per_dispatch_uncorrected" in e:
+                return int(e["hbm_bytes_per_dispatch_uncorrected"]), os.path.basename(f)
+    return None, None
+
+
 def cpu_baseline(sample, preset):
     """Reference liblzma (oracle/_ref, the real 5.8.3 sources) MT encoder on the host cores, timed on a
     bounded sample of the same workload.  Test infrastructure used as a reported baseline only."""
@@ -162,12 +180,14 @@ def main():
             "ratio": {"ours": round(local_out_bytes / n, 5)},
             "roofline": {
                 "bound": "hbm",
-                "kernel": "k_span_encode",
+                "kernel": "k_span_encode_t<%s,%s>" % ("true" if opts.gpu_depth2 else "false", "true" if opts.gpu_parser else "false"),
                 "achieved": round(achieved, 3),
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 6),
-                "traffic": None,
+                "traffic": pmc_traffic(opts)[0],
+                "traffic_source": pmc_traffic(opts)[1],
+                "algorithmic_bytes_per_launch": int(alg_bytes / max(launches, 1)),
                 "avg_launch_ms": round(enc_ms / max(launches, 1), 3),
                 "launches": launches,
             },
