@@ -23,7 +23,8 @@ for f in glob.glob(os.path.join(src, "**", "*counter_collection.csv"), recursive
         disp[(k, r["Counter_Name"])].add(r["Dispatch_Id"])
 res = {}
 for k, d in agg.items():
-    short = k.split("(")[0].replace("(anonymous namespace)::", "").replace("void ", "").strip()[:80]
+    short = k.replace("(anonymous namespace)::", "").replace("void ", "")
+    short = short.split("(")[0].strip()[:80] if not short.startswith("rocprim") else "rocprim::radix_sort_onesweep(*)"
     e = {c: v for c, v in d.items()}
     e["dispatches"] = max(len(disp[(k, c)]) for c in d)
     res.setdefault(short, {}).update(e)
