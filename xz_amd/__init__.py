@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libxz_amd.so")
+LIB_PATH = os.environ.get("XZ_AMD_LIB") or os.path.join(_HERE, "libxz_amd.so")   # env override: A/B builds
 
 CHECK_NONE, CHECK_CRC32, CHECK_CRC64 = 0, 1, 4
 MF_HC3, MF_HC4, MF_BT4 = 0x03, 0x04, 0x14

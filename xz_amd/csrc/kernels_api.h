@@ -23,6 +23,7 @@ typedef struct {
 	uint8_t *scratch;            /* span s writes at scratch + s * span_cap */
 	uint64_t span_cap;
 	uint32_t *span_bytes;        /* out: bytes produced per span */
+	uint32_t *lit;               /* literal-coder probabilities: 6144 x u32 per span */
 	uint32_t *trace;             /* optional debug: 4 x u32 per symbol (span,pos,back,len) */
 	uint32_t *trace_count;
 	uint32_t trace_cap;

@@ -475,6 +475,7 @@ struct Lz {
     uint32_t rep0, rep1, rep2, rep3;
     uint32_t lc, lp, pb;
     uint32_t cnt_len, cnt_match, cnt_align;   // coded lengths / matches / align-coded matches since refresh
+    uint32_t* lit;                            // literal coder probabilities of this span (global memory, L2-resident)
 };
 
 __device__ __forceinline__ uint32_t dist_slot_of(uint32_t d)
@@ -482,6 +483,21 @@ __device__ __forceinline__ uint32_t dist_slot_of(uint32_t d)
     if (d <= 4) return d;
     const uint32_t i = 31 - __builtin_clz(d);
     return (i + i) + ((d >> (i - 1)) & 1);
+}
+
+// Literal-coder probabilities (6144 of the 7990 model entries at lc=3) live in global memory, one
+// 24 KiB slice per span, so the LDS footprint of a wavefront drops from 16 KiB to 3.6 KiB and the
+// CU can hold 2x (and more) wavefronts: the kernel is issue-latency bound per wave and throughput
+// scales with resident waves (measured: halving occupancy costs 1.8x).  A literal touches 8 of them:
+// one gather and one scatter per symbol, L1 bypassed (sc1) so the wave reads back its own updates
+// from L2.
+__device__ __forceinline__ uint32_t lit_load(const uint32_t* p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void lit_store(uint32_t* p, uint32_t v)
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ---- wave-parallel symbol coder -------------------------------------------------------------
@@ -522,7 +538,7 @@ __device__ __forceinline__ void rc_run(RC& rc, uint32_t packed, uint32_t n)
     }
 }
 
-__device__ __forceinline__ void rc_emit(RC& rc, uint16_t* probs, const SegSel& s, uint32_t total)
+__device__ __forceinline__ void rc_emit(RC& rc, uint16_t* probs, uint32_t* lit, const SegSel& s, uint32_t total)
 {
     uint32_t idx = 0, bit = 0;
     bool direct = false;
@@ -550,8 +566,14 @@ __device__ __forceinline__ void rc_emit(RC& rc, uint16_t* probs, const SegSel& s
     }
     uint32_t p = 0;
     if (s.hit && !direct) {
-        p = probs[idx];
-        probs[idx] = (uint16_t)(bit ? p - (p >> 5) : p + ((2048 - p) >> 5));
+        if (idx >= P_LITERAL) {
+            uint32_t* g = lit + (idx - P_LITERAL);
+            p = lit_load(g);
+            lit_store(g, bit ? p - (p >> 5) : p + ((2048 - p) >> 5));
+        } else {
+            p = probs[idx];
+            probs[idx] = (uint16_t)(bit ? p - (p >> 5) : p + ((2048 - p) >> 5));
+        }
     }
     const uint32_t packed = p | (bit << 12) | (direct ? 0x2000u : 0u);
     rc_run(rc, packed, total);
@@ -566,6 +588,7 @@ __device__ __forceinline__ void encode_symbol(RC& rc, uint16_t* probs, Lz& z, co
     s.type = 0; s.base = 0; s.sym = 0; s.i = 0; s.n = 0; s.hit = false;
     uint32_t off = 0;
     if (back == LITERAL) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // previous literal's probability scatter
         seg_add(s, off, 1, SEG_BIT, P_IS_MATCH + z.state * 16 + ps, 0);
         const uint32_t cur = uni(in[g]);
         const uint32_t prev = upos ? uni(in[g - 1]) : 0;
@@ -579,7 +602,7 @@ __device__ __forceinline__ void encode_symbol(RC& rc, uint16_t* probs, Lz& z, co
             const uint32_t mb = uni(in[g - z.rep0 - 1]);
             seg_add(s, off, 8, SEG_MATCHED, sub, cur | (mb << 8));
         }
-        rc_emit(rc, probs, s, off);
+        rc_emit(rc, probs, z.lit, s, off);
         return;
     }
     seg_add(s, off, 1, SEG_BIT, P_IS_MATCH + z.state * 16 + ps, 1);
@@ -607,7 +630,7 @@ __device__ __forceinline__ void encode_symbol(RC& rc, uint16_t* probs, Lz& z, co
         }
         if (len == 1) {
             z.state = z.state < 7 ? 9 : 11;
-            rc_emit(rc, probs, s, off);
+            rc_emit(rc, probs, z.lit, s, off);
             return;
         }
         len_base = P_REP_LEN;
@@ -656,7 +679,7 @@ __device__ __forceinline__ void encode_symbol(RC& rc, uint16_t* probs, Lz& z, co
         }
         z.rep3 = z.rep2; z.rep2 = z.rep1; z.rep1 = z.rep0; z.rep0 = dist;
     }
-    rc_emit(rc, probs, s, off);
+    rc_emit(rc, probs, z.lit, s, off);
 }
 
 __device__ __forceinline__ bool change_pair(uint32_t small_dist, uint32_t big_dist)
@@ -952,6 +975,7 @@ __device__ __forceinline__ uint32_t pr_literal_wave(const uint16_t* probs, const
     const uint32_t mask = (0x100u << z.lp) - (0x100u >> z.lc);
     const uint32_t sub = P_LITERAL + 3u * ((((upos << 8) + prev) & mask) << z.lc);
     uint32_t p = 0;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // own earlier literal updates must have landed
     if (lane < 8) {
         const uint32_t k = lane;                         // bit number, MSB first
         const uint32_t bit = (cur >> (7 - k)) & 1;
@@ -962,7 +986,9 @@ __device__ __forceinline__ uint32_t pr_literal_wave(const uint16_t* probs, const
             const bool same = (mb >> (8 - k)) == (cur >> (8 - k));   // k leading bits equal
             if (same) idx = 0x100 + (((mb >> (7 - k)) & 1) << 8) + pre;
         }
-        p = pr_bit(probs, ptab, sub + idx, bit);
+        (void)probs;
+        const uint32_t pv = lit_load(z.lit + (sub - P_LITERAL) + idx);
+        p = ptab[(pv ^ ((0u - bit) & 0x7FFu)) >> 4];
     }
     return wave_sum(p);
 }
@@ -1242,14 +1268,25 @@ __device__ __forceinline__ bool fast_parse_list(const Env& e, const Work& w, Pre
 // of the reference), OPT the parser (false = optimum_fast of the reference).
 // ------------------------------------------------------------------------------------------
 template <bool PARETO, bool OPT>
-__global__ __launch_bounds__(64) void k_span_encode_t(xzamd_span_args a)
+#ifndef XZAMD_WAVES_FAST
+#define XZAMD_WAVES_FAST 4
+#endif
+#ifndef XZAMD_WAVES_OPT
+#define XZAMD_WAVES_OPT 2
+#endif
+__global__ __launch_bounds__(64)
+__attribute__((amdgpu_waves_per_eu(OPT ? XZAMD_WAVES_OPT : XZAMD_WAVES_FAST, OPT ? XZAMD_WAVES_OPT : XZAMD_WAVES_FAST)))
+void k_span_encode_t(xzamd_span_args a)
 {
     // One LDS pool, carved by hand (a single __shared__ object: no aliasing or ordering surprises).
-    constexpr uint32_t W_PROBS = 4096;                                   // 8192 x u16
+    constexpr uint32_t W_PROBS = 928;                                    // 1856 x u16 >= P_LITERAL (1846): all but the literal coders
     constexpr uint32_t W_LIST = (PARETO || OPT) ? 128 : 0;               // ml[64], md[64]
     constexpr uint32_t W_NODES = OPT ? 7 * (WMAX + 1) + 1 : 0;           // price, back, info, reps[4]
     constexpr uint32_t W_TABS = OPT ? (128 + 256 + 8 + 32) : 0;          // dsp, dp, ap (u16), ptab (u8)
-    __shared__ __attribute__((aligned(16))) uint32_t pool[W_PROBS + W_LIST + W_NODES + W_TABS];
+#ifndef XZAMD_LDS_PAD_WORDS
+#define XZAMD_LDS_PAD_WORDS 0        /* occupancy experiments only */
+#endif
+    __shared__ __attribute__((aligned(16))) uint32_t pool[W_PROBS + W_LIST + W_NODES + W_TABS + XZAMD_LDS_PAD_WORDS];
     uint16_t* const probs = reinterpret_cast<uint16_t*>(pool);
     const uint32_t lane = threadIdx.x;
     const uint32_t span = blockIdx.x;
@@ -1309,6 +1346,7 @@ __global__ __launch_bounds__(64) void k_span_encode_t(xzamd_span_args a)
     Lz z;
     z.lc = a.lc; z.lp = a.lp; z.pb = a.pb;
     z.cnt_len = z.cnt_match = z.cnt_align = 0;
+    z.lit = a.lit + (uint64_t)span * 6144u;
     RC rc;
     rc.cpos = 0; rc.out = outp; rc.reset();
 
@@ -1334,7 +1372,14 @@ __global__ __launch_bounds__(64) void k_span_encode_t(xzamd_span_args a)
         if (need_state_reset) {
             // lzma_lzma_encoder_reset (lzma_encoder.c:529-598)
             uint32_t* p32 = reinterpret_cast<uint32_t*>(probs);
-            for (uint32_t i = lane; i < 4096; i += 64) p32[i] = 0x04000400u;
+            for (uint32_t i = lane; i < 928; i += 64) p32[i] = 0x04000400u;
+            {
+                uint4* l4 = reinterpret_cast<uint4*>(z.lit);
+                const uint4 v = make_uint4(1024u, 1024u, 1024u, 1024u);
+                for (uint32_t i = lane; i < 6144 / 4; i += 64) l4[i] = v;
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            wave_sync();
             z.state = 0; z.rep0 = z.rep1 = z.rep2 = z.rep3 = 0;
             tables_valid = false;
             q_pos = q_end = 0;
@@ -1348,8 +1393,7 @@ __global__ __launch_bounds__(64) void k_span_encode_t(xzamd_span_args a)
 
         if (!initialized) {
             // encode_init (lzma_encoder.c:267-293)
-            rc.bit(probs, P_IS_MATCH, 0);
-            rc.tree(probs, P_LITERAL, 8, uni(in[block_start]));
+            encode_symbol(rc, probs, z, in, block_start, 0, LITERAL, 1);
             cur = block_start + 1;
             initialized = true;
         }

@@ -252,7 +252,7 @@ struct xzamd_ctx {
 	char err_msg_buf[200];
 	/* device buffers */
 	dbuf keys_a, keys_b, vals_a, vals_b, rank, sorted_pos, prev2, prev3, rank8, sorted8, sort_tmp;
-	dbuf scratch, span_bytes, strip_crc, block_crc, segs, lits, trace, errw;
+	dbuf scratch, span_bytes, strip_crc, block_crc, segs, lits, trace, errw, litp;
 	/* pinned host buffers */
 	dbuf h_span_bytes, h_block_crc, h_segs, h_lits;
 	void *ev[10];
@@ -319,7 +319,7 @@ void xzamd_ctx_destroy(xzamd_ctx *c)
 	xzk_set_device(c->device);
 	dbuf *d[] = { &c->keys_a, &c->keys_b, &c->vals_a, &c->vals_b, &c->rank, &c->sorted_pos,
 		&c->prev2, &c->prev3, &c->rank8, &c->sorted8, &c->sort_tmp, &c->scratch, &c->span_bytes, &c->strip_crc,
-		&c->block_crc, &c->segs, &c->lits, &c->trace, &c->errw };
+		&c->block_crc, &c->segs, &c->lits, &c->trace, &c->errw, &c->litp };
 	for (size_t i = 0; i < sizeof(d) / sizeof(d[0]); ++i)
 		if (d[i]->p) xzk_free(d[i]->p);
 	dbuf *h[] = { &c->h_span_bytes, &c->h_block_crc, &c->h_segs, &c->h_lits };
@@ -529,6 +529,7 @@ int xzamd_stream_encode_device(xzamd_ctx *c,
 		GROW(strip_crc, 8ull * spb_crc * nb, 0);
 		GROW(block_crc, 8ull * nb, 0);
 		GROW(errw, 64, 0);
+		GROW(litp, (uint64_t)nspans * 6144ull * 4ull, 0);
 		GROW(h_span_bytes, 4ull * nspans, 1);
 		GROW(h_block_crc, 8ull * nb, 1);
 		/* plan capacity: per Block header + spans + trailer, or the stored form */
@@ -570,6 +571,7 @@ int xzamd_stream_encode_device(xzamd_ctx *c,
 			a.span_cap = span_cap;
 			a.span_bytes = (uint32_t *)c->span_bytes.p;
 			a.err = (uint32_t *)c->errw.p;
+			a.lit = (uint32_t *)c->litp.p;
 			if (xzk_memset(c->errw.p, 0, 64, st)) { rc = fail(c, XZAMD_DEVICE_ERROR, "memset", 1); goto done; }
 			if (c->trace_on) {
 				a.trace_count = (uint32_t *)c->trace.p;
