@@ -107,11 +107,12 @@ typedef struct {
 	uint64_t blocks_stored;      /* Blocks that took the uncompressed fallback */
 	/* HIP-event time per stage, summed over batches (milliseconds) */
 	float ms_chains;             /* hash keys + radix sorts + link kernels */
-	float ms_encode;             /* k_span_encode (the dominant kernel) */
+	float ms_encode;             /* k_find (when the optimal parser runs) + k_span_encode */
 	float ms_crc;
 	float ms_assemble;
 	float ms_total;              /* first launch -> last kernel done */
 	uint32_t encode_launches;
+	float ms_find;               /* the k_find part of ms_encode */
 } xzamd_stats;
 void xzamd_get_stats(const xzamd_ctx *ctx, xzamd_stats *out);
 

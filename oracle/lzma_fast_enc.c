@@ -367,6 +367,7 @@ static void find_pareto(enc *e, uint32_t p)
 	}
 }
 
+#define LIST_K 16
 /* One "round" at position x: matches + the four rep-match lengths with reps r[]. */
 static void do_round(enc *e, uint32_t x, const uint32_t r[4])
 {
@@ -374,6 +375,14 @@ static void do_round(enc *e, uint32_t x, const uint32_t r[4])
 		find_pareto(e, x);
 	else
 		find_exact(e, x);
+	if (e->prm.parser && e->m_count > LIST_K) {
+		/* the optimal parser reads per-position lists of at most LIST_K entries (the GPU's
+		 * k_find_t writes them for the whole batch): the LIST_K longest are kept */
+		const uint32_t drop = e->m_count - LIST_K;
+		memmove(e->m_len, e->m_len + drop, LIST_K * sizeof(e->m_len[0]));
+		memmove(e->m_dist, e->m_dist + drop, LIST_K * sizeof(e->m_dist[0]));
+		e->m_count = LIST_K;
+	}
 	const uint32_t rem = e->span_end - x;
 	const uint32_t buf_avail = rem < MATCH_LEN_MAX ? rem : MATCH_LEN_MAX;
 	for (uint32_t i = 0; i < 4; ++i)

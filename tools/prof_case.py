@@ -16,4 +16,4 @@ for _ in range(reps):
     out, _ = enc.encode(t, opts=opts)
     torch.cuda.synchronize(); dt = time.time() - t0
     st = enc.stats()
-    print(f"preset {preset} {mib} MiB: {dt*1e3:.1f} ms, {mib*1.048576/dt:.1f} MB/s, ratio {out.numel()/(mib<<20):.4f}, encode {st.ms_encode:.1f} ms chains {st.ms_chains:.1f} ms", flush=True)
+    print(f"preset {preset} {mib} MiB: {dt*1e3:.1f} ms, {mib*1.048576/dt:.1f} MB/s, ratio {out.numel()/(mib<<20):.4f}, encode {st.ms_encode:.1f} ms (find {st.ms_find:.1f}) chains {st.ms_chains:.1f} ms", flush=True)

@@ -29,7 +29,8 @@ class Stats(C.Structure):
     _fields_ = [("in_bytes", C.c_uint64), ("out_bytes", C.c_uint64), ("blocks", C.c_uint64),
                 ("spans", C.c_uint64), ("batches", C.c_uint64), ("blocks_stored", C.c_uint64),
                 ("ms_chains", C.c_float), ("ms_encode", C.c_float), ("ms_crc", C.c_float),
-                ("ms_assemble", C.c_float), ("ms_total", C.c_float), ("encode_launches", C.c_uint32)]
+                ("ms_assemble", C.c_float), ("ms_total", C.c_float), ("encode_launches", C.c_uint32),
+                ("ms_find", C.c_float)]
 
 
 class BlockInfo(C.Structure):

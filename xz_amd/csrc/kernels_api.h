@@ -24,6 +24,10 @@ typedef struct {
 	uint64_t span_cap;
 	uint32_t *span_bytes;        /* out: bytes produced per span */
 	uint32_t *lit;               /* literal-coder probabilities: 6144 x u32 per span */
+	/* per-position match lists (parser != 0): 16 entries per position, written by xzk_find_matches */
+	const uint16_t *mlen;
+	const uint32_t *mdist;
+	const uint8_t *mcnt;
 	uint32_t *trace;             /* optional debug: 4 x u32 per symbol (span,pos,back,len) */
 	uint32_t *trace_count;
 	uint32_t trace_cap;
@@ -55,6 +59,7 @@ int xzk_build_chains(const uint8_t *d_in, uint32_t n, uint32_t block_size, uint3
 		void *sort_tmp, uint64_t sort_tmp_bytes,
 		uint32_t *rank, uint32_t *sorted_pos, uint32_t *prev2, uint32_t *prev3,
 		uint32_t *rank8, uint32_t *sorted8, void *stream);
+int xzk_find_matches(const xzamd_span_args *a, uint16_t *mlen, uint32_t *mdist, uint8_t *mcnt, void *stream);
 int xzk_span_encode(const xzamd_span_args *a, uint32_t nspans, void *stream);
 int xzk_crc64_blocks(const uint8_t *d_in, uint32_t n, uint32_t block_size, uint32_t nblocks,
 		uint32_t strip, uint64_t *d_strip_crc, uint64_t *d_block_crc, void *stream);

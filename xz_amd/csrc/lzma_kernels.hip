@@ -324,7 +324,12 @@ struct Env {
     uint32_t nice, depth, hb, cyclic;
     uint32_t depth2, block_end;
     uint32_t n_last;                            // last valid byte offset of the batch (prefetch clamp)
+    // match lists written by k_find_t (LIST_K entries per position), read by the list-driven parser
+    const uint16_t* __restrict__ mlen;
+    const uint32_t* __restrict__ mdist;
+    const uint8_t* __restrict__ mcnt;
 };
+constexpr uint32_t LIST_K = 16;               // entries kept per position (the LIST_K longest)
 
 // ------------------------------------------------------------------------------------------
 // Software prefetch of the parse-independent per-position data.  Rounds mostly visit consecutive
@@ -389,6 +394,7 @@ __device__ __forceinline__ void fetch(const Env& e, Pre& P, uint32_t x, PreA& a,
     P.valid = true;
 }
 
+template <bool REPS = true>
 __device__ __forceinline__ void do_round(const Env& e, Pre& P, uint32_t x, uint32_t end,
         uint32_t r0, uint32_t r1, uint32_t r2, uint32_t r3, Round& R)
 {
@@ -423,7 +429,7 @@ __device__ __forceinline__ void do_round(const Env& e, Pre& P, uint32_t x, uint3
             if (same_bucket && x - qp < e.cyclic) { chain_valid = true; q = qp; lim = len_limit; }
         }
     }
-    if (lane >= 60) {
+    if (REPS && lane >= 60) {
         const uint32_t rep = lane == 60 ? r0 : lane == 61 ? r1 : lane == 62 ? r2 : r3;
         q = x - rep - 1;
         lim = buf_avail;
@@ -709,6 +715,16 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v)
     return v;
 }
 
+#ifdef XZAMD_TIMING
+#define TM_BEGIN(v) const uint64_t v = __builtin_amdgcn_s_memtime()
+#define TM_END(w, k, v) do { if (threadIdx.x == 0) (w).tm[k] += __builtin_amdgcn_s_memtime() - (v); } while (0)
+#define TM_COUNT(w, k) do { if (threadIdx.x == 0) (w).tm[k] += 1; } while (0)
+#else
+#define TM_BEGIN(v) do { } while (0)
+#define TM_END(w, k, v) do { } while (0)
+#define TM_COUNT(w, k) do { } while (0)
+#endif
+
 // Per-wave LDS carve for the list-based paths.
 struct Work {
     uint32_t* ml;       // [64] kept matches, ascending length (== ascending distance)
@@ -717,13 +733,16 @@ struct Work {
     uint32_t* n_price;  // [WMAX+1] node price; after backtracking: out-edge `back`
     uint32_t* n_back;   // [WMAX+1] in-edge back
     uint32_t* n_info;   // [WMAX+1] in-len (9) | state (4) << 9 | out-len (9) << 13
-    uint32_t* n_reps;   // [(WMAX+1)*4]
+    uint4* n_reps4;     // [WMAX+1] rep distances of the node (complete when the parser reaches it)
     uint16_t* dsp;      // [4*64]  dist-slot price (+ direct bits for slot >= 14)
     uint16_t* dp;       // [4*128] full price of distances < 128
     uint16_t* ap;       // [16]    align price
     uint8_t* ptab;      // [128]   bit price table (price_tablegen.c:31-58)
     uint32_t* err;      // debug/consistency word block (global)
     uint32_t ptv;       // the same price table in registers: lane l (< 32) holds entries 4l..4l+3
+#ifdef XZAMD_TIMING
+    unsigned long long* tm;   // [16] cycle accumulators in LDS (profiling builds only)
+#endif
 };
 
 struct RoundL {
@@ -755,6 +774,7 @@ __device__ __forceinline__ void list_from_mask(const Work& w, const Round& R, Ro
 
 // find_pareto(): lanes 0 = hash2, 1 = hash3, 2 = own slot of the 4-byte chain, 3..2+d4 = 4-byte
 // chain, A = 3+d4 = own slot of the 8-byte chain, A+1..A+d8 = 8-byte chain, 60..63 = reps.
+template <bool REPS = true>
 __device__ __forceinline__ void do_round_pareto(const Env& e, const Work& w, Pre& P, uint32_t x, uint32_t end,
         uint32_t r0, uint32_t r1, uint32_t r2, uint32_t r3, RoundL& R)
 {
@@ -799,7 +819,7 @@ __device__ __forceinline__ void do_round_pareto(const Env& e, const Work& w, Pre
             if ((flags8 & ((1ull << j) - 1)) == 0 && x - qp < e.cyclic) { valid = true; q = qp; lim = len_limit; }
         }
     }
-    if (lane >= 60) {
+    if (REPS && lane >= 60) {
         const uint32_t rep = lane == 60 ? r0 : lane == 61 ? r1 : lane == 62 ? r2 : r3;
         q = x - rep - 1;
         lim = buf_avail;
@@ -852,6 +872,49 @@ __device__ __forceinline__ void do_round_pareto(const Env& e, const Work& w, Pre
         longest = wave_cmplen(e.in, x, x - dd - 1, longest, buf_avail);
     }
     R.longest = longest;
+}
+
+// ---- list-driven rounds ------------------------------------------------------------------------
+// The match finder is parse independent (find and skip both insert), so k_find_t runs it for every
+// position of the batch as a separate, fully parallel kernel.  The parser then streams the lists:
+// positions are visited strictly in order, so the record of x+1 is always in flight while x is
+// priced.  Only the four rep-match lengths depend on the parse; lanes 60..63 measure them here.
+struct ListPre { uint32_t pos; bool valid; uint32_t sl, sd, cnt; };
+
+
+__device__ __forceinline__ void lists_load(const Env& e, uint32_t x, uint32_t& sl, uint32_t& sd, uint32_t& cnt)
+{
+    const uint32_t lane = threadIdx.x;
+    x = x < e.n_last ? x : e.n_last;
+    const uint64_t base = (uint64_t)x * LIST_K;
+    sl = 0; sd = 0;
+    if (lane < LIST_K) { sl = e.mlen[base + lane]; sd = e.mdist[base + lane]; }
+    cnt = e.mcnt[x];
+}
+
+__device__ __forceinline__ void round_lists(const Env& e, ListPre& LP, uint32_t x, uint32_t end,
+        uint32_t r0, uint32_t r1, uint32_t r2, uint32_t r3, RoundL& R)
+{
+    const uint32_t lane = threadIdx.x;
+    if (!(LP.valid && LP.pos == x)) lists_load(e, x, LP.sl, LP.sd, LP.cnt);
+    const uint32_t sl = LP.sl, sd = LP.sd, cv = LP.cnt;
+    lists_load(e, x + 1, LP.sl, LP.sd, LP.cnt);
+    LP.pos = x + 1;
+    LP.valid = true;
+    const uint32_t avail = end - x;
+    const uint32_t buf_avail = avail < MATCH_LEN_MAX ? avail : MATCH_LEN_MAX;
+    uint32_t q = 0, lim = 0;
+    if (lane >= 60) {
+        const uint32_t rep = lane == 60 ? r0 : lane == 61 ? r1 : lane == 62 ? r2 : r3;
+        q = x - rep - 1;
+        lim = buf_avail;
+    }
+    R.L = lane_cmplen(e.in, q, x, lim);
+    const uint32_t cnt = uni(cv);
+    R.SL = sl;
+    R.SD = sd;
+    R.cnt = cnt;
+    R.longest = cnt ? lane_of(sl, cnt - 1) : 0;
 }
 
 // ---- prices (rangecoder/price.h:28-92) ------------------------------------------------------
@@ -916,25 +979,55 @@ __device__ __forceinline__ uint32_t pr_dist_full(const uint16_t* probs, const ui
     return price;
 }
 
-// Length price tables live in registers: lane holds lengths 2 + lane + 64*it, it = 0..4;
-// low 16 bits = match length coder, high 16 = rep length coder.
-struct LenTab { uint32_t v[4][5]; };
+// Length price tables live in registers, lane = length: lane holds lengths 2 + lane + 64*it.
+// The low/mid trees depend on pos_state but cover only lengths 2..17 (lanes 0..15 of it == 0);
+// the high tree is shared by all pos_states.  Low 16 bits = match length coder, high 16 = rep.
+struct LenTab { uint32_t lo[4]; uint32_t hi[5]; };
 
-__device__ __forceinline__ void refresh_len_tables(const uint16_t* probs, const uint8_t* ptab, LenTab& t, uint32_t nps)
+__device__ __forceinline__ uint32_t lt_get(const LenTab& t, uint32_t ps, int it)
+{
+    if (it != 0) return t.hi[it];
+    const uint32_t lo = ps == 0 ? t.lo[0] : ps == 1 ? t.lo[1] : ps == 2 ? t.lo[2] : t.lo[3];
+    return threadIdx.x < 16 ? lo : t.hi[0];
+}
+
+// tmp: 256 words of LDS that are dead while the tables are rebuilt (the parser's node array)
+__device__ __forceinline__ void refresh_len_tables(const uint16_t* probs, const uint8_t* ptab, LenTab& t, uint32_t nps,
+        uint32_t* tmp)
 {
     const uint32_t lane = threadIdx.x;
+    const uint32_t m1 = pr_bit(probs, ptab, P_MATCH_LEN + LEN_CHOICE, 1), r1 = pr_bit(probs, ptab, P_REP_LEN + LEN_CHOICE, 1);
+    {
+        const uint32_t mh = m1 + pr_bit(probs, ptab, P_MATCH_LEN + LEN_CHOICE2, 1);
+        const uint32_t rh = r1 + pr_bit(probs, ptab, P_REP_LEN + LEN_CHOICE2, 1);
+#pragma unroll 1
+        for (uint32_t k = 0; k < 4; ++k) {
+            const uint32_t sym = lane + 64u * k;
+            const uint32_t pm = mh + pr_tree(probs, ptab, P_MATCH_LEN + LEN_HIGH, 8, sym);
+            const uint32_t prr = rh + pr_tree(probs, ptab, P_REP_LEN + LEN_HIGH, 8, sym);
+            tmp[sym] = pm | (prr << 16);
+        }
+    }
+    wave_sync();
+#pragma unroll
+    for (int it = 0; it < 5; ++it) {
+        const uint32_t len = 2 + lane + 64u * it;
+        t.hi[it] = (len >= 18 && len <= MATCH_LEN_MAX) ? tmp[len - 18] : 0;
+    }
+    wave_sync();
+    const uint32_t m0 = pr_bit(probs, ptab, P_MATCH_LEN + LEN_CHOICE, 0), r0 = pr_bit(probs, ptab, P_REP_LEN + LEN_CHOICE, 0);
+    const uint32_t mm = m1 + pr_bit(probs, ptab, P_MATCH_LEN + LEN_CHOICE2, 0);
+    const uint32_t rm = r1 + pr_bit(probs, ptab, P_REP_LEN + LEN_CHOICE2, 0);
 #pragma unroll
     for (int ps = 0; ps < 4; ++ps) {
-#pragma unroll
-        for (int it = 0; it < 5; ++it) {
-            const uint32_t len = 2 + lane + 64u * it;
-            uint32_t pm = 0, prr = 0;
-            if (len <= MATCH_LEN_MAX && (uint32_t)ps < nps) {
-                pm = pr_len(probs, ptab, P_MATCH_LEN, ps, len);
-                prr = pr_len(probs, ptab, P_REP_LEN, ps, len);
-            }
-            t.v[ps][it] = pm | (prr << 16);
+        uint32_t v = 0;
+        if (lane < 16 && (uint32_t)ps < nps) {
+            const uint32_t sub = (lane < 8 ? LEN_LOW : LEN_MID) + (uint32_t)ps * 8, sym = lane & 7;
+            const uint32_t pm = (lane < 8 ? m0 : mm) + pr_tree(probs, ptab, P_MATCH_LEN + sub, 3, sym);
+            const uint32_t prr = (lane < 8 ? r0 : rm) + pr_tree(probs, ptab, P_REP_LEN + sub, 3, sym);
+            v = pm | (prr << 16);
         }
+        t.lo[ps] = v;
     }
 }
 
@@ -965,32 +1058,76 @@ __device__ __forceinline__ uint32_t tab_dist(const Work& w, uint32_t dist, uint3
     return (uint32_t)w.dsp[ds * 64 + dist_slot_of(dist)] + w.ap[dist & 15];
 }
 
-// literal price, 8 bits evaluated by lanes 0..7 (get_literal_price, optimum_normal.c:21-53)
-__device__ __forceinline__ uint32_t pr_literal_wave(const uint16_t* probs, const uint8_t* ptab, const Lz& z,
-        uint32_t b_cur, uint32_t b_prev, uint32_t b_mb, uint32_t upos, uint32_t state)
+// ---- literal prices (get_literal_price, optimum_normal.c:21-53) --------------------------------
+// Probabilities do not change inside a parser window, so everything that depends only on the input
+// bytes is priced once per 64 nodes, lane = node.  With N_i / A_i / B_i the price of bit i of the
+// byte in the plain coder, in the matched coder when the match byte has the same bit, and in the
+// matched coder when it differs, a literal costs
+//     plain (state < 7):                          sum N_i
+//     matched, first differing bit k of (byte ^ match byte):  sum_{i<k} A_i + B_k + sum_{i>k} N_i
+//     matched, match byte == byte (k = 8):        sum A_i
+// i.e. ten values per node, none of which depends on the path; the node later picks one by k.
+// 24 independent gathers per lane, one memory round trip per 64 nodes.
+struct LitChunk { uint32_t v[5]; };     // (V0,V1) (V2,V3) (V4,V5) (V6,V7) 16 bits each; V8 | plain << 11 | byte << 22
+
+__device__ __forceinline__ void lit_chunk(const uint8_t* __restrict__ in, const uint8_t* ptab, const Lz& z,
+        uint32_t x0, uint32_t block_start, uint32_t span_end, LitChunk& c)
 {
     const uint32_t lane = threadIdx.x;
-    const uint32_t cur = uni(b_cur);
-    const uint32_t prev = upos ? uni(b_prev) : 0;
+    uint32_t x = x0 + lane;
+    if (x >= span_end) x = span_end - 1;
+    const uint32_t cur = in[x];
+    const uint32_t prev = x > block_start ? in[x - 1] : 0;
+    const uint32_t upos = x - block_start;
     const uint32_t mask = (0x100u << z.lp) - (0x100u >> z.lc);
-    const uint32_t sub = P_LITERAL + 3u * ((((upos << 8) + prev) & mask) << z.lc);
-    uint32_t p = 0;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // own earlier literal updates must have landed
-    if (lane < 8) {
-        const uint32_t k = lane;                         // bit number, MSB first
-        const uint32_t bit = (cur >> (7 - k)) & 1;
-        const uint32_t pre = (0x100u | cur) >> (8 - k);  // 1 followed by the k bits already coded
-        uint32_t idx = pre;
-        if (state >= 7) {
-            const uint32_t mb = uni(b_mb);
-            const bool same = (mb >> (8 - k)) == (cur >> (8 - k));   // k leading bits equal
-            if (same) idx = 0x100 + (((mb >> (7 - k)) & 1) << 8) + pre;
-        }
-        (void)probs;
-        const uint32_t pv = lit_load(z.lit + (sub - P_LITERAL) + idx);
-        p = ptab[(pv ^ ((0u - bit) & 0x7FFu)) >> 4];
+    const uint32_t* sub = z.lit + 3u * ((((upos << 8) + prev) & mask) << z.lc);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the coder's probability updates must have landed
+    uint32_t pn[8], pa[8], pb[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const uint32_t pre = (0x100u | cur) >> (8 - i);
+        const uint32_t bit = (cur >> (7 - i)) & 1;
+        pn[i] = lit_load(sub + pre);
+        pa[i] = lit_load(sub + 0x100u + (bit << 8) + pre);
+        pb[i] = lit_load(sub + 0x100u + ((bit ^ 1u) << 8) + pre);
     }
-    return wave_sum(p);
+    uint32_t N[8], A[8], B[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const uint32_t bit = (cur >> (7 - i)) & 1;
+        const uint32_t flip = (0u - bit) & 0x7FFu;
+        N[i] = ptab[(pn[i] ^ flip) >> 4];
+        A[i] = ptab[(pa[i] ^ flip) >> 4];
+        B[i] = ptab[(pb[i] ^ flip) >> 4];
+    }
+    uint32_t sufN[9];                      // sufN[k] = sum_{i>=k} N_i
+    sufN[8] = 0;
+#pragma unroll
+    for (int i = 7; i >= 0; --i) sufN[i] = sufN[i + 1] + N[i];
+    uint32_t V[9], preA = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        V[k] = preA + B[k] + sufN[k + 1];
+        preA += A[k];
+    }
+    V[8] = preA;
+    c.v[0] = V[0] | (V[1] << 16);
+    c.v[1] = V[2] | (V[3] << 16);
+    c.v[2] = V[4] | (V[5] << 16);
+    c.v[3] = V[6] | (V[7] << 16);
+    c.v[4] = V[8] | (sufN[0] << 11) | (cur << 22);
+}
+
+// price of the literal at chunk node jj; mb = match byte (only used when state >= 7)
+__device__ __forceinline__ uint32_t lit_price(const LitChunk& c, uint32_t jj, uint32_t state, uint32_t mb)
+{
+    const uint32_t w4 = lane_of(c.v[4], jj);
+    if (state < 7) return (w4 >> 11) & 0x7FFu;
+    const uint32_t d = ((w4 >> 22) ^ mb) & 0xFFu;
+    if (d == 0) return w4 & 0x7FFu;
+    const uint32_t k = (uint32_t)__builtin_clz(d) - 24;          // first differing bit, MSB first
+    const uint32_t r = k < 2 ? lane_of(c.v[0], jj) : k < 4 ? lane_of(c.v[1], jj) : k < 6 ? lane_of(c.v[2], jj) : lane_of(c.v[3], jj);
+    return (k & 1) ? r >> 16 : r & 0xFFFFu;
 }
 
 __device__ __forceinline__ uint32_t state_after(uint32_t s, uint32_t back, uint32_t len)
@@ -1000,13 +1137,18 @@ __device__ __forceinline__ uint32_t state_after(uint32_t s, uint32_t back, uint3
     return s < 7 ? 7u : 10u;
 }
 
-// Relax all rep / match lengths out of node j (lane = length). PS is the compile-time pos_state.
-template <int PS>
-__device__ __forceinline__ void relax_lengths(const Work& w, const LenTab& lt, uint32_t SL, uint32_t SD, uint32_t j, uint32_t reach,
+// Relax all rep / match lengths out of node j (lane = length).  A lane that improves its target
+// node also writes the node's coder state and rep distances (they follow from this edge), so a node
+// is complete the moment the parser reaches it.  Written as selects, not branches: per-lane `if`s
+// cost the compiler an exec-mask save/restore and a branch each.
+__device__ __forceinline__ void relax_lengths(const Work& w, const LenTab& lt, uint32_t PS, uint32_t SL, uint32_t SD, uint32_t j, uint32_t reach,
         uint32_t longest, uint32_t cnt, uint32_t rl0, uint32_t rl1, uint32_t rl2, uint32_t rl3,
-        uint32_t prep0, uint32_t prep1, uint32_t prep2, uint32_t prep3, uint32_t pmatch, uint32_t upos_dbg = 0)
+        uint32_t prep0, uint32_t prep1, uint32_t prep2, uint32_t prep3, uint32_t pmatch,
+        uint32_t s, uint32_t r0, uint32_t r1, uint32_t r2, uint32_t r3)
 {
     const uint32_t lane = threadIdx.x;
+    const uint32_t info_rep = (s < 7 ? 8u : 11u) << 9, info_match = (s < 7 ? 7u : 10u) << 9;
+    const uint32_t lo_ps = PS == 0 ? lt.lo[0] : PS == 1 ? lt.lo[1] : PS == 2 ? lt.lo[2] : lt.lo[3];
 #pragma unroll
     for (int it = 0; it < 5; ++it) {
         if (2 + 64u * it > reach) break;
@@ -1014,112 +1156,97 @@ __device__ __forceinline__ void relax_lengths(const Work& w, const LenTab& lt, u
         uint32_t idx_m = 0;                       // first entry whose length reaches l (or the last one)
         for (uint32_t k = 0; k + 1 < cnt; ++k) idx_m += (lane_of(SL, k) < l) ? 1u : 0u;
         const uint32_t dist_m = __shfl(SD, idx_m);
-        if (l <= reach) {
-            const uint32_t lpm = lt.v[PS][it] & 0xFFFFu, lpr = lt.v[PS][it] >> 16;
-            uint32_t best = w.n_price[j + l], bb = 0;
-            bool upd = false;
-            if (rl0 >= l && prep0 + lpr < best) { best = prep0 + lpr; bb = 0; upd = true; }
-            if (rl1 >= l && prep1 + lpr < best) { best = prep1 + lpr; bb = 1; upd = true; }
-            if (rl2 >= l && prep2 + lpr < best) { best = prep2 + lpr; bb = 2; upd = true; }
-            if (rl3 >= l && prep3 + lpr < best) { best = prep3 + lpr; bb = 3; upd = true; }
-            if (l <= longest) {
-                const uint32_t dist = dist_m;
-#ifdef XZAMD_PARANOID
-                if (dist >= upos_dbg && w.err && atomicCAS(w.err, 0u, 3u) == 0u) {
-                    w.err[1] = upos_dbg; w.err[2] = j; w.err[3] = l; w.err[4] = idx; w.err[5] = cnt; w.err[6] = dist; w.err[7] = longest;
-                }
-#endif
-                const uint32_t pr = pmatch + lpm + tab_dist(w, dist, l < 6 ? l - 2 : 3);
-                if (pr < best) { best = pr; bb = dist + 4; upd = true; }
-            }
-            if (upd) {
-                w.n_price[j + l] = best;
-                w.n_back[j + l] = bb;
-                w.n_info[j + l] = l;
-            }
+        const uint32_t cur = w.n_price[j + l];
+        const uint32_t lv = it == 0 ? (lane < 16 ? lo_ps : lt.hi[0]) : lt.hi[it];
+        const uint32_t lpm = lv & 0xFFFFu, lpr = lv >> 16;
+        // distance price: both table forms are read, one is selected
+        const uint32_t ds = l < 6 ? l - 2 : 3;
+        const uint32_t p_small = w.dp[ds * 128 + (dist_m & 127)];
+        const uint32_t dbig = dist_m < 128 ? 128u : dist_m;               // branch-free slot; unused below 128
+        const uint32_t di = 31 - (uint32_t)__builtin_clz(dbig);
+        const uint32_t p_big = (uint32_t)w.dsp[ds * 64 + 2 * di + ((dbig >> (di - 1)) & 1)] + w.ap[dist_m & 15];
+        const uint32_t c0 = rl0 >= l ? prep0 + lpr : PRICE_INF;
+        const uint32_t c1 = rl1 >= l ? prep1 + lpr : PRICE_INF;
+        const uint32_t c2 = rl2 >= l ? prep2 + lpr : PRICE_INF;
+        const uint32_t c3 = rl3 >= l ? prep3 + lpr : PRICE_INF;
+        const uint32_t c4 = l <= longest ? pmatch + lpm + (dist_m < 128 ? p_small : p_big) : PRICE_INF;
+        uint32_t best = cur, bb = 0;
+        { const bool t = c0 < best; best = t ? c0 : best; bb = t ? 0u : bb; }
+        { const bool t = c1 < best; best = t ? c1 : best; bb = t ? 1u : bb; }
+        { const bool t = c2 < best; best = t ? c2 : best; bb = t ? 2u : bb; }
+        { const bool t = c3 < best; best = t ? c3 : best; bb = t ? 3u : bb; }
+        { const bool t = c4 < best; best = t ? c4 : best; bb = t ? dist_m + 4 : bb; }
+        const uint32_t n0 = bb == 0 ? r0 : bb == 1 ? r1 : bb == 2 ? r2 : bb == 3 ? r3 : bb - 4;
+        const uint32_t n1 = bb == 0 ? r1 : r0;
+        const uint32_t n2 = bb <= 1 ? r2 : r1;
+        const uint32_t n3 = bb <= 2 ? r3 : r2;
+        if (l <= reach && best < cur) {
+            w.n_price[j + l] = best;
+            w.n_back[j + l] = bb;
+            w.n_info[j + l] = l | (bb < 4 ? info_rep : info_match);
+            w.n_reps4[j + l] = make_uint4(n0, n1, n2, n3);
         }
     }
 }
 
 // One window of the optimal parser (oracle: optimum_window).  Returns with the chosen symbol path
 // stored as out-edges: node t -> (n_price[t] = back, out-len in n_info[t]); q_end = last node.
-template <bool PARETO>
-__device__ __forceinline__ bool optimum_window(const Env& e, const Work& w, Pre& P, uint16_t* probs, const Lz& z, LenTab& lt,
+__device__ __forceinline__ bool optimum_window(const Env& e, const Work& w, ListPre& P, uint16_t* probs, const Lz& z, LenTab& lt,
         const uint8_t* __restrict__ in, uint32_t pos, uint32_t block_start, uint32_t span_end, bool cached,
         RoundL& RL, uint32_t& q_end)
 {
     const uint32_t lane = threadIdx.x;
     const uint32_t pbm = (1u << z.pb) - 1;
+    // Bit-price combinations that depend only on (state, pos_state): lane = state * 4 + pos_state
+    // holds all seven of them; a node fetches its set with four readlanes.
+    uint32_t c01 = 0, c23 = 0, c45 = 0, c6 = 0;
+    {
+        const uint32_t s = lane >> 2, ps = lane & 3;
+        if (lane < 48 && ps <= pbm) {
+            const uint8_t* pt = w.ptab;
+            const uint32_t m0 = pr_bit(probs, pt, P_IS_MATCH + s * 16 + ps, 0), m1 = pr_bit(probs, pt, P_IS_MATCH + s * 16 + ps, 1);
+            const uint32_t e0 = pr_bit(probs, pt, P_IS_REP + s, 0), e1 = pr_bit(probs, pt, P_IS_REP + s, 1);
+            const uint32_t g0 = pr_bit(probs, pt, P_IS_REP0 + s, 0), g1 = pr_bit(probs, pt, P_IS_REP0 + s, 1);
+            const uint32_t l0 = pr_bit(probs, pt, P_IS_REP0_LONG + s * 16 + ps, 0), l1 = pr_bit(probs, pt, P_IS_REP0_LONG + s * 16 + ps, 1);
+            const uint32_t h0 = pr_bit(probs, pt, P_IS_REP1 + s, 0), h1 = pr_bit(probs, pt, P_IS_REP1 + s, 1);
+            const uint32_t k0 = pr_bit(probs, pt, P_IS_REP2 + s, 0), k1 = pr_bit(probs, pt, P_IS_REP2 + s, 1);
+            const uint32_t prep = m1 + e1, p11 = prep + g1 + h1;
+            c01 = m0 | ((prep + g0 + l0) << 16);                 // literal | short rep
+            c23 = (prep + g0 + l1) | ((prep + g1 + h0) << 16);   // rep0 | rep1
+            c45 = (p11 + k0) | ((p11 + k1) << 16);               // rep2 | rep3
+            c6 = m1 + e0;                                        // match
+        }
+    }
     if (lane == 0) {
         w.n_price[0] = 0;
         w.n_info[0] = z.state << 9;
-        w.n_reps[0] = z.rep0; w.n_reps[1] = z.rep1; w.n_reps[2] = z.rep2; w.n_reps[3] = z.rep3;
     }
-    wave_sync();
     uint32_t n_end = 0, j = 0;
     bool next_cached = false;
+    LitChunk lc;                          // lane = node - (j & ~63): the node's literal prices
+    lc.v[0] = lc.v[1] = lc.v[2] = lc.v[3] = lc.v[4] = 0;
     for (;;) {
         const uint32_t x = pos + j;
-        uint32_t s, r0, r1, r2, r3;
+        uint32_t s, r0, r1, r2, r3, Pj;
+        TM_BEGIN(t_derive);
+        TM_COUNT(w, 9);
         if (j > 0) {
-            const uint32_t info = uni(w.n_info[j]);
-            const uint32_t ilen = info & 0x1FF;
-            const uint32_t bk = uni(w.n_back[j]);
-            const uint32_t pv = j - ilen;
-            const uint32_t ps_ = (uni(w.n_info[pv]) >> 9) & 15;
-            const uint32_t a0 = uni(w.n_reps[pv * 4]), a1 = uni(w.n_reps[pv * 4 + 1]);
-            const uint32_t a2 = uni(w.n_reps[pv * 4 + 2]), a3 = uni(w.n_reps[pv * 4 + 3]);
-#ifdef XZAMD_PARANOID
-            if (ilen == 0 || ilen > j || (bk != LITERAL && bk >= 4 && bk - 4 >= (pos + pv) - block_start)) {
-                if (lane == 0 && w.err && atomicCAS(w.err, 0u, 4u) == 0u) {
-                    w.err[1] = (pos + j) - block_start; w.err[2] = j; w.err[3] = ilen; w.err[4] = bk; w.err[5] = info; w.err[6] = n_end; w.err[7] = uni(w.n_price[j]);
-                }
-                q_end = 0;
-                return false;
-            }
-#endif
-            s = state_after(ps_, bk, ilen);
-            if (bk == LITERAL || bk == 0) { r0 = a0; r1 = a1; r2 = a2; r3 = a3; }
-            else if (bk == 1) { r0 = a1; r1 = a0; r2 = a2; r3 = a3; }
-            else if (bk == 2) { r0 = a2; r1 = a0; r2 = a1; r3 = a3; }
-            else if (bk == 3) { r0 = a3; r1 = a0; r2 = a1; r3 = a2; }
-            else { r0 = bk - 4; r1 = a0; r2 = a1; r3 = a2; }
-            if (lane == 0) {
-                w.n_info[j] = ilen | (s << 9);
-                w.n_reps[j * 4] = r0; w.n_reps[j * 4 + 1] = r1; w.n_reps[j * 4 + 2] = r2; w.n_reps[j * 4 + 3] = r3;
-            }
-            wave_sync();
+            const uint4 rr = w.n_reps4[j];
+            s = (uni(w.n_info[j]) >> 9) & 15;
+            Pj = uni(w.n_price[j]);
+            r0 = uni(rr.x); r1 = uni(rr.y); r2 = uni(rr.z); r3 = uni(rr.w);
         } else {
-            s = z.state; r0 = z.rep0; r1 = z.rep1; r2 = z.rep2; r3 = z.rep3;
+            s = z.state; r0 = z.rep0; r1 = z.rep1; r2 = z.rep2; r3 = z.rep3; Pj = 0;
         }
-#ifdef XZAMD_PARANOID
-        {
-            const uint32_t up = x - block_start;
-            if (r0 >= up || r1 >= up || r2 >= up || r3 >= up) {
-                if (lane == 0 && w.err && atomicCAS(w.err, 0u, 2u) == 0u) {
-                    w.err[1] = up; w.err[2] = j; w.err[3] = r0; w.err[4] = r1; w.err[5] = r2; w.err[6] = r3;
-                    w.err[7] = j ? w.n_back[j] : 0;
-                }
-                q_end = 0;
-                return false;
-            }
-        }
-#endif
-        // bytes the literal price needs: issued now, consumed after the round
-        const uint32_t b_cur = in[x];
-        const uint32_t b_prev = x > block_start ? in[x - 1] : 0;
-        const uint32_t b_mb = in[x - r0 - 1];
-        if (!(j == 0 && cached)) {
-            if constexpr (PARETO) {
-                do_round_pareto(e, w, P, x, span_end, r0, r1, r2, r3, RL);
-            } else {
-                Round R;
-                do_round(e, P, x, span_end, r0, r1, r2, r3, R);
-                list_from_mask(w, R, RL);
-            }
-        }
+        TM_END(w, 0, t_derive);
+        TM_BEGIN(t_round);
+        const uint32_t b_mb = in[x - r0 - 1];           // issued now, used only for a matched literal
+        if ((j & 63) == 0) lit_chunk(in, w.ptab, z, x, block_start, span_end, lc);
+        if (!(j == 0 && cached)) round_lists(e, P, x, span_end, r0, r1, r2, r3, RL);
         uint32_t longest = RL.longest;
+        TM_END(w, 1, t_round);
         if (j > 0 && longest >= e.nice) { next_cached = true; break; }
+        TM_BEGIN(t_bits);
         const uint32_t rp0 = lane_of(RL.L, 60), rp1 = lane_of(RL.L, 61), rp2 = lane_of(RL.L, 62), rp3 = lane_of(RL.L, 63);
         uint32_t rl0 = rp0 >= 2 ? rp0 : 0, rl1 = rp1 >= 2 ? rp1 : 0, rl2 = rp2 >= 2 ? rp2 : 0, rl3 = rp3 >= 2 ? rp3 : 0;
         if (j == 0) {
@@ -1130,7 +1257,8 @@ __device__ __forceinline__ bool optimum_window(const Env& e, const Work& w, Pre&
             else if (rl3 >= e.nice) { sb = 3; sl = rl3; }
             else if (longest >= e.nice) { sb = lane_of(RL.SD, RL.cnt - 1) + 4; sl = longest; }
             if (sl) {
-                if (lane == 0) { w.n_price[0] = sb; w.n_info[0] = (w.n_info[0] & 0x1FFF) | (sl << 13); }
+                wave_sync();
+                if (lane == 0) { w.n_price[0] = sb; w.n_info[0] = (z.state << 9) | (sl << 13); }
                 wave_sync();
                 q_end = sl;
                 return false;
@@ -1151,43 +1279,40 @@ __device__ __forceinline__ bool optimum_window(const Env& e, const Work& w, Pre&
 
         const uint32_t upos = x - block_start;
         const uint32_t ps = upos & pbm;
-        const uint32_t P = uni(w.n_price[j]);
-        const uint32_t pm1 = P + pr_bit_u(probs, w.ptv, P_IS_MATCH + s * 16 + ps, 1);
-        const uint32_t prep = pm1 + pr_bit_u(probs, w.ptv, P_IS_REP + s, 1);
+        const uint32_t ci = s * 4 + ps;
+        const uint32_t v01 = lane_of(c01, ci), v23 = lane_of(c23, ci), v45 = lane_of(c45, ci), v6 = lane_of(c6, ci);
+        TM_END(w, 2, t_bits);
+        TM_BEGIN(t_lit);
         // literal and short rep -> node j+1
         {
-            const uint32_t plit = P + pr_bit_u(probs, w.ptv, P_IS_MATCH + s * 16 + ps, 0)
-                    + pr_literal_wave(probs, w.ptab, z, b_cur, b_prev, b_mb, upos, s);
-            uint32_t best = uni(w.n_price[j + 1]), bb = 0;
+            const uint32_t lp = lit_price(lc, j & 63, s, s < 7 ? 0u : uni(b_mb));
+            const uint32_t plit = Pj + (v01 & 0xFFFFu) + lp;
+            uint32_t best = uni(w.n_price[j + 1]), bb = 0, ns = 0;
             bool upd = false;
-            if (plit < best) { best = plit; bb = LITERAL; upd = true; }
+            if (plit < best) { best = plit; bb = LITERAL; upd = true; ns = s <= 3 ? 0 : (s <= 9 ? s - 3 : s - 6); }
             if (rp0 >= 1) {
-                const uint32_t psr = prep + pr_bit_u(probs, w.ptv, P_IS_REP0 + s, 0)
-                        + pr_bit_u(probs, w.ptv, P_IS_REP0_LONG + s * 16 + ps, 0);
-                if (psr < best) { best = psr; bb = 0; upd = true; }
+                const uint32_t psr = Pj + (v01 >> 16);
+                if (psr < best) { best = psr; bb = 0; upd = true; ns = s < 7 ? 9u : 11u; }
             }
-            if (upd && lane == 0) { w.n_price[j + 1] = best; w.n_back[j + 1] = bb; w.n_info[j + 1] = 1; }
+            if (upd && lane == 0) {
+                w.n_price[j + 1] = best; w.n_back[j + 1] = bb; w.n_info[j + 1] = 1 | (ns << 9);
+                w.n_reps4[j + 1] = make_uint4(r0, r1, r2, r3);
+            }
             wave_sync();
         }
+        TM_END(w, 3, t_lit);
+        TM_BEGIN(t_relax);
         if (reach >= 2) {
-            const uint32_t b0 = pr_bit_u(probs, w.ptv, P_IS_REP0 + s, 0), b1 = pr_bit_u(probs, w.ptv, P_IS_REP0 + s, 1);
-            const uint32_t prep0 = prep + b0 + pr_bit_u(probs, w.ptv, P_IS_REP0_LONG + s * 16 + ps, 1);
-            const uint32_t prep1 = prep + b1 + pr_bit_u(probs, w.ptv, P_IS_REP1 + s, 0);
-            const uint32_t p11 = prep + b1 + pr_bit_u(probs, w.ptv, P_IS_REP1 + s, 1);
-            const uint32_t prep2 = p11 + pr_bit_u(probs, w.ptv, P_IS_REP2 + s, 0);
-            const uint32_t prep3 = p11 + pr_bit_u(probs, w.ptv, P_IS_REP2 + s, 1);
-            const uint32_t pmatch = pm1 + pr_bit_u(probs, w.ptv, P_IS_REP + s, 0);
-            switch (ps & 3) {
-            case 0: relax_lengths<0>(w, lt, RL.SL, RL.SD, j, reach, longest, RL.cnt, rl0, rl1, rl2, rl3, prep0, prep1, prep2, prep3, pmatch, upos); break;
-            case 1: relax_lengths<1>(w, lt, RL.SL, RL.SD, j, reach, longest, RL.cnt, rl0, rl1, rl2, rl3, prep0, prep1, prep2, prep3, pmatch, upos); break;
-            case 2: relax_lengths<2>(w, lt, RL.SL, RL.SD, j, reach, longest, RL.cnt, rl0, rl1, rl2, rl3, prep0, prep1, prep2, prep3, pmatch, upos); break;
-            default: relax_lengths<3>(w, lt, RL.SL, RL.SD, j, reach, longest, RL.cnt, rl0, rl1, rl2, rl3, prep0, prep1, prep2, prep3, pmatch, upos); break;
-            }
+            relax_lengths(w, lt, ps & 3, RL.SL, RL.SD, j, reach, longest, RL.cnt, rl0, rl1, rl2, rl3,
+                    Pj + (v23 & 0xFFFFu), Pj + (v23 >> 16), Pj + (v45 & 0xFFFFu), Pj + (v45 >> 16), Pj + v6,
+                    s, r0, r1, r2, r3);
             wave_sync();
         }
+        TM_END(w, 4, t_relax);
         ++j;
         if (j == n_end) break;
     }
+    TM_BEGIN(t_back);
     // backtrack from node j: turn in-edges into out-edges
     if (lane == 0) {
         uint32_t t = j;
@@ -1201,6 +1326,8 @@ __device__ __forceinline__ bool optimum_window(const Env& e, const Work& w, Pre&
         }
     }
     wave_sync();
+    TM_END(w, 5, t_back);
+    TM_COUNT(w, 11);
     q_end = j;
     return next_cached;
 }
@@ -1267,26 +1394,33 @@ __device__ __forceinline__ bool fast_parse_list(const Env& e, const Work& w, Pre
 // Span encoder: one wavefront per span.  PARETO selects the match finder (false = exact HC3/HC4
 // of the reference), OPT the parser (false = optimum_fast of the reference).
 // ------------------------------------------------------------------------------------------
-template <bool PARETO, bool OPT>
+template <int FINDER, bool OPT>      // FINDER: 0 = exact HC3/HC4 in-kernel, 1 = HC4+H8 in-kernel, 2 = lists from k_find_t
 #ifndef XZAMD_WAVES_FAST
 #define XZAMD_WAVES_FAST 4
 #endif
 #ifndef XZAMD_WAVES_OPT
-#define XZAMD_WAVES_OPT 2
+#define XZAMD_WAVES_OPT 3
 #endif
 __global__ __launch_bounds__(64)
 __attribute__((amdgpu_waves_per_eu(OPT ? XZAMD_WAVES_OPT : XZAMD_WAVES_FAST, OPT ? XZAMD_WAVES_OPT : XZAMD_WAVES_FAST)))
 void k_span_encode_t(xzamd_span_args a)
 {
+    constexpr bool PARETO = FINDER == 1;
+    constexpr bool LISTS = FINDER == 2;
+    static_assert(!LISTS || OPT, "the fast parsers run with the in-kernel finders");
     // One LDS pool, carved by hand (a single __shared__ object: no aliasing or ordering surprises).
     constexpr uint32_t W_PROBS = 928;                                    // 1856 x u16 >= P_LITERAL (1846): all but the literal coders
-    constexpr uint32_t W_LIST = (PARETO || OPT) ? 128 : 0;               // ml[64], md[64]
+    constexpr uint32_t W_LIST = 0;
     constexpr uint32_t W_NODES = OPT ? 7 * (WMAX + 1) + 1 : 0;           // price, back, info, reps[4]
     constexpr uint32_t W_TABS = OPT ? (128 + 256 + 8 + 32) : 0;          // dsp, dp, ap (u16), ptab (u8)
 #ifndef XZAMD_LDS_PAD_WORDS
 #define XZAMD_LDS_PAD_WORDS 0        /* occupancy experiments only */
 #endif
     __shared__ __attribute__((aligned(16))) uint32_t pool[W_PROBS + W_LIST + W_NODES + W_TABS + XZAMD_LDS_PAD_WORDS];
+#ifdef XZAMD_TIMING
+    __shared__ unsigned long long tm_lds[16];
+    if (threadIdx.x < 16) tm_lds[threadIdx.x] = 0;
+#endif
     uint16_t* const probs = reinterpret_cast<uint16_t*>(pool);
     const uint32_t lane = threadIdx.x;
     const uint32_t span = blockIdx.x;
@@ -1308,27 +1442,29 @@ void k_span_encode_t(xzamd_span_args a)
     e.rank8 = a.rank8; e.sorted8 = a.sorted8;
     e.nice = a.nice_len; e.depth = a.depth; e.hb = a.hash_bytes; e.cyclic = a.dict_size + 1;
     e.depth2 = a.depth2; e.block_end = block_end; e.n_last = a.n - 1;
+    e.mlen = a.mlen; e.mdist = a.mdist; e.mcnt = a.mcnt;
+    ListPre LP;
+    LP.valid = false; LP.pos = 0; LP.sl = LP.sd = LP.cnt = 0;
     Pre P;
     P.valid = false; P.pos = 0; P.ent = 0;
     P.a.rk = P.a.d2 = P.a.d3 = P.a.rk8 = 0; P.an = P.a;
 
     Work w{};
-    if constexpr (PARETO || OPT) {
-        w.ml = pool + W_PROBS;
-        w.md = pool + W_PROBS + 64;
-    }
     if constexpr (OPT) {
         uint32_t* nb = pool + W_PROBS + W_LIST;
-        w.n_price = nb;
-        w.n_back = nb + (WMAX + 1);
-        w.n_info = nb + 2 * (WMAX + 1);
-        w.n_reps = nb + 3 * (WMAX + 1);
+        w.n_reps4 = reinterpret_cast<uint4*>(nb);           // 16-byte aligned: W_PROBS * 4 is a multiple of 16
+        w.n_price = nb + 4 * (WMAX + 1);
+        w.n_back = nb + 5 * (WMAX + 1);
+        w.n_info = nb + 6 * (WMAX + 1);
         uint32_t* tb = nb + W_NODES;
         w.dsp = reinterpret_cast<uint16_t*>(tb);            // 256 x u16 = 128 words
         w.dp = reinterpret_cast<uint16_t*>(tb + 128);       // 512 x u16 = 256 words
         w.ap = reinterpret_cast<uint16_t*>(tb + 384);       // 16 x u16 = 8 words
         w.ptab = reinterpret_cast<uint8_t*>(tb + 392);      // 128 x u8 = 32 words
         w.err = a.err;
+#ifdef XZAMD_TIMING
+        w.tm = tm_lds;
+#endif
         // bit price table (price_tablegen.c:31-58)
         for (uint32_t t = lane; t < 128; t += 64) {
             uint32_t wv = t * 16 + 8, bit_count = 0;
@@ -1410,11 +1546,13 @@ void k_span_encode_t(xzamd_span_args a)
             if constexpr (OPT) {
                 if (q_pos == q_end) {
                     // price-table refresh policy (oracle: refresh_tables)
-                    if (!tables_valid || z.cnt_len >= 64) { refresh_len_tables(probs, w.ptab, lt, 1u << z.pb); z.cnt_len = 0; }
+                    TM_BEGIN(t_refresh);
+                    if (!tables_valid || z.cnt_len >= 64) { refresh_len_tables(probs, w.ptab, lt, 1u << z.pb, w.n_price); z.cnt_len = 0; }
                     if (!tables_valid || z.cnt_match >= 128) { refresh_dist_tables(probs, w); z.cnt_match = 0; }
                     if (!tables_valid || z.cnt_align >= 16) { refresh_align_table(probs, w); z.cnt_align = 0; }
                     tables_valid = true;
-                    cached = optimum_window<PARETO>(e, w, P, probs, z, lt, in, cur, block_start, span_end, cached, RL, q_end);
+                    TM_END(w, 7, t_refresh);
+                    cached = optimum_window(e, w, LP, probs, z, lt, in, cur, block_start, span_end, cached, RL, q_end);
                     q_pos = 0;
                     if (q_end == 0) {            // consistency failure reported by the parser
                         if (lane == 0) a.span_bytes[span] = 0;
@@ -1546,6 +1684,7 @@ void k_span_encode_t(xzamd_span_args a)
 #ifdef XZAMD_TIMING
             tm_encode += __builtin_amdgcn_s_memtime() - te0;
             ++tm_syms;
+            if constexpr (OPT) { if (lane == 0) { tm_lds[6] += __builtin_amdgcn_s_memtime() - te0; tm_lds[10] += 1; } }
 #endif
             if (a.trace && lane == 0) {
                 // debug only: symbol stream for the parity tests (compared with the oracle's parse)
@@ -1606,12 +1745,80 @@ void k_span_encode_t(xzamd_span_args a)
     }
     if (lane == 0) a.span_bytes[span] = out_off;
 #ifdef XZAMD_TIMING
+    if constexpr (OPT) {
+        if (lane == 0 && a.err) {
+            tm_lds[8] = __builtin_amdgcn_s_memtime() - tm_start;
+            unsigned long long* g = reinterpret_cast<unsigned long long*>(a.err + 16);
+            for (int i = 0; i < 12; ++i) atomicAdd(g + i, tm_lds[i]);
+            atomicMax(g + 12, tm_lds[8]);
+            atomicMax(g + 13, (1ull << 62) - tm_lds[8]);
+        }
+    }
     if (lane == 0 && span == 0 && a.err) {
         const uint64_t tot = __builtin_amdgcn_s_memtime() - tm_start;
         a.err[8] = (uint32_t)(tot >> 8); a.err[9] = (uint32_t)(tm_round1 >> 8); a.err[10] = (uint32_t)(tm_round2 >> 8);
         a.err[11] = (uint32_t)(tm_encode >> 8); a.err[12] = (uint32_t)tm_rounds; a.err[13] = (uint32_t)tm_syms;
     }
 #endif
+}
+
+// ------------------------------------------------------------------------------------------
+// Batch match finder: one wavefront per run of FIND_RUN consecutive positions, lanes = candidates
+// (the same round as above, without the rep lanes).  Writes, per position, the kept matches sorted
+// by length -- at most the LIST_K longest -- with the > nice_len extension folded into the last one.
+// No LDS, no dependence between runs: occupancy is bounded by registers only.
+// ------------------------------------------------------------------------------------------
+constexpr uint32_t FIND_RUN = 256;
+
+template <bool PARETO>
+__global__ __launch_bounds__(64) void k_find_t(xzamd_span_args a, uint16_t* __restrict__ mlen,
+        uint32_t* __restrict__ mdist, uint8_t* __restrict__ mcnt)
+{
+    const uint32_t lane = threadIdx.x;
+    const uint32_t x0 = blockIdx.x * FIND_RUN;
+    if (x0 >= a.n) return;
+    const uint32_t x1 = min(a.n, x0 + FIND_RUN);
+    Env e;
+    e.in = a.in; e.rank = a.rank; e.sorted_pos = a.sorted_pos; e.prev2 = a.prev2; e.prev3 = a.prev3;
+    e.rank8 = a.rank8; e.sorted8 = a.sorted8;
+    e.nice = a.nice_len; e.depth = a.depth; e.hb = a.hash_bytes; e.cyclic = a.dict_size + 1;
+    e.depth2 = a.depth2; e.block_end = 0; e.n_last = a.n - 1;
+    e.mlen = nullptr; e.mdist = nullptr; e.mcnt = nullptr;
+    Pre P;
+    P.valid = false; P.pos = 0; P.ent = 0;
+    P.a.rk = P.a.d2 = P.a.d3 = P.a.rk8 = 0; P.an = P.a;
+    Work w{};
+    uint32_t span_end = 0;
+    for (uint32_t x = x0; x < x1; ++x) {
+        if (x >= span_end) {
+            const uint32_t blk = x / a.block_size;
+            const uint32_t block_start = blk * a.block_size;
+            const uint32_t block_end = min(a.n, block_start + a.block_size);
+            const uint64_t k = (x - block_start) / a.span_size;
+            const uint64_t se = (uint64_t)block_start + (k + 1) * a.span_size;
+            span_end = se < block_end ? (uint32_t)se : block_end;
+            e.block_end = block_end;
+        }
+        RoundL RL;
+        RL.SL = 0; RL.SD = 0;
+        if constexpr (PARETO) {
+            do_round_pareto<false>(e, w, P, x, span_end, 0, 0, 0, 0, RL);
+        } else {
+            Round R;
+            do_round<false>(e, P, x, span_end, 0, 0, 0, 0, R);
+            list_from_mask(w, R, RL);
+        }
+        const uint32_t cnt = RL.cnt;
+        const uint32_t drop = cnt > LIST_K ? cnt - LIST_K : 0;
+        uint32_t len = RL.SL;
+        if (lane + 1 == cnt) len = RL.longest;
+        if (lane >= drop && lane < cnt) {
+            const uint64_t o = (uint64_t)x * LIST_K + (lane - drop);
+            mlen[o] = (uint16_t)len;
+            mdist[o] = RL.SD;
+        }
+        if (lane == 0) mcnt[x] = (uint8_t)(cnt - drop);
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1807,17 +2014,29 @@ int xzk_build_chains(const uint8_t* d_in, uint32_t n, uint32_t block_size, uint3
     return (int)hipGetLastError();
 }
 
+int xzk_find_matches(const xzamd_span_args* a, uint16_t* mlen, uint32_t* mdist, uint8_t* mcnt, void* stream_)
+{
+    hipStream_t st = (hipStream_t)stream_;
+    const uint32_t runs = (a->n + FIND_RUN - 1) / FIND_RUN;
+    if (runs == 0) return 0;
+    if (a->depth2)
+        hipLaunchKernelGGL((k_find_t<true>), dim3(runs), dim3(64), 0, st, *a, mlen, mdist, mcnt);
+    else
+        hipLaunchKernelGGL((k_find_t<false>), dim3(runs), dim3(64), 0, st, *a, mlen, mdist, mcnt);
+    return (int)hipGetLastError();
+}
+
 int xzk_span_encode(const xzamd_span_args* a, uint32_t nspans, void* stream_)
 {
     hipStream_t st = (hipStream_t)stream_;
-    if (a->depth2 == 0 && a->parser == 0)
-        hipLaunchKernelGGL((k_span_encode_t<false, false>), dim3(nspans), dim3(64), 0, st, *a);
-    else if (a->depth2 == 0)
-        hipLaunchKernelGGL((k_span_encode_t<false, true>), dim3(nspans), dim3(64), 0, st, *a);
-    else if (a->parser == 0)
-        hipLaunchKernelGGL((k_span_encode_t<true, false>), dim3(nspans), dim3(64), 0, st, *a);
-    else
-        hipLaunchKernelGGL((k_span_encode_t<true, true>), dim3(nspans), dim3(64), 0, st, *a);
+    if (a->parser) {
+        if (!a->mlen || !a->mdist || !a->mcnt) return (int)hipErrorInvalidValue;
+        hipLaunchKernelGGL((k_span_encode_t<2, true>), dim3(nspans), dim3(64), 0, st, *a);
+    } else if (a->depth2 == 0) {
+        hipLaunchKernelGGL((k_span_encode_t<0, false>), dim3(nspans), dim3(64), 0, st, *a);
+    } else {
+        hipLaunchKernelGGL((k_span_encode_t<1, false>), dim3(nspans), dim3(64), 0, st, *a);
+    }
     return (int)hipGetLastError();
 }
 

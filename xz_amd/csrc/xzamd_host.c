@@ -252,7 +252,7 @@ struct xzamd_ctx {
 	char err_msg_buf[200];
 	/* device buffers */
 	dbuf keys_a, keys_b, vals_a, vals_b, rank, sorted_pos, prev2, prev3, rank8, sorted8, sort_tmp;
-	dbuf scratch, span_bytes, strip_crc, block_crc, segs, lits, trace, errw, litp;
+	dbuf scratch, span_bytes, strip_crc, block_crc, segs, lits, trace, errw, litp, mlen, mdist, mcnt;
 	/* pinned host buffers */
 	dbuf h_span_bytes, h_block_crc, h_segs, h_lits;
 	void *ev[10];
@@ -319,7 +319,7 @@ void xzamd_ctx_destroy(xzamd_ctx *c)
 	xzk_set_device(c->device);
 	dbuf *d[] = { &c->keys_a, &c->keys_b, &c->vals_a, &c->vals_b, &c->rank, &c->sorted_pos,
 		&c->prev2, &c->prev3, &c->rank8, &c->sorted8, &c->sort_tmp, &c->scratch, &c->span_bytes, &c->strip_crc,
-		&c->block_crc, &c->segs, &c->lits, &c->trace, &c->errw, &c->litp };
+		&c->block_crc, &c->segs, &c->lits, &c->trace, &c->errw, &c->litp, &c->mlen, &c->mdist, &c->mcnt };
 	for (size_t i = 0; i < sizeof(d) / sizeof(d[0]); ++i)
 		if (d[i]->p) xzk_free(d[i]->p);
 	dbuf *h[] = { &c->h_span_bytes, &c->h_block_crc, &c->h_segs, &c->h_lits };
@@ -440,6 +440,8 @@ int xzamd_stream_encode_device(xzamd_ctx *c,
 			|| opt->gpu_nice_len < opt->gpu_mf || opt->gpu_nice_len > 273
 			|| opt->dict_size < 4096 || opt->dict_size > (1u << 30))
 		return fail(c, XZAMD_OPTIONS_ERROR, "unsupported match finder options for the device path", 0);
+	if (opt->gpu_parser && opt->pb > 2)
+		return fail(c, XZAMD_OPTIONS_ERROR, "the optimal parser's price tables cover pb <= 2", 0);
 	if (block_size == 0)
 		block_size = xzamd_mt_block_size(opt);
 	if (block_size >= (1ull << 31))
@@ -528,8 +530,12 @@ int xzamd_stream_encode_device(xzamd_ctx *c,
 		GROW(span_bytes, 4ull * nspans, 0);
 		GROW(strip_crc, 8ull * spb_crc * nb, 0);
 		GROW(block_crc, 8ull * nb, 0);
-		GROW(errw, 64, 0);
+		GROW(errw, 256, 0);
 		GROW(litp, (uint64_t)nspans * 6144ull * 4ull, 0);
+		if (opt->gpu_parser) {
+			/* per-position match lists: 16 x (u16 len + u32 dist) + count */
+			GROW(mlen, 32ull * n, 0); GROW(mdist, 64ull * n, 0); GROW(mcnt, (uint64_t)n, 0);
+		}
 		GROW(h_span_bytes, 4ull * nspans, 1);
 		GROW(h_block_crc, 8ull * nb, 1);
 		/* plan capacity: per Block header + spans + trailer, or the stored form */
@@ -572,7 +578,7 @@ int xzamd_stream_encode_device(xzamd_ctx *c,
 			a.span_bytes = (uint32_t *)c->span_bytes.p;
 			a.err = (uint32_t *)c->errw.p;
 			a.lit = (uint32_t *)c->litp.p;
-			if (xzk_memset(c->errw.p, 0, 64, st)) { rc = fail(c, XZAMD_DEVICE_ERROR, "memset", 1); goto done; }
+			if (xzk_memset(c->errw.p, 0, 256, st)) { rc = fail(c, XZAMD_DEVICE_ERROR, "memset", 1); goto done; }
 			if (c->trace_on) {
 				a.trace_count = (uint32_t *)c->trace.p;
 				a.trace = (uint32_t *)((uint8_t *)c->trace.p + 16);
@@ -587,7 +593,17 @@ int xzamd_stream_encode_device(xzamd_ctx *c,
 			a.depth = opt->gpu_depth;
 			a.hash_bytes = hb;
 			a.lc = opt->lc; a.lp = opt->lp; a.pb = opt->pb;
-			int e = xzk_span_encode(&a, nspans, st);
+			int e = 0;
+			if (opt->gpu_parser) {
+				/* 2a. batch match finder -> lists the parser streams */
+				a.mlen = (const uint16_t *)c->mlen.p;
+				a.mdist = (const uint32_t *)c->mdist.p;
+				a.mcnt = (const uint8_t *)c->mcnt.p;
+				e = xzk_find_matches(&a, (uint16_t *)c->mlen.p, (uint32_t *)c->mdist.p, (uint8_t *)c->mcnt.p, st);
+				if (e) { rc = fail(c, XZAMD_DEVICE_ERROR, "find_matches launch", e); goto done; }
+				xzk_event_record(c->ev[5], st);
+			}
+			e = xzk_span_encode(&a, nspans, st);
 			if (e) { rc = fail(c, XZAMD_DEVICE_ERROR, "span_encode launch", e); goto done; }
 		}
 		xzk_event_record(c->ev[2], st);
@@ -601,14 +617,25 @@ int xzamd_stream_encode_device(xzamd_ctx *c,
 		}
 		xzk_event_record(c->ev[3], st);
 		{
-			uint32_t herr[16] = { 0 };
+			uint32_t herr[64] = { 0 };
 			int e = xzk_d2h(c->h_span_bytes.p, c->span_bytes.p, 4ull * nspans, st);
-			if (!e) e = xzk_d2h(herr, c->errw.p, 64, st);
+			if (!e) e = xzk_d2h(herr, c->errw.p, 256, st);
 			if (!e) e = xzk_sync(st);
 			if (e) { rc = fail(c, XZAMD_DEVICE_ERROR, "span encode / d2h sizes", e); goto done; }
 			if (getenv("XZAMD_TIMING") && herr[8])
 				fprintf(stderr, "[timing span0] total %u round1 %u round2 %u encode %u (x256 clk) rounds %u symbols %u\n",
 						herr[8], herr[9], herr[10], herr[11], herr[12], herr[13]);
+			if (getenv("XZAMD_TIMING")) {
+				const uint64_t *t = (const uint64_t *)(herr + 16);
+				if (t[8])
+					fprintf(stderr, "[timing opt, Mcycles summed over spans] total %llu | derive %llu round %llu bits %llu lit %llu relax %llu "
+							"backtrack %llu encode %llu refresh %llu | nodes %llu symbols %llu windows %llu | span max %llu min %llu Mcyc\n",
+							(unsigned long long)(t[8] >> 20), (unsigned long long)(t[0] >> 20), (unsigned long long)(t[1] >> 20),
+							(unsigned long long)(t[2] >> 20), (unsigned long long)(t[3] >> 20), (unsigned long long)(t[4] >> 20),
+							(unsigned long long)(t[5] >> 20), (unsigned long long)(t[6] >> 20), (unsigned long long)(t[7] >> 20),
+							(unsigned long long)t[9], (unsigned long long)t[10], (unsigned long long)t[11],
+							(unsigned long long)(t[12] >> 20), (unsigned long long)(((1ull << 62) - t[13]) >> 20));
+			}
 			if (herr[0]) {
 				snprintf(c->err_msg_buf, sizeof(c->err_msg_buf),
 						"span encoder consistency check %u failed: %u %u %u %u %u %u %u",
@@ -695,6 +722,7 @@ int xzamd_stream_encode_device(xzamd_ctx *c,
 		float ms;
 		if (!xzk_event_elapsed_ms(c->ev[0], c->ev[1], &ms)) c->stats.ms_chains += ms;
 		if (!xzk_event_elapsed_ms(c->ev[1], c->ev[2], &ms)) c->stats.ms_encode += ms;
+		if (opt->gpu_parser && !xzk_event_elapsed_ms(c->ev[1], c->ev[5], &ms)) c->stats.ms_find += ms;
 		if (!xzk_event_elapsed_ms(c->ev[2], c->ev[3], &ms)) c->stats.ms_crc += ms;
 		if (!xzk_event_elapsed_ms(c->ev[3], c->ev[4], &ms)) c->stats.ms_assemble += ms;
 		c->stats.blocks += nb;
