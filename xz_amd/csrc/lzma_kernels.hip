@@ -1763,6 +1763,135 @@ void k_span_encode_t(xzamd_span_args a)
 }
 
 // ------------------------------------------------------------------------------------------
+// HC4+H8 finder, batch form (oracle: find_pareto + the LIST_K truncation of do_round).  Same lane
+// roles as do_round_pareto, but the Pareto filter is a sort instead of loops over candidates: the
+// scalar unit (one per CU, shared by all waves) is what the loop form saturates.
+//   key  = (distance-1) << 6 | lane          unique; invalid lanes get the largest keys
+//   rank = number of smaller keys: the 8-byte chain is already sorted (distances ascend along a
+//          chain), so a chain lane only counts the <= 10 hash2/hash3/4-byte-chain keys below it
+//          and one of those binary-searches the chain;
+//   one ds_permute puts (length, distance) in key order, a DPP max-scan finds the entries longer
+//   than everything closer, and the survivors are stored straight from their lanes.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t dpp_max_step(uint32_t v, uint32_t moved) { return max(v, moved); }
+
+__device__ __forceinline__ uint32_t prefix_max_dpp(uint32_t v)
+{
+    // Hillis-Steele inside each row of 16 lanes, then the row totals (gfx9 row_bcast)
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false));   // row_shr:1
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, false));   // row_shr:2
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, false));   // row_shr:4
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, false));   // row_shr:8
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false));   // row_bcast:15 -> rows 1, 3
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false));   // row_bcast:31 -> rows 2, 3
+    return v;
+}
+
+// 16 bytes per trip; lanes leave at their first mismatch
+__device__ __forceinline__ uint32_t lane_cmplen16(const uint8_t* __restrict__ in, uint32_t q, uint32_t x, uint32_t lim)
+{
+    uint32_t len = 0;
+    while (len + 16 <= lim) {
+        uint4 a, b;
+        __builtin_memcpy(&a, in + q + len, 16);
+        __builtin_memcpy(&b, in + x + len, 16);
+        const uint32_t d0 = a.x ^ b.x, d1 = a.y ^ b.y, d2 = a.z ^ b.z, d3 = a.w ^ b.w;
+        if (d0 | d1 | d2 | d3) {
+            const uint32_t off = d0 ? 0u : d1 ? 4u : d2 ? 8u : 12u;
+            const uint32_t d = d0 ? d0 : d1 ? d1 : d2 ? d2 : d3;
+            return len + off + ((uint32_t)__builtin_ctz(d) >> 3);
+        }
+        len += 16;
+    }
+    while (len < lim && in[q + len] == in[x + len]) ++len;
+    return len;
+}
+
+__device__ __forceinline__ void find_pareto_store(const Env& e, Pre& P, uint32_t x, uint32_t end,
+        uint16_t* __restrict__ mlen, uint32_t* __restrict__ mdist, uint8_t* __restrict__ mcnt)
+{
+    PreA pa;
+    uint32_t pent;
+    fetch<true>(e, P, x, pa, pent);
+    const uint32_t lane = threadIdx.x;
+    const uint32_t avail = end - x;
+    const uint32_t buf_avail = avail < MATCH_LEN_MAX ? avail : MATCH_LEN_MAX;
+    uint32_t len_limit = avail;
+    if (e.nice <= len_limit) len_limit = e.nice;
+    else if (len_limit < 4) {                           // "pending": nothing is reported
+        if (lane == 0) mcnt[x] = 0;
+        return;
+    }
+    const uint32_t d4 = e.depth, d8 = e.depth2, A = 3 + d4;
+    const uint32_t d2 = pa.d2, d3 = pa.d3;
+    const bool have8 = e.block_end - x >= 8;
+    const bool in4 = lane >= 2 && lane <= 2 + d4;
+    const bool in8 = have8 && lane >= A && lane <= A + d8;
+    const uint32_t ent = (!have8 && lane >= A) ? 0x80000000u : pent;
+    const uint64_t fl = __ballot((in4 || in8) && (ent >> 31));
+    const uint32_t qp = ent & 0x7FFFFFFFu;
+    const uint32_t jj = in4 ? lane - 2 : lane - A;                 // candidate number inside its chain
+    const uint64_t before = (in4 ? fl >> 2 : fl >> A) & ((1ull << (jj & 63)) - 1);
+    const bool chain_ok = (in4 || in8) && jj >= 1 && before == 0 && x - qp < e.cyclic;
+    const bool ok2 = lane == 0 && d2 != 0 && d2 < e.cyclic;
+    const bool ok3 = lane == 1 && d3 != 0 && d3 != d2 && d3 < e.cyclic;
+    const bool valid = chain_ok || ok2 || ok3;
+    const uint32_t q = lane == 0 ? x - d2 : lane == 1 ? x - d3 : qp;
+    const uint32_t minlen = lane == 0 ? 2u : lane == 1 ? 3u : 4u;
+    const uint32_t L = lane_cmplen16(e.in, valid ? q : 0u, x, valid ? len_limit : 0u);
+    const uint32_t Le = (valid && L >= minlen) ? L : 0u;
+    const uint32_t dist1 = x - q - 1;
+    const uint32_t key = valid ? ((dist1 << 6) | lane) : (0xFFFFFFC0u | lane);
+
+    // how many hash2 / hash3 / 4-byte-chain keys are smaller than mine
+    uint32_t c = 0;
+    c += lane_of(key, 0) < key ? 1u : 0u;
+    c += lane_of(key, 1) < key ? 1u : 0u;
+    for (uint32_t sidx = 3; sidx <= 2 + d4; ++sidx) c += lane_of(key, sidx) < key ? 1u : 0u;
+    // how many 8-byte-chain keys are smaller than mine (binary search over the sorted chain lanes)
+    const bool is8 = lane > A && lane <= A + d8;
+    const uint32_t n8 = (uint32_t)__builtin_popcountll(__ballot(is8 && valid));
+    uint32_t lo = 0, hi = n8;
+#pragma unroll
+    for (int it = 0; it < 6; ++it) {
+        const uint32_t mid = (lo + hi) >> 1;
+        const uint32_t km = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((A + 1 + mid) << 2), (int)key);
+        const bool act = lo < hi, lt = km < key;
+        lo = (act && lt) ? mid + 1 : lo;
+        hi = (act && !lt) ? mid : hi;
+    }
+    const uint32_t rank = !valid ? 63u : is8 ? (lane - (A + 1)) + c : c + lo;
+    const uint32_t n = (uint32_t)__builtin_popcountll(__ballot(valid));
+    uint32_t sL = lane_scatter(rank, Le);
+    const uint32_t sD = lane_scatter(rank, dist1);
+    sL = lane < n ? sL : 0u;
+    const uint32_t pm = prefix_max_dpp(sL);
+    uint32_t excl = (uint32_t)__shfl_up((int)pm, 1);
+    excl = lane == 0 ? 0u : excl;
+    const bool keep = sL > excl;
+    const uint64_t kmask = __ballot(keep);
+    const uint32_t cnt = (uint32_t)__builtin_popcountll(kmask);
+    if (cnt == 0) {
+        if (lane == 0) mcnt[x] = 0;
+        return;
+    }
+    const uint32_t top = 63 - (uint32_t)__builtin_clzll(kmask);
+    uint32_t longest = lane_of(sL, top);
+    if (longest == e.nice) {
+        const uint32_t dd = lane_of(sD, top);
+        longest = wave_cmplen(e.in, x, x - dd - 1, longest, buf_avail);
+    }
+    const uint32_t idx = __builtin_amdgcn_mbcnt_hi((uint32_t)(kmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)kmask, 0u));
+    const uint32_t drop = cnt > LIST_K ? cnt - LIST_K : 0;
+    if (keep && idx >= drop) {
+        const uint64_t o = (uint64_t)x * LIST_K + (idx - drop);
+        mlen[o] = (uint16_t)(lane == top ? longest : sL);
+        mdist[o] = sD;
+    }
+    if (lane == 0) mcnt[x] = (uint8_t)(cnt - drop);
+}
+
+// ------------------------------------------------------------------------------------------
 // Batch match finder: one wavefront per run of FIND_RUN consecutive positions, lanes = candidates
 // (the same round as above, without the rep lanes).  Writes, per position, the kept matches sorted
 // by length -- at most the LIST_K longest -- with the > nice_len extension folded into the last one.
@@ -1799,11 +1928,13 @@ __global__ __launch_bounds__(64) void k_find_t(xzamd_span_args a, uint16_t* __re
             span_end = se < block_end ? (uint32_t)se : block_end;
             e.block_end = block_end;
         }
+        if constexpr (PARETO) {
+            find_pareto_store(e, P, x, span_end, mlen, mdist, mcnt);
+            continue;
+        }
         RoundL RL;
         RL.SL = 0; RL.SD = 0;
-        if constexpr (PARETO) {
-            do_round_pareto<false>(e, w, P, x, span_end, 0, 0, 0, 0, RL);
-        } else {
+        {
             Round R;
             do_round<false>(e, P, x, span_end, 0, 0, 0, 0, R);
             list_from_mask(w, R, RL);
