@@ -34,13 +34,20 @@ from xz_amd import parallel  # noqa: E402
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
+def span_kernel_name(opts, pmc=False):
+    """Name of the dominant kernel for these options (template args: finder source, parser)."""
+    finder = 2 if opts.gpu_parser else (1 if opts.gpu_depth2 else 0)
+    sep = ", " if pmc else ","
+    return "k_span_encode_t<%d%s%s>" % (finder, sep, "true" if opts.gpu_parser else "false")
+
+
 def pmc_traffic(opts):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
     (FETCH_SIZE and WRITE_SIZE in separate passes, tools/prof_bench.sh -> profiles/*pmc_summary.json).
     PMC counters cannot be collected from inside this process; None when no profile of the same
     kernel variant is present."""
     import glob
-    want = "k_span_encode_t<%s, %s>" % ("true" if opts.gpu_depth2 else "false", "true" if opts.gpu_parser else "false")
+    want = span_kernel_name(opts, pmc=True)
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_summary.json")), reverse=True):
         try:
             d = json.load(open(f))
@@ -131,7 +138,7 @@ def main():
     for _ in range(args.steps):
         out, binfo = step()
         st = enc.stats()
-        enc_ms += st.ms_encode
+        enc_ms += st.ms_encode - st.ms_find      # the span kernel alone (k_find_t is timed separately)
         launches += st.encode_launches
     torch.cuda.synchronize()
     if world > 1:
@@ -172,7 +179,7 @@ def main():
                             f"output = complete .xz Stream in HBM",
                 "device_match_finder": (f"HC{opts.gpu_mf & 15} depth {opts.gpu_depth}" + (f" + H8 depth {opts.gpu_depth2} (Pareto merge)" if opts.gpu_depth2 else "")
                                         + f", nice {opts.gpu_nice_len} (sort-built chains)"),
-                "device_parser": ("windowed optimal parser (256-node DP, exact prices)" if opts.gpu_parser
+                "device_parser": ("windowed optimal parser (256-node DP, exact prices) over per-position match lists from k_find_t" if opts.gpu_parser
                                   else "lzma_lzma_optimum_fast semantics (greedy + 1-byte lazy)"),
                 "span_kib": (opts.span_size or (131072 if opts.gpu_parser else 65536)) >> 10,
                 "parallelism": f"{world} x (one wavefront per span, {int(st.spans)} spans per GPU)",
@@ -180,7 +187,7 @@ def main():
             "ratio": {"ours": round(local_out_bytes / n, 5)},
             "roofline": {
                 "bound": "hbm",
-                "kernel": "k_span_encode_t<%s,%s>" % ("true" if opts.gpu_depth2 else "false", "true" if opts.gpu_parser else "false"),
+                "kernel": span_kernel_name(opts),
                 "achieved": round(achieved, 3),
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
@@ -191,7 +198,8 @@ def main():
                 "avg_launch_ms": round(enc_ms / max(launches, 1), 3),
                 "launches": launches,
             },
-            "stage_ms_last_step": {"chains": round(st.ms_chains, 2), "encode": round(st.ms_encode, 2),
+            "stage_ms_last_step": {"chains": round(st.ms_chains, 2), "find": round(st.ms_find, 2),
+                                   "span_encode": round(st.ms_encode - st.ms_find, 2),
                                    "crc": round(st.ms_crc, 2), "assemble": round(st.ms_assemble, 2),
                                    "total": round(st.ms_total, 2)},
         }
