@@ -63,11 +63,12 @@ enum : uint32_t {
 static_assert(P_TOTAL <= 8192, "model must fit the 16 KiB LDS slice");
 
 // Make LDS stores of some lanes visible to later LDS loads of other lanes of the same wavefront:
-// compiler-level fence + drain of the LDS queue.
+// LDS hand-off between lanes of the wave.  DS instructions of one wave execute in issue order, so a
+// ds_write is visible to any later ds_read of the same wave without waiting; what has to be
+// prevented is the COMPILER moving accesses across the hand-off.
 __device__ __forceinline__ void wave_sync()
 {
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
 }
 
@@ -177,8 +178,12 @@ struct RC {
             const uint32_t carry = (uint32_t)(low >> 32);
             const uint32_t lane = threadIdx.x;
             // byte 0 = cache + carry, then cache_size-1 bytes of 0xFF + carry
-            for (uint32_t i = lane; i < cache_size; i += 64)
-                out[cpos + i] = (uint8_t)((i == 0 ? cache : 0xFFu) + carry);
+            if (cache_size == 1) {                   // the usual case: one pending byte
+                if (lane == 0) out[cpos] = (uint8_t)(cache + carry);
+            } else {
+                for (uint32_t i = lane; i < cache_size; i += 64)
+                    out[cpos + i] = (uint8_t)((i == 0 ? cache : 0xFFu) + carry);
+            }
             cpos += cache_size;
             cache_size = 0;
             cache = (uint32_t)(low >> 24) & 0xFF;
@@ -523,7 +528,13 @@ struct SegSel {            // per lane: which segment this lane's pair belongs t
 __device__ __forceinline__ void seg_add(SegSel& s, uint32_t& off, uint32_t n, uint32_t type, uint32_t base, uint32_t sym)
 {
     const uint32_t k = threadIdx.x;
-    if (k >= off && k < off + n) { s.type = type; s.base = base; s.sym = sym; s.i = k - off; s.n = n; s.hit = true; }
+    const bool h = k - off < n;                 // off <= k < off + n (unsigned wrap)
+    s.type = h ? type : s.type;
+    s.base = h ? base : s.base;
+    s.sym = h ? sym : s.sym;
+    s.i = h ? k - off : s.i;
+    s.n = h ? n : s.n;
+    s.hit = s.hit || h;
     off += n;
 }
 
@@ -746,7 +757,8 @@ struct Work {
 };
 
 struct RoundL {
-    uint32_t L;         // per lane; lanes 60..63 = rep lengths
+    uint32_t rp[4];     // list-driven parser: the four rep-match lengths
+    uint32_t L;         // per lane; lanes 60..63 = rep lengths (in-kernel finders)
     uint32_t SL, SD;    // kept matches sorted by length: lane r holds entry r (length, zero-based distance)
     uint32_t cnt;       // number of entries
     uint32_t longest;   // incl. the > nice_len extension
@@ -903,13 +915,21 @@ __device__ __forceinline__ void round_lists(const Env& e, ListPre& LP, uint32_t 
     LP.valid = true;
     const uint32_t avail = end - x;
     const uint32_t buf_avail = avail < MATCH_LEN_MAX ? avail : MATCH_LEN_MAX;
-    uint32_t q = 0, lim = 0;
-    if (lane >= 60) {
-        const uint32_t rep = lane == 60 ? r0 : lane == 61 ? r1 : lane == 62 ? r2 : r3;
-        q = x - rep - 1;
-        lim = buf_avail;
+    // rep-match lengths, lane = byte offset: one 64-byte row of the text against the four rep
+    // sources, a ballot each.  No per-lane loops; only a match of >= 64 bytes takes the slow path.
+    {
+        const uint32_t off = lane < buf_avail ? lane : 0u;      // lanes past the end re-read byte 0 (masked below)
+        const uint32_t cx = e.in[x + off];
+        const uint32_t c0 = e.in[x - r0 - 1 + off], c1 = e.in[x - r1 - 1 + off];
+        const uint32_t c2 = e.in[x - r2 - 1 + off], c3 = e.in[x - r3 - 1 + off];
+        const bool live = lane < buf_avail;
+        const uint64_t m0 = __ballot(!live || c0 != cx), m1 = __ballot(!live || c1 != cx);
+        const uint64_t m2 = __ballot(!live || c2 != cx), m3 = __ballot(!live || c3 != cx);
+        R.rp[0] = m0 ? (uint32_t)__builtin_ctzll(m0) : wave_cmplen(e.in, x, x - r0 - 1, 64, buf_avail);
+        R.rp[1] = m1 ? (uint32_t)__builtin_ctzll(m1) : wave_cmplen(e.in, x, x - r1 - 1, 64, buf_avail);
+        R.rp[2] = m2 ? (uint32_t)__builtin_ctzll(m2) : wave_cmplen(e.in, x, x - r2 - 1, 64, buf_avail);
+        R.rp[3] = m3 ? (uint32_t)__builtin_ctzll(m3) : wave_cmplen(e.in, x, x - r3 - 1, 64, buf_avail);
     }
-    R.L = lane_cmplen(e.in, q, x, lim);
     const uint32_t cnt = uni(cv);
     R.SL = sl;
     R.SD = sd;
@@ -1034,12 +1054,14 @@ __device__ __forceinline__ void refresh_len_tables(const uint16_t* probs, const 
 __device__ __forceinline__ void refresh_dist_tables(const uint16_t* probs, const Work& w)
 {
     const uint32_t lane = threadIdx.x;
+#pragma unroll 1
     for (uint32_t i = lane; i < 256; i += 64) {
         const uint32_t ds = i >> 6, slot = i & 63;
         uint32_t pr = pr_tree(probs, w.ptab, P_DIST_SLOT + ds * 64, 6, slot);
         if (slot >= 14) pr += (((slot >> 1) - 1) - 4) << 4;
         w.dsp[i] = (uint16_t)pr;
     }
+#pragma unroll 1
     for (uint32_t i = lane; i < 512; i += 64)
         w.dp[i] = (uint16_t)pr_dist_full(probs, w.ptab, i & 127, i >> 7);
     wave_sync();
@@ -1170,13 +1192,12 @@ __device__ __forceinline__ void relax_lengths(const Work& w, const LenTab& lt, u
         const uint32_t c2 = rl2 >= l ? prep2 + lpr : PRICE_INF;
         const uint32_t c3 = rl3 >= l ? prep3 + lpr : PRICE_INF;
         const uint32_t c4 = l <= longest ? pmatch + lpm + (dist_m < 128 ? p_small : p_big) : PRICE_INF;
-        uint32_t best = cur, bb = 0;
+        uint32_t best = cur, bb = 0, n0 = r0;
         { const bool t = c0 < best; best = t ? c0 : best; bb = t ? 0u : bb; }
-        { const bool t = c1 < best; best = t ? c1 : best; bb = t ? 1u : bb; }
-        { const bool t = c2 < best; best = t ? c2 : best; bb = t ? 2u : bb; }
-        { const bool t = c3 < best; best = t ? c3 : best; bb = t ? 3u : bb; }
-        { const bool t = c4 < best; best = t ? c4 : best; bb = t ? dist_m + 4 : bb; }
-        const uint32_t n0 = bb == 0 ? r0 : bb == 1 ? r1 : bb == 2 ? r2 : bb == 3 ? r3 : bb - 4;
+        { const bool t = c1 < best; best = t ? c1 : best; bb = t ? 1u : bb; n0 = t ? r1 : n0; }
+        { const bool t = c2 < best; best = t ? c2 : best; bb = t ? 2u : bb; n0 = t ? r2 : n0; }
+        { const bool t = c3 < best; best = t ? c3 : best; bb = t ? 3u : bb; n0 = t ? r3 : n0; }
+        { const bool t = c4 < best; best = t ? c4 : best; bb = t ? dist_m + 4 : bb; n0 = t ? dist_m : n0; }
         const uint32_t n1 = bb == 0 ? r1 : r0;
         const uint32_t n2 = bb <= 1 ? r2 : r1;
         const uint32_t n3 = bb <= 2 ? r3 : r2;
@@ -1247,7 +1268,7 @@ __device__ __forceinline__ bool optimum_window(const Env& e, const Work& w, List
         TM_END(w, 1, t_round);
         if (j > 0 && longest >= e.nice) { next_cached = true; break; }
         TM_BEGIN(t_bits);
-        const uint32_t rp0 = lane_of(RL.L, 60), rp1 = lane_of(RL.L, 61), rp2 = lane_of(RL.L, 62), rp3 = lane_of(RL.L, 63);
+        const uint32_t rp0 = RL.rp[0], rp1 = RL.rp[1], rp2 = RL.rp[2], rp3 = RL.rp[3];
         uint32_t rl0 = rp0 >= 2 ? rp0 : 0, rl1 = rp1 >= 2 ? rp1 : 0, rl2 = rp2 >= 2 ? rp2 : 0, rl3 = rp3 >= 2 ? rp3 : 0;
         if (j == 0) {
             uint32_t sb = LITERAL, sl = 0;
@@ -1273,7 +1294,8 @@ __device__ __forceinline__ bool optimum_window(const Env& e, const Work& w, List
         const uint32_t rmax = max(max(rl0, rl1), max(rl2, rl3));
         const uint32_t reach = max(longest, rmax);
         const uint32_t new_end = max(max(n_end, j + reach), j + 1);
-        for (uint32_t t = n_end + 1 + lane; t <= new_end; t += 64) w.n_price[t] = PRICE_INF;
+        for (uint32_t tb = n_end + 1; tb <= new_end; tb += 64)
+            if (tb + lane <= new_end) w.n_price[tb + lane] = PRICE_INF;
         n_end = new_end;
         wave_sync();
 
@@ -1496,6 +1518,7 @@ void k_span_encode_t(xzamd_span_args a)
     R.mask = 0; R.L = 0; R.D = 0; R.longest = 0;
     RoundL RL;
     RL.L = 0; RL.SL = 0; RL.SD = 0; RL.cnt = 0; RL.longest = 0;
+    RL.rp[0] = RL.rp[1] = RL.rp[2] = RL.rp[3] = 0;
     LenTab lt;
     uint32_t q_pos = 0, q_end = 0;  // pending path of the optimal parser (nodes in LDS)
     bool tables_valid = false;
