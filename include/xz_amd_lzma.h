@@ -63,6 +63,10 @@ typedef enum {
 
 #define LZMA_FILTER_LZMA2 UINT64_C(0x21)
 #define LZMA_FILTER_X86   UINT64_C(0x04)
+/* api/lzma/bcj.h:81-98 */
+typedef struct {
+	uint32_t start_offset;
+} lzma_options_bcj;
 #define LZMA_PRESET_EXTREME UINT32_C(0x80000000)
 #define LZMA_PRESET_DEFAULT UINT32_C(6)
 

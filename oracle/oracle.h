@@ -70,6 +70,9 @@ uint64_t orc_xz_frame(const uint8_t *const *payloads, const uint64_t *payload_si
 		uint64_t nblocks, uint64_t block_size, uint32_t dict_size,
 		int check, uint8_t *out, uint64_t out_cap);
 
+/* x86 BCJ encoder over one whole Block, in place (simple/x86.c:26-118, fresh state). */
+void orc_x86_encode(uint8_t *buf, uint64_t size);
+
 /* ------------------------------------------------------------------ */
 /* Decoder (verifier)                                                   */
 /* ------------------------------------------------------------------ */

@@ -83,6 +83,61 @@ int ref_encode_mt_opts(const uint8_t *in, size_t in_size,
 	return (int)r;
 }
 
+/* MT encode with the chain {x86 BCJ, LZMA2(preset)}. */
+int ref_encode_mt_x86(const uint8_t *in, size_t in_size, uint32_t preset,
+		uint32_t threads, uint64_t block_size, int check,
+		uint8_t *out, size_t out_cap, size_t *out_size)
+{
+	lzma_options_lzma opt;
+	if (lzma_lzma_preset(&opt, preset))
+		return (int)LZMA_OPTIONS_ERROR;
+	lzma_filter f[3] = { { LZMA_FILTER_X86, NULL }, { LZMA_FILTER_LZMA2, &opt }, { LZMA_VLI_UNKNOWN, NULL } };
+	lzma_stream strm = LZMA_STREAM_INIT;
+	lzma_mt mt;
+	memset(&mt, 0, sizeof(mt));
+	mt.threads = threads;
+	mt.block_size = block_size;
+	mt.filters = f;
+	mt.check = (lzma_check)check;
+	lzma_ret r = lzma_stream_encoder_mt(&strm, &mt);
+	if (r != LZMA_OK)
+		return (int)r;
+	strm.next_in = in;
+	strm.avail_in = in_size;
+	strm.next_out = out;
+	strm.avail_out = out_cap;
+	do {
+		r = lzma_code(&strm, LZMA_FINISH);
+	} while (r == LZMA_OK && strm.avail_out > 0);
+	*out_size = out_cap - strm.avail_out;
+	lzma_end(&strm);
+	return (int)r;
+}
+
+/* The x86 BCJ encoder's output for one buffer (= one Block: fresh filter state, start offset 0):
+ * raw-encode with {x86, LZMA2}, raw-decode with {LZMA2} only.  out must hold in_size bytes. */
+int ref_x86_filter(const uint8_t *in, size_t in_size, uint8_t *out)
+{
+	lzma_options_lzma opt;
+	if (lzma_lzma_preset(&opt, 0))
+		return -1;
+	lzma_filter enc[3] = { { LZMA_FILTER_X86, NULL }, { LZMA_FILTER_LZMA2, &opt }, { LZMA_VLI_UNKNOWN, NULL } };
+	lzma_filter dec[2] = { { LZMA_FILTER_LZMA2, &opt }, { LZMA_VLI_UNKNOWN, NULL } };
+	size_t cap = in_size + in_size / 4 + 65536;
+	uint8_t *tmp = malloc(cap);
+	if (!tmp)
+		return -2;
+	size_t tpos = 0;
+	lzma_ret r = lzma_raw_buffer_encode(enc, NULL, in, in_size, tmp, &tpos, cap);
+	if (r != LZMA_OK) { free(tmp); return (int)r; }
+	size_t ipos = 0, opos = 0;
+	r = lzma_raw_buffer_decode(dec, NULL, tmp, &ipos, tpos, out, &opos, in_size);
+	free(tmp);
+	if (r != LZMA_OK || opos != in_size)
+		return 100 + (int)r;
+	return 0;
+}
+
 /* Raw LZMA2 encode of one buffer (what one worker's filter chain produces
  * for one Block: stream_encoder_mt.c:219-298 minus header/padding/check). */
 int ref_raw_lzma2_encode(const uint8_t *in, size_t in_size,

@@ -307,3 +307,64 @@ uint64_t orc_xz_frame(const uint8_t *const *payloads, const uint64_t *payload_si
 	__builtin_free(unp);
 	return pos;
 }
+
+
+/* ------------------------------------------------------------------ */
+/* x86 BCJ encoder (simple/x86.c:26-118) for one whole Block            */
+/* ------------------------------------------------------------------ */
+/* Fresh state (x86.c:121-136: prev_mask = 0, prev_pos = -5), start offset 0, the whole Block as one
+ * buffer; the last <= 4 bytes pass through (simple_coder.c:178-181).  In place. */
+void orc_x86_encode(uint8_t *buf, uint64_t size)
+{
+	static const uint32_t mask_to_bit[5] = { 0, 1, 2, 2, 3 };
+	uint32_t prev_mask = 0;
+	uint32_t prev_pos = (uint32_t)(-5);
+	if (size < 5)
+		return;
+	const uint64_t limit = size - 5;
+	uint64_t pos = 0;
+	while (pos <= limit) {
+		uint8_t b = buf[pos];
+		if (b != 0xE8 && b != 0xE9) {
+			++pos;
+			continue;
+		}
+		const uint32_t offset = (uint32_t)pos - prev_pos;
+		prev_pos = (uint32_t)pos;
+		if (offset > 5) {
+			prev_mask = 0;
+		} else {
+			for (uint32_t i = 0; i < offset; ++i) {
+				prev_mask &= 0x77;
+				prev_mask <<= 1;
+			}
+		}
+		b = buf[pos + 4];
+		if ((b == 0 || b == 0xFF) && (prev_mask >> 1) <= 4 && (prev_mask >> 1) != 3) {
+			uint32_t src = ((uint32_t)b << 24) | ((uint32_t)buf[pos + 3] << 16)
+					| ((uint32_t)buf[pos + 2] << 8) | buf[pos + 1];
+			uint32_t dest;
+			for (;;) {
+				dest = src + ((uint32_t)pos + 5);
+				if (prev_mask == 0)
+					break;
+				const uint32_t i = mask_to_bit[prev_mask >> 1];
+				b = (uint8_t)(dest >> (24 - i * 8));
+				if (!(b == 0 || b == 0xFF))
+					break;
+				src = dest ^ ((1u << (32 - i * 8)) - 1);
+			}
+			buf[pos + 4] = (uint8_t)(~(((dest >> 24) & 1) - 1));
+			buf[pos + 3] = (uint8_t)(dest >> 16);
+			buf[pos + 2] = (uint8_t)(dest >> 8);
+			buf[pos + 1] = (uint8_t)dest;
+			pos += 5;
+			prev_mask = 0;
+		} else {
+			++pos;
+			prev_mask |= 1;
+			if (b == 0 || b == 0xFF)
+				prev_mask |= 0x10;
+		}
+	}
+}

@@ -230,6 +230,64 @@ def ref_encode_mt(data, preset, threads=1, block_size=0, check=4):
     return out[: n.value].tobytes()
 
 
+def ref_encode_mt_x86(data, preset, threads=1, block_size=0, check=4):
+    """Reference MT encoder with the chain {x86 BCJ, LZMA2(preset)}."""
+    data = as_u8(data)
+    cap = len(data) + len(data) // 4 + 65536
+    out = np.empty(cap, dtype=np.uint8)
+    n = C.c_size_t(0)
+    f = ref().ref_encode_mt_x86
+    f.argtypes = [C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint64, C.c_int, C.c_void_p, C.c_size_t,
+                  C.POINTER(C.c_size_t)]
+    r = f(_ptr(data), len(data), preset, threads, block_size, check, _ptr(out), cap, C.byref(n))
+    assert r == 1, r
+    return out[: n.value].tobytes()
+
+
+def ref_x86_filter(data):
+    """What the reference's x86 BCJ encoder makes of one Block (fresh state, start offset 0)."""
+    data = as_u8(data)
+    out = np.empty(max(len(data), 1), dtype=np.uint8)
+    f = ref().ref_x86_filter
+    f.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
+    r = f(_ptr(data), len(data), _ptr(out))
+    assert r == 0, r
+    return out[: len(data)].tobytes()
+
+
+def orc_x86_encode(data):
+    buf = np.array(as_u8(data), dtype=np.uint8, copy=True)
+    f = orc().orc_x86_encode
+    f.argtypes = [C.c_void_p, C.c_uint64]
+    f.restype = None
+    if len(buf):
+        f(_ptr(buf), len(buf))
+    return buf.tobytes()
+
+
+def corpus_x86(n, seed=1, density=24, runs=True):
+    """Seeded x86-flavoured bytes: text-ish/zero/random background with CALL/JMP opcodes (E8/E9) whose
+    rel32 has a 00/FF top byte, back-to-back opcodes, opcodes inside operands, and (runs=True) long
+    stretches without any opcode-free 5-byte gap (worst case for chunk-parallel BCJ)."""
+    rng = np.random.default_rng(seed)
+    a = rng.integers(0, 256, n, dtype=np.uint8)
+    a[rng.random(n) < 0.35] = 0
+    k = 0
+    while k + 8 < n:
+        k += int(rng.integers(1, density))
+        if k + 5 >= n:
+            break
+        a[k] = 0xE8 if rng.random() < 0.7 else 0xE9
+        a[k + 4] = 0x00 if rng.random() < 0.5 else 0xFF
+        if rng.random() < 0.15:
+            a[k + 1 + int(rng.integers(0, 3))] = 0xE8
+    if runs and n > 20000:
+        s0 = n // 3
+        a[s0:s0 + 9000:3] = 0xE8          # 9000 bytes without a synchronisation point
+        a[s0 + 1:s0 + 9000:3] = 0xFF
+    return a.tobytes()
+
+
 def ref_decode(stream, out_cap):
     stream = as_u8(stream)
     out = np.empty(max(out_cap, 1), dtype=np.uint8)

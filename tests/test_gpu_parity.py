@@ -105,6 +105,58 @@ def test_successor_finder_and_optimal_parser_identical_to_oracle(enc, preset, pa
             assert rr == 1 and rdec == bytes(data), ("liblzma decoder", name)
 
 
+@pytest.mark.parametrize("preset", [0, 1, 3])
+def test_x86_bcj_chain_identical_to_reference(enc, preset):
+    """Chain {x86 BCJ, LZMA2} (simple/x86.c): with one span per Block the whole .xz Stream equals the
+    reference MT encoder's, Block Headers with two filters included; several Blocks, a Block whose
+    size is not a multiple of the BCJ chunk, and input with long stretches without synchronisation
+    points."""
+    import xz_amd
+    if not o.have_ref():
+        pytest.skip("oracle/_ref not built")
+    opts = xz_amd.preset_options(preset, span_size=xz_amd.SPAN_WHOLE_BLOCK)
+    opts.bcj = xz_amd.BCJ_X86
+    cases = {"x86": o.corpus_x86(700000, 4), "dense": o.corpus_x86(300000, 5, density=6),
+             "text": o.corpus_lorem(100000), "tiny4": bytes([0xE8, 0, 0, 0]), "tiny5": bytes([0xE8, 1, 0, 0, 0]),
+             "all_e8": bytes([0xE8]) * 70000, "rnd": o.corpus_random()}
+    for name, data in cases.items():
+        for bs in (1 << 20, 200000, 65537):
+            got, _ = gpu_encode(enc, data, opts, bs)
+            ref = o.ref_encode_mt_x86(data, preset, threads=2, block_size=bs)
+            assert o.first_diff(got, ref) == -1, (name, preset, bs)
+
+
+@pytest.mark.parametrize("preset", [1, 6, 9 | 0x80000000])
+def test_x86_bcj_default_spans_roundtrip(enc, preset):
+    """Span-parallel mode with the BCJ pre-pass: decodes bit-exactly through the REAL reference decoder,
+    and the LZMA2 payload is what the oracle makes of the reference-filtered Block."""
+    import xz_amd
+    if not o.have_ref():
+        pytest.skip("oracle/_ref not built")
+    opts = xz_amd.preset_options(preset)
+    opts.bcj = xz_amd.BCJ_X86
+    data = o.corpus_x86(900000, 9)
+    bs = 400000
+    got, binfo = gpu_encode(enc, data, opts, bs)
+    rr, dec = o.ref_decode(got, len(data) + 16)
+    assert rr == 1 and dec == data
+    assert len(binfo) == 3
+    # plain LZMA2 of the same data must differ (the filter really ran) ...
+    plain = xz_amd.preset_options(preset)
+    got_plain, _ = gpu_encode(enc, data, plain, bs)
+    assert got_plain != got
+    # ... and encoding the reference-filtered Blocks with the plain chain gives the same LZMA2 payload
+    filt = b"".join(o.ref_x86_filter(data[i:i + bs]) for i in range(0, len(data), bs))
+    got_f, binfo_f = gpu_encode(enc, filt, plain, bs)
+    assert len(binfo_f) == len(binfo)
+    for a, b in zip(binfo, binfo_f):
+        blk_a = got[a.out_offset:a.out_offset + a.total_size]
+        blk_b = got_f[b.out_offset:b.out_offset + b.total_size]
+        hs_a, hs_b = (blk_a[0] + 1) * 4, (blk_b[0] + 1) * 4
+        assert hs_a >= hs_b and blk_a[1] == 0xC1 and blk_b[1] == 0xC0
+        assert blk_a[hs_a:-8] == blk_b[hs_b:-8]          # LZMA2 payload + padding; the Checks differ by design
+
+
 def test_custom_options_and_small_dictionary(enc):
     import xz_amd
     data = o.corpus_mixed(500000, 8)

@@ -17,12 +17,13 @@ PRESET_EXTREME = 0x80000000
 SPAN_WHOLE_BLOCK = 0xFFFFFFFF
 SPAN_DEFAULT = 0
 F_BLOCKS_ONLY = 1
+BCJ_X86 = 4
 
 
 class LzmaOptions(C.Structure):
     _fields_ = [(n, C.c_uint32) for n in (
         "dict_size", "lc", "lp", "pb", "mode", "nice_len", "mf", "depth",
-        "gpu_mf", "gpu_nice_len", "gpu_depth", "span_size", "gpu_depth2", "gpu_parser")]
+        "gpu_mf", "gpu_nice_len", "gpu_depth", "span_size", "gpu_depth2", "gpu_parser", "bcj")]
 
 
 class Stats(C.Structure):

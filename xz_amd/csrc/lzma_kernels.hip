@@ -1976,6 +1976,89 @@ __global__ __launch_bounds__(64) void k_find_t(xzamd_span_args a, uint16_t* __re
 }
 
 // ------------------------------------------------------------------------------------------
+// x86 BCJ encoder (simple/x86.c:26-118), one Block = one fresh filter (x86.c:121-136), start offset 0.
+// The filter is a sequential state machine, but (1) every decision reads ORIGINAL bytes only -- a
+// converted CALL/JMP skips its own four operand bytes, nothing re-reads a patched byte -- and (2) its
+// state (prev_mask, prev_pos) is void at any position preceded by five bytes without an E8/E9: the
+// next opcode then sees offset > 5 and clears prev_mask whatever came before, and no conversion can
+// straddle such a position.  So a chunk owner starts at the first such synchronisation point of its
+// chunk and runs to the first one at or after the chunk end (= where the next owner starts): exact,
+// chunk-parallel, and sequential only on input without synchronisation points.
+// `out` already holds a copy of `in`; only converted operands are written.
+// ------------------------------------------------------------------------------------------
+constexpr uint32_t BCJ_CHUNK = 2048;
+
+__device__ __forceinline__ bool x86_is_op(uint32_t b) { return (b & 0xFEu) == 0xE8u; }
+__device__ __forceinline__ bool x86_ms(uint32_t b) { return b == 0u || b == 0xFFu; }
+
+__global__ __launch_bounds__(256) void k_x86_bcj(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, uint32_t n,
+        uint32_t block_size, uint32_t chunks_per_block, uint32_t nchunks)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nchunks) return;
+    const uint32_t blk = t / chunks_per_block, k = t - blk * chunks_per_block;
+    const uint32_t bs = blk * block_size;
+    if (bs >= n) return;
+    const uint32_t size = min(n - bs, block_size);
+    if (size < 5) return;
+    const uint32_t limit = size - 5;                 // last position the filter examines
+    const uint32_t s = k * BCJ_CHUNK;
+    if (s > limit) return;
+    const uint32_t e = s + BCJ_CHUNK;                // may exceed size; only compared
+    const uint8_t* __restrict__ b = in + bs;
+    uint8_t* __restrict__ o = out + bs;
+    uint32_t pos = 0, run = 0;                       // run = non-opcode bytes immediately before pos
+    if (k != 0) {
+        bool found = false;
+        for (uint32_t q = s - 5; q <= limit && q < e; ++q) {
+            if (q >= s && run >= 5) { pos = q; found = true; break; }
+            run = x86_is_op(b[q]) ? 0u : run + 1;
+        }
+        if (!found) return;                           // the previous owner runs through this chunk
+    }
+    uint32_t prev_mask = 0, prev_pos = pos - 6;       // "long ago" (x86.c:133: -5 at the Block start acts the same)
+    while (pos <= limit) {
+        if (pos >= e && run >= 5) break;              // next owner's start
+        const uint32_t c = b[pos];
+        if (!x86_is_op(c)) { ++pos; ++run; continue; }
+        const uint32_t offset = pos - prev_pos;
+        prev_pos = pos;
+        if (offset > 5) prev_mask = 0;
+        else for (uint32_t i = 0; i < offset; ++i) prev_mask = (prev_mask & 0x77u) << 1;
+        uint32_t b4 = b[pos + 4];
+        if (x86_ms(b4) && (prev_mask >> 1) <= 4 && (prev_mask >> 1) != 3) {
+            const uint32_t b1 = b[pos + 1], b2 = b[pos + 2], b3 = b[pos + 3];
+            uint32_t src = (b4 << 24) | (b3 << 16) | (b2 << 8) | b1;
+            uint32_t dest;
+            for (;;) {
+                dest = src + (pos + 5);
+                if (prev_mask == 0) break;
+                const uint32_t pm = prev_mask >> 1;
+                const uint32_t i = pm == 0 ? 0u : pm == 1 ? 1u : pm <= 3 ? 2u : 3u;    // MASK_TO_BIT_NUMBER
+                const uint32_t bb = (dest >> (24 - i * 8)) & 0xFFu;
+                if (!x86_ms(bb)) break;
+                src = dest ^ ((1u << (32 - i * 8)) - 1);
+            }
+            o[pos + 4] = (uint8_t)(~(((dest >> 24) & 1) - 1));
+            o[pos + 3] = (uint8_t)(dest >> 16);
+            o[pos + 2] = (uint8_t)(dest >> 8);
+            o[pos + 1] = (uint8_t)dest;
+            run = x86_is_op(b1) ? 0u : 1u;
+            run = x86_is_op(b2) ? 0u : run + 1;
+            run = x86_is_op(b3) ? 0u : run + 1;
+            run = x86_is_op(b4) ? 0u : run + 1;
+            pos += 5;
+            prev_mask = 0;
+        } else {
+            ++pos;
+            run = 0;
+            prev_mask |= 1;
+            if (x86_ms(b4)) prev_mask |= 0x10;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // CRC64 (check/crc64_fast.c; ECMA-182 reflected, poly 0xC96C5795D7870F42)
 // ------------------------------------------------------------------------------------------
 constexpr uint64_t CRC64_POLY = 0xC96C5795D7870F42ull;
@@ -2191,6 +2274,19 @@ int xzk_span_encode(const xzamd_span_args* a, uint32_t nspans, void* stream_)
     } else {
         hipLaunchKernelGGL((k_span_encode_t<1, false>), dim3(nspans), dim3(64), 0, st, *a);
     }
+    return (int)hipGetLastError();
+}
+
+int xzk_x86_bcj(const uint8_t* d_in, uint8_t* d_out, uint32_t n, uint32_t block_size, uint32_t nblocks, void* stream_)
+{
+    hipStream_t st = (hipStream_t)stream_;
+    int e = (int)hipMemcpyAsync(d_out, d_in, n, hipMemcpyDeviceToDevice, st);
+    if (e) return e;
+    const uint32_t cpb = (block_size + BCJ_CHUNK - 1) / BCJ_CHUNK;
+    const uint64_t nch = (uint64_t)cpb * nblocks;
+    if (nch == 0 || nch > 0xFFFFFFFFull) return nch ? (int)hipErrorInvalidValue : 0;
+    hipLaunchKernelGGL(k_x86_bcj, dim3((uint32_t)((nch + 255) / 256)), dim3(256), 0, st, d_in, d_out, n, block_size, cpb,
+            (uint32_t)nch);
     return (int)hipGetLastError();
 }
 

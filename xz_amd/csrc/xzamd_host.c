@@ -141,23 +141,27 @@ uint64_t xzamd_block_buffer_bound(uint64_t u)
 	return headers + ((lz2 + 3) & ~3ull);
 }
 
-static uint32_t block_header_size(uint64_t csize, uint64_t usize)
+static uint32_t block_header_size(uint64_t csize, uint64_t usize, int x86)
 {
-	/* block_header_encoder.c:17-70 for the chain {LZMA2} */
-	uint32_t s = 1 + 1 + 4 + vli_len(csize) + vli_len(usize) + 3;
+	/* block_header_encoder.c:17-70 for the chains {LZMA2} and {x86, LZMA2} */
+	uint32_t s = 1 + 1 + 4 + vli_len(csize) + vli_len(usize) + 3 + (x86 ? 2 : 0);
 	return (s + 3) & ~3u;
 }
 
-static void block_header_put(uint8_t *out, uint32_t hs, uint64_t csize, uint64_t usize, uint8_t dict_byte)
+static void block_header_put(uint8_t *out, uint32_t hs, uint64_t csize, uint64_t usize, uint8_t dict_byte, int x86)
 {
 	/* block_header_encoder.c:73-131 */
 	const uint32_t body = hs - 4;
 	memset(out, 0, body);
 	out[0] = (uint8_t)(body / 4);
-	out[1] = 0xC0;   /* both sizes present, one filter */
+	out[1] = x86 ? 0xC1 : 0xC0;   /* both sizes present, number of filters - 1 */
 	uint32_t p = 2;
 	p += vli_put(out + p, csize);
 	p += vli_put(out + p, usize);
+	if (x86) {                    /* filter_flags_encoder.c:30-55: id 0x04, no properties (start offset 0) */
+		out[p++] = 0x04;
+		out[p++] = 0x00;
+	}
 	out[p++] = 0x21;
 	out[p++] = 0x01;
 	out[p++] = dict_byte;
@@ -252,7 +256,7 @@ struct xzamd_ctx {
 	char err_msg_buf[200];
 	/* device buffers */
 	dbuf keys_a, keys_b, vals_a, vals_b, rank, sorted_pos, prev2, prev3, rank8, sorted8, sort_tmp;
-	dbuf scratch, span_bytes, strip_crc, block_crc, segs, lits, trace, errw, litp, mlen, mdist, mcnt;
+	dbuf scratch, span_bytes, strip_crc, block_crc, segs, lits, trace, errw, litp, mlen, mdist, mcnt, bcj;
 	/* pinned host buffers */
 	dbuf h_span_bytes, h_block_crc, h_segs, h_lits;
 	void *ev[10];
@@ -319,7 +323,7 @@ void xzamd_ctx_destroy(xzamd_ctx *c)
 	xzk_set_device(c->device);
 	dbuf *d[] = { &c->keys_a, &c->keys_b, &c->vals_a, &c->vals_b, &c->rank, &c->sorted_pos,
 		&c->prev2, &c->prev3, &c->rank8, &c->sorted8, &c->sort_tmp, &c->scratch, &c->span_bytes, &c->strip_crc,
-		&c->block_crc, &c->segs, &c->lits, &c->trace, &c->errw, &c->litp, &c->mlen, &c->mdist, &c->mcnt };
+		&c->block_crc, &c->segs, &c->lits, &c->trace, &c->errw, &c->litp, &c->mlen, &c->mdist, &c->mcnt, &c->bcj };
 	for (size_t i = 0; i < sizeof(d) / sizeof(d[0]); ++i)
 		if (d[i]->p) xzk_free(d[i]->p);
 	dbuf *h[] = { &c->h_span_bytes, &c->h_block_crc, &c->h_segs, &c->h_lits };
@@ -440,6 +444,8 @@ int xzamd_stream_encode_device(xzamd_ctx *c,
 			|| opt->gpu_nice_len < opt->gpu_mf || opt->gpu_nice_len > 273
 			|| opt->dict_size < 4096 || opt->dict_size > (1u << 30))
 		return fail(c, XZAMD_OPTIONS_ERROR, "unsupported match finder options for the device path", 0);
+	if (opt->bcj != 0 && opt->bcj != XZAMD_BCJ_X86)
+		return fail(c, XZAMD_OPTIONS_ERROR, "only the x86 BCJ filter is supported in front of LZMA2", 0);
 	if (opt->gpu_parser && opt->pb > 2)
 		return fail(c, XZAMD_OPTIONS_ERROR, "the optimal parser's price tables cover pb <= 2", 0);
 	if (block_size == 0)
@@ -476,7 +482,8 @@ int xzamd_stream_encode_device(xzamd_ctx *c,
 	const uint64_t total_blocks = (in_size + block_size - 1) / block_size;
 	if (nblocks_out) *nblocks_out = total_blocks;
 	const uint64_t bound = xzamd_block_buffer_bound(block_size);
-	const uint32_t hs_fixed = block_header_size(bound, block_size);
+	const int x86 = opt->bcj == XZAMD_BCJ_X86;
+	const uint32_t hs_fixed = block_header_size(bound, block_size, x86);
 	const uint8_t dbyte = dict_size_byte(opt->dict_size);
 
 	memset(&c->stats, 0, sizeof(c->stats));
@@ -547,10 +554,18 @@ int xzamd_stream_encode_device(xzamd_ctx *c,
 		GROW(h_segs, max_segs * sizeof(xzamd_copy_seg), 1);
 		GROW(h_lits, max_lits, 1);
 
-		/* 1. match-finder structure */
+		/* 0. BCJ pre-pass: LZMA2 sees the filtered copy, the Check and stored Blocks the original */
+		const uint8_t *enc_in = d_in + in_off;
 		xzk_event_record(c->ev[0], st);
+		if (x86) {
+			GROW(bcj, (uint64_t)n + 16, 0);
+			int e = xzk_x86_bcj(d_in + in_off, (uint8_t *)c->bcj.p, n, (uint32_t)block_size, (uint32_t)nb, st);
+			if (e) { rc = fail(c, XZAMD_DEVICE_ERROR, "x86 bcj", e); goto done; }
+			enc_in = (const uint8_t *)c->bcj.p;
+		}
+		/* 1. match-finder structure */
 		{
-			int e = xzk_build_chains(d_in + in_off, n, (uint32_t)block_size, (uint32_t)nb, hb, hmask, hbits,
+			int e = xzk_build_chains(enc_in, n, (uint32_t)block_size, (uint32_t)nb, hb, hmask, hbits,
 					(uint32_t *)c->keys_a.p, (uint32_t *)c->keys_b.p, (uint32_t *)c->vals_a.p,
 					(uint32_t *)c->vals_b.p, c->sort_tmp.p, sort_bytes,
 					(uint32_t *)c->rank.p, (uint32_t *)c->sorted_pos.p, (uint32_t *)c->prev2.p,
@@ -564,7 +579,7 @@ int xzamd_stream_encode_device(xzamd_ctx *c,
 		{
 			xzamd_span_args a;
 			memset(&a, 0, sizeof(a));
-			a.in = d_in + in_off;
+			a.in = enc_in;
 			a.rank = (const uint32_t *)c->rank.p;
 			a.sorted_pos = (const uint32_t *)c->sorted_pos.p;
 			a.prev2 = (const uint32_t *)c->prev2.p;
@@ -665,9 +680,9 @@ int xzamd_stream_encode_device(xzamd_ctx *c,
 			if (hs_fixed + payload + pad + cbytes > bound) {
 				/* stream_encoder_mt.c:298,316-344 -> block_buffer_encoder.c:88-162 */
 				const uint64_t csz = usize + ((usize + 65535) / 65536) * 3 + 1;
-				const uint32_t hs = block_header_size(csz, usize);
+				const uint32_t hs = block_header_size(csz, usize, 0);      /* stored Blocks drop the BCJ filter */
 				if (opos + hs + csz + 3 + cbytes > out_cap) { rc = fail(c, XZAMD_BUF_ERROR, "output buffer too small", 0); goto done; }
-				block_header_put(small, hs, csz, usize, 0x00);
+				block_header_put(small, hs, csz, usize, 0x00, 0);
 				opos = plan_lit(&pl, small, hs, opos);
 				uint8_t ctl = 0x01;
 				for (uint64_t ip = 0; ip < usize; ip += 65536) {
@@ -683,7 +698,7 @@ int xzamd_stream_encode_device(xzamd_ctx *c,
 				++c->stats.blocks_stored;
 			} else {
 				if (opos + hs_fixed + payload + pad + cbytes > out_cap) { rc = fail(c, XZAMD_BUF_ERROR, "output buffer too small", 0); goto done; }
-				block_header_put(small, hs_fixed, payload, usize, dbyte);
+				block_header_put(small, hs_fixed, payload, usize, dbyte, x86);
 				opos = plan_lit(&pl, small, hs_fixed, opos);
 				for (uint32_t s = 0; s < spb; ++s)
 					opos = plan_seg(&pl, 0, (uint64_t)(b * spb + s) * span_cap, sb[b * spb + s], opos);

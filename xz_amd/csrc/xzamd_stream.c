@@ -105,8 +105,17 @@ static lzma_ret parse_options(const lzma_mt *o, xzamd_lzma_options *opt, uint64_
 		return LZMA_OPTIONS_ERROR;
 	if (o->filters != NULL) {
 		const lzma_filter *f = o->filters;
+		uint32_t bcj = 0;
+		if (f[0].id == LZMA_FILTER_X86) {
+			/* {x86, LZMA2}: start offset must be 0 (bcj.h:81-98, NULL options = defaults) */
+			const lzma_options_bcj *b = (const lzma_options_bcj *)f[0].options;
+			if (b != NULL && b->start_offset != 0)
+				return LZMA_OPTIONS_ERROR;
+			bcj = XZAMD_BCJ_X86;
+			++f;
+		}
 		if (f[0].id != LZMA_FILTER_LZMA2 || f[0].options == NULL || f[1].id != LZMA_VLI_UNKNOWN)
-			return LZMA_OPTIONS_ERROR;      /* only plain LZMA2 chains on the device path */
+			return LZMA_OPTIONS_ERROR;      /* device path: {LZMA2} and {x86, LZMA2} */
 		const lzma_options_lzma *l = (const lzma_options_lzma *)f[0].options;
 		if (l->preset_dict != NULL && l->preset_dict_size != 0)
 			return LZMA_OPTIONS_ERROR;
@@ -139,6 +148,7 @@ static lzma_ret parse_options(const lzma_mt *o, xzamd_lzma_options *opt, uint64_
 			return LZMA_OPTIONS_ERROR;
 		}
 		opt->span_size = XZAMD_SPAN_DEFAULT;
+		opt->bcj = bcj;
 	} else if (xzamd_lzma_preset(opt, o->preset)) {
 		return LZMA_OPTIONS_ERROR;
 	}
