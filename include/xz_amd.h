@@ -102,6 +102,7 @@ void xzamd_ctx_destroy(xzamd_ctx *ctx);
 /* Bytes of input processed per device batch (default 1 GiB, < 2 GiB). */
 int xzamd_ctx_set_batch_bytes(xzamd_ctx *ctx, uint64_t bytes);
 const char *xzamd_last_error(const xzamd_ctx *ctx);
+int xzamd_ctx_device(const xzamd_ctx *ctx);          /* device ordinal the context lives on */
 
 typedef struct {
 	uint64_t in_bytes, out_bytes;

@@ -1830,21 +1830,27 @@ __device__ __forceinline__ uint32_t lane_cmplen16(const uint8_t* __restrict__ in
     return len;
 }
 
-__device__ __forceinline__ void find_pareto_store(const Env& e, Pre& P, uint32_t x, uint32_t end,
-        uint16_t* __restrict__ mlen, uint32_t* __restrict__ mdist, uint8_t* __restrict__ mcnt)
+// candidate of this lane at position x (lane roles as in do_round_pareto)
+struct Cand {
+    uint32_t q;          // candidate position (valid lanes)
+    uint32_t minlen;     // 2 / 3 / 4
+    bool valid;
+    uint32_t len_limit, buf_avail;     // uniform
+    bool mf_ok;                        // uniform: false = "pending", nothing is reported
+};
+
+__device__ __forceinline__ void cand_setup(const Env& e, Pre& P, uint32_t x, uint32_t end, Cand& c)
 {
     PreA pa;
     uint32_t pent;
     fetch<true>(e, P, x, pa, pent);
     const uint32_t lane = threadIdx.x;
     const uint32_t avail = end - x;
-    const uint32_t buf_avail = avail < MATCH_LEN_MAX ? avail : MATCH_LEN_MAX;
-    uint32_t len_limit = avail;
-    if (e.nice <= len_limit) len_limit = e.nice;
-    else if (len_limit < 4) {                           // "pending": nothing is reported
-        if (lane == 0) mcnt[x] = 0;
-        return;
-    }
+    c.buf_avail = avail < MATCH_LEN_MAX ? avail : MATCH_LEN_MAX;
+    c.len_limit = avail;
+    c.mf_ok = true;
+    if (e.nice <= c.len_limit) c.len_limit = e.nice;
+    else if (c.len_limit < 4) c.mf_ok = false;
     const uint32_t d4 = e.depth, d8 = e.depth2, A = 3 + d4;
     const uint32_t d2 = pa.d2, d3 = pa.d3;
     const bool have8 = e.block_end - x >= 8;
@@ -1858,19 +1864,56 @@ __device__ __forceinline__ void find_pareto_store(const Env& e, Pre& P, uint32_t
     const bool chain_ok = (in4 || in8) && jj >= 1 && before == 0 && x - qp < e.cyclic;
     const bool ok2 = lane == 0 && d2 != 0 && d2 < e.cyclic;
     const bool ok3 = lane == 1 && d3 != 0 && d3 != d2 && d3 < e.cyclic;
-    const bool valid = chain_ok || ok2 || ok3;
-    const uint32_t q = lane == 0 ? x - d2 : lane == 1 ? x - d3 : qp;
-    const uint32_t minlen = lane == 0 ? 2u : lane == 1 ? 3u : 4u;
-    const uint32_t L = lane_cmplen16(e.in, valid ? q : 0u, x, valid ? len_limit : 0u);
-    const uint32_t Le = (valid && L >= minlen) ? L : 0u;
-    const uint32_t dist1 = x - q - 1;
+    c.valid = c.mf_ok && (chain_ok || ok2 || ok3);
+    c.q = lane == 0 ? x - d2 : lane == 1 ? x - d3 : qp;
+    c.minlen = lane == 0 ? 2u : lane == 1 ? 3u : 4u;
+}
+
+// bytes matched inside one 16-byte trip (16 = all)
+__device__ __forceinline__ uint32_t match16(const uint4& a, const uint4& b)
+{
+    const uint32_t d0 = a.x ^ b.x, d1 = a.y ^ b.y, d2 = a.z ^ b.z, d3 = a.w ^ b.w;
+    const uint32_t off = d0 ? 0u : d1 ? 4u : d2 ? 8u : 12u;
+    const uint32_t d = d0 ? d0 : d1 ? d1 : d2 ? d2 : d3;
+    return d ? off + ((uint32_t)__builtin_ctz(d) >> 3) : 16u;
+}
+
+// continue a compare whose first `len` bytes are known equal
+__device__ __forceinline__ uint32_t lane_cmplen16_from(const uint8_t* __restrict__ in, uint32_t q, uint32_t x, uint32_t len,
+        uint32_t lim)
+{
+    while (len + 16 <= lim) {
+        uint4 a, b;
+        __builtin_memcpy(&a, in + q + len, 16);
+        __builtin_memcpy(&b, in + x + len, 16);
+        const uint32_t m = match16(a, b);
+        len += m;
+        if (m < 16) return len;
+    }
+    while (len < lim && in[q + len] == in[x + len]) ++len;
+    return len;
+}
+
+// Pareto filter + store for one position, given every lane's match length L
+__device__ __forceinline__ void pareto_finish(const Env& e, uint32_t x, const Cand& c, uint32_t L,
+        uint16_t* __restrict__ mlen, uint32_t* __restrict__ mdist, uint8_t* __restrict__ mcnt)
+{
+    const uint32_t lane = threadIdx.x;
+    if (!c.mf_ok) {
+        if (lane == 0) mcnt[x] = 0;
+        return;
+    }
+    const uint32_t d4 = e.depth, d8 = e.depth2, A = 3 + d4;
+    const bool valid = c.valid;
+    const uint32_t Le = (valid && L >= c.minlen) ? L : 0u;
+    const uint32_t dist1 = x - c.q - 1;
     const uint32_t key = valid ? ((dist1 << 6) | lane) : (0xFFFFFFC0u | lane);
 
     // how many hash2 / hash3 / 4-byte-chain keys are smaller than mine
-    uint32_t c = 0;
-    c += lane_of(key, 0) < key ? 1u : 0u;
-    c += lane_of(key, 1) < key ? 1u : 0u;
-    for (uint32_t sidx = 3; sidx <= 2 + d4; ++sidx) c += lane_of(key, sidx) < key ? 1u : 0u;
+    uint32_t cs = 0;
+    cs += lane_of(key, 0) < key ? 1u : 0u;
+    cs += lane_of(key, 1) < key ? 1u : 0u;
+    for (uint32_t sidx = 3; sidx <= 2 + d4; ++sidx) cs += lane_of(key, sidx) < key ? 1u : 0u;
     // how many 8-byte-chain keys are smaller than mine (binary search over the sorted chain lanes)
     const bool is8 = lane > A && lane <= A + d8;
     const uint32_t n8 = (uint32_t)__builtin_popcountll(__ballot(is8 && valid));
@@ -1883,7 +1926,7 @@ __device__ __forceinline__ void find_pareto_store(const Env& e, Pre& P, uint32_t
         lo = (act && lt) ? mid + 1 : lo;
         hi = (act && !lt) ? mid : hi;
     }
-    const uint32_t rank = !valid ? 63u : is8 ? (lane - (A + 1)) + c : c + lo;
+    const uint32_t rank = !valid ? 63u : is8 ? (lane - (A + 1)) + cs : cs + lo;
     const uint32_t n = (uint32_t)__builtin_popcountll(__ballot(valid));
     uint32_t sL = lane_scatter(rank, Le);
     const uint32_t sD = lane_scatter(rank, dist1);
@@ -1902,7 +1945,7 @@ __device__ __forceinline__ void find_pareto_store(const Env& e, Pre& P, uint32_t
     uint32_t longest = lane_of(sL, top);
     if (longest == e.nice) {
         const uint32_t dd = lane_of(sD, top);
-        longest = wave_cmplen(e.in, x, x - dd - 1, longest, buf_avail);
+        longest = wave_cmplen(e.in, x, x - dd - 1, longest, c.buf_avail);
     }
     const uint32_t idx = __builtin_amdgcn_mbcnt_hi((uint32_t)(kmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)kmask, 0u));
     const uint32_t drop = cnt > LIST_K ? cnt - LIST_K : 0;
@@ -1912,6 +1955,43 @@ __device__ __forceinline__ void find_pareto_store(const Env& e, Pre& P, uint32_t
         mdist[o] = sD;
     }
     if (lane == 0) mcnt[x] = (uint8_t)(cnt - drop);
+}
+
+__device__ __forceinline__ void find_pareto_store(const Env& e, Pre& P, uint32_t x, uint32_t end,
+        uint16_t* __restrict__ mlen, uint32_t* __restrict__ mdist, uint8_t* __restrict__ mcnt)
+{
+    Cand c;
+    cand_setup(e, P, x, end, c);
+    const uint32_t L = lane_cmplen16_from(e.in, c.valid ? c.q : 0u, x, 0, c.valid ? c.len_limit : 0u);
+    pareto_finish(e, x, c, L, mlen, mdist, mcnt);
+}
+
+// Two consecutive positions at once: both first compare trips are in flight together (the kernel
+// is bound by memory latency per wave; occupancy is already at the 8 waves/SIMD maximum).
+__device__ __forceinline__ void find_pareto_store2(const Env& e, Pre& P, uint32_t x, uint32_t end,
+        uint16_t* __restrict__ mlen, uint32_t* __restrict__ mdist, uint8_t* __restrict__ mcnt)
+{
+    Cand c0, c1;
+    cand_setup(e, P, x, end, c0);
+    cand_setup(e, P, x + 1, end, c1);
+    uint32_t L0, L1;
+    if (c0.len_limit >= 16 && c1.len_limit >= 16) {
+        const uint32_t q0 = c0.valid ? c0.q : 0u, q1 = c1.valid ? c1.q : 0u;
+        uint4 a0, b0, a1, b1;
+        __builtin_memcpy(&a0, e.in + q0, 16);
+        __builtin_memcpy(&b0, e.in + x, 16);
+        __builtin_memcpy(&a1, e.in + q1, 16);
+        __builtin_memcpy(&b1, e.in + x + 1, 16);
+        const uint32_t m0 = c0.valid ? match16(a0, b0) : 0u;
+        const uint32_t m1 = c1.valid ? match16(a1, b1) : 0u;
+        L0 = lane_cmplen16_from(e.in, q0, x, m0, m0 == 16 ? c0.len_limit : 0u);
+        L1 = lane_cmplen16_from(e.in, q1, x + 1, m1, m1 == 16 ? c1.len_limit : 0u);
+    } else {
+        L0 = lane_cmplen16_from(e.in, c0.valid ? c0.q : 0u, x, 0, c0.valid ? c0.len_limit : 0u);
+        L1 = lane_cmplen16_from(e.in, c1.valid ? c1.q : 0u, x + 1, 0, c1.valid ? c1.len_limit : 0u);
+    }
+    pareto_finish(e, x, c0, L0, mlen, mdist, mcnt);
+    pareto_finish(e, x + 1, c1, L1, mlen, mdist, mcnt);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1952,7 +2032,12 @@ __global__ __launch_bounds__(64) void k_find_t(xzamd_span_args a, uint16_t* __re
             e.block_end = block_end;
         }
         if constexpr (PARETO) {
-            find_pareto_store(e, P, x, span_end, mlen, mdist, mcnt);
+            if (x + 1 < x1 && x + 1 < span_end) {
+                find_pareto_store2(e, P, x, span_end, mlen, mdist, mcnt);
+                ++x;
+            } else {
+                find_pareto_store(e, P, x, span_end, mlen, mdist, mcnt);
+            }
             continue;
         }
         RoundL RL;

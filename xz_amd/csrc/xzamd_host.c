@@ -344,6 +344,7 @@ int xzamd_ctx_set_batch_bytes(xzamd_ctx *c, uint64_t bytes)
 }
 
 const char *xzamd_last_error(const xzamd_ctx *c) { return c ? c->err : "no context"; }
+int xzamd_ctx_device(const xzamd_ctx *c) { return c ? c->device : -1; }
 void xzamd_get_stats(const xzamd_ctx *c, xzamd_stats *out) { *out = c->stats; }
 const char *xzamd_version(void) { return "xz_amd 0.1 (gfx950)"; }
 

@@ -22,6 +22,7 @@
 #include "../../include/xz_amd_lzma.h"
 #include "kernels_api.h"
 
+#include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -81,10 +82,62 @@ static lzma_ret map_rc(int rc)
 	}
 }
 
+/* One parked set of device/pinned resources: hipMalloc of the work buffers (tens of GiB for a 1 GiB
+ * batch) and hipHostMalloc of the staging area cost seconds, so lzma_end() parks them and the next
+ * lzma_stream_encoder_mt() of the process picks them up instead of allocating again. */
+static struct {
+	pthread_mutex_t mu;
+	int full;
+	xzamd_ctx *ctx;
+	uint8_t *stage; uint64_t stage_cap;
+	uint8_t *outq; uint64_t outq_cap;
+	void *d_in; uint64_t d_in_cap;
+	void *d_out; uint64_t d_out_cap;
+} g_park = { PTHREAD_MUTEX_INITIALIZER, 0, NULL, NULL, 0, NULL, 0, NULL, 0, NULL, 0 };
+
+static int park_resources(lzma_internal *in)
+{
+	int parked = 0;
+	pthread_mutex_lock(&g_park.mu);
+	if (!g_park.full && in->ctx) {
+		g_park.ctx = in->ctx;
+		g_park.stage = in->stage; g_park.stage_cap = in->stage_cap;
+		g_park.outq = in->outq; g_park.outq_cap = in->outq_cap;
+		g_park.d_in = in->d_in; g_park.d_in_cap = in->d_in_cap;
+		g_park.d_out = in->d_out; g_park.d_out_cap = in->d_out_cap;
+		g_park.full = 1;
+		parked = 1;
+	}
+	pthread_mutex_unlock(&g_park.mu);
+	return parked;
+}
+
+static int unpark_resources(lzma_internal *in)
+{
+	int got = 0, dev = -1;
+	if (xzk_get_device(&dev))
+		return 0;
+	pthread_mutex_lock(&g_park.mu);
+	if (g_park.full && xzamd_ctx_device(g_park.ctx) == dev) {
+		in->ctx = g_park.ctx;
+		in->stage = g_park.stage; in->stage_cap = g_park.stage_cap;
+		in->outq = g_park.outq; in->outq_cap = g_park.outq_cap;
+		in->d_in = g_park.d_in; in->d_in_cap = g_park.d_in_cap;
+		in->d_out = g_park.d_out; in->d_out_cap = g_park.d_out_cap;
+		g_park.full = 0;
+		got = 1;
+	}
+	pthread_mutex_unlock(&g_park.mu);
+	return got;
+}
+
 static void internal_free(lzma_internal *in)
 {
 	if (!in) return;
 	const lzma_allocator *a = in->allocator;
+	if (park_resources(in)) {
+		in->ctx = NULL; in->stage = NULL; in->outq = NULL; in->d_in = NULL; in->d_out = NULL;
+	}
 	if (in->stage) xzk_host_free(in->stage);
 	if (in->outq) xzk_host_free(in->outq);
 	if (in->d_in) xzk_free(in->d_in);
@@ -193,10 +246,12 @@ lzma_ret lzma_stream_encoder_mt(lzma_stream *strm, const lzma_mt *options)
 	in->check = check;
 	in->sequence = ISEQ_RUN;
 	in->sseq = SEQ_HEADER;
-	int rc = xzamd_ctx_create(&in->ctx, -1);
-	if (rc) {
-		internal_free(in);
-		return rc == XZAMD_MEM_ERROR ? LZMA_MEM_ERROR : LZMA_PROG_ERROR;
+	if (!unpark_resources(in)) {
+		int rc = xzamd_ctx_create(&in->ctx, -1);
+		if (rc) {
+			internal_free(in);
+			return rc == XZAMD_MEM_ERROR ? LZMA_MEM_ERROR : LZMA_PROG_ERROR;
+		}
 	}
 	/* batch = whole Blocks, at most the context's device batch */
 	uint64_t maxb = (1ull << 30) / block_size;
@@ -339,7 +394,8 @@ static lzma_ret stream_code(lzma_internal *in, const uint8_t *inb, size_t *in_po
 				if (in->stage_len == in->stage_max)
 					break;
 				if (in->stage_len == in->stage_cap) {
-					uint64_t nc = in->stage_cap ? in->stage_cap * 2 : in->block_size;
+					/* second growth step goes straight to the full batch: each step is a pinned allocation + copy */
+					uint64_t nc = in->stage_cap ? in->stage_max : in->block_size;
 					if (nc < (1u << 20)) nc = 1u << 20;
 					if (nc > in->stage_max) nc = in->stage_max;
 					lzma_ret r = grow_pinned(&in->stage, &in->stage_cap, in->stage_len, nc);
