@@ -1810,26 +1810,6 @@ __device__ __forceinline__ uint32_t prefix_max_dpp(uint32_t v)
     return v;
 }
 
-// 16 bytes per trip; lanes leave at their first mismatch
-__device__ __forceinline__ uint32_t lane_cmplen16(const uint8_t* __restrict__ in, uint32_t q, uint32_t x, uint32_t lim)
-{
-    uint32_t len = 0;
-    while (len + 16 <= lim) {
-        uint4 a, b;
-        __builtin_memcpy(&a, in + q + len, 16);
-        __builtin_memcpy(&b, in + x + len, 16);
-        const uint32_t d0 = a.x ^ b.x, d1 = a.y ^ b.y, d2 = a.z ^ b.z, d3 = a.w ^ b.w;
-        if (d0 | d1 | d2 | d3) {
-            const uint32_t off = d0 ? 0u : d1 ? 4u : d2 ? 8u : 12u;
-            const uint32_t d = d0 ? d0 : d1 ? d1 : d2 ? d2 : d3;
-            return len + off + ((uint32_t)__builtin_ctz(d) >> 3);
-        }
-        len += 16;
-    }
-    while (len < lim && in[q + len] == in[x + len]) ++len;
-    return len;
-}
-
 // candidate of this lane at position x (lane roles as in do_round_pareto)
 struct Cand {
     uint32_t q;          // candidate position (valid lanes)
@@ -1966,34 +1946,6 @@ __device__ __forceinline__ void find_pareto_store(const Env& e, Pre& P, uint32_t
     pareto_finish(e, x, c, L, mlen, mdist, mcnt);
 }
 
-// Two consecutive positions at once: both first compare trips are in flight together (the kernel
-// is bound by memory latency per wave; occupancy is already at the 8 waves/SIMD maximum).
-__device__ __forceinline__ void find_pareto_store2(const Env& e, Pre& P, uint32_t x, uint32_t end,
-        uint16_t* __restrict__ mlen, uint32_t* __restrict__ mdist, uint8_t* __restrict__ mcnt)
-{
-    Cand c0, c1;
-    cand_setup(e, P, x, end, c0);
-    cand_setup(e, P, x + 1, end, c1);
-    uint32_t L0, L1;
-    if (c0.len_limit >= 16 && c1.len_limit >= 16) {
-        const uint32_t q0 = c0.valid ? c0.q : 0u, q1 = c1.valid ? c1.q : 0u;
-        uint4 a0, b0, a1, b1;
-        __builtin_memcpy(&a0, e.in + q0, 16);
-        __builtin_memcpy(&b0, e.in + x, 16);
-        __builtin_memcpy(&a1, e.in + q1, 16);
-        __builtin_memcpy(&b1, e.in + x + 1, 16);
-        const uint32_t m0 = c0.valid ? match16(a0, b0) : 0u;
-        const uint32_t m1 = c1.valid ? match16(a1, b1) : 0u;
-        L0 = lane_cmplen16_from(e.in, q0, x, m0, m0 == 16 ? c0.len_limit : 0u);
-        L1 = lane_cmplen16_from(e.in, q1, x + 1, m1, m1 == 16 ? c1.len_limit : 0u);
-    } else {
-        L0 = lane_cmplen16_from(e.in, c0.valid ? c0.q : 0u, x, 0, c0.valid ? c0.len_limit : 0u);
-        L1 = lane_cmplen16_from(e.in, c1.valid ? c1.q : 0u, x + 1, 0, c1.valid ? c1.len_limit : 0u);
-    }
-    pareto_finish(e, x, c0, L0, mlen, mdist, mcnt);
-    pareto_finish(e, x + 1, c1, L1, mlen, mdist, mcnt);
-}
-
 // ------------------------------------------------------------------------------------------
 // Batch match finder: one wavefront per run of FIND_RUN consecutive positions, lanes = candidates
 // (the same round as above, without the rep lanes).  Writes, per position, the kept matches sorted
@@ -2032,12 +1984,7 @@ __global__ __launch_bounds__(64) void k_find_t(xzamd_span_args a, uint16_t* __re
             e.block_end = block_end;
         }
         if constexpr (PARETO) {
-            if (x + 1 < x1 && x + 1 < span_end) {
-                find_pareto_store2(e, P, x, span_end, mlen, mdist, mcnt);
-                ++x;
-            } else {
-                find_pareto_store(e, P, x, span_end, mlen, mdist, mcnt);
-            }
+            find_pareto_store(e, P, x, span_end, mlen, mdist, mcnt);
             continue;
         }
         RoundL RL;
