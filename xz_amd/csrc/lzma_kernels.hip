@@ -539,23 +539,33 @@ __device__ __forceinline__ void seg_add(SegSel& s, uint32_t& off, uint32_t n, ui
 }
 
 // serial part: t = p (12 bits) | bit << 12 | direct << 13, one entry per lane 0..n-1
-__device__ __forceinline__ void rc_run(RC& rc, uint32_t packed, uint32_t n)
+// Entries [d0, d1) are direct bits (rc_direct), all others probability-coded; the latter are
+// written without data-dependent branches (the bit only selects via a mask).
+__device__ __forceinline__ void rc_run(RC& rc, uint32_t packed, uint32_t n, uint32_t d0, uint32_t d1)
 {
-    for (uint32_t k = 0; k < n; ++k) {
-        const uint32_t t = lane_of(packed, k);
-        rc.normalize();
-        if (t & 0x2000u) {
-            rc.range >>= 1;
-            if (t & 0x1000u) rc.low += rc.range;
-        } else {
+    uint32_t k = 0;
+    for (;;) {
+        const uint32_t stop = k < d0 ? d0 : n;
+        for (; k < stop; ++k) {
+            const uint32_t t = lane_of(packed, k);
+            rc.normalize();
+            const uint32_t m = 0u - ((t >> 12) & 1u);          // all ones for a 1 bit
             const uint32_t bound = (rc.range >> 11) * (t & 0xFFFu);
-            if (t & 0x1000u) { rc.low += bound; rc.range -= bound; }
-            else rc.range = bound;
+            rc.low += bound & m;
+            rc.range = bound + ((rc.range - 2 * bound) & m);   // 1: range - bound, 0: bound
+        }
+        if (k >= n) break;
+        for (; k < d1; ++k) {
+            const uint32_t t = lane_of(packed, k);
+            rc.normalize();
+            rc.range >>= 1;
+            rc.low += rc.range & (0u - ((t >> 12) & 1u));
         }
     }
 }
 
-__device__ __forceinline__ void rc_emit(RC& rc, uint16_t* probs, uint32_t* lit, const SegSel& s, uint32_t total)
+__device__ __forceinline__ void rc_emit(RC& rc, uint16_t* probs, uint32_t* lit, const SegSel& s, uint32_t total,
+        uint32_t d0, uint32_t d1)
 {
     uint32_t idx = 0, bit = 0;
     bool direct = false;
@@ -593,7 +603,7 @@ __device__ __forceinline__ void rc_emit(RC& rc, uint16_t* probs, uint32_t* lit, 
         }
     }
     const uint32_t packed = p | (bit << 12) | (direct ? 0x2000u : 0u);
-    rc_run(rc, packed, total);
+    rc_run(rc, packed, total, d0, d1);
 }
 
 // g = global offset of the byte, upos = its offset inside the Block
@@ -619,11 +629,11 @@ __device__ __forceinline__ void encode_symbol(RC& rc, uint16_t* probs, Lz& z, co
             const uint32_t mb = uni(in[g - z.rep0 - 1]);
             seg_add(s, off, 8, SEG_MATCHED, sub, cur | (mb << 8));
         }
-        rc_emit(rc, probs, z.lit, s, off);
+        rc_emit(rc, probs, z.lit, s, off, off, off);
         return;
     }
     seg_add(s, off, 1, SEG_BIT, P_IS_MATCH + z.state * 16 + ps, 1);
-    uint32_t len_base;
+    uint32_t len_base, dir0 = ~0u, dir1 = ~0u;
     if (back < 4) {
         seg_add(s, off, 1, SEG_BIT, P_IS_REP + z.state, 1);
         if (back == 0) {
@@ -647,7 +657,7 @@ __device__ __forceinline__ void encode_symbol(RC& rc, uint16_t* probs, Lz& z, co
         }
         if (len == 1) {
             z.state = z.state < 7 ? 9 : 11;
-            rc_emit(rc, probs, z.lit, s, off);
+            rc_emit(rc, probs, z.lit, s, off, off, off);
             return;
         }
         len_base = P_REP_LEN;
@@ -689,14 +699,17 @@ __device__ __forceinline__ void encode_symbol(RC& rc, uint16_t* probs, Lz& z, co
             if (slot < 14) {
                 seg_add(s, off, fb, SEG_REV, P_DIST_SPECIAL + base - slot - 1, red);
             } else {
+                dir0 = off;
                 seg_add(s, off, fb - 4, SEG_DIRECT, 0, red >> 4);
+                dir1 = off;
                 seg_add(s, off, 4, SEG_REV, P_DIST_ALIGN, red & 15);
                 ++z.cnt_align;
             }
         }
         z.rep3 = z.rep2; z.rep2 = z.rep1; z.rep1 = z.rep0; z.rep0 = dist;
     }
-    rc_emit(rc, probs, z.lit, s, off);
+    if (dir0 == ~0u) dir0 = dir1 = off;
+    rc_emit(rc, probs, z.lit, s, off, dir0, dir1);
 }
 
 __device__ __forceinline__ bool change_pair(uint32_t small_dist, uint32_t big_dist)
