@@ -99,7 +99,9 @@ uint64_t xzamd_stream_buffer_bound(uint64_t in_size, uint64_t block_size);
 /* Context = one GPU (device ordinal, -1 = current) + its work buffers. */
 int xzamd_ctx_create(xzamd_ctx **ctx, int device);
 void xzamd_ctx_destroy(xzamd_ctx *ctx);
-/* Bytes of input processed per device batch (default 1 GiB, < 2 GiB). */
+/* Bytes of input processed per device batch (default 2 GiB - 1 MiB; must be < 2 GiB: positions are 31-bit).
+ * Presets whose match lists need the 96-byte format (dictionary > 8 MiB with the optimal parser) are
+ * capped at 1 GiB per batch. */
 int xzamd_ctx_set_batch_bytes(xzamd_ctx *ctx, uint64_t bytes);
 const char *xzamd_last_error(const xzamd_ctx *ctx);
 int xzamd_ctx_device(const xzamd_ctx *ctx);          /* device ordinal the context lives on */

@@ -28,6 +28,7 @@ typedef struct {
 	const uint16_t *mlen;
 	const uint32_t *mdist;
 	const uint8_t *mcnt;
+	uint32_t list_packed;        /* 1: mdist holds length << 23 | distance-1 and mlen is unused (dict_size <= 8 MiB) */
 	uint32_t *trace;             /* optional debug: 4 x u32 per symbol (span,pos,back,len) */
 	uint32_t *trace_count;
 	uint32_t trace_cap;

@@ -333,6 +333,7 @@ struct Env {
     const uint16_t* __restrict__ mlen;
     const uint32_t* __restrict__ mdist;
     const uint8_t* __restrict__ mcnt;
+    uint32_t packed;                            // lists are one u32 per entry: length << 23 | distance-1 (dict <= 8 MiB)
 };
 constexpr uint32_t LIST_K = 16;               // entries kept per position (the LIST_K longest)
 
@@ -913,7 +914,11 @@ __device__ __forceinline__ void lists_load(const Env& e, uint32_t x, uint32_t& s
     x = x < e.n_last ? x : e.n_last;
     const uint64_t base = (uint64_t)x * LIST_K;
     sl = 0; sd = 0;
-    if (lane < LIST_K) { sl = e.mlen[base + lane]; sd = e.mdist[base + lane]; }
+    if (e.packed) {
+        if (lane < LIST_K) { const uint32_t v = e.mdist[base + lane]; sl = v >> 23; sd = v & 0x7FFFFFu; }
+    } else {
+        if (lane < LIST_K) { sl = e.mlen[base + lane]; sd = e.mdist[base + lane]; }
+    }
     cnt = e.mcnt[x];
 }
 
@@ -1477,7 +1482,7 @@ void k_span_encode_t(xzamd_span_args a)
     e.rank8 = a.rank8; e.sorted8 = a.sorted8;
     e.nice = a.nice_len; e.depth = a.depth; e.hb = a.hash_bytes; e.cyclic = a.dict_size + 1;
     e.depth2 = a.depth2; e.block_end = block_end; e.n_last = a.n - 1;
-    e.mlen = a.mlen; e.mdist = a.mdist; e.mcnt = a.mcnt;
+    e.mlen = a.mlen; e.mdist = a.mdist; e.mcnt = a.mcnt; e.packed = a.list_packed;
     ListPre LP;
     LP.valid = false; LP.pos = 0; LP.sl = LP.sd = LP.cnt = 0;
     Pre P;
@@ -1944,8 +1949,13 @@ __device__ __forceinline__ void pareto_finish(const Env& e, uint32_t x, const Ca
     const uint32_t drop = cnt > LIST_K ? cnt - LIST_K : 0;
     if (keep && idx >= drop) {
         const uint64_t o = (uint64_t)x * LIST_K + (idx - drop);
-        mlen[o] = (uint16_t)(lane == top ? longest : sL);
-        mdist[o] = sD;
+        const uint32_t len = lane == top ? longest : sL;
+        if (e.packed) {
+            mdist[o] = (len << 23) | sD;
+        } else {
+            mlen[o] = (uint16_t)len;
+            mdist[o] = sD;
+        }
     }
     if (lane == 0) mcnt[x] = (uint8_t)(cnt - drop);
 }
@@ -1980,7 +1990,7 @@ __global__ __launch_bounds__(64) void k_find_t(xzamd_span_args a, uint16_t* __re
     e.rank8 = a.rank8; e.sorted8 = a.sorted8;
     e.nice = a.nice_len; e.depth = a.depth; e.hb = a.hash_bytes; e.cyclic = a.dict_size + 1;
     e.depth2 = a.depth2; e.block_end = 0; e.n_last = a.n - 1;
-    e.mlen = nullptr; e.mdist = nullptr; e.mcnt = nullptr;
+    e.mlen = nullptr; e.mdist = nullptr; e.mcnt = nullptr; e.packed = a.list_packed;
     Pre P;
     P.valid = false; P.pos = 0; P.ent = 0;
     P.a.rk = P.a.d2 = P.a.d3 = P.a.rk8 = 0; P.an = P.a;
@@ -2013,8 +2023,12 @@ __global__ __launch_bounds__(64) void k_find_t(xzamd_span_args a, uint16_t* __re
         if (lane + 1 == cnt) len = RL.longest;
         if (lane >= drop && lane < cnt) {
             const uint64_t o = (uint64_t)x * LIST_K + (lane - drop);
-            mlen[o] = (uint16_t)len;
-            mdist[o] = RL.SD;
+            if (e.packed) {
+                mdist[o] = (len << 23) | RL.SD;
+            } else {
+                mlen[o] = (uint16_t)len;
+                mdist[o] = RL.SD;
+            }
         }
         if (lane == 0) mcnt[x] = (uint8_t)(cnt - drop);
     }
@@ -2312,7 +2326,7 @@ int xzk_span_encode(const xzamd_span_args* a, uint32_t nspans, void* stream_)
 {
     hipStream_t st = (hipStream_t)stream_;
     if (a->parser) {
-        if (!a->mlen || !a->mdist || !a->mcnt) return (int)hipErrorInvalidValue;
+        if ((!a->mlen && !a->list_packed) || !a->mdist || !a->mcnt) return (int)hipErrorInvalidValue;
         hipLaunchKernelGGL((k_span_encode_t<2, true>), dim3(nspans), dim3(64), 0, st, *a);
     } else if (a->depth2 == 0) {
         hipLaunchKernelGGL((k_span_encode_t<0, false>), dim3(nspans), dim3(64), 0, st, *a);

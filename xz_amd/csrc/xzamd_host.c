@@ -20,7 +20,7 @@
 
 #define DEFAULT_SPAN (64u * 1024u)          /* fast parser */
 #define DEFAULT_SPAN_OPT (128u * 1024u)     /* optimal parser: fewer state resets, still >> resident waves */
-#define DEFAULT_BATCH (1ull << 30)
+#define DEFAULT_BATCH ((1ull << 31) - (1ull << 20))   /* positions are 31-bit; more spans per launch = shorter tails */
 #define CRC_STRIP 4096u
 
 /* ------------------------------------------------------------------ */
@@ -470,8 +470,15 @@ int xzamd_stream_encode_device(xzamd_ctx *c,
 	const uint32_t spb = (uint32_t)((block_size + span - 1) / span);
 	const uint64_t span_cap = ((uint64_t)span + (span >> 3) + 4096 + 15) & ~15ull;
 
-	/* batch = whole Blocks, n < 2^31, (nblocks+1) << hbits < 2^32 */
-	uint64_t max_blocks = c->batch_bytes / block_size;
+	/* Match lists of the optimal parser: 16 x u32 (length << 23 | distance-1) per position when
+	 * distances fit 23 bits, else 16 x (u16 + u32). */
+	const int list_packed = opt->gpu_parser && opt->dict_size <= (1u << 23);
+	/* batch = whole Blocks, n < 2^31, (nblocks+1) << hbits < 2^32.  The 96-byte list format keeps
+	 * the batch at 1 GiB (HBM footprint ~140 B per input byte). */
+	uint64_t batch_bytes = c->batch_bytes;
+	if (opt->gpu_parser && !list_packed && batch_bytes > (1ull << 30))
+		batch_bytes = 1ull << 30;
+	uint64_t max_blocks = batch_bytes / block_size;
 	if (max_blocks == 0) max_blocks = 1;
 	const uint64_t key_blocks = (1ull << (32 - kbits_max)) - 2;
 	if (max_blocks > key_blocks) max_blocks = key_blocks;
@@ -481,6 +488,11 @@ int xzamd_stream_encode_device(xzamd_ctx *c,
 		return fail(c, XZAMD_OPTIONS_ERROR, "block_size too large for one device batch", 0);
 
 	const uint64_t total_blocks = (in_size + block_size - 1) / block_size;
+	/* even batches: a short last launch cannot fill the GPU (one wavefront per span) */
+	if (total_blocks > max_blocks) {
+		const uint64_t nbatch = (total_blocks + max_blocks - 1) / max_blocks;
+		max_blocks = (total_blocks + nbatch - 1) / nbatch;
+	}
 	if (nblocks_out) *nblocks_out = total_blocks;
 	const uint64_t bound = xzamd_block_buffer_bound(block_size);
 	const int x86 = opt->bcj == XZAMD_BCJ_X86;
@@ -542,7 +554,8 @@ int xzamd_stream_encode_device(xzamd_ctx *c,
 		GROW(litp, (uint64_t)nspans * 6144ull * 4ull, 0);
 		if (opt->gpu_parser) {
 			/* per-position match lists: 16 x (u16 len + u32 dist) + count */
-			GROW(mlen, 32ull * n, 0); GROW(mdist, 64ull * n, 0); GROW(mcnt, (uint64_t)n, 0);
+			if (!list_packed) GROW(mlen, 32ull * n, 0);
+			GROW(mdist, 64ull * n, 0); GROW(mcnt, (uint64_t)n, 0);
 		}
 		GROW(h_span_bytes, 4ull * nspans, 1);
 		GROW(h_block_crc, 8ull * nb, 1);
@@ -612,10 +625,11 @@ int xzamd_stream_encode_device(xzamd_ctx *c,
 			int e = 0;
 			if (opt->gpu_parser) {
 				/* 2a. batch match finder -> lists the parser streams */
-				a.mlen = (const uint16_t *)c->mlen.p;
+				a.mlen = list_packed ? NULL : (const uint16_t *)c->mlen.p;
+				a.list_packed = (uint32_t)list_packed;
 				a.mdist = (const uint32_t *)c->mdist.p;
 				a.mcnt = (const uint8_t *)c->mcnt.p;
-				e = xzk_find_matches(&a, (uint16_t *)c->mlen.p, (uint32_t *)c->mdist.p, (uint8_t *)c->mcnt.p, st);
+				e = xzk_find_matches(&a, list_packed ? NULL : (uint16_t *)c->mlen.p, (uint32_t *)c->mdist.p, (uint8_t *)c->mcnt.p, st);
 				if (e) { rc = fail(c, XZAMD_DEVICE_ERROR, "find_matches launch", e); goto done; }
 				xzk_event_record(c->ev[5], st);
 			}
