@@ -263,6 +263,48 @@ def test_liblzma_client_through_lzma_code(tmp_path, preset, bs, iobuf):
         assert sysxz.stdout == data
 
 
+@pytest.mark.parametrize("level", [1, 6])
+def test_ld_preload_interposer_with_stock_xz(tmp_path, level):
+    """The unmodified `xz` binary of the image (5.2.5, dynamically linked against its own liblzma) with
+    LD_PRELOAD=libxz_amd_preload.so: its multi-threaded encoder runs on the GPU, everything else stays in
+    the real liblzma.  Output must equal the device API's Stream for the same preset and decode with the
+    plain binary."""
+    import os
+    import shutil
+    import subprocess
+    import torch
+    import xz_amd
+    xz = shutil.which("xz")
+    pre = os.path.join(os.path.dirname(xz_amd.LIB_PATH), "libxz_amd_preload.so")
+    if not xz:
+        pytest.skip("no xz binary")
+    assert os.path.exists(pre), "libxz_amd_preload.so not built"
+    data = xz_amd.corpus_text(40 << 20, seed=5).tobytes()[: (33 << 20) + 12345]
+    src = tmp_path / "input.bin"
+    src.write_bytes(data)
+    env = dict(os.environ, LD_PRELOAD=pre, XZ_AMD_VERBOSE="1")
+    p = subprocess.run([xz, "-T4", f"-{level}", "-c", str(src)], capture_output=True, env=env, timeout=600)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    assert b"lzma_stream_encoder_mt -> GPU" in p.stderr, p.stderr.decode()[-2000:]
+    got = p.stdout
+    # plain xz (no preload) decodes it
+    d = subprocess.run([xz, "-dc"], input=got, capture_output=True, timeout=600)
+    assert d.returncode == 0 and d.stdout == data
+    # and the preload does not disturb decoding either
+    d2 = subprocess.run([xz, "-dc"], input=got, capture_output=True, env=env, timeout=600)
+    assert d2.returncode == 0 and d2.stdout == data
+    # same bytes as the device API with the same preset
+    enc = xz_amd.Encoder(0)
+    t = torch.frombuffer(bytearray(data), dtype=torch.uint8).cuda()
+    want, _ = enc.encode(t, preset=level)
+    assert o.first_diff(got, want.cpu().numpy().tobytes()) == -1
+    enc.close()
+    # XZ_AMD_DISABLE routes to the real liblzma
+    env2 = dict(env, XZ_AMD_DISABLE="1")
+    p2 = subprocess.run([xz, "-T4", f"-{level}", "-c", str(src)], capture_output=True, env=env2, timeout=900)
+    assert p2.returncode == 0 and b"-> GPU" not in p2.stderr
+
+
 def test_lzma_code_semantics(tmp_path):
     """Option validation and action sequencing as in get_options (stream_encoder_mt.c:956-1000) and
     lzma_code (common/common.c:203-376), driven through ctypes."""
