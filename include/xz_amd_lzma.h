@@ -19,9 +19,9 @@
  *   - lzma_mt.threads is validated like the reference but only sizes nothing:
  *     parallelism comes from the GPU; lzma_mt.timeout is accepted and ignored
  *     (lzma_code may block while a device batch runs).
- *   - filters: {LZMA2} chains; LZMA_SYNC_FLUSH is unsupported exactly like the
+ *   - filters: {LZMA2} and {x86 BCJ, LZMA2} chains; LZMA_SYNC_FLUSH is unsupported exactly like the
  *     reference MT encoder (stream_encoder_mt.c:1201-1205).
- *   - check: LZMA_CHECK_NONE and LZMA_CHECK_CRC64 (the xz default); others
+ *   - check: LZMA_CHECK_NONE, LZMA_CHECK_CRC32 and LZMA_CHECK_CRC64 (the xz default); others
  *     return LZMA_UNSUPPORTED_CHECK.
  */
 #ifndef XZ_AMD_LZMA_H

@@ -157,6 +157,24 @@ def test_x86_bcj_default_spans_roundtrip(enc, preset):
         assert blk_a[hs_a:-8] == blk_b[hs_b:-8]          # LZMA2 payload + padding; the Checks differ by design
 
 
+@pytest.mark.parametrize("check", [0, 1, 4])
+def test_block_checks_identical_to_reference(enc, check):
+    """None / CRC32 / CRC64 Block checks (check/crc32_fast.c, crc64_fast.c): whole Stream equals the
+    reference MT encoder's; Blocks longer than one CRC strip, a short last Block, an empty-ish one."""
+    import torch
+    import xz_amd
+    if not o.have_ref():
+        pytest.skip("oracle/_ref not built")
+    opts = xz_amd.preset_options(1, span_size=xz_amd.SPAN_WHOLE_BLOCK)
+    for data in (o.corpus_mixed(700000, 8), o.corpus_lorem(4097), b"z"):
+        for bs in (1 << 20, 100000):
+            t = torch.frombuffer(bytearray(data), dtype=torch.uint8).cuda()
+            out, _ = enc.encode(t, opts=opts, block_size=bs, check=check)
+            got = out.cpu().numpy().tobytes()
+            ref = o.ref_encode_mt(data, 1, threads=2, block_size=bs, check=check)
+            assert o.first_diff(got, ref) == -1, (check, len(data), bs)
+
+
 def test_custom_options_and_small_dictionary(enc):
     import xz_amd
     data = o.corpus_mixed(500000, 8)

@@ -64,8 +64,9 @@ int xzk_find_matches(const xzamd_span_args *a, uint16_t *mlen, uint32_t *mdist, 
 int xzk_span_encode(const xzamd_span_args *a, uint32_t nspans, void *stream);
 /* x86 BCJ encoder: d_out = filtered copy of d_in, every Block filtered independently (simple/x86.c). */
 int xzk_x86_bcj(const uint8_t *d_in, uint8_t *d_out, uint32_t n, uint32_t block_size, uint32_t nblocks, void *stream);
-int xzk_crc64_blocks(const uint8_t *d_in, uint32_t n, uint32_t block_size, uint32_t nblocks,
-		uint32_t strip, uint64_t *d_strip_crc, uint64_t *d_block_crc, void *stream);
+/* Block checks: CRC64 (crc32 = 0) or CRC32 (crc32 = 1, zero-extended into d_block_crc). */
+int xzk_crc_blocks(const uint8_t *d_in, uint32_t n, uint32_t block_size, uint32_t nblocks,
+		uint32_t strip, int crc32, uint64_t *d_strip_crc, uint64_t *d_block_crc, void *stream);
 int xzk_assemble(const xzamd_copy_seg *d_segs, uint32_t nsegs, const uint8_t *d_scratch,
 		const uint8_t *d_lits, const uint8_t *d_in, uint8_t *d_out, void *stream);
 

@@ -2120,41 +2120,49 @@ __global__ __launch_bounds__(256) void k_x86_bcj(const uint8_t* __restrict__ in,
 // ------------------------------------------------------------------------------------------
 // CRC64 (check/crc64_fast.c; ECMA-182 reflected, poly 0xC96C5795D7870F42)
 // ------------------------------------------------------------------------------------------
-constexpr uint64_t CRC64_POLY = 0xC96C5795D7870F42ull;
+// Both Block checks of the device path share the code: T = uint64_t is CRC64 (ECMA-182 reflected,
+// check/crc64_fast.c), T = uint32_t is CRC32 (IEEE reflected, check/crc32_fast.c).
+template <typename T> struct CrcP;
+template <> struct CrcP<uint64_t> { static constexpr uint64_t POLY = 0xC96C5795D7870F42ull; static constexpr uint64_t TOP = 1ull << 63; };
+template <> struct CrcP<uint32_t> { static constexpr uint32_t POLY = 0xEDB88320u; static constexpr uint32_t TOP = 1u << 31; };
 
-__device__ __forceinline__ uint64_t gf_mul(uint64_t a, uint64_t b)
+// product of two residues in the reflected representation (MSB = x^0)
+template <typename T>
+__device__ __forceinline__ T gf_mul(T a, T b)
 {
-    uint64_t r = 0;
-    for (int i = 0; i < 64; ++i) {
-        if (a & 0x8000000000000000ull) r ^= b;
+    T r = 0;
+    for (int i = 0; i < (int)(8 * sizeof(T)); ++i) {
+        if (a & CrcP<T>::TOP) r ^= b;
         a <<= 1;
-        b = (b >> 1) ^ ((b & 1) ? CRC64_POLY : 0ull);
+        b = (T)((b >> 1) ^ ((b & 1) ? CrcP<T>::POLY : (T)0));
     }
     return r;
 }
 
-__device__ __forceinline__ uint64_t gf_xpow8(uint64_t nbytes)
+template <typename T>
+__device__ __forceinline__ T gf_xpow8(uint64_t nbytes)
 {
-    uint64_t base = 0x8000000000000000ull >> 8;     // x^8
-    uint64_t acc = 0x8000000000000000ull;           // 1
+    T base = (T)(CrcP<T>::TOP >> 8);     // x^8
+    T acc = CrcP<T>::TOP;                // 1
     while (nbytes) {
-        if (nbytes & 1) acc = gf_mul(acc, base);
-        base = gf_mul(base, base);
+        if (nbytes & 1) acc = gf_mul<T>(acc, base);
+        base = gf_mul<T>(base, base);
         nbytes >>= 1;
     }
     return acc;
 }
 
-// Standard CRC64 (init ~0, final ~) of each strip of `strip` bytes; strips never straddle Blocks.
-__global__ __launch_bounds__(256) void k_crc64_strips(const uint8_t* __restrict__ in, uint32_t n,
+// Standard CRC (init ~0, final ~) of each strip of `strip` bytes; strips never straddle Blocks.
+template <typename T>
+__global__ __launch_bounds__(256) void k_crc_strips(const uint8_t* __restrict__ in, uint32_t n,
         uint32_t block_size, uint32_t strip, uint32_t strips_per_block, uint32_t nstrips,
-        uint64_t* __restrict__ out)
+        T* __restrict__ out)
 {
-    __shared__ uint64_t T[256];
+    __shared__ T tab[256];
     {
-        uint64_t r = threadIdx.x;
-        for (int k = 0; k < 8; ++k) r = (r >> 1) ^ ((r & 1) ? CRC64_POLY : 0ull);
-        T[threadIdx.x] = r;
+        T r = (T)threadIdx.x;
+        for (int k = 0; k < 8; ++k) r = (T)((r >> 1) ^ ((r & 1) ? CrcP<T>::POLY : (T)0));
+        tab[threadIdx.x] = r;
     }
     __syncthreads();
     const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2163,17 +2171,19 @@ __global__ __launch_bounds__(256) void k_crc64_strips(const uint8_t* __restrict_
     const uint32_t bstart = b * block_size;
     const uint32_t bend = min(n, bstart + block_size);
     const uint32_t beg = bstart + (s - b * strips_per_block) * strip;
-    uint64_t crc = ~0ull;
+    T crc = (T)~(T)0;
     if (beg < bend) {
         const uint32_t end = min(bend, beg + strip);
         for (uint32_t i = beg; i < end; ++i)
-            crc = T[(crc ^ in[i]) & 0xFF] ^ (crc >> 8);
+            crc = (T)(tab[(crc ^ in[i]) & 0xFF] ^ (crc >> 8));
     }
-    out[s] = ~crc;
+    out[s] = (T)~crc;
 }
 
 // One wave per Block: fold the strip CRCs left to right: crc(A||B) = crc(A)*x^(8|B|) ^ crc(B).
-__global__ __launch_bounds__(64) void k_crc64_fold(const uint64_t* __restrict__ strips, uint32_t n,
+// The Block's check is written as a uint64_t (CRC32 zero-extended).
+template <typename T>
+__global__ __launch_bounds__(64) void k_crc_fold(const T* __restrict__ strips, uint32_t n,
         uint32_t block_size, uint32_t strip, uint32_t strips_per_block, uint64_t* __restrict__ block_crc)
 {
     const uint32_t b = blockIdx.x;
@@ -2184,24 +2194,24 @@ __global__ __launch_bounds__(64) void k_crc64_fold(const uint64_t* __restrict__ 
     const uint32_t ns = (blen + strip - 1) / strip;          // strips actually used
     const uint32_t per = (ns + 63) / 64;
     const uint32_t s0 = min(ns, lane * per), s1 = min(ns, s0 + per);
-    const uint64_t xs = gf_xpow8(strip);
+    const T xs = gf_xpow8<T>(strip);
     // lane-local fold over its contiguous strips
-    uint64_t acc = 0;       // crc of the empty string is 0 and is the identity of the fold
+    T acc = 0;              // crc of the empty string is 0 and is the identity of the fold
     uint64_t bytes = 0;
     for (uint32_t s = s0; s < s1; ++s) {
         const uint32_t len = min(strip, blen - s * strip);
-        const uint64_t c = strips[(uint64_t)b * strips_per_block + s];
-        acc = gf_mul(acc, len == strip ? xs : gf_xpow8(len)) ^ c;
+        const T c = strips[(uint64_t)b * strips_per_block + s];
+        acc = (T)(gf_mul<T>(acc, len == strip ? xs : gf_xpow8<T>(len)) ^ c);
         bytes += len;
     }
     // sequential combine across lanes (64 steps, once per Block)
-    uint64_t total = 0;
+    T total = 0;
     for (uint32_t l = 0; l < 64; ++l) {
-        const uint64_t cl = __shfl(acc, l);
-        const uint64_t bl = __shfl(bytes, l);
-        if (bl) total = gf_mul(total, gf_xpow8(bl)) ^ cl;
+        const T cl = (T)__shfl((unsigned long long)acc, l);
+        const uint64_t bl = __shfl((unsigned long long)bytes, l);
+        if (bl) total = (T)(gf_mul<T>(total, gf_xpow8<T>(bl)) ^ cl);
     }
-    if (lane == 0) block_crc[b] = total;
+    if (lane == 0) block_crc[b] = (uint64_t)total;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2349,16 +2359,24 @@ int xzk_x86_bcj(const uint8_t* d_in, uint8_t* d_out, uint32_t n, uint32_t block_
     return (int)hipGetLastError();
 }
 
-int xzk_crc64_blocks(const uint8_t* d_in, uint32_t n, uint32_t block_size, uint32_t nblocks,
-        uint32_t strip, uint64_t* d_strip_crc, uint64_t* d_block_crc, void* stream_)
+int xzk_crc_blocks(const uint8_t* d_in, uint32_t n, uint32_t block_size, uint32_t nblocks,
+        uint32_t strip, int crc32, uint64_t* d_strip_crc, uint64_t* d_block_crc, void* stream_)
 {
     hipStream_t st = (hipStream_t)stream_;
     const uint32_t spb = (block_size + strip - 1) / strip;
     const uint32_t ns = spb * nblocks;
-    hipLaunchKernelGGL(k_crc64_strips, dim3((ns + 255) / 256), dim3(256), 0, st, d_in, n, block_size, strip, spb, ns,
-            d_strip_crc);
-    hipLaunchKernelGGL(k_crc64_fold, dim3(nblocks), dim3(64), 0, st, d_strip_crc, n, block_size, strip, spb,
-            d_block_crc);
+    if (crc32) {
+        uint32_t* strips = reinterpret_cast<uint32_t*>(d_strip_crc);
+        hipLaunchKernelGGL((k_crc_strips<uint32_t>), dim3((ns + 255) / 256), dim3(256), 0, st, d_in, n, block_size, strip,
+                spb, ns, strips);
+        hipLaunchKernelGGL((k_crc_fold<uint32_t>), dim3(nblocks), dim3(64), 0, st, strips, n, block_size, strip, spb,
+                d_block_crc);
+    } else {
+        hipLaunchKernelGGL((k_crc_strips<uint64_t>), dim3((ns + 255) / 256), dim3(256), 0, st, d_in, n, block_size, strip,
+                spb, ns, d_strip_crc);
+        hipLaunchKernelGGL((k_crc_fold<uint64_t>), dim3(nblocks), dim3(64), 0, st, d_strip_crc, n, block_size, strip, spb,
+                d_block_crc);
+    }
     return (int)hipGetLastError();
 }
 

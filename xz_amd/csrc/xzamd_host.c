@@ -435,8 +435,6 @@ int xzamd_stream_encode_device(xzamd_ctx *c,
 		return fail(c, XZAMD_PROG_ERROR, "check id out of range", 0);
 	if (cbytes == 0xFFFFFFFFu)
 		return fail(c, XZAMD_UNSUPPORTED_CHECK, "only CRC32/CRC64/none are supported", 0);
-	if (check == XZAMD_CHECK_CRC32)
-		return fail(c, XZAMD_UNSUPPORTED_CHECK, "CRC32 Block check not implemented on the device path", 0);
 	if (opt->lc + opt->lp > 3 || opt->pb > 4)
 		return fail(c, XZAMD_OPTIONS_ERROR, "lc+lp <= 3 and pb <= 4 required (LDS model size)", 0);
 	if ((opt->gpu_mf != XZAMD_MF_HC3 && opt->gpu_mf != XZAMD_MF_HC4)
@@ -638,9 +636,9 @@ int xzamd_stream_encode_device(xzamd_ctx *c,
 		}
 		xzk_event_record(c->ev[2], st);
 		/* 3. Block checks */
-		if (check == XZAMD_CHECK_CRC64) {
-			int e = xzk_crc64_blocks(d_in + in_off, n, (uint32_t)block_size, (uint32_t)nb, CRC_STRIP,
-					(uint64_t *)c->strip_crc.p, (uint64_t *)c->block_crc.p, st);
+		if (check == XZAMD_CHECK_CRC64 || check == XZAMD_CHECK_CRC32) {
+			int e = xzk_crc_blocks(d_in + in_off, n, (uint32_t)block_size, (uint32_t)nb, CRC_STRIP,
+					check == XZAMD_CHECK_CRC32, (uint64_t *)c->strip_crc.p, (uint64_t *)c->block_crc.p, st);
 			if (e) { rc = fail(c, XZAMD_DEVICE_ERROR, "crc64 launch", e); goto done; }
 			e = xzk_d2h(c->h_block_crc.p, c->block_crc.p, 8ull * nb, st);
 			if (e) { rc = fail(c, XZAMD_DEVICE_ERROR, "d2h crc", e); goto done; }
@@ -726,6 +724,9 @@ int xzamd_stream_encode_device(xzamd_ctx *c,
 				le32(tail + tl, (uint32_t)v);
 				le32(tail + tl + 4, (uint32_t)(v >> 32));
 				tl += 8;
+			} else if (check == XZAMD_CHECK_CRC32) {
+				le32(tail + tl, (uint32_t)bcrc[b]);
+				tl += 4;
 			}
 			opos = plan_lit(&pl, tail, tl, opos);
 			const uint64_t gi = b0 + b;

@@ -213,7 +213,7 @@ static lzma_ret parse_options(const lzma_mt *o, xzamd_lzma_options *opt, uint64_
 		return LZMA_OPTIONS_ERROR;
 	if ((unsigned)o->check > 15)
 		return LZMA_PROG_ERROR;
-	if (o->check != LZMA_CHECK_NONE && o->check != LZMA_CHECK_CRC64)
+	if (o->check != LZMA_CHECK_NONE && o->check != LZMA_CHECK_CRC32 && o->check != LZMA_CHECK_CRC64)
 		return LZMA_UNSUPPORTED_CHECK;
 	*check = (int)o->check;
 	return LZMA_OK;
