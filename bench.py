@@ -59,7 +59,31 @@ def pmc_traffic(opts):
     return None, None
 
 
-def cpu_baseline(sample, preset):
+def corpus_elf(n, rank):
+    """x86-64 ELF shared objects found on the box, in sorted order, cycled with a per-cycle byte perturbation
+    so cycles are not identical (SURVEY.md 8d C4/C5 recipe).  Not synthetic: bench.py says so in `data`."""
+    import glob
+    files = sorted(glob.glob("/opt/rocm/lib/*.so*") + glob.glob("/usr/lib/x86_64-linux-gnu/*.so*"))
+    files = [f for f in files if os.path.isfile(f) and not os.path.islink(f) and os.path.getsize(f) > 65536]
+    if not files:
+        raise SystemExit("no ELF files found for --corpus elf")
+    out = np.empty(n, dtype=np.uint8)
+    pos, cycle, i = 0, 0, rank % len(files)
+    while pos < n:
+        a = np.fromfile(files[i], dtype=np.uint8, count=min(n - pos, 256 << 20))
+        if cycle:
+            a = a.copy()
+            a[cycle::4099] ^= np.uint8(cycle & 0xFF)
+        out[pos:pos + len(a)] = a
+        pos += len(a)
+        i += 1
+        if i == len(files):
+            i = 0
+            cycle += 1
+    return out
+
+
+def cpu_baseline(sample, preset, bcj=False):
     """Reference liblzma (oracle/_ref, the real 5.8.3 sources) MT encoder on the host cores, timed on a
     bounded sample of the same workload.  Test infrastructure used as a reported baseline only."""
     try:
@@ -68,11 +92,11 @@ def cpu_baseline(sample, preset):
             return None, None
         cores = int(o.ref().ref_cputhreads())
         t0 = time.time()
-        enc = o.ref_encode_mt(sample, preset, threads=max(cores, 1), block_size=0)
+        enc = (o.ref_encode_mt_x86 if bcj else o.ref_encode_mt)(sample, preset, threads=max(cores, 1), block_size=0)
         dt = time.time() - t0
         return {"value": round(len(sample) / dt / 1e6, 2), "unit": "MB/s", "cores": cores, "kind": "reference",
                 "sample": f"first {len(sample) >> 20} MiB of rank 0's input, liblzma 5.8.3 lzma_stream_encoder_mt "
-                          f"preset {preset} threads={cores} default block size, {dt:.1f} s wall",
+                          f"preset {preset & 31}{'e' if preset >> 31 else ''}{' + x86 BCJ' if bcj else ''} threads={cores} default block size, {dt:.1f} s wall",
                 "ratio": round(len(enc) / max(len(sample), 1), 5)}, enc
     except Exception as e:  # noqa: BLE001
         return {"value": None, "unit": "MB/s", "cores": 0, "kind": "reference", "sample": f"failed: {e}"}, None
@@ -84,11 +108,15 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--size-mib", type=int, default=4096, help="input MiB per GPU")
-    ap.add_argument("--preset", type=int, default=6)
+    ap.add_argument("--preset", type=lambda v: int(v, 0), default=6, help="0-9, | 0x80000000 for -e")
     ap.add_argument("--span-kib", type=int, default=0, help="0 = library default")
     ap.add_argument("--parser", choices=["default", "fast", "optimal"], default="default",
                     help="device parser override (default: what the preset maps to)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--bcj", action="store_true", help="chain {x86 BCJ, LZMA2} (SURVEY.md 8d config C5)")
+    ap.add_argument("--corpus", choices=["text", "elf"], default="text",
+                    help="text: seeded synthetic enwik-style text (the headline workload); elf: the x86-64 shared "
+                         "objects present on the box, concatenated and cycled (config C5's input)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -112,7 +140,9 @@ def main():
         opts.gpu_parser = 1 if args.parser == "optimal" else 0
     block_size = xz_amd.mt_block_size(opts)
 
-    host = xz_amd.corpus_text(n, seed=1000 + rank)
+    if args.bcj:
+        opts.bcj = xz_amd.BCJ_X86
+    host = corpus_elf(n, rank) if args.corpus == "elf" else xz_amd.corpus_text(n, seed=1000 + rank)
     data = torch.from_numpy(host).to(dev)
     enc = xz_amd.Encoder(local_rank)
     out_buf = torch.empty(xz_amd.lib().xzamd_stream_buffer_bound(n, block_size) + 64, dtype=torch.uint8, device=dev)
@@ -172,10 +202,11 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "u8",
-            "data": "synthetic",
+            "data": "synthetic" if args.corpus == "text" else "x86-64 ELF shared objects of the box, concatenated/cycled",
             "config": {
-                "workload": f"preset -{args.preset} options (dict {opts.dict_size >> 20} MiB, {block_size >> 20} MiB Blocks, "
-                            f"CRC64), {args.size_mib} MiB synthetic enwik-style text per GPU, input resident in HBM, "
+                "workload": f"preset -{args.preset & 31}{'e' if args.preset >> 31 else ''} options (dict {opts.dict_size >> 20} MiB, {block_size >> 20} MiB Blocks, "
+                            f"CRC64{', x86 BCJ + LZMA2' if args.bcj else ''}), {args.size_mib} MiB "
+                            f"{'synthetic enwik-style text' if args.corpus == 'text' else 'ELF shared objects'} per GPU, input resident in HBM, "
                             f"output = complete .xz Stream in HBM",
                 "device_match_finder": (f"HC{opts.gpu_mf & 15} depth {opts.gpu_depth}" + (f" + H8 depth {opts.gpu_depth2} (Pareto merge)" if opts.gpu_depth2 else "")
                                         + f", nice {opts.gpu_nice_len} (sort-built chains)"),
@@ -210,7 +241,7 @@ def main():
             except Exception:  # noqa: BLE001
                 cores = 1
             sample_n = min(n, min(max(1, cores), 32) * block_size)
-            cb, ref_enc = cpu_baseline(host[:sample_n], args.preset)
+            cb, ref_enc = cpu_baseline(host[:sample_n], args.preset, args.bcj)
             if cb is not None:
                 res["cpu_baseline"] = cb
                 # our ratio on the same sample + bit-exact round trip of that output through the
