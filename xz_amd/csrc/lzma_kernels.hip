@@ -1593,16 +1593,37 @@ void k_span_encode_t(xzamd_span_args a)
                     if (!tables_valid || z.cnt_align >= 16) { refresh_align_table(probs, w); z.cnt_align = 0; }
                     tables_valid = true;
                     TM_END(w, 7, t_refresh);
-                    cached = optimum_window(e, w, LP, probs, z, lt, in, cur, block_start, span_end, cached, RL, q_end);
-                    q_pos = 0;
-                    if (q_end == 0) {            // consistency failure reported by the parser
-                        if (lane == 0) a.span_bytes[span] = 0;
-                        return;
+                    // Node 0's round is done here so that a window opening with a >= nice_len rep or
+                    // match (optimum_window's j == 0 rule; the common case in binary data) is coded
+                    // straight away, without building the window's price tables.
+                    if (!cached) {
+                        round_lists(e, LP, cur, span_end, z.rep0, z.rep1, z.rep2, z.rep3, RL);
+                        cached = true;
+                    }
+                    uint32_t sb = LITERAL, sl = 0;
+                    if (RL.rp[0] >= e.nice) { sb = 0; sl = RL.rp[0]; }
+                    else if (RL.rp[1] >= e.nice) { sb = 1; sl = RL.rp[1]; }
+                    else if (RL.rp[2] >= e.nice) { sb = 2; sl = RL.rp[2]; }
+                    else if (RL.rp[3] >= e.nice) { sb = 3; sl = RL.rp[3]; }
+                    else if (RL.longest >= e.nice) { sb = lane_of(RL.SD, RL.cnt - 1) + 4; sl = RL.longest; }
+                    if (sl) {
+                        back = sb; len = sl;
+                        cached = false;
+                        q_pos = q_end = 0;
+                    } else {
+                        cached = optimum_window(e, w, LP, probs, z, lt, in, cur, block_start, span_end, cached, RL, q_end);
+                        q_pos = 0;
+                        if (q_end == 0) {            // consistency failure reported by the parser
+                            if (lane == 0) a.span_bytes[span] = 0;
+                            return;
+                        }
                     }
                 }
-                back = uni(w.n_price[q_pos]);
-                len = (uni(w.n_info[q_pos]) >> 13) & 0x1FF;
-                q_pos += len;
+                if (q_pos != q_end) {
+                    back = uni(w.n_price[q_pos]);
+                    len = (uni(w.n_info[q_pos]) >> 13) & 0x1FF;
+                    q_pos += len;
+                }
             } else if constexpr (PARETO) {
                 cached = fast_parse_list<true>(e, w, P, z, cur, span_end, cached, RL, back, len);
             } else {
