@@ -141,6 +141,15 @@ lzma_ret lzma_code(lzma_stream *strm, lzma_action action);
 void lzma_end(lzma_stream *strm);
 void lzma_get_progress(lzma_stream *strm, uint64_t *progress_in, uint64_t *progress_out);
 
+/* One-shot buffer API (common/stream_buffer_encoder.c:43-141, common/easy_buffer_encoder.c:16-27), same
+ * return codes (LZMA_BUF_ERROR and *out_pos untouched if the output does not fit).  Unlike the reference,
+ * which writes a single Block here, the Stream has the MT layout (one Block per default block_size). */
+size_t lzma_stream_buffer_bound(size_t uncompressed_size);
+lzma_ret lzma_stream_buffer_encode(lzma_filter *filters, lzma_check check, const lzma_allocator *allocator,
+		const uint8_t *in, size_t in_size, uint8_t *out, size_t *out_pos, size_t out_size);
+lzma_ret lzma_easy_buffer_encode(uint32_t preset, lzma_check check, const lzma_allocator *allocator,
+		const uint8_t *in, size_t in_size, uint8_t *out, size_t *out_pos, size_t out_size);
+
 #ifdef __cplusplus
 }
 #endif

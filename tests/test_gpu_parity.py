@@ -323,6 +323,37 @@ def test_ld_preload_interposer_with_stock_xz(tmp_path, level):
     assert p2.returncode == 0 and b"-> GPU" not in p2.stderr
 
 
+def test_one_shot_buffer_api():
+    """lzma_easy_buffer_encode / lzma_stream_buffer_encode / lzma_stream_buffer_bound
+    (common/easy_buffer_encoder.c, stream_buffer_encoder.c): same bytes as the streaming API, BUF_ERROR
+    without touching *out_pos when the output does not fit."""
+    import ctypes as C
+    import xz_amd
+    L = xz_amd.lib()
+    L.lzma_stream_buffer_bound.restype = C.c_size_t
+    L.lzma_stream_buffer_bound.argtypes = [C.c_size_t]
+    L.lzma_easy_buffer_encode.argtypes = [C.c_uint32, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p,
+                                          C.POINTER(C.c_size_t), C.c_size_t]
+    data = o.corpus_mixed(3 << 20, 12)
+    bound = L.lzma_stream_buffer_bound(len(data))
+    assert bound >= len(data) + 64
+    out = C.create_string_buffer(bound + 7)
+    pos = C.c_size_t(7)
+    r = L.lzma_easy_buffer_encode(6, 4, None, data, len(data), out, C.byref(pos), len(out))
+    assert r == 0 and pos.value > 7 + 64
+    got = out.raw[7:pos.value]
+    rr, dec = o.ref_decode(got, len(data) + 16) if o.have_ref() else (1, data)
+    assert rr == 1 and dec == data
+    opts = xz_amd.preset_options(6)
+    want = o.orc_xz_stream(data, o.params_for_gpu_options(opts), xz_amd.mt_block_size(opts))
+    assert o.first_diff(got, want) == -1
+    small = C.create_string_buffer(1000)
+    pos = C.c_size_t(3)
+    assert L.lzma_easy_buffer_encode(6, 4, None, data, len(data), small, C.byref(pos), len(small)) == 10   # LZMA_BUF_ERROR
+    assert pos.value == 3
+    assert L.lzma_easy_buffer_encode(6, 4, None, data, len(data), None, C.byref(pos), 0) == 11            # LZMA_PROG_ERROR
+
+
 def test_lzma_code_semantics(tmp_path):
     """Option validation and action sequencing as in get_options (stream_encoder_mt.c:956-1000) and
     lzma_code (common/common.c:203-376), driven through ctypes."""

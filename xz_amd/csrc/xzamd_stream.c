@@ -23,6 +23,7 @@
 #include "kernels_api.h"
 
 #include <pthread.h>
+#include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -534,4 +535,70 @@ void lzma_get_progress(lzma_stream *strm, uint64_t *progress_in, uint64_t *progr
 		*progress_in = strm->total_in;
 		*progress_out = strm->total_out;
 	}
+}
+
+/* ------------------------------------------------------------------ */
+/* One-shot buffer API (common/stream_buffer_encoder.c:43-141,          */
+/* common/easy_buffer_encoder.c:16-27): same engine, no caller-visible  */
+/* streaming state.  The reference writes ONE Block here; this writes   */
+/* the MT layout (a Block per block_size bytes), which decodes the same.*/
+/* ------------------------------------------------------------------ */
+size_t lzma_stream_buffer_bound(size_t uncompressed_size)
+{
+	/* stream_buffer_encoder.c:24-40 semantics: 0 = too big */
+	const uint64_t bs = 1ull << 20;           /* smallest default Block size (3 x 256 KiB dict -> 1 MiB floor) */
+	const uint64_t b = xzamd_stream_buffer_bound(uncompressed_size, bs);
+	return b > (uint64_t)SIZE_MAX ? 0 : (size_t)b;
+}
+
+static lzma_ret buffer_encode(const lzma_mt *mt, const lzma_allocator *allocator,
+		const uint8_t *in, size_t in_size, uint8_t *out, size_t *out_pos_ptr, size_t out_size)
+{
+	if (out == NULL || out_pos_ptr == NULL || *out_pos_ptr > out_size || (in == NULL && in_size != 0))
+		return LZMA_PROG_ERROR;
+	lzma_stream strm;
+	memset(&strm, 0, sizeof(strm));
+	strm.allocator = allocator;
+	lzma_ret r = lzma_stream_encoder_mt(&strm, mt);
+	if (r != LZMA_OK)
+		return r;
+	strm.next_in = in;
+	strm.avail_in = in_size;
+	strm.next_out = out + *out_pos_ptr;
+	strm.avail_out = out_size - *out_pos_ptr;
+	do {
+		r = lzma_code(&strm, LZMA_FINISH);
+	} while (r == LZMA_OK && strm.avail_out > 0);
+	const size_t produced = (out_size - *out_pos_ptr) - strm.avail_out;
+	lzma_end(&strm);
+	if (r == LZMA_STREAM_END) {
+		*out_pos_ptr += produced;
+		return LZMA_OK;
+	}
+	/* output did not fit: *out_pos is left untouched like the reference does (:128-137) */
+	return r == LZMA_OK ? LZMA_BUF_ERROR : r;
+}
+
+lzma_ret lzma_stream_buffer_encode(lzma_filter *filters, lzma_check check, const lzma_allocator *allocator,
+		const uint8_t *in, size_t in_size, uint8_t *out, size_t *out_pos, size_t out_size)
+{
+	if (filters == NULL)
+		return LZMA_PROG_ERROR;
+	lzma_mt mt;
+	memset(&mt, 0, sizeof(mt));
+	mt.threads = 1;
+	mt.filters = filters;
+	mt.check = check;
+	return buffer_encode(&mt, allocator, in, in_size, out, out_pos, out_size);
+}
+
+lzma_ret lzma_easy_buffer_encode(uint32_t preset, lzma_check check, const lzma_allocator *allocator,
+		const uint8_t *in, size_t in_size, uint8_t *out, size_t *out_pos, size_t out_size)
+{
+	lzma_mt mt;
+	memset(&mt, 0, sizeof(mt));
+	mt.threads = 1;
+	mt.preset = preset;
+	mt.check = check;
+	return buffer_encode(&mt, allocator, in, in_size, out, out_pos, out_size);
 }
