@@ -65,10 +65,11 @@ static_assert(P_TOTAL <= 8192, "model must fit the 16 KiB LDS slice");
 // Make LDS stores of some lanes visible to later LDS loads of other lanes of the same wavefront:
 // LDS hand-off between lanes of the wave.  DS instructions of one wave execute in issue order, so a
 // ds_write is visible to any later ds_read of the same wave without waiting; what has to be
-// prevented is the COMPILER moving accesses across the hand-off.
+// prevented is the COMPILER moving accesses across the hand-off.  A compiler-only barrier: a fence
+// builtin would also drain vmcnt, i.e. wait for every prefetch in flight at each hand-off.
 __device__ __forceinline__ void wave_sync()
 {
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    asm volatile("" ::: "memory");
     __builtin_amdgcn_wave_barrier();
 }
 
