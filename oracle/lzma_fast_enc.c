@@ -49,7 +49,8 @@
 #define LIT 0xFFFFFFFFu
 #define NO_DELTA 0xFFFFFFFFu
 #define H8_BITS 22
-#define WMAX 256u                 /* optimal-parser window (nodes 0..WMAX) */
+#define WMAX 232u                 /* optimal-parser window (nodes 0..WMAX); sized so the GPU's node arrays +
+                                   * model + price tables fit 10 KiB of LDS per wavefront */
 #define PRICE_INF (1u << 30)
 
 /* ------------------------------------------------------------------ */

@@ -724,7 +724,10 @@ __device__ __forceinline__ bool change_pair(uint32_t small_dist, uint32_t big_di
 // parser.  Semantics are defined by oracle/lzma_fast_enc.c (find_pareto / optimum_window); the
 // code below is their wave-parallel form and must stay bit-exact with them.
 // ------------------------------------------------------------------------------------------
-constexpr uint32_t WMAX = 256;            // optimal-parser window: nodes 0..WMAX
+#ifndef XZAMD_WMAX
+#define XZAMD_WMAX 232        /* LDS per wave <= 10 KiB -> 16 waves per CU */
+#endif
+constexpr uint32_t WMAX = XZAMD_WMAX;            // optimal-parser window: nodes 0..WMAX
 constexpr uint32_t PRICE_INF = 1u << 30;
 constexpr uint32_t H8_BITS = 22;
 
@@ -757,12 +760,12 @@ struct Work {
     uint32_t* md;       // [64] zero-based distances
     // optimal parser only
     uint32_t* n_price;  // [WMAX+1] node price; after backtracking: out-edge `back`
-    uint32_t* n_back;   // [WMAX+1] in-edge back
-    uint32_t* n_info;   // [WMAX+1] in-len (9) | state (4) << 9 | out-len (9) << 13
+    uint32_t* n_info;   // [WMAX+1] in-len (9) | state (4) << 9 | out-len (9) << 13 | in-edge kind (3) << 22
+                        //          kind: 0..3 = rep index, 4 = match (its distance is the node's rep0), 5 = literal
     uint4* n_reps4;     // [WMAX+1] rep distances of the node (complete when the parser reaches it)
     uint16_t* dsp;      // [4*64]  dist-slot price (+ direct bits for slot >= 14)
-    uint16_t* dp;       // [4*128] full price of distances < 128
-    uint16_t* ap;       // [16]    align price
+    uint16_t* xt;       // [128]   price of the footer bits of distances < 128 (slots 4..13, 0 below)
+    uint16_t* ap;       // [16]    align price; == xt + 128, so one table: index dist < 128 ? dist : 128 + (dist & 15)
     uint8_t* ptab;      // [128]   bit price table (price_tablegen.c:31-58)
     uint32_t* err;      // debug/consistency word block (global)
     uint32_t ptv;       // the same price table in registers: lane l (< 32) holds entries 4l..4l+3
@@ -1080,9 +1083,20 @@ __device__ __forceinline__ void refresh_dist_tables(const uint16_t* probs, const
         if (slot >= 14) pr += (((slot >> 1) - 1) - 4) << 4;
         w.dsp[i] = (uint16_t)pr;
     }
+    // footer of distances < 128: the reverse bit tree of slots 4..13 (lzma_encoder.c:160-168); the
+    // slot part is in dsp, so  price(dist < 128) = dsp[ds][slot] + xt[dist]  (the sum the reference
+    // keeps in dist_prices[], optimum_normal.c:132-183)
 #pragma unroll 1
-    for (uint32_t i = lane; i < 512; i += 64)
-        w.dp[i] = (uint16_t)pr_dist_full(probs, w.ptab, i & 127, i >> 7);
+    for (uint32_t d = lane; d < 128; d += 64) {
+        uint32_t pr = 0;
+        if (d >= 4) {
+            const uint32_t slot = dist_slot_of(d);
+            const uint32_t fb = (slot >> 1) - 1;
+            const uint32_t base = (2 | (slot & 1)) << fb;
+            pr = pr_tree_rev(probs, w.ptab, P_DIST_SPECIAL + base - slot - 1, fb, d - base);
+        }
+        w.xt[d] = (uint16_t)pr;
+    }
     wave_sync();
 }
 
@@ -1095,8 +1109,7 @@ __device__ __forceinline__ void refresh_align_table(const uint16_t* probs, const
 
 __device__ __forceinline__ uint32_t tab_dist(const Work& w, uint32_t dist, uint32_t ds)
 {
-    if (dist < 128) return w.dp[ds * 128 + dist];
-    return (uint32_t)w.dsp[ds * 64 + dist_slot_of(dist)] + w.ap[dist & 15];
+    return (uint32_t)w.dsp[ds * 64 + dist_slot_of(dist)] + w.xt[dist < 128 ? dist : 128 + (dist & 15)];
 }
 
 // ---- literal prices (get_literal_price, optimum_normal.c:21-53) --------------------------------
@@ -1190,27 +1203,30 @@ __device__ __forceinline__ void relax_lengths(const Work& w, const LenTab& lt, u
     const uint32_t lane = threadIdx.x;
     const uint32_t info_rep = (s < 7 ? 8u : 11u) << 9, info_match = (s < 7 ? 7u : 10u) << 9;
     const uint32_t lo_ps = PS == 0 ? lt.lo[0] : PS == 1 ? lt.lo[1] : PS == 2 ? lt.lo[2] : lt.lo[3];
-#pragma unroll
-    for (int it = 0; it < 5; ++it) {
+    // not unrolled: one pass covers 64 lengths and is all that nearly every node needs; five copies of
+    // the body would only cost instruction-cache space
+#pragma unroll 1
+    for (uint32_t it = 0; it < 5; ++it) {
         if (2 + 64u * it > reach) break;
         const uint32_t l = 2 + lane + 64u * it;
         uint32_t idx_m = 0;                       // first entry whose length reaches l (or the last one)
         for (uint32_t k = 0; k + 1 < cnt; ++k) idx_m += (lane_of(SL, k) < l) ? 1u : 0u;
         const uint32_t dist_m = __shfl(SD, idx_m);
         const uint32_t cur = w.n_price[j + l];
-        const uint32_t lv = it == 0 ? (lane < 16 ? lo_ps : lt.hi[0]) : lt.hi[it];
+        const uint32_t hv = it == 0 ? lt.hi[0] : it == 1 ? lt.hi[1] : it == 2 ? lt.hi[2] : it == 3 ? lt.hi[3] : lt.hi[4];
+        const uint32_t lv = (it == 0 && lane < 16) ? lo_ps : hv;
         const uint32_t lpm = lv & 0xFFFFu, lpr = lv >> 16;
-        // distance price: both table forms are read, one is selected
+        // distance price = slot price (+ direct bits) + footer / align price: two table reads
         const uint32_t ds = l < 6 ? l - 2 : 3;
-        const uint32_t p_small = w.dp[ds * 128 + (dist_m & 127)];
-        const uint32_t dbig = dist_m < 128 ? 128u : dist_m;               // branch-free slot; unused below 128
-        const uint32_t di = 31 - (uint32_t)__builtin_clz(dbig);
-        const uint32_t p_big = (uint32_t)w.dsp[ds * 64 + 2 * di + ((dbig >> (di - 1)) & 1)] + w.ap[dist_m & 15];
+        const uint32_t dnz = dist_m < 4 ? 4u : dist_m;                     // branch-free slot (fastpos.h:78-86)
+        const uint32_t di = 31 - (uint32_t)__builtin_clz(dnz);
+        const uint32_t slot = dist_m < 4 ? dist_m : 2 * di + ((dnz >> (di - 1)) & 1);
+        const uint32_t p_dist = (uint32_t)w.dsp[ds * 64 + slot] + w.xt[dist_m < 128 ? dist_m : 128 + (dist_m & 15)];
         const uint32_t c0 = rl0 >= l ? prep0 + lpr : PRICE_INF;
         const uint32_t c1 = rl1 >= l ? prep1 + lpr : PRICE_INF;
         const uint32_t c2 = rl2 >= l ? prep2 + lpr : PRICE_INF;
         const uint32_t c3 = rl3 >= l ? prep3 + lpr : PRICE_INF;
-        const uint32_t c4 = l <= longest ? pmatch + lpm + (dist_m < 128 ? p_small : p_big) : PRICE_INF;
+        const uint32_t c4 = l <= longest ? pmatch + lpm + p_dist : PRICE_INF;
         uint32_t best = cur, bb = 0, n0 = r0;
         { const bool t = c0 < best; best = t ? c0 : best; bb = t ? 0u : bb; }
         { const bool t = c1 < best; best = t ? c1 : best; bb = t ? 1u : bb; n0 = t ? r1 : n0; }
@@ -1222,8 +1238,7 @@ __device__ __forceinline__ void relax_lengths(const Work& w, const LenTab& lt, u
         const uint32_t n3 = bb <= 2 ? r3 : r2;
         if (l <= reach && best < cur) {
             w.n_price[j + l] = best;
-            w.n_back[j + l] = bb;
-            w.n_info[j + l] = l | (bb < 4 ? info_rep : info_match);
+            w.n_info[j + l] = l | (bb < 4 ? info_rep | (bb << 22) : info_match | (4u << 22));
             w.n_reps4[j + l] = make_uint4(n0, n1, n2, n3);
         }
     }
@@ -1336,7 +1351,7 @@ __device__ __forceinline__ bool optimum_window(const Env& e, const Work& w, List
                 if (psr < best) { best = psr; bb = 0; upd = true; ns = s < 7 ? 9u : 11u; }
             }
             if (upd && lane == 0) {
-                w.n_price[j + 1] = best; w.n_back[j + 1] = bb; w.n_info[j + 1] = 1 | (ns << 9);
+                w.n_price[j + 1] = best; w.n_info[j + 1] = 1 | (ns << 9) | ((bb == LITERAL ? 5u : 0u) << 22);
                 w.n_reps4[j + 1] = make_uint4(r0, r1, r2, r3);
             }
             wave_sync();
@@ -1358,11 +1373,12 @@ __device__ __forceinline__ bool optimum_window(const Env& e, const Work& w, List
     if (lane == 0) {
         uint32_t t = j;
         while (t > 0) {
-            const uint32_t ilen = w.n_info[t] & 0x1FF;
-            const uint32_t bk = w.n_back[t];
+            const uint32_t info = w.n_info[t];
+            const uint32_t ilen = info & 0x1FF, kind = (info >> 22) & 7;
+            const uint32_t bk = kind < 4 ? kind : kind == 4 ? w.n_reps4[t].x + 4 : LITERAL;
             const uint32_t pv = t - ilen;
             w.n_price[pv] = bk;
-            w.n_info[pv] = (w.n_info[pv] & 0x1FFF) | (ilen << 13);
+            w.n_info[pv] = (w.n_info[pv] & 0x01C01FFFu) | (ilen << 13);     // keep in-len, state and in-edge kind of pv
             t = pv;
         }
     }
@@ -1440,7 +1456,7 @@ template <int FINDER, bool OPT>      // FINDER: 0 = exact HC3/HC4 in-kernel, 1 =
 #define XZAMD_WAVES_FAST 4
 #endif
 #ifndef XZAMD_WAVES_OPT
-#define XZAMD_WAVES_OPT 3
+#define XZAMD_WAVES_OPT 4
 #endif
 __global__ __launch_bounds__(64)
 __attribute__((amdgpu_waves_per_eu(OPT ? XZAMD_WAVES_OPT : XZAMD_WAVES_FAST, OPT ? XZAMD_WAVES_OPT : XZAMD_WAVES_FAST)))
@@ -1452,8 +1468,8 @@ void k_span_encode_t(xzamd_span_args a)
     // One LDS pool, carved by hand (a single __shared__ object: no aliasing or ordering surprises).
     constexpr uint32_t W_PROBS = 928;                                    // 1856 x u16 >= P_LITERAL (1846): all but the literal coders
     constexpr uint32_t W_LIST = 0;
-    constexpr uint32_t W_NODES = OPT ? 7 * (WMAX + 1) + 1 : 0;           // price, back, info, reps[4]
-    constexpr uint32_t W_TABS = OPT ? (128 + 256 + 8 + 32) : 0;          // dsp, dp, ap (u16), ptab (u8)
+    constexpr uint32_t W_NODES = OPT ? 6 * (WMAX + 1) + 2 : 0;           // reps[4], price, info (16-byte multiple)
+    constexpr uint32_t W_TABS = OPT ? (128 + 72 + 32) : 0;               // dsp, xt + ap (u16), ptab (u8)
 #ifndef XZAMD_LDS_PAD_WORDS
 #define XZAMD_LDS_PAD_WORDS 0        /* occupancy experiments only */
 #endif
@@ -1495,13 +1511,12 @@ void k_span_encode_t(xzamd_span_args a)
         uint32_t* nb = pool + W_PROBS + W_LIST;
         w.n_reps4 = reinterpret_cast<uint4*>(nb);           // 16-byte aligned: W_PROBS * 4 is a multiple of 16
         w.n_price = nb + 4 * (WMAX + 1);
-        w.n_back = nb + 5 * (WMAX + 1);
-        w.n_info = nb + 6 * (WMAX + 1);
+        w.n_info = nb + 5 * (WMAX + 1);
         uint32_t* tb = nb + W_NODES;
         w.dsp = reinterpret_cast<uint16_t*>(tb);            // 256 x u16 = 128 words
-        w.dp = reinterpret_cast<uint16_t*>(tb + 128);       // 512 x u16 = 256 words
-        w.ap = reinterpret_cast<uint16_t*>(tb + 384);       // 16 x u16 = 8 words
-        w.ptab = reinterpret_cast<uint8_t*>(tb + 392);      // 128 x u8 = 32 words
+        w.xt = reinterpret_cast<uint16_t*>(tb + 128);       // 128 x u16 = 64 words
+        w.ap = w.xt + 128;                                  // 16 x u16 = 8 words, contiguous with xt
+        w.ptab = reinterpret_cast<uint8_t*>(tb + 200);      // 128 x u8 = 32 words
         w.err = a.err;
 #ifdef XZAMD_TIMING
         w.tm = tm_lds;
@@ -1589,7 +1604,7 @@ void k_span_encode_t(xzamd_span_args a)
                 if (q_pos == q_end) {
                     // price-table refresh policy (oracle: refresh_tables)
                     TM_BEGIN(t_refresh);
-                    if (!tables_valid || z.cnt_len >= 64) { refresh_len_tables(probs, w.ptab, lt, 1u << z.pb, w.n_price); z.cnt_len = 0; }
+                    if (!tables_valid || z.cnt_len >= 64) { refresh_len_tables(probs, w.ptab, lt, 1u << z.pb, reinterpret_cast<uint32_t*>(w.n_reps4)); z.cnt_len = 0; }
                     if (!tables_valid || z.cnt_match >= 128) { refresh_dist_tables(probs, w); z.cnt_match = 0; }
                     if (!tables_valid || z.cnt_align >= 16) { refresh_align_table(probs, w); z.cnt_align = 0; }
                     tables_valid = true;
