@@ -210,7 +210,7 @@ def main():
                             f"output = complete .xz Stream in HBM",
                 "device_match_finder": (f"HC{opts.gpu_mf & 15} depth {opts.gpu_depth}" + (f" + H8 depth {opts.gpu_depth2} (Pareto merge)" if opts.gpu_depth2 else "")
                                         + f", nice {opts.gpu_nice_len} (sort-built chains)"),
-                "device_parser": ("windowed optimal parser (256-node DP, exact prices) over per-position match lists from k_find_t" if opts.gpu_parser
+                "device_parser": ("windowed optimal parser (232-node DP, exact prices) over per-position match lists from k_find_t" if opts.gpu_parser
                                   else "lzma_lzma_optimum_fast semantics (greedy + 1-byte lazy)"),
                 "span_kib": (opts.span_size or (131072 if opts.gpu_parser else 65536)) >> 10,
                 "parallelism": f"{world} x (one wavefront per span, {int(st.spans)} spans per GPU)",
