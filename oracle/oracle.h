@@ -14,7 +14,15 @@
  *     (copied as data into tests/golden/) and everything liblzma_ref produces;
  *   - fast-mode encoder (HC3/HC4 + optimum_fast + range coder + LZMA2
  *     chunking): output is BYTE-IDENTICAL to the reference's raw LZMA2
- *     encoder for presets 0-3 on every test corpus.
+ *     encoder for presets 0-3 on every test corpus;
+ *   - x86 BCJ encoder: byte-identical to the reference filter's output.
+ * PARITY UNPINNED (by the reference) for the two algorithms that are OURS and
+ * have no counterpart to compare bytes with: find_pareto (HC4+H8 finder, the
+ * BT4 successor) and optimum_window (windowed optimal parser) -- what presets
+ * 4-9 run.  Their pins are indirect: every stream they produce must decode
+ * bit-exactly through the REAL reference decoder, the symbol coder / range
+ * coder / chunker underneath them are the pinned ones, and their compressed
+ * size is tracked against `xz -6` (+4.4 % on the bench corpus).
  * Reference citations are file:line relative to /root/reference.
  */
 #ifndef XZ_AMD_ORACLE_H
