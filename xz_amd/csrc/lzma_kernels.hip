@@ -214,16 +214,6 @@ struct RC {
             m = (m << 1) + b;
         } while (nbits);
     }
-    __device__ __forceinline__ void tree_rev(uint16_t* probs, uint32_t base, uint32_t nbits, uint32_t sym)
-    {
-        uint32_t m = 1;
-        do {
-            const uint32_t b = sym & 1;
-            sym >>= 1;
-            bit(probs, base + m, b);
-            m = (m << 1) + b;
-        } while (--nbits);
-    }
     __device__ __forceinline__ void direct(uint32_t value, uint32_t nbits)
     {
         do {
@@ -731,19 +721,6 @@ constexpr uint32_t WMAX = XZAMD_WMAX;            // optimal-parser window: nodes
 constexpr uint32_t PRICE_INF = 1u << 30;
 constexpr uint32_t H8_BITS = 22;
 
-__device__ __forceinline__ uint32_t wave_max(uint32_t v)
-{
-#pragma unroll
-    for (int s = 32; s > 0; s >>= 1) v = max(v, (uint32_t)__shfl_xor(v, s));
-    return v;
-}
-__device__ __forceinline__ uint32_t wave_sum(uint32_t v)
-{
-#pragma unroll
-    for (int s = 32; s > 0; s >>= 1) v += (uint32_t)__shfl_xor(v, s);
-    return v;
-}
-
 #ifdef XZAMD_TIMING
 #define TM_BEGIN(v) const uint64_t v = __builtin_amdgcn_s_memtime()
 #define TM_END(w, k, v) do { if (threadIdx.x == 0) (w).tm[k] += __builtin_amdgcn_s_memtime() - (v); } while (0)
@@ -756,8 +733,6 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v)
 
 // Per-wave LDS carve for the list-based paths.
 struct Work {
-    uint32_t* ml;       // [64] kept matches, ascending length (== ascending distance)
-    uint32_t* md;       // [64] zero-based distances
     // optimal parser only
     uint32_t* n_price;  // [WMAX+1] node price; after backtracking: out-edge `back`
     uint32_t* n_info;   // [WMAX+1] in-len (9) | state (4) << 9 | out-len (9) << 13 | in-edge kind (3) << 22
@@ -964,12 +939,6 @@ __device__ __forceinline__ uint32_t pr_bit(const uint16_t* probs, const uint8_t*
 {
     return ptab[(probs[idx] ^ ((0u - bit) & 0x7FFu)) >> 4];
 }
-// uniform variant: probability index is wave-uniform -> table lookup by readlane, no second LDS trip
-__device__ __forceinline__ uint32_t pr_bit_u(const uint16_t* probs, uint32_t ptv, uint32_t idx, uint32_t bit)
-{
-    const uint32_t t = (uni(probs[idx]) ^ ((0u - bit) & 0x7FFu)) >> 4;
-    return (lane_of(ptv, t >> 2) >> ((t & 3) * 8)) & 0xFFu;
-}
 __device__ __forceinline__ uint32_t pr_tree(const uint16_t* probs, const uint8_t* ptab, uint32_t base,
         uint32_t nbits, uint32_t sym)
 {
@@ -994,44 +963,10 @@ __device__ __forceinline__ uint32_t pr_tree_rev(const uint16_t* probs, const uin
     } while (--nbits);
     return price;
 }
-__device__ __forceinline__ uint32_t pr_len(const uint16_t* probs, const uint8_t* ptab, uint32_t base,
-        uint32_t ps, uint32_t len)
-{
-    len -= 2;
-    if (len < 8)
-        return pr_bit(probs, ptab, base + LEN_CHOICE, 0) + pr_tree(probs, ptab, base + LEN_LOW + ps * 8, 3, len);
-    len -= 8;
-    if (len < 8)
-        return pr_bit(probs, ptab, base + LEN_CHOICE, 1) + pr_bit(probs, ptab, base + LEN_CHOICE2, 0)
-                + pr_tree(probs, ptab, base + LEN_MID + ps * 8, 3, len);
-    return pr_bit(probs, ptab, base + LEN_CHOICE, 1) + pr_bit(probs, ptab, base + LEN_CHOICE2, 1)
-            + pr_tree(probs, ptab, base + LEN_HIGH, 8, len - 8);
-}
-__device__ __forceinline__ uint32_t pr_dist_full(const uint16_t* probs, const uint8_t* ptab, uint32_t dist, uint32_t ds)
-{
-    const uint32_t slot = dist_slot_of(dist);
-    uint32_t price = pr_tree(probs, ptab, P_DIST_SLOT + ds * 64, 6, slot);
-    if (slot >= 4) {
-        const uint32_t fb = (slot >> 1) - 1;
-        const uint32_t base = (2 | (slot & 1)) << fb;
-        const uint32_t red = dist - base;
-        if (slot < 14) price += pr_tree_rev(probs, ptab, P_DIST_SPECIAL + base - slot - 1, fb, red);
-        else price += ((fb - 4) << 4) + pr_tree_rev(probs, ptab, P_DIST_ALIGN, 4, red & 15);
-    }
-    return price;
-}
-
 // Length price tables live in registers, lane = length: lane holds lengths 2 + lane + 64*it.
 // The low/mid trees depend on pos_state but cover only lengths 2..17 (lanes 0..15 of it == 0);
 // the high tree is shared by all pos_states.  Low 16 bits = match length coder, high 16 = rep.
 struct LenTab { uint32_t lo[4]; uint32_t hi[5]; };
-
-__device__ __forceinline__ uint32_t lt_get(const LenTab& t, uint32_t ps, int it)
-{
-    if (it != 0) return t.hi[it];
-    const uint32_t lo = ps == 0 ? t.lo[0] : ps == 1 ? t.lo[1] : ps == 2 ? t.lo[2] : t.lo[3];
-    return threadIdx.x < 16 ? lo : t.hi[0];
-}
 
 // tmp: 256 words of LDS that are dead while the tables are rebuilt (the parser's node array)
 __device__ __forceinline__ void refresh_len_tables(const uint16_t* probs, const uint8_t* ptab, LenTab& t, uint32_t nps,
@@ -1107,11 +1042,6 @@ __device__ __forceinline__ void refresh_align_table(const uint16_t* probs, const
     wave_sync();
 }
 
-__device__ __forceinline__ uint32_t tab_dist(const Work& w, uint32_t dist, uint32_t ds)
-{
-    return (uint32_t)w.dsp[ds * 64 + dist_slot_of(dist)] + w.xt[dist < 128 ? dist : 128 + (dist & 15)];
-}
-
 // ---- literal prices (get_literal_price, optimum_normal.c:21-53) --------------------------------
 // Probabilities do not change inside a parser window, so everything that depends only on the input
 // bytes is priced once per 64 nodes, lane = node.  With N_i / A_i / B_i the price of bit i of the
@@ -1182,13 +1112,6 @@ __device__ __forceinline__ uint32_t lit_price(const LitChunk& c, uint32_t jj, ui
     const uint32_t k = (uint32_t)__builtin_clz(d) - 24;          // first differing bit, MSB first
     const uint32_t r = k < 2 ? lane_of(c.v[0], jj) : k < 4 ? lane_of(c.v[1], jj) : k < 6 ? lane_of(c.v[2], jj) : lane_of(c.v[3], jj);
     return (k & 1) ? r >> 16 : r & 0xFFFFu;
-}
-
-__device__ __forceinline__ uint32_t state_after(uint32_t s, uint32_t back, uint32_t len)
-{
-    if (back == LITERAL) return s <= 3 ? 0 : (s <= 9 ? s - 3 : s - 6);
-    if (back < 4) return len == 1 ? (s < 7 ? 9u : 11u) : (s < 7 ? 8u : 11u);
-    return s < 7 ? 7u : 10u;
 }
 
 // Relax all rep / match lengths out of node j (lane = length).  A lane that improves its target
@@ -1856,8 +1779,6 @@ void k_span_encode_t(xzamd_span_args a)
 //   one ds_permute puts (length, distance) in key order, a DPP max-scan finds the entries longer
 //   than everything closer, and the survivors are stored straight from their lanes.
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t dpp_max_step(uint32_t v, uint32_t moved) { return max(v, moved); }
-
 __device__ __forceinline__ uint32_t prefix_max_dpp(uint32_t v)
 {
     // Hillis-Steele inside each row of 16 lanes, then the row totals (gfx9 row_bcast)
