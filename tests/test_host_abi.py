@@ -78,3 +78,29 @@ def test_no_gpu_means_error_not_fallback(product_lib):
     import xz_amd
     with pytest.raises(xz_amd.XzAmdError):
         xz_amd.Encoder()
+
+
+def test_preload_interposer_falls_back_without_gpu(tmp_path):
+    """libxz_amd_preload.so with the stock xz binary on a machine WITHOUT a usable device context must
+    fall through to the real liblzma (preload.c): same bytes as plain xz, decodes, verbose note printed.
+    (With a GPU the MT encoder is routed to the device: tests/test_gpu_parity.py.)"""
+    import shutil
+    import subprocess
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: covered by the gpu-marked interposer test")
+    xz = shutil.which("xz")
+    pre = os.path.join(ROOT, "xz_amd", "libxz_amd_preload.so")
+    if not xz or not os.path.exists(pre):
+        pytest.skip("xz binary or preload library missing")
+    data = (b"The quick brown fox jumps over the lazy dog. " * 40000)[:1500000]
+    src = tmp_path / "in.bin"
+    src.write_bytes(data)
+    env = dict(os.environ, LD_PRELOAD=pre, XZ_AMD_VERBOSE="1")
+    p = subprocess.run([xz, "-T2", "-1", "-c", str(src)], capture_output=True, env=env, timeout=300)
+    assert p.returncode == 0, p.stderr.decode()[-1000:]
+    assert b"using liblzma" in p.stderr or b"cannot open" in p.stderr
+    plain = subprocess.run([xz, "-T2", "-1", "-c", str(src)], capture_output=True, timeout=300)
+    assert p.stdout == plain.stdout
+    d = subprocess.run([xz, "-dc"], input=p.stdout, capture_output=True, env=env, timeout=300)
+    assert d.returncode == 0 and d.stdout == data
