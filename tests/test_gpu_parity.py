@@ -237,6 +237,30 @@ def test_large_roundtrip_properties(enc):
         assert hashlib.sha256(dec).digest() == hashlib.sha256(host.tobytes()).digest()
 
 
+def test_out_of_memory_falls_back_to_smaller_batches(monkeypatch):
+    """A failed device allocation halves the batch (whole Blocks) instead of failing the encode; the Stream
+    does not depend on how Blocks were batched."""
+    import torch
+    import xz_amd
+    data = xz_amd.corpus_text(24 << 20, seed=3)
+    t = torch.from_numpy(data).cuda()
+    opts = xz_amd.preset_options(6)
+    e1 = xz_amd.Encoder(0)
+    want, _ = e1.encode(t, opts=opts, block_size=1 << 20)
+    want = want.cpu().numpy().tobytes()
+    assert e1.stats().batches == 1
+    e1.close()
+    monkeypatch.setenv("XZAMD_TEST_ALLOC_LIMIT_MIB", "300")     # match lists need 64 B per input byte
+    e2 = xz_amd.Encoder(0)
+    got, _ = e2.encode(t, opts=opts, block_size=1 << 20)
+    assert e2.stats().batches > 1
+    assert got.cpu().numpy().tobytes() == want
+    monkeypatch.setenv("XZAMD_TEST_ALLOC_LIMIT_MIB", "1")       # not even one Block fits: a clean error
+    with pytest.raises(xz_amd.XzAmdError):
+        e2.encode(t, opts=opts, block_size=1 << 20)
+    e2.close()
+
+
 def test_missing_gpu_fails_loudly():
     """The product path has no CPU fallback (checked structurally: ctx_create fails without a device)."""
     import ctypes as C

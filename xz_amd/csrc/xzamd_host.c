@@ -284,6 +284,12 @@ static int dgrow(xzamd_ctx *c, dbuf *b, uint64_t bytes, int host)
 		b->cap = 0;
 	}
 	bytes = (bytes + 255) & ~255ull;
+	{
+		/* test hook: pretend allocations above this size fail (exercises the smaller-batch retry) */
+		const char *lim = getenv("XZAMD_TEST_ALLOC_LIMIT_MIB");
+		if (lim && *lim && bytes > ((uint64_t)atoll(lim) << 20))
+			return fail(c, XZAMD_MEM_ERROR, "allocation above XZAMD_TEST_ALLOC_LIMIT_MIB", 0);
+	}
 	int e = host ? xzk_host_alloc(&b->p, bytes) : xzk_malloc(&b->p, bytes);
 	if (e)
 		return fail(c, XZAMD_MEM_ERROR, host ? "hipHostMalloc" : "hipMalloc", e);
@@ -517,7 +523,7 @@ int xzamd_stream_encode_device(xzamd_ctx *c,
 
 	int rc = XZAMD_OK;
 	xzk_event_record(c->ev[8], st);
-	for (uint64_t b0 = 0; b0 < total_blocks && rc == XZAMD_OK; b0 += max_blocks) {
+	for (uint64_t b0 = 0; b0 < total_blocks && rc == XZAMD_OK; ) {
 		const uint64_t nb = total_blocks - b0 < max_blocks ? total_blocks - b0 : max_blocks;
 		const uint64_t in_off = b0 * block_size;
 		const uint64_t n64 = in_size - in_off < nb * block_size ? in_size - in_off : nb * block_size;
@@ -525,7 +531,11 @@ int xzamd_stream_encode_device(xzamd_ctx *c,
 		const uint32_t nspans = (uint32_t)(nb * spb);
 		const uint32_t spb_crc = (uint32_t)((block_size + CRC_STRIP - 1) / CRC_STRIP);
 
-#define GROW(buf, bytes, host) do { int r_ = dgrow(c, &c->buf, (bytes), host); if (r_) { rc = r_; goto done; } } while (0)
+		/* Out of device memory: retry this batch with half the Blocks (dgrow has released the buffer
+		 * it failed on; the others are reused or shrink-to-fit is not needed: capacities only grow). */
+#define GROW(buf, bytes, host) do { int r_ = dgrow(c, &c->buf, (bytes), host); \
+		if (r_ == XZAMD_MEM_ERROR && nb > 1) { max_blocks = (nb + 1) / 2; goto retry_smaller; } \
+		if (r_) { rc = r_; goto done; } } while (0)
 		uint64_t sort_bytes = 0;
 		{
 			uint32_t bb = 0;
@@ -760,6 +770,10 @@ int xzamd_stream_encode_device(xzamd_ctx *c,
 		c->stats.spans += nspans;
 		c->stats.batches += 1;
 		c->stats.encode_launches += 1;
+		b0 += nb;
+		continue;
+retry_smaller:
+		c->err[0] = 0;
 	}
 done:
 	if (rc == XZAMD_OK && whole) {
