@@ -278,8 +278,13 @@ uint64_t lzma_stream_encoder_mt_memusage(const lzma_mt *options)
 	uint64_t maxb = (1ull << 30) / bs;
 	if (maxb == 0) maxb = 1;
 	const uint64_t stage = maxb * bs;
-	/* host: staging + output queue; device: input + output + 32 B/byte of chain tables + span scratch */
-	return stage * 2 + stage * 2 + stage * 34;
+	/* host: staging + output queue; device: input + output, 40 B/byte of sort buffers and chain tables
+	 * (48 with the 8-byte chain family), span scratch, and for the optimal parser the match lists
+	 * (65 B/byte packed, 97 B/byte for dictionaries above 8 MiB) */
+	uint64_t per_byte = 2 + 2 + (opt.gpu_depth2 ? 48 : 40) + 2;
+	if (opt.gpu_parser)
+		per_byte += opt.dict_size <= (1u << 23) ? 65 : 97;
+	return stage * per_byte;
 }
 
 static lzma_ret grow_pinned(uint8_t **buf, uint64_t *cap, uint64_t keep, uint64_t want)
