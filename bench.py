@@ -110,6 +110,7 @@ def main():
     ap.add_argument("--size-mib", type=int, default=4096, help="input MiB per GPU")
     ap.add_argument("--preset", type=lambda v: int(v, 0), default=6, help="0-9, | 0x80000000 for -e")
     ap.add_argument("--span-kib", type=int, default=0, help="0 = library default")
+    ap.add_argument("--block-mib", type=int, default=0, help="0 = lzma_mt_block_size of the preset (BASELINE configs[1]: 16)")
     ap.add_argument("--parser", choices=["default", "fast", "optimal"], default="default",
                     help="device parser override (default: what the preset maps to)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -138,7 +139,7 @@ def main():
         opts.span_size = args.span_kib << 10
     if args.parser != "default":
         opts.gpu_parser = 1 if args.parser == "optimal" else 0
-    block_size = xz_amd.mt_block_size(opts)
+    block_size = (args.block_mib << 20) if args.block_mib else xz_amd.mt_block_size(opts)
 
     if args.bcj:
         opts.bcj = xz_amd.BCJ_X86
@@ -251,7 +252,7 @@ def main():
                     s_out, _ = enc.encode(data[:sample_n], opts=opts, block_size=block_size)
                     res["ratio"]["ours_on_sample"] = round(s_out.numel() / sample_n, 5)
                     if cb.get("ratio"):
-                        res["ratio"]["reference_xz_T0_6_on_sample"] = cb["ratio"]
+                        res["ratio"][f"reference_xz_T0_{args.preset & 31}{'e' if args.preset >> 31 else ''}_on_sample"] = cb["ratio"]
                         res["ratio"]["size_vs_reference_pct"] = round(100.0 * (s_out.numel() / sample_n / cb["ratio"] - 1), 2)
                     vn = min(sample_n, 64 << 20)
                     v_out, _ = enc.encode(data[:vn], opts=opts, block_size=block_size)
