@@ -104,3 +104,12 @@ def test_preload_interposer_falls_back_without_gpu(tmp_path):
     assert p.stdout == plain.stdout
     d = subprocess.run([xz, "-dc"], input=p.stdout, capture_output=True, env=env, timeout=300)
     assert d.returncode == 0 and d.stdout == data
+
+
+def test_preload_library_exports_the_interposed_symbols():
+    pre = os.path.join(ROOT, "xz_amd", "libxz_amd_preload.so")
+    if not os.path.exists(pre):
+        pytest.skip("preload library not built")
+    L = C.CDLL(pre)
+    for sym in ("lzma_stream_encoder_mt", "lzma_code", "lzma_end", "lzma_get_progress"):
+        assert hasattr(L, sym), sym
