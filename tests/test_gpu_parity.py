@@ -237,6 +237,30 @@ def test_large_roundtrip_properties(enc):
         assert hashlib.sha256(dec).digest() == hashlib.sha256(host.tobytes()).digest()
 
 
+def test_batches_and_chain_build_overlap_do_not_change_the_stream(monkeypatch):
+    """Several device batches: the next batch's chain build runs on a low-priority stream underneath the
+    span kernel of the current one.  Output must equal the single-batch Stream, with and without overlap."""
+    import torch
+    import xz_amd
+    data = xz_amd.corpus_text(48 << 20, seed=9)
+    t = torch.from_numpy(data).cuda()
+    for preset in (6, 1):
+        opts = xz_amd.preset_options(preset)
+        e = xz_amd.Encoder(0)
+        want, _ = e.encode(t, opts=opts, block_size=1 << 20)
+        want = want.cpu().numpy().tobytes()
+        assert e.stats().batches == 1
+        e.set_batch_bytes(8 << 20)
+        got, _ = e.encode(t, opts=opts, block_size=1 << 20)
+        assert e.stats().batches == 6
+        assert got.cpu().numpy().tobytes() == want, preset
+        monkeypatch.setenv("XZAMD_NO_OVERLAP", "1")
+        got2, _ = e.encode(t, opts=opts, block_size=1 << 20)
+        assert got2.cpu().numpy().tobytes() == want, preset
+        monkeypatch.delenv("XZAMD_NO_OVERLAP")
+        e.close()
+
+
 def test_out_of_memory_falls_back_to_smaller_batches(monkeypatch):
     """A failed device allocation halves the batch (whole Blocks) instead of failing the encode; the Stream
     does not depend on how Blocks were batched."""

@@ -2365,6 +2365,14 @@ int xzk_set_device(int dev) { return (int)hipSetDevice(dev); }
 int xzk_get_device(int* dev) { return (int)hipGetDevice(dev); }
 int xzk_device_count(int* n) { return (int)hipGetDeviceCount(n); }
 int xzk_stream_create(void** st) { return (int)hipStreamCreateWithFlags((hipStream_t*)st, hipStreamNonBlocking); }
+// lowest-priority stream of the device (work on it only fills slots the caller's stream leaves free)
+int xzk_stream_create_low(void** st)
+{
+    int least = 0, greatest = 0;
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = 0;
+    return (int)hipStreamCreateWithPriority((hipStream_t*)st, hipStreamNonBlocking, least);
+}
+int xzk_stream_wait_event(void* st, void* ev) { return (int)hipStreamWaitEvent((hipStream_t)st, (hipEvent_t)ev, 0); }
 int xzk_stream_destroy(void* st) { return (int)hipStreamDestroy((hipStream_t)st); }
 int xzk_event_create(void** ev) { return (int)hipEventCreate((hipEvent_t*)ev); }
 int xzk_event_destroy(void* ev) { return (int)hipEventDestroy((hipEvent_t)ev); }

@@ -251,6 +251,8 @@ typedef struct {
 struct xzamd_ctx {
 	int device;
 	void *own_stream;
+	void *lo_stream;             /* lowest priority: the next batch's chain build runs here, under the span kernel */
+	void *ev_lo[4];              /* find done (hi), chains begin / end (lo), input ready (hi) */
 	uint64_t batch_bytes;
 	char err[256];
 	char err_msg_buf[200];
@@ -312,6 +314,9 @@ int xzamd_ctx_create(xzamd_ctx **out, int device)
 	if (device >= ndev || xzk_set_device(device)) { free(c); return XZAMD_DEVICE_ERROR; }
 	c->device = device;
 	if (xzk_stream_create(&c->own_stream)) { free(c); return XZAMD_DEVICE_ERROR; }
+	if (xzk_stream_create_low(&c->lo_stream)) c->lo_stream = NULL;      /* no overlap then */
+	for (int i = 0; i < 4; ++i)
+		if (xzk_event_create(&c->ev_lo[i])) { c->ev_lo[i] = NULL; c->lo_stream = NULL; }
 	for (int i = 0; i < 10; ++i)
 		if (xzk_event_create(&c->ev[i])) { free(c); return XZAMD_DEVICE_ERROR; }
 	c->batch_bytes = DEFAULT_BATCH;
@@ -337,6 +342,9 @@ void xzamd_ctx_destroy(xzamd_ctx *c)
 		if (h[i]->p) xzk_host_free(h[i]->p);
 	for (int i = 0; i < 10; ++i)
 		if (c->ev[i]) xzk_event_destroy(c->ev[i]);
+	for (int i = 0; i < 4; ++i)
+		if (c->ev_lo[i]) xzk_event_destroy(c->ev_lo[i]);
+	if (c->lo_stream) xzk_stream_destroy(c->lo_stream);
 	if (c->own_stream) xzk_stream_destroy(c->own_stream);
 	free(c);
 }
@@ -422,6 +430,47 @@ static uint64_t plan_seg(plan *p, uint32_t kind, uint64_t src, uint64_t n, uint6
 	xzamd_copy_seg *s = &p->segs[p->nsegs++];
 	s->src = src; s->dst = dst; s->len = n; s->kind = kind; s->pad_ = 0;
 	return dst + n;
+}
+
+/* Geometry of the batch that starts at Block b0. */
+typedef struct {
+	uint64_t nb, in_off;
+	uint32_t n;
+	uint64_t sort_bytes;
+} batch_geo;
+
+static int batch_geometry(xzamd_ctx *c, const xzamd_lzma_options *opt, uint64_t b0, uint64_t total_blocks,
+		uint64_t max_blocks, uint64_t block_size, uint64_t in_size, uint32_t hbits, batch_geo *g)
+{
+	g->nb = total_blocks - b0 < max_blocks ? total_blocks - b0 : max_blocks;
+	g->in_off = b0 * block_size;
+	const uint64_t n64 = in_size - g->in_off < g->nb * block_size ? in_size - g->in_off : g->nb * block_size;
+	g->n = (uint32_t)n64;
+	g->sort_bytes = 0;
+	uint32_t bb = 0;
+	while ((1u << bb) < g->nb + 1) ++bb;
+	const uint32_t bits[4] = { 10 + bb, 16 + bb, hbits + bb, 22 + bb };
+	for (int i = 0; i < (opt->gpu_depth2 ? 4 : 3); ++i) {
+		uint64_t sbytes = 0;
+		int e = xzk_sort_temp_bytes(g->n, bits[i], &sbytes);
+		if (e)
+			return fail(c, XZAMD_DEVICE_ERROR, "rocprim temp size", e);
+		if (sbytes > g->sort_bytes) g->sort_bytes = sbytes;
+	}
+	return XZAMD_OK;
+}
+
+static int launch_chains(xzamd_ctx *c, const xzamd_lzma_options *opt, const uint8_t *enc_in, const batch_geo *g,
+		uint64_t block_size, uint32_t hb, uint32_t hmask, uint32_t hbits, void *st)
+{
+	int e = xzk_build_chains(enc_in, g->n, (uint32_t)block_size, (uint32_t)g->nb, hb, hmask, hbits,
+			(uint32_t *)c->keys_a.p, (uint32_t *)c->keys_b.p, (uint32_t *)c->vals_a.p,
+			(uint32_t *)c->vals_b.p, c->sort_tmp.p, g->sort_bytes,
+			(uint32_t *)c->rank.p, (uint32_t *)c->sorted_pos.p, (uint32_t *)c->prev2.p,
+			(uint32_t *)c->prev3.p,
+			opt->gpu_depth2 ? (uint32_t *)c->rank8.p : NULL,
+			opt->gpu_depth2 ? (uint32_t *)c->sorted8.p : NULL, st);
+	return e ? fail(c, XZAMD_DEVICE_ERROR, "build_chains", e) : XZAMD_OK;
 }
 
 #define HIPCHK(call, what) do { int e_ = (call); if (e_) return fail(c, XZAMD_DEVICE_ERROR, what, e_); } while (0)
@@ -522,12 +571,18 @@ int xzamd_stream_encode_device(xzamd_ctx *c,
 	}
 
 	int rc = XZAMD_OK;
+	/* chain-build overlap: more than one batch, no BCJ copy to double-buffer, not disabled */
+	const int overlap = c->lo_stream != NULL && !x86 && total_blocks > max_blocks && getenv("XZAMD_NO_OVERLAP") == NULL;
+	int prefetched = 0, chains_on_lo = 0;
+	uint64_t prefetched_b0 = 0;
 	xzk_event_record(c->ev[8], st);
 	for (uint64_t b0 = 0; b0 < total_blocks && rc == XZAMD_OK; ) {
-		const uint64_t nb = total_blocks - b0 < max_blocks ? total_blocks - b0 : max_blocks;
-		const uint64_t in_off = b0 * block_size;
-		const uint64_t n64 = in_size - in_off < nb * block_size ? in_size - in_off : nb * block_size;
-		const uint32_t n = (uint32_t)n64;
+		batch_geo g;
+		rc = batch_geometry(c, opt, b0, total_blocks, max_blocks, block_size, in_size, hbits, &g);
+		if (rc != XZAMD_OK) goto done;
+		const uint64_t nb = g.nb, in_off = g.in_off, n64 = g.n;
+		const uint32_t n = g.n;
+		const uint64_t sort_bytes = g.sort_bytes;
 		const uint32_t nspans = (uint32_t)(nb * spb);
 		const uint32_t spb_crc = (uint32_t)((block_size + CRC_STRIP - 1) / CRC_STRIP);
 
@@ -536,18 +591,6 @@ int xzamd_stream_encode_device(xzamd_ctx *c,
 #define GROW(buf, bytes, host) do { int r_ = dgrow(c, &c->buf, (bytes), host); \
 		if (r_ == XZAMD_MEM_ERROR && nb > 1) { max_blocks = (nb + 1) / 2; goto retry_smaller; } \
 		if (r_) { rc = r_; goto done; } } while (0)
-		uint64_t sort_bytes = 0;
-		{
-			uint32_t bb = 0;
-			while ((1u << bb) < nb + 1) ++bb;
-			const uint32_t bits[4] = { 10 + bb, 16 + bb, hbits + bb, 22 + bb };
-			for (int i = 0; i < (opt->gpu_depth2 ? 4 : 3); ++i) {
-				uint64_t sbytes = 0;
-				int e = xzk_sort_temp_bytes(n, bits[i], &sbytes);
-				if (e) { rc = fail(c, XZAMD_DEVICE_ERROR, "rocprim temp size", e); goto done; }
-				if (sbytes > sort_bytes) sort_bytes = sbytes;
-			}
-		}
 		GROW(keys_a, 4ull * n, 0); GROW(keys_b, 4ull * n, 0);
 		GROW(vals_a, 4ull * n, 0); GROW(vals_b, 4ull * n, 0);
 		GROW(rank, 4ull * n, 0); GROW(sorted_pos, 4ull * n, 0);
@@ -585,17 +628,17 @@ int xzamd_stream_encode_device(xzamd_ctx *c,
 			if (e) { rc = fail(c, XZAMD_DEVICE_ERROR, "x86 bcj", e); goto done; }
 			enc_in = (const uint8_t *)c->bcj.p;
 		}
-		/* 1. match-finder structure */
-		{
-			int e = xzk_build_chains(enc_in, n, (uint32_t)block_size, (uint32_t)nb, hb, hmask, hbits,
-					(uint32_t *)c->keys_a.p, (uint32_t *)c->keys_b.p, (uint32_t *)c->vals_a.p,
-					(uint32_t *)c->vals_b.p, c->sort_tmp.p, sort_bytes,
-					(uint32_t *)c->rank.p, (uint32_t *)c->sorted_pos.p, (uint32_t *)c->prev2.p,
-					(uint32_t *)c->prev3.p,
-					opt->gpu_depth2 ? (uint32_t *)c->rank8.p : NULL,
-					opt->gpu_depth2 ? (uint32_t *)c->sorted8.p : NULL, st);
-			if (e) { rc = fail(c, XZAMD_DEVICE_ERROR, "build_chains", e); goto done; }
+		/* 1. match-finder structure: built on the caller's stream, unless the previous iteration already
+		 * started it on the low-priority stream underneath its span kernel */
+		if (prefetched && prefetched_b0 == b0) {
+			if (xzk_stream_wait_event(st, c->ev_lo[2])) { rc = fail(c, XZAMD_DEVICE_ERROR, "wait chains", 1); goto done; }
+			chains_on_lo = 1;
+		} else {
+			rc = launch_chains(c, opt, enc_in, &g, block_size, hb, hmask, hbits, st);
+			if (rc != XZAMD_OK) goto done;
+			chains_on_lo = 0;
 		}
+		prefetched = 0;
 		xzk_event_record(c->ev[1], st);
 		/* 2. span encode */
 		{
@@ -640,6 +683,23 @@ int xzamd_stream_encode_device(xzamd_ctx *c,
 				e = xzk_find_matches(&a, list_packed ? NULL : (uint16_t *)c->mlen.p, (uint32_t *)c->mdist.p, (uint8_t *)c->mcnt.p, st);
 				if (e) { rc = fail(c, XZAMD_DEVICE_ERROR, "find_matches launch", e); goto done; }
 				xzk_event_record(c->ev[5], st);
+			}
+			/* The chain arrays are free once the finder is done (the fast kernels read them, so they
+			 * keep them): build the NEXT batch's chains now, on the lowest-priority stream.  The span
+			 * kernel takes every slot it can use; the sorts fill what its tail leaves idle. */
+			if (overlap && opt->gpu_parser && b0 + nb < total_blocks) {
+				batch_geo g2;
+				if (batch_geometry(c, opt, b0 + nb, total_blocks, max_blocks, block_size, in_size, hbits, &g2) == XZAMD_OK
+						&& g2.n <= n && g2.sort_bytes + 256 <= c->sort_tmp.cap) {
+					int e2 = xzk_event_record(c->ev_lo[0], st);
+					if (!e2) e2 = xzk_stream_wait_event(c->lo_stream, c->ev_lo[0]);
+					if (!e2) e2 = xzk_event_record(c->ev_lo[1], c->lo_stream);
+					if (!e2 && launch_chains(c, opt, d_in + g2.in_off, &g2, block_size, hb, hmask, hbits, c->lo_stream) != XZAMD_OK) e2 = 1;
+					if (!e2) e2 = xzk_event_record(c->ev_lo[2], c->lo_stream);
+					if (e2) { rc = fail(c, XZAMD_DEVICE_ERROR, "chain prefetch", e2); goto done; }
+					prefetched = 1;
+					prefetched_b0 = b0 + nb;
+				}
 			}
 			e = xzk_span_encode(&a, nspans, st);
 			if (e) { rc = fail(c, XZAMD_DEVICE_ERROR, "span_encode launch", e); goto done; }
@@ -761,7 +821,8 @@ int xzamd_stream_encode_device(xzamd_ctx *c,
 			if (e) { rc = fail(c, XZAMD_DEVICE_ERROR, "assemble", e); goto done; }
 		}
 		float ms;
-		if (!xzk_event_elapsed_ms(c->ev[0], c->ev[1], &ms)) c->stats.ms_chains += ms;
+		if (chains_on_lo) { if (!xzk_event_elapsed_ms(c->ev_lo[1], c->ev_lo[2], &ms)) c->stats.ms_chains += ms; }
+		else if (!xzk_event_elapsed_ms(c->ev[0], c->ev[1], &ms)) c->stats.ms_chains += ms;
 		if (!xzk_event_elapsed_ms(c->ev[1], c->ev[2], &ms)) c->stats.ms_encode += ms;
 		if (opt->gpu_parser && !xzk_event_elapsed_ms(c->ev[1], c->ev[5], &ms)) c->stats.ms_find += ms;
 		if (!xzk_event_elapsed_ms(c->ev[2], c->ev[3], &ms)) c->stats.ms_crc += ms;
@@ -774,6 +835,7 @@ int xzamd_stream_encode_device(xzamd_ctx *c,
 		continue;
 retry_smaller:
 		c->err[0] = 0;
+		if (prefetched) { xzk_sync(c->lo_stream); prefetched = 0; }
 	}
 done:
 	if (rc == XZAMD_OK && whole) {
@@ -794,6 +856,7 @@ done:
 	}
 	xzk_event_record(c->ev[9], st);
 	xzk_sync(st);
+	if (c->lo_stream) xzk_sync(c->lo_stream);      /* a prefetched chain build abandoned by an error path */
 	{
 		float ms;
 		if (!xzk_event_elapsed_ms(c->ev[8], c->ev[9], &ms)) c->stats.ms_total = ms;
