@@ -81,7 +81,8 @@ typedef struct {
 	uint32_t gpu_depth2; /* 0 = exact HC3/HC4 semantics of the reference; else candidates from the
 	                        second, 8-byte-context chain family (HC4+H8 Pareto finder, the BT4
 	                        successor); gpu_depth + gpu_depth2 <= 56 */
-	uint32_t gpu_parser; /* 0 = lzma_lzma_optimum_fast semantics, 1 = windowed optimal parser */
+	uint32_t gpu_parser; /* 0 = lzma_lzma_optimum_fast semantics, 1 = windowed optimal parser (232-node DP over
+	                        per-position match lists; needs pb <= 2, else XZAMD_OPTIONS_ERROR) */
 	uint32_t bcj;        /* 0 = chain {LZMA2}; XZAMD_BCJ_X86 = chain {x86 BCJ, LZMA2} (simple/x86.c, start offset 0) */
 } xzamd_lzma_options;
 #define XZAMD_BCJ_X86 4u    /* LZMA_FILTER_X86, api/lzma/bcj.h:20 */
