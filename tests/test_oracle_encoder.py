@@ -30,6 +30,15 @@ def test_golden_hash(cname, preset):
     assert len(enc) == exp["size"] and hashlib.sha256(enc).hexdigest() == exp["sha256"]
 
 
+def _bench_text(n):
+    """First bytes of bench.py's corpus (xzamd_corpus_text is plain host code of the product library; used
+    here only as a data generator)."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import xz_amd
+    return xz_amd.corpus_text(max(n, 1 << 16), seed=1000).tobytes()[:n]
+
+
 def _edge_inputs():
     rng = np.random.default_rng(21)
     lorem = o.corpus_lorem(1 << 20)
@@ -39,6 +48,8 @@ def _edge_inputs():
         "period3": b"abc" * 30000, "lorem1M": lorem, "mixed": o.corpus_mixed(700000, 5),
         "rnd": rnd, "sandwich": lorem[:150000] + rnd[:200000] + lorem[:100000],
         "long_match": lorem[:5000] * 40, "binaryish": bytes(rng.integers(0, 4, size=200000, dtype=np.uint8)),
+        "x86ish": o.corpus_x86(400000, 31), "x86_filtered": o.orc_x86_encode(o.corpus_x86(300000, 32)),
+        "enwik_style": _bench_text(600000),
     }
 
 
