@@ -44,7 +44,7 @@ def baseline_metric():
 
 def span_kernel_name(opts, pmc=False):
     """Name of the dominant kernel for these options (template args: finder source, parser)."""
-    finder = 2 if opts.gpu_parser else (1 if opts.gpu_depth2 else 0)
+    finder = 2 if opts.gpu_parser else 0
     sep = ", " if pmc else ","
     return "k_span_encode_t<%d%s%s>" % (finder, sep, "true" if opts.gpu_parser else "false")
 
@@ -217,9 +217,10 @@ def main():
                             f"CRC64{', x86 BCJ + LZMA2' if args.bcj else ''}), {args.size_mib} MiB "
                             f"{'synthetic enwik-style text' if args.corpus == 'text' else 'ELF shared objects'} per GPU, input resident in HBM, "
                             f"output = complete .xz Stream in HBM",
-                "device_match_finder": (f"HC{opts.gpu_mf & 15} depth {opts.gpu_depth}" + (f" + H8 depth {opts.gpu_depth2} (Pareto merge)" if opts.gpu_depth2 else "")
-                                        + f", nice {opts.gpu_nice_len} (sort-built chains)"),
-                "device_parser": ("windowed optimal parser (232-node DP, exact prices) over per-position match lists from k_find_t" if opts.gpu_parser
+                "device_match_finder": ((f"suffix-neighbourhood finder (32-byte-prefix suffix order, {opts.gpu_sa_window} slots per side + hash2/3/4/8)"
+                                         if opts.gpu_sa_window else f"HC{opts.gpu_mf & 15} depth {opts.gpu_depth} (sort-built chains)")
+                                        + f", nice {opts.gpu_nice_len}"),
+                "device_parser": ("windowed optimal parser (232-node DP, exact prices, compound edges) over per-position match lists" if opts.gpu_parser
                                   else "lzma_lzma_optimum_fast semantics (greedy + 1-byte lazy)"),
                 "span_kib": (opts.span_size or (131072 if opts.gpu_parser else 65536)) >> 10,
                 "parallelism": f"{world} x (one wavefront per span, {int(st.spans)} spans per GPU)",

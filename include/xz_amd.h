@@ -76,16 +76,19 @@ typedef struct {
 	/* --- what the device path actually runs --- */
 	uint32_t gpu_mf;     /* XZAMD_MF_HC3 / XZAMD_MF_HC4 */
 	uint32_t gpu_nice_len;
-	uint32_t gpu_depth;  /* candidates taken from the main (3/4-byte hash) chain */
+	uint32_t gpu_depth;  /* candidates taken from the main (3/4-byte hash) chain (exact finder only) */
 	uint32_t span_size;  /* bytes per independently coded span; XZAMD_SPAN_* */
-	uint32_t gpu_depth2; /* 0 = exact HC3/HC4 semantics of the reference; else candidates from the
-	                        second, 8-byte-context chain family (HC4+H8 Pareto finder, the BT4
-	                        successor); gpu_depth + gpu_depth2 <= 56 */
+	uint32_t gpu_sa_window; /* 0 = exact HC3/HC4 semantics of the reference; else the suffix-neighbourhood
+	                        finder (the BT4 successor): recency records among this many slots (<= 30) on
+	                        either side of a position in 32-byte-prefix suffix order, plus the nearest
+	                        equal hash2/hash3/hash4/hash8; needs gpu_mf = HC4 and gpu_parser = 1 */
 	uint32_t gpu_parser; /* 0 = lzma_lzma_optimum_fast semantics, 1 = windowed optimal parser (232-node DP over
-	                        per-position match lists; needs pb <= 2, else XZAMD_OPTIONS_ERROR) */
+	                        per-position match lists incl. the reference's compound edges; needs pb <= 2,
+	                        else XZAMD_OPTIONS_ERROR) */
 	uint32_t bcj;        /* 0 = chain {LZMA2}; XZAMD_BCJ_X86 = chain {x86 BCJ, LZMA2} (simple/x86.c, start offset 0) */
 } xzamd_lzma_options;
 #define XZAMD_BCJ_X86 4u    /* LZMA_FILTER_X86, api/lzma/bcj.h:20 */
+#define XZAMD_SA_WINDOW_MAX 30u
 
 /* lzma_lzma_preset() (lzma/lzma_encoder_presets.c:17-63) + the device mapping.
  * Returns nonzero for an invalid preset. */
@@ -101,8 +104,7 @@ uint64_t xzamd_stream_buffer_bound(uint64_t in_size, uint64_t block_size);
 int xzamd_ctx_create(xzamd_ctx **ctx, int device);
 void xzamd_ctx_destroy(xzamd_ctx *ctx);
 /* Bytes of input processed per device batch (default 2 GiB - 1 MiB; must be < 2 GiB: positions are 31-bit).
- * Presets whose match lists need the 96-byte format (dictionary > 8 MiB with the optimal parser) are
- * capped at 1 GiB per batch. */
+ */
 int xzamd_ctx_set_batch_bytes(xzamd_ctx *ctx, uint64_t bytes);
 const char *xzamd_last_error(const xzamd_ctx *ctx);
 int xzamd_ctx_device(const xzamd_ctx *ctx);          /* device ordinal the context lives on */
@@ -161,6 +163,14 @@ uint64_t xzamd_frame_index_footer(uint8_t *out, uint64_t out_cap, int check,
  * `cap` symbols; xzamd_trace_read copies it out. Not for production use. */
 int xzamd_trace_enable(xzamd_ctx *ctx, uint32_t cap);
 int xzamd_trace_read(xzamd_ctx *ctx, uint32_t *out, uint32_t cap, uint32_t *count);
+
+/* Debug hook for the parity tests: copy a work buffer of the LAST batch of the last encode to the host
+ * (suffix order slot -> position, position -> slot, the 8 x u32 match-list records, their u16 lengths). */
+#define XZAMD_DEBUG_SA 1
+#define XZAMD_DEBUG_SA_RANK 2
+#define XZAMD_DEBUG_LISTS 3
+#define XZAMD_DEBUG_LIST_LENS 4
+int xzamd_debug_fetch(xzamd_ctx *ctx, int what, void *host_out, uint64_t bytes);
 
 /* Seeded synthetic corpora used by bench.py and the tests (host memory). */
 void xzamd_corpus_lorem(uint8_t *out, uint64_t n);                 /* tests/create_compress_files.c:110-152 continued */

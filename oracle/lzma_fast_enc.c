@@ -31,15 +31,30 @@
  * bit-exactly, tests/test_gpu_parity.py):
  *   span_size != 0   independent state-reset spans (control 0xC0), matches may
  *                    not cross a span end, chains stay Block-global;
- *   depth2 != 0      "HC4+H8" match finder: a second chain family keyed by a
- *                    22-bit hash of 8 bytes; all candidates (hash2, hash3,
- *                    <= depth 4-byte-chain, <= depth2 8-byte-chain) are merged
- *                    by the Pareto rule "closer or longer" -- the GPU successor
- *                    of BT4 (lz_encoder_mf.c:450-743 is sequential per insert);
+ *   sa_window != 0   "suffix-neighbourhood" match finder, the parallel successor
+ *                    of BT4 (lz_encoder_mf.c:450-743 relinks its tree at every
+ *                    insert, i.e. is sequential per Block).  BT4's tree is the
+ *                    Cartesian tree of (suffix order, insertion time), so the
+ *                    nodes its descent visits from position p are exactly the
+ *                    "recency records" met when walking away from p in suffix
+ *                    order: earlier positions, each more recent than every one
+ *                    nearer in suffix order.  We therefore sort all positions of
+ *                    the Block by their first 32 bytes (8-byte chunks, two
+ *                    rank-doubling rounds, ties by position) and take, for each
+ *                    position, the records among the sa_window slots to the left
+ *                    and to the right of its own slot, plus the nearest previous
+ *                    position with equal hash2 / hash3 / hash4 / 8-byte hash.  All candidates
+ *                    are merged by the Pareto rule "longer than everything
+ *                    closer"; the LIST_K longest survive.
  *   parser == 1      price-based forward dynamic program over a bounded window
  *                    (the role of lzma_encoder_optimum_normal.c:803-858, not its
  *                    code): exact current-probability prices, edges literal /
- *                    short rep / rep0-3 x all lengths / match x all lengths.
+ *                    short rep / rep0-3 x all lengths / match x all lengths and
+ *                    the reference's three compound edges "literal + rep0",
+ *                    "rep + literal + rep0", "match + literal + rep0"
+ *                    (:562-597, :635-687, :728-790).  A window that is cut by
+ *                    the node limit (not by convergence) only commits the
+ *                    symbols that end WTAIL nodes before the cut.
  */
 #include "oracle.h"
 #include <stdlib.h>
@@ -48,9 +63,18 @@
 #define MATCH_LEN_MAX 273u
 #define LIT 0xFFFFFFFFu
 #define NO_DELTA 0xFFFFFFFFu
-#define H8_BITS 22
 #define WMAX 232u                 /* optimal-parser window (nodes 0..WMAX); sized so the GPU's node arrays +
                                    * model + price tables fit 10 KiB of LDS per wavefront */
+#ifndef WTAIL
+#define WTAIL 24u
+#endif
+#define WTAIL_                 /* symbols ending less than WTAIL nodes before a forced window cut are re-parsed */
+#ifndef LIST_K
+#define LIST_K 7u
+#endif
+#define LIST_K_                 /* matches kept per position (the LIST_K longest) */
+#define SA_WMAX 30u               /* widest suffix-order window per side (60 records + 4 hash candidates = 64 lanes) */
+#define LEN2_MAX 127u             /* cap of the rep0 run of a compound edge */
 #define PRICE_INF (1u << 30)
 
 /* ------------------------------------------------------------------ */
@@ -78,7 +102,8 @@ enum {
 typedef struct {
 	uint32_t price;
 	uint32_t back;      /* edge arriving here: LIT / rep index / dist + 4 */
-	uint32_t len;       /* its length */
+	uint32_t len;       /* its length (0: the compound edge is just "literal + rep0") */
+	uint32_t len2;      /* != 0: compound edge, followed by one literal and a rep0 match of len2 */
 	uint32_t state;     /* valid once the node has been visited */
 	uint32_t reps[4];
 } node;
@@ -91,11 +116,13 @@ typedef struct {
 	/* parse-independent chain links (0 = none) */
 	uint32_t *prev2, *prev3;    /* delta to the previous position with equal hash2 / hash3 */
 	uint32_t *son;              /* main chain: previous position + 1 */
-	uint32_t *son8;             /* 8-byte-context chain: previous position + 1 */
+	uint32_t *prev4, *prev8;    /* delta to the previous position with equal hash4 / 8-byte hash (sa_window != 0) */
+	uint32_t *sa, *sa_rank;     /* suffix-neighbourhood finder: slot -> position, position -> slot */
 	uint32_t span_end;          /* exclusive end for avail computations */
 	/* result of the last find */
 	uint32_t m_len[MATCH_LEN_MAX + 8], m_dist[MATCH_LEN_MAX + 8];
 	uint32_t m_count, m_longest;
+	uint32_t m_len2[2];         /* [0]: longest entry, [1]: second longest: rep0 run after the byte following the match */
 	uint32_t rep_len[4];
 	/* lzma state */
 	uint16_t probs[P_TOTAL_MAX];
@@ -109,7 +136,7 @@ typedef struct {
 	uint32_t cpos;
 	/* optimal parser */
 	node *nodes;
-	uint32_t q_back[WMAX + 1], q_len[WMAX + 1], q_head, q_count;
+	uint32_t q_back[WMAX + 2], q_len[WMAX + 2], q_head, q_count;
 	uint8_t price_tab[128];
 	/* cached price tables (role of length_update_prices / fill_dist_prices /
 	 * fill_align_prices), refreshed at window starts by symbol counters */
@@ -139,6 +166,7 @@ static const uint32_t *crc_table0(void)
 	return t;
 }
 
+#define H8_BITS 22
 static uint32_t hash8_of(const uint8_t *p)
 {
 	uint64_t v;
@@ -164,8 +192,8 @@ static int build_links(enc *e)
 	uint32_t *head2 = (uint32_t *)calloc(1024, 4);
 	uint32_t *head3 = (uint32_t *)calloc(65536, 4);
 	uint32_t *headm = (uint32_t *)calloc((size_t)e->hash_mask + 1, 4);
-	uint32_t *head8 = e->prm.depth2 ? (uint32_t *)calloc((size_t)1 << H8_BITS, 4) : NULL;
-	if (!head2 || !head3 || !headm || (e->prm.depth2 && !head8))
+	uint32_t *head8 = e->prev8 ? (uint32_t *)calloc((size_t)1 << H8_BITS, 4) : NULL;
+	if (!head2 || !head3 || !headm || (e->prev8 && !head8))
 		return -1;
 	for (uint32_t p = 0; p < n; ++p) {
 		const uint8_t *cur = e->in + p;
@@ -185,14 +213,79 @@ static int build_links(enc *e)
 			h = (temp ^ ((uint32_t)cur[2] << 8) ^ (T[cur[3]] << 5)) & e->hash_mask;
 		}
 		e->son[p] = headm[h];
+		if (e->prev4)
+			e->prev4[p] = headm[h] ? p + 1 - headm[h] : 0;
 		headm[h] = p + 1;
 		if (head8 && n - p >= 8) {
 			const uint32_t h8 = hash8_of(cur);
-			e->son8[p] = head8[h8];
+			e->prev8[p] = head8[h8] ? p + 1 - head8[h8] : 0;
 			head8[h8] = p + 1;
 		}
 	}
 	free(head2); free(head3); free(headm); free(head8);
+	return 0;
+}
+
+/* ---- suffix order of the Block by its first 32 bytes (OUR definition) --------
+ * Order: compare four 8-byte chunks (big-endian, bytes past the Block end read as
+ * zero); a chunk that STARTS at or past the Block end sorts before every real
+ * chunk; remaining ties by position.  Built the way the GPU builds it: a stable
+ * LSD radix sort on the first chunk, then two rank-doubling rounds on the key
+ * (rank(p), rank(p + h)), h = 8, 16, where rank = 1 + first slot of the group of
+ * equal keys and 0 stands for "past the end". */
+static void radix_sort_u64(uint64_t *key, uint32_t *val, uint64_t *key2, uint32_t *val2, uint32_t n)
+{
+	uint32_t *cnt = (uint32_t *)malloc(65537 * sizeof(uint32_t));
+	for (int pass = 0; pass < 4; ++pass) {
+		const int sh = pass * 16;
+		memset(cnt, 0, 65537 * sizeof(uint32_t));
+		for (uint32_t i = 0; i < n; ++i)
+			++cnt[((key[i] >> sh) & 0xFFFF) + 1];
+		for (uint32_t d = 0; d < 65536; ++d)
+			cnt[d + 1] += cnt[d];
+		for (uint32_t i = 0; i < n; ++i) {
+			const uint32_t o = cnt[(key[i] >> sh) & 0xFFFF]++;
+			key2[o] = key[i];
+			val2[o] = val[i];
+		}
+		uint64_t *tk = key; key = key2; key2 = tk;
+		uint32_t *tv = val; val = val2; val2 = tv;
+	}
+	free(cnt);      /* four passes: the result is back in (key, val) */
+}
+
+static int build_sa(enc *e)
+{
+	const uint32_t n = e->n;
+	uint64_t *key = (uint64_t *)malloc((size_t)(n + 1) * 8), *key2 = (uint64_t *)malloc((size_t)(n + 1) * 8);
+	uint32_t *val2 = (uint32_t *)malloc((size_t)(n + 1) * 4);
+	uint32_t *sa = e->sa, *rk = e->sa_rank;
+	if (!key || !key2 || !val2) { free(key); free(key2); free(val2); return -1; }
+	for (uint32_t p = 0; p < n; ++p) {
+		uint64_t v = 0;
+		for (uint32_t i = 0; i < 8; ++i)
+			v = (v << 8) | (p + i < n ? e->in[p + i] : 0);
+		key[p] = v;
+		sa[p] = p;
+	}
+	for (uint32_t h = 8; ; h *= 2) {
+		radix_sort_u64(key, sa, key2, val2, n);
+		/* rank = 1 + first slot of the group */
+		uint32_t g = 0;
+		for (uint32_t i = 0; i < n; ++i) {
+			if (i && key[i] != key[i - 1]) g = i;
+			rk[sa[i]] = g + 1;
+		}
+		if (h == 32)
+			break;
+		for (uint32_t i = 0; i < n; ++i) {
+			const uint32_t p = sa[i];
+			key[i] = ((uint64_t)rk[p] << 32) | (p + h < n ? rk[p + h] : 0);
+		}
+	}
+	for (uint32_t i = 0; i < n; ++i)
+		rk[sa[i]] = i;              /* position -> slot */
+	free(key); free(key2); free(val2);
 	return 0;
 }
 
@@ -293,69 +386,79 @@ static void find_exact(enc *e, uint32_t p)
 	}
 }
 
-/* ---- HC4+H8 with Pareto merge (OUR definition, see file header) ----------- */
-static void find_pareto(enc *e, uint32_t p)
+/* ---- suffix-neighbourhood finder (OUR definition, see file header) -------- */
+static void find_sn(enc *e, uint32_t p)
 {
 	const uint8_t *cur = e->in + p;
 	const uint32_t nice = e->prm.nice_len;
 	const uint32_t avail = e->span_end - p;
+	const uint32_t W = e->prm.sa_window;
 	e->m_count = 0;
 	e->m_longest = 0;
+	e->m_len2[0] = e->m_len2[1] = 0;
 	uint32_t len_limit = avail;
 	if (nice <= len_limit)
 		len_limit = nice;
 	else if (len_limit < 4)
 		return;
 
-	/* candidates in a fixed order (== GPU lane order): hash2, hash3, 4-byte chain, 8-byte chain */
+	/* candidates: nearest equal hash2 / hash3 / hash4 / 8-byte hash, then the recency records of both sides */
 	uint32_t cd[64], cl[64], nc = 0;
-	const uint32_t d2 = e->prev2[p], d3 = e->prev3[p];
+	const uint32_t d2 = e->prev2[p], d3 = e->prev3[p], d4 = e->prev4[p], d8 = e->prev8[p];
 	if (d2 && d2 < e->cyclic_size) {
 		uint32_t L = cmplen(cur - d2, cur, 0, len_limit);
 		if (L >= 2) { cd[nc] = d2; cl[nc] = L; ++nc; }
 	}
-	if (d3 && d3 != d2 && d3 < e->cyclic_size) {
+	if (d3 && d3 < e->cyclic_size) {
 		uint32_t L = cmplen(cur - d3, cur, 0, len_limit);
 		if (L >= 3) { cd[nc] = d3; cl[nc] = L; ++nc; }
 	}
-	uint32_t cm = e->son[p];
-	for (uint32_t k = 0; k < e->depth && cm; ++k) {
-		const uint32_t delta = p + 1 - cm;
-		if (delta >= e->cyclic_size)
-			break;
-		uint32_t L = cmplen(cur - delta, cur, 0, len_limit);
-		if (L >= 4) { cd[nc] = delta; cl[nc] = L; ++nc; }
-		cm = e->son[p - delta];
+	if (d4 && d4 < e->cyclic_size) {
+		uint32_t L = cmplen(cur - d4, cur, 0, len_limit);
+		if (L >= 4) { cd[nc] = d4; cl[nc] = L; ++nc; }
 	}
-	if (e->n - p >= 8) {
-		cm = e->son8[p];
-		for (uint32_t k = 0; k < e->prm.depth2 && cm; ++k) {
-			const uint32_t delta = p + 1 - cm;
-			if (delta >= e->cyclic_size)
+	if (d8 && d8 < e->cyclic_size) {
+		uint32_t L = cmplen(cur - d8, cur, 0, len_limit);
+		if (L >= 4) { cd[nc] = d8; cl[nc] = L; ++nc; }
+	}
+	const uint32_t r = e->sa_rank[p];
+	for (int side = 0; side < 2; ++side) {
+		uint32_t recent = 0;        /* most recent eligible position seen so far on this side, + 1 */
+		for (uint32_t k = 1; k <= W; ++k) {
+			if (side == 0 ? r < k : r + k >= e->n)
 				break;
-			uint32_t L = cmplen(cur - delta, cur, 0, len_limit);
-			if (L >= 4) { cd[nc] = delta; cl[nc] = L; ++nc; }
-			cm = e->son8[p - delta];
+			const uint32_t q = e->sa[side == 0 ? r - k : r + k];
+			if (q < p && p - q < e->cyclic_size && q + 1 > recent) {
+				recent = q + 1;
+				uint32_t L = cmplen(cur - (p - q), cur, 0, len_limit);
+				if (L >= 4) { cd[nc] = p - q; cl[nc] = L; ++nc; }
+			}
 		}
 	}
-	/* keep candidate i iff L_i > max{ L_j : (delta_j, j) < (delta_i, i) } */
+	/* Pareto set: (L, delta) survives iff no candidate is closer and at least as long; duplicates merge */
 	uint32_t count = 0;
 	for (uint32_t i = 0; i < nc; ++i) {
-		uint32_t m = 0;
-		for (uint32_t j = 0; j < nc; ++j)
-			if ((cd[j] < cd[i] || (cd[j] == cd[i] && j < i)) && cl[j] > m)
-				m = cl[j];
-		if (cl[i] > m) {
-			/* insert sorted by delta (== sorted by length) */
-			uint32_t k = count++;
-			while (k > 0 && e->m_dist[k - 1] > cd[i] - 1) {
-				e->m_dist[k] = e->m_dist[k - 1];
-				e->m_len[k] = e->m_len[k - 1];
-				--k;
-			}
-			e->m_dist[k] = cd[i] - 1;
-			e->m_len[k] = cl[i];
+		int keep = 1;
+		for (uint32_t j = 0; j < nc && keep; ++j)
+			if ((cd[j] < cd[i] && cl[j] >= cl[i]) || (cd[j] == cd[i] && j < i))
+				keep = 0;
+		if (!keep)
+			continue;
+		uint32_t k = count++;       /* insert sorted by delta (== sorted by length) */
+		while (k > 0 && e->m_dist[k - 1] > cd[i] - 1) {
+			e->m_dist[k] = e->m_dist[k - 1];
+			e->m_len[k] = e->m_len[k - 1];
+			--k;
 		}
+		e->m_dist[k] = cd[i] - 1;
+		e->m_len[k] = cl[i];
+	}
+	if (count > LIST_K) {
+		/* per-position lists hold the LIST_K longest (the GPU's k_find writes them for the whole batch) */
+		const uint32_t drop = count - LIST_K;
+		memmove(e->m_len, e->m_len + drop, LIST_K * sizeof(e->m_len[0]));
+		memmove(e->m_dist, e->m_dist + drop, LIST_K * sizeof(e->m_dist[0]));
+		count = LIST_K;
 	}
 	e->m_count = count;
 	if (count > 0) {
@@ -365,24 +468,36 @@ static void find_pareto(enc *e, uint32_t p)
 			lb = cmplen(cur, cur - e->m_dist[count - 1] - 1, lb, limit);
 		}
 		e->m_longest = lb;
+		/* rep0 run behind the byte that follows the match, for the two longest entries
+		 * (the "match + literal + rep0" edge, lzma_encoder_optimum_normal.c:728-790) */
+		for (uint32_t t = 0; t < 2 && t < count; ++t) {
+			const uint32_t L = t == 0 ? lb : e->m_len[count - 2];
+			const uint32_t dist = e->m_dist[count - 1 - t];
+			uint32_t l2 = 0;
+			if (L + 1 < avail) {
+				uint32_t lim = L + 1 + LEN2_MAX;
+				if (lim > avail) lim = avail;
+				l2 = cmplen(cur, cur - dist - 1, L + 1, lim) - (L + 1);
+			}
+			e->m_len2[t] = l2;
+		}
 	}
 }
 
-#define LIST_K 16
 /* One "round" at position x: matches + the four rep-match lengths with reps r[]. */
 static void do_round(enc *e, uint32_t x, const uint32_t r[4])
 {
-	if (e->prm.depth2)
-		find_pareto(e, x);
-	else
+	if (e->prm.sa_window) {
+		find_sn(e, x);
+	} else {
 		find_exact(e, x);
-	if (e->prm.parser && e->m_count > LIST_K) {
-		/* the optimal parser reads per-position lists of at most LIST_K entries (the GPU's
-		 * k_find_t writes them for the whole batch): the LIST_K longest are kept */
-		const uint32_t drop = e->m_count - LIST_K;
-		memmove(e->m_len, e->m_len + drop, LIST_K * sizeof(e->m_len[0]));
-		memmove(e->m_dist, e->m_dist + drop, LIST_K * sizeof(e->m_dist[0]));
-		e->m_count = LIST_K;
+		e->m_len2[0] = e->m_len2[1] = 0;
+		if (e->prm.parser && e->m_count > LIST_K) {
+			const uint32_t drop = e->m_count - LIST_K;
+			memmove(e->m_len, e->m_len + drop, LIST_K * sizeof(e->m_len[0]));
+			memmove(e->m_dist, e->m_dist + drop, LIST_K * sizeof(e->m_dist[0]));
+			e->m_count = LIST_K;
+		}
 	}
 	const uint32_t rem = e->span_end - x;
 	const uint32_t buf_avail = rem < MATCH_LEN_MAX ? rem : MATCH_LEN_MAX;
@@ -882,13 +997,28 @@ static void reps_after(const uint32_t r[4], uint32_t back, uint32_t out[4])
 	}
 }
 
-static inline void relax(node *nd, uint32_t price, uint32_t back, uint32_t len)
+static inline void relax(node *nd, uint32_t price, uint32_t back, uint32_t len, uint32_t len2)
 {
 	if (price < nd->price) {
 		nd->price = price;
 		nd->back = back;
 		nd->len = len;
+		nd->len2 = len2;
 	}
+}
+
+/* Number of equal bytes of in[x..] and in[x - dist - 1 ..] behind the first mismatch, as the GPU sees
+ * it: one 64-byte row starting at x (offsets >= buf_avail count as mismatches).  `first` = offset of
+ * the first mismatch, must be a real one inside the row.  Returns 0 when there is no such run. */
+static uint32_t row_run_after(const uint8_t *cur, uint32_t dist, uint32_t first, uint32_t buf_avail)
+{
+	const uint32_t row = buf_avail < 64 ? buf_avail : 64;
+	if (first >= row)
+		return 0;
+	uint32_t o = first + 1;
+	while (o < row && cur[o] == cur[(int64_t)o - dist - 1])
+		++o;
+	return o - (first + 1);
 }
 
 /* ---- optimal parser (OUR definition).  Parses one window starting at `pos`
@@ -905,15 +1035,24 @@ static int optimum_window(enc *e, uint32_t pos, int cached)
 	nd[0].state = e->state;
 	memcpy(nd[0].reps, e->reps, sizeof(nd[0].reps));
 	uint32_t n_end = 0;
-	int next_cached = 0;
+	int next_cached = 0, forced = 0;
 	uint32_t j = 0;
 	for (;;) {
 		const uint32_t x = pos + j;
 		if (j > 0) {
 			/* the path into node j is final: derive its coder state */
-			const node *pv = &nd[j - nd[j].len];
-			nd[j].state = state_after(pv->state, nd[j].back, nd[j].len);
-			reps_after(pv->reps, nd[j].back, nd[j].reps);
+			const uint32_t tot = nd[j].len + (nd[j].len2 ? 1 + nd[j].len2 : 0);
+			const node *pv = &nd[j - tot];
+			uint32_t st = pv->state;
+			if (nd[j].len) {
+				st = state_after(st, nd[j].back, nd[j].len);
+				reps_after(pv->reps, nd[j].back, nd[j].reps);
+			} else {
+				memcpy(nd[j].reps, pv->reps, sizeof(nd[j].reps));
+			}
+			if (nd[j].len2)
+				st = state_after(state_after(st, LIT, 1), 0, 2);    /* literal, then a long rep0: always 8 */
+			nd[j].state = st;
 		}
 		if (!(j == 0 && cached))
 			do_round(e, x, nd[j].reps);
@@ -955,56 +1094,118 @@ static int optimum_window(enc *e, uint32_t pos, int cached)
 		if (buf_avail == 0)
 			break;      /* cannot happen: j < n_end <= span */
 
+		const uint8_t *cur = e->in + x;
 		const uint32_t s = nd[j].state, ps = x & pbm, P = nd[j].price;
 		const uint32_t pm1 = P + pr_bit(e, P_IS_MATCH + s * 16 + ps, 1);
 		/* literal */
-		relax(&nd[j + 1], P + pr_bit(e, P_IS_MATCH + s * 16 + ps, 0) + pr_literal(e, x, s, nd[j].reps[0]), LIT, 1);
+		const uint32_t plit = P + pr_bit(e, P_IS_MATCH + s * 16 + ps, 0) + pr_literal(e, x, s, nd[j].reps[0]);
+		relax(&nd[j + 1], plit, LIT, 1, 0);
 		/* short rep */
 		const uint32_t prep = pm1 + pr_bit(e, P_IS_REP + s, 1);
 		if (e->rep_len[0] >= 1)
-			relax(&nd[j + 1], prep + pr_bit(e, P_IS_REP0 + s, 0) + pr_bit(e, P_IS_REP0_LONG + s * 16 + ps, 0), 0, 1);
+			relax(&nd[j + 1], prep + pr_bit(e, P_IS_REP0 + s, 0) + pr_bit(e, P_IS_REP0_LONG + s * 16 + ps, 0), 0, 1, 0);
 		/* reps, every length */
-		for (uint32_t i = 0; i < 4; ++i) {
-			if (rl[i] < 2) continue;
-			uint32_t pure;
-			if (i == 0)
-				pure = pr_bit(e, P_IS_REP0 + s, 0) + pr_bit(e, P_IS_REP0_LONG + s * 16 + ps, 1);
-			else if (i == 1)
-				pure = pr_bit(e, P_IS_REP0 + s, 1) + pr_bit(e, P_IS_REP1 + s, 0);
-			else
-				pure = pr_bit(e, P_IS_REP0 + s, 1) + pr_bit(e, P_IS_REP1 + s, 1) + pr_bit(e, P_IS_REP2 + s, i - 2);
+		uint32_t pure[4];
+		pure[0] = pr_bit(e, P_IS_REP0 + s, 0) + pr_bit(e, P_IS_REP0_LONG + s * 16 + ps, 1);
+		pure[1] = pr_bit(e, P_IS_REP0 + s, 1) + pr_bit(e, P_IS_REP1 + s, 0);
+		pure[2] = pr_bit(e, P_IS_REP0 + s, 1) + pr_bit(e, P_IS_REP1 + s, 1) + pr_bit(e, P_IS_REP2 + s, 0);
+		pure[3] = pr_bit(e, P_IS_REP0 + s, 1) + pr_bit(e, P_IS_REP1 + s, 1) + pr_bit(e, P_IS_REP2 + s, 1);
+		for (uint32_t i = 0; i < 4; ++i)
 			for (uint32_t l = 2; l <= rl[i]; ++l)
-				relax(&nd[j + l], prep + pure + e->lp[1][ps & 3][l - 2], i, l);
-		}
+				relax(&nd[j + l], prep + pure[i] + e->lp[1][ps & 3][l - 2], i, l, 0);
 		/* matches, every length: the closest candidate that is long enough */
+		const uint32_t pmatch = pm1 + pr_bit(e, P_IS_REP + s, 0);
 		if (longest >= 2) {
-			const uint32_t pmatch = pm1 + pr_bit(e, P_IS_REP + s, 0);
 			uint32_t k = 0;
 			for (uint32_t l = 2; l <= longest; ++l) {
 				while (k + 1 < e->m_count && e->m_len[k] < l)
 					++k;
 				const uint32_t dist = e->m_dist[k];
 				relax(&nd[j + l], pmatch + e->lp[0][ps & 3][l - 2] + tab_dist(e, dist, l < 6 ? l - 2 : 3),
-						dist + 4, l);
+						dist + 4, l, 0);
 			}
 		}
+		/* compound edges: X + literal + rep0 (lzma_encoder_optimum_normal.c:562-597, 635-687,
+		 * 728-790).  After "literal, long rep0" the state is 8 whatever X was.  rep0 price after a
+		 * literal coded in state sl at position-state psn: */
+#define REP0_AFTER_LIT(sl, psn, l2) (pr_bit(e, P_IS_MATCH + (sl) * 16 + (psn), 1) + pr_bit(e, P_IS_REP + (sl), 1) \
+		+ pr_bit(e, P_IS_REP0 + (sl), 0) + pr_bit(e, P_IS_REP0_LONG + (sl) * 16 + (psn), 1) + e->lp[1][(psn) & 3][(l2) - 2])
+		/* (a) literal + rep0: the rep0 byte differs here and a run of >= 2 follows inside the row */
+		if (e->rep_len[0] == 0) {
+			const uint32_t l2 = row_run_after(cur, nd[j].reps[0], 0, buf_avail);
+			if (l2 >= 2 && j + 1 + l2 <= WMAX) {
+				const uint32_t s2 = state_after(s, LIT, 1), ps2 = (x + 1) & pbm;
+				while (n_end < j + 1 + l2) nd[++n_end].price = PRICE_INF;
+				relax(&nd[j + 1 + l2], plit + REP0_AFTER_LIT(s2, ps2, l2), LIT, 0, l2);
+			}
+		}
+		/* (b) rep_i at its full length + literal + rep0 (row-limited: the rep ends inside the row) */
+		for (uint32_t i = 0; i < 4; ++i) {
+			const uint32_t L1 = e->rep_len[i];
+			if (L1 < 2 || L1 > room || L1 >= buf_avail)
+				continue;
+			const uint32_t l2 = row_run_after(cur, nd[j].reps[i], L1, buf_avail);
+			if (l2 < 2 || j + L1 + 1 + l2 > WMAX)
+				continue;
+			const uint32_t sr = state_after(s, i, L1), psl = (x + L1) & pbm;
+			uint32_t pr = prep + pure[i] + e->lp[1][ps & 3][L1 - 2] + pr_bit(e, P_IS_MATCH + sr * 16 + psl, 0)
+				+ pr_literal(e, x + L1, sr, nd[j].reps[i]);
+			const uint32_t sl = state_after(sr, LIT, 1), psn = (x + L1 + 1) & pbm;
+			pr += REP0_AFTER_LIT(sl, psn, l2);
+			while (n_end < j + L1 + 1 + l2) nd[++n_end].price = PRICE_INF;
+			relax(&nd[j + L1 + 1 + l2], pr, i, L1, l2);
+		}
+		/* (c) one of the two longest matches at its full length + literal + rep0; the run lengths come
+		 * with the match list (find_sn) */
+		for (uint32_t t = 0; t < 2 && t < e->m_count; ++t) {
+			const uint32_t k = e->m_count - 1 - t;
+			const uint32_t L1 = t == 0 ? e->m_longest : e->m_len[k];
+			const uint32_t dist = e->m_dist[k], l2 = e->m_len2[t];
+			if (L1 < 2 || L1 > room || l2 < 2 || L1 > 61 || j + L1 + 1 + l2 > WMAX)
+				continue;
+			const uint32_t sm = state_after(s, dist + 4, L1), psl = (x + L1) & pbm;
+			uint32_t pr = pmatch + e->lp[0][ps & 3][L1 - 2] + tab_dist(e, dist, L1 < 6 ? L1 - 2 : 3)
+				+ pr_bit(e, P_IS_MATCH + sm * 16 + psl, 0) + pr_literal(e, x + L1, sm, dist);
+			const uint32_t sl = state_after(sm, LIT, 1), psn = (x + L1 + 1) & pbm;
+			pr += REP0_AFTER_LIT(sl, psn, l2);
+			while (n_end < j + L1 + 1 + l2) nd[++n_end].price = PRICE_INF;
+			relax(&nd[j + L1 + 1 + l2], pr, dist + 4, L1, l2);
+		}
+#undef REP0_AFTER_LIT
 		++j;
-		if (j == n_end)
+		if (j == n_end) {
+			forced = j >= WMAX;     /* cut by the node limit, not by convergence */
 			break;
+		}
 	}
 	/* backtrack from node j */
 	uint32_t cnt = 0, t = j;
 	while (t > 0) {
-		++cnt;
-		t -= nd[t].len;
+		cnt += nd[t].len2 ? (nd[t].len ? 3 : 2) : 1;
+		t -= nd[t].len + (nd[t].len2 ? 1 + nd[t].len2 : 0);
 	}
 	e->q_count = cnt;
 	e->q_head = 0;
 	t = j;
-	for (uint32_t i = cnt; i-- > 0; ) {
-		e->q_back[i] = nd[t].back;
-		e->q_len[i] = nd[t].len;
-		t -= nd[t].len;
+	for (uint32_t i = cnt; i > 0; ) {
+		if (nd[t].len2) {
+			--i; e->q_back[i] = 0; e->q_len[i] = nd[t].len2;
+			--i; e->q_back[i] = LIT; e->q_len[i] = 1;
+		}
+		if (nd[t].len) {
+			--i; e->q_back[i] = nd[t].back; e->q_len[i] = nd[t].len;
+		}
+		t -= nd[t].len + (nd[t].len2 ? 1 + nd[t].len2 : 0);
+	}
+	if (forced && pos + j < e->span_end) {
+		/* decisions close to a forced cut were made without lookahead: commit only the symbols
+		 * that end at or before node j - WTAIL (at least one), re-parse the rest */
+		uint32_t acc = 0, keep = 0;
+		while (keep < cnt && acc + e->q_len[keep] <= j - WTAIL) {
+			acc += e->q_len[keep];
+			++keep;
+		}
+		e->q_count = keep ? keep : 1;
 	}
 	return next_cached;
 }
@@ -1135,7 +1336,7 @@ static uint32_t hash_mask_for(uint32_t dict_size, uint32_t hash_bytes)
 static void enc_free(enc *e)
 {
 	if (!e) return;
-	free(e->prev2); free(e->prev3); free(e->son); free(e->son8); free(e->cbuf); free(e->nodes); free(e);
+	free(e->prev2); free(e->prev3); free(e->son); free(e->prev4); free(e->prev8); free(e->sa); free(e->sa_rank); free(e->cbuf); free(e->nodes); free(e);
 }
 
 static enc *enc_new(const uint8_t *in, uint32_t n, const orc_enc_params *p)
@@ -1153,11 +1354,17 @@ static enc *enc_new(const uint8_t *in, uint32_t n, const orc_enc_params *p)
 	e->prev2 = (uint32_t *)calloc((size_t)n + 1, 4);
 	e->prev3 = (uint32_t *)calloc((size_t)n + 1, 4);
 	e->son = (uint32_t *)calloc((size_t)n + 1, 4);
-	e->son8 = p->depth2 ? (uint32_t *)calloc((size_t)n + 1, 4) : NULL;
+	if (p->sa_window) {
+		e->prev4 = (uint32_t *)calloc((size_t)n + 1, 4);
+		e->prev8 = (uint32_t *)calloc((size_t)n + 1, 4);
+		e->sa = (uint32_t *)calloc((size_t)n + 1, 4);
+		e->sa_rank = (uint32_t *)calloc((size_t)n + 1, 4);
+	}
 	e->cbuf = (uint8_t *)malloc(1 << 17);
 	e->nodes = (node *)calloc(WMAX + MATCH_LEN_MAX + 2, sizeof(node));
-	if (!e->prev2 || !e->prev3 || !e->son || (p->depth2 && !e->son8) || !e->cbuf || !e->nodes
-			|| build_links(e)) {
+	if (!e->prev2 || !e->prev3 || !e->son || !e->cbuf || !e->nodes
+			|| (p->sa_window && (!e->prev4 || !e->prev8 || !e->sa || !e->sa_rank))
+			|| build_links(e) || (p->sa_window && build_sa(e))) {
 		enc_free(e);
 		return NULL;
 	}
@@ -1169,7 +1376,7 @@ int orc_lzma2_encode_block(const uint8_t *in, uint32_t n, const orc_enc_params *
 		uint8_t *out, uint64_t cap, uint64_t *out_size, orc_trace *trace)
 {
 	if ((p->mf != 3 && p->mf != 4) || p->lc + p->lp > 4 || p->pb > 4
-			|| (p->depth2 && (p->mf != 4 || p->depth == 0 || p->depth + p->depth2 > 56))
+			|| (p->sa_window && (p->mf != 4 || p->sa_window > SA_WMAX))
 			|| p->parser > 1)
 		return -2;
 	enc *e = enc_new(in, n, p);
@@ -1209,6 +1416,50 @@ int orc_mf_dump(const uint8_t *in, uint32_t n, const orc_enc_params *p,
 			pairs[(size_t)i * max_pairs * 2 + 2 * k] = e->m_len[k];
 			pairs[(size_t)i * max_pairs * 2 + 2 * k + 1] = e->m_dist[k];
 		}
+	}
+	enc_free(e);
+	return 0;
+}
+
+/* Debug/test hooks for the device parity tests: the suffix order and the per-position match-list
+ * records exactly as the GPU's k_find_sn / k_find_exact store them (packed format: 7 entries
+ * length << 23 | distance-1 sorted by length, then count | len2a << 8 | len2b << 16; entries past
+ * the count are reported as 0). */
+int orc_sa_dump(const uint8_t *in, uint32_t n, uint32_t *sa_out, uint32_t *rank_out)
+{
+	orc_enc_params p;
+	memset(&p, 0, sizeof(p));
+	p.dict_size = 1u << 23; p.lc = 3; p.pb = 2; p.nice_len = 64; p.mf = 4; p.depth = 1; p.sa_window = 1; p.parser = 1;
+	enc *e = enc_new(in, n, &p);
+	if (!e) return -3;
+	memcpy(sa_out, e->sa, (size_t)n * 4);
+	memcpy(rank_out, e->sa_rank, (size_t)n * 4);
+	enc_free(e);
+	return 0;
+}
+
+int orc_list_dump(const uint8_t *in, uint32_t n, const orc_enc_params *p, uint32_t *words)
+{
+	enc *e = enc_new(in, n, p);
+	if (!e) return -3;
+	static const uint32_t zero_reps[4] = { 0, 0, 0, 0 };
+	const uint32_t span = p->span_size ? p->span_size : (n ? n : 1);
+	for (uint32_t x = 0; x < n; ++x) {
+		const uint32_t se = (x / span + 1) * span;
+		e->span_end = se < n && se > x ? se : n;
+		uint32_t *w = words + (size_t)x * 8;
+		memset(w, 0, 32);
+		if (x == 0 && 0) continue;
+		e->m_count = 0; e->m_longest = 0; e->m_len2[0] = e->m_len2[1] = 0;
+		if (x > 0 || p->sa_window) {
+			/* position 0 has no earlier data; the exact finder's prefetch-free form needs x >= 1 */
+			if (x > 0) do_round(e, x, zero_reps);
+		}
+		for (uint32_t k = 0; k < e->m_count; ++k) {
+			const uint32_t len = k + 1 == e->m_count ? e->m_longest : e->m_len[k];
+			w[k] = (len << 23) | e->m_dist[k];
+		}
+		w[7] = e->m_count | (e->m_len2[0] << 8) | (e->m_len2[1] << 16);
 	}
 	enc_free(e);
 	return 0;

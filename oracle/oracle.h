@@ -118,8 +118,9 @@ typedef struct {
 	uint32_t depth;     /* 0 = reference default (4 + nice_len/4) */
 	uint32_t span_size; /* 0 = whole Block is one span (== reference);
 	                       else independent state-reset spans (GPU mode) */
-	uint32_t depth2;    /* 0 = exact HC3/HC4; else HC4+H8 Pareto finder with
-	                       `depth` 4-byte-chain + `depth2` 8-byte-chain candidates */
+	uint32_t sa_window; /* 0 = exact HC3/HC4; else the suffix-neighbourhood finder: recency records among
+	                       `sa_window` (<= 30) slots on either side in 32-byte-prefix suffix order, plus the
+	                       nearest equal hash2/hash3/hash4 (`depth` unused) */
 	uint32_t parser;    /* 0 = optimum_fast (reference); 1 = windowed optimal parser (ours) */
 } orc_enc_params;
 
@@ -139,6 +140,11 @@ int orc_lzma2_encode_block(const uint8_t *in, uint32_t n, const orc_enc_params *
 int orc_mf_dump(const uint8_t *in, uint32_t n, const orc_enc_params *p,
 		const uint32_t *pos_list, const uint32_t *end_list, uint32_t npos,
 		uint32_t max_pairs, uint32_t *counts, uint32_t *pairs, uint32_t *longest);
+
+/* Device-parity debug hooks (OUR structures): suffix order of one Block (slot -> position and
+ * position -> slot) and the 8-word match-list record of every position, as the GPU stores them. */
+int orc_sa_dump(const uint8_t *in, uint32_t n, uint32_t *sa_out, uint32_t *rank_out);
+int orc_list_dump(const uint8_t *in, uint32_t n, const orc_enc_params *p, uint32_t *words);
 
 /* ------------------------------------------------------------------ */
 /* Synthetic corpora                                     */

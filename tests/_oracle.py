@@ -39,7 +39,7 @@ def _load(path):
 class OrcParams(C.Structure):
     _fields_ = [("dict_size", C.c_uint32), ("lc", C.c_uint32), ("lp", C.c_uint32),
                 ("pb", C.c_uint32), ("nice_len", C.c_uint32), ("mf", C.c_uint32),
-                ("depth", C.c_uint32), ("span_size", C.c_uint32), ("depth2", C.c_uint32),
+                ("depth", C.c_uint32), ("span_size", C.c_uint32), ("sa_window", C.c_uint32),
                 ("parser", C.c_uint32)]
 
 
@@ -265,6 +265,31 @@ def orc_x86_encode(data):
     return buf.tobytes()
 
 
+def orc_sa_dump(data):
+    """(slot -> position, position -> slot) of one Block in the oracle's 32-byte-prefix suffix order."""
+    data = as_u8(data)
+    n = len(data)
+    sa = np.zeros(max(n, 1), dtype=np.uint32)
+    rk = np.zeros(max(n, 1), dtype=np.uint32)
+    f = orc().orc_sa_dump
+    f.restype = C.c_int
+    f.argtypes = [u8p, C.c_uint32, u32p, u32p]
+    assert f(_ptr(data), n, _ptr(sa, u32p), _ptr(rk, u32p)) == 0
+    return sa[:n], rk[:n]
+
+
+def orc_list_dump(data, prm):
+    """8 x u32 match-list record of every position of one Block (packed format), as the GPU stores it."""
+    data = as_u8(data)
+    n = len(data)
+    w = np.zeros((max(n, 1), 8), dtype=np.uint32)
+    f = orc().orc_list_dump
+    f.restype = C.c_int
+    f.argtypes = [u8p, C.c_uint32, C.POINTER(OrcParams), u32p]
+    assert f(_ptr(data), n, C.byref(prm), _ptr(w, u32p)) == 0
+    return w[:n]
+
+
 def corpus_x86(n, seed=1, density=24, runs=True):
     """Seeded x86-flavoured bytes: text-ish/zero/random background with CALL/JMP opcodes (E8/E9) whose
     rel32 has a 00/FF top byte, back-to-back opcodes, opcodes inside operands, and (runs=True) long
@@ -403,7 +428,7 @@ def params_for_gpu_options(opts, span_size=None):
     if sp == 0:
         sp = 131072 if opts.gpu_parser else 65536    # xzamd_host.c DEFAULT_SPAN_OPT / DEFAULT_SPAN
     p.span_size = 0 if sp == 0xFFFFFFFF else sp
-    p.depth2 = opts.gpu_depth2
+    p.sa_window = opts.gpu_sa_window
     p.parser = opts.gpu_parser
     return p
 

@@ -77,22 +77,24 @@ def test_span_mode_identical_to_oracle(enc, preset, span):
             assert rr == 1 and rdec == bytes(data), ("liblzma decoder", name)
 
 
-@pytest.mark.parametrize("preset,parser,depth2,span", [
-    (6, 0, None, 0),          # HC4+H8 Pareto finder with the fast parser
-    (6, 0, None, 0xFFFFFFFF),
+@pytest.mark.parametrize("preset,parser,window,span", [
     (2, 1, None, 65536),      # exact HC4 finder with the windowed optimal parser
     (1, 1, None, 0xFFFFFFFF),
+    (6, None, None, 0xFFFFFFFF),
+    (6, None, 7, 8192),       # narrow suffix-order window
     (4, None, None, 0), (5, None, None, 4096), (7, None, None, 0),
     (3 | 0x80000000, None, None, 0),
 ])
-def test_successor_finder_and_optimal_parser_identical_to_oracle(enc, preset, parser, depth2, span):
+def test_successor_finder_and_optimal_parser_identical_to_oracle(enc, preset, parser, window, span):
     """Presets 4-9 / -e (BT4 + normal mode in the reference) run OUR finder and parser; the bar is
-    bit-exactness with their CPU restatement (oracle find_pareto / optimum_window) plus a bit-exact
-    round trip through the real reference decoder."""
+    bit-exactness with their CPU restatement (oracle build_sa / find_sn / optimum_window) plus a
+    bit-exact round trip through the real reference decoder."""
     import xz_amd
     opts = xz_amd.preset_options(preset, span_size=span)
     if parser is not None:
         opts.gpu_parser = parser
+    if window is not None:
+        opts.gpu_sa_window = window
     prm = o.params_for_gpu_options(opts)
     for name, data in inputs().items():
         if len(data) > 420000:
@@ -103,6 +105,67 @@ def test_successor_finder_and_optimal_parser_identical_to_oracle(enc, preset, pa
         if o.have_ref():
             rr, rdec = o.ref_decode(got, len(data) + 16)
             assert rr == 1 and rdec == bytes(data), ("liblzma decoder", name)
+
+
+def test_suffix_order_and_match_lists_identical_to_oracle(enc):
+    """The two device structures behind presets 4-9, stage by stage: the 32-byte-prefix suffix order of every
+    Block (rocprim radix sorts + rank doubling vs the oracle's build_sa) and the per-position match-list
+    records of k_find_sn (vs the oracle's find_sn), several Blocks per batch, ragged last Block."""
+    import xz_amd
+    cases = {"lorem": o.corpus_lorem(300000), "mixed": o.corpus_mixed(260000, 11),
+             "runs": (b"a" * 70000 + b"ab" * 30000 + bytes(range(256)) * 300)[:200000],
+             "text": xz_amd.corpus_text(250000, seed=3).tobytes()}
+    for name, data in cases.items():
+        for bs, span, window in ((1 << 20, 0, None), (65536, 8192, None), (100000, 0xFFFFFFFF, 5)):
+            opts = xz_amd.preset_options(6, span_size=span)
+            if window is not None:
+                opts.gpu_sa_window = window
+            prm = o.params_for_gpu_options(opts)
+            gpu_encode(enc, data, opts, bs)
+            n = len(data)
+            sa = enc.debug_fetch(1, n)
+            rk = enc.debug_fetch(2, n)
+            lists = enc.debug_fetch(3, 8 * n).reshape(n, 8)
+            for b0 in range(0, n, bs):
+                blk = data[b0:b0 + bs]
+                osa, ork = o.orc_sa_dump(blk)
+                assert (sa[b0:b0 + len(blk)] == osa + b0).all(), ("suffix order", name, bs, b0,
+                                                                  int(np.nonzero(sa[b0:b0 + len(blk)] != osa + b0)[0][0]))
+                assert (rk[b0:b0 + len(blk)] == ork + b0).all(), ("rank", name, bs, b0)
+                want = o.orc_list_dump(blk, prm)
+                got = lists[b0:b0 + len(blk)].copy()
+                cnt = got[:, 7] & 0xFF
+                for k in range(7):
+                    got[cnt <= k, k] = 0            # entries past the count are undefined on the device
+                bad = np.nonzero((got != want).any(axis=1))[0]
+                bad = bad[bad > 0]                  # position 0 of a Block: no earlier data, never read by the parser
+                assert len(bad) == 0, ("match lists", name, bs, b0, int(bad[0]), got[bad[0]].tolist(), want[bad[0]].tolist())
+
+
+SIZE_TOLERANCE = 0.03
+
+
+@pytest.mark.parametrize("preset", [6, 9 | 0x80000000])
+def test_size_within_tolerance_of_reference(enc, preset):
+    """Stated tolerance (README/DESIGN): at the same preset and Block size the device output is at most 3 %
+    larger than the REAL liblzma's (oracle/_ref).  Inputs: the bench corpus, the reference's own text
+    generator continued (lorem-LCG), x86-64 shared objects of the image."""
+    import xz_amd
+    from test_oracle_encoder import _elf_mix
+    if not o.have_ref():
+        pytest.skip("oracle/_ref not built")
+    cases = {"bench_text": xz_amd.corpus_text(16 << 20, seed=1000).tobytes(), "lorem": o.corpus_lorem(8 << 20)}
+    elf = _elf_mix(16 << 20)
+    if len(elf) == 16 << 20:
+        cases["elf"] = elf
+    opts = xz_amd.preset_options(preset)
+    bs = xz_amd.mt_block_size(opts)
+    for name, data in cases.items():
+        got, _ = gpu_encode(enc, data, opts, bs)
+        ref = o.ref_encode_mt(data, preset, threads=2, block_size=bs)
+        r, dec = o.ref_decode(got, len(data) + 16)
+        assert r == 1 and dec == data, ("liblzma decoder", name)
+        assert len(got) <= len(ref) * (1 + SIZE_TOLERANCE), (name, hex(preset), len(got), len(ref), len(got) / len(ref) - 1)
 
 
 @pytest.mark.parametrize("preset", [0, 1, 3])

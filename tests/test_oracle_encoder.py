@@ -107,8 +107,8 @@ def test_parse_trace_consistency():
 
 
 # ---- OUR definitions (GPU successor of BT4 + windowed optimal parser): CPU-side sanity ----------
-@pytest.mark.parametrize("depth2,parser,span", [(48, 0, 0), (48, 1, 0), (0, 1, 65536), (48, 1, 131072), (24, 1, 4096)])
-def test_pareto_and_optimal_parser_roundtrip(depth2, parser, span):
+@pytest.mark.parametrize("depth2,parser,span", [(30, 1, 0), (0, 1, 65536), (30, 1, 131072), (24, 1, 4096), (1, 1, 8192)])
+def test_sn_finder_and_optimal_parser_roundtrip(depth2, parser, span):
     for name, data in _edge_inputs().items():
         if len(data) > 400000:
             data = data[:400000]
@@ -124,14 +124,52 @@ def test_pareto_and_optimal_parser_roundtrip(depth2, parser, span):
 
 
 def test_optimal_parser_beats_fast_parser():
-    """The point of the windowed optimal parser and of the second chain family: smaller output."""
+    """The point of the suffix-neighbourhood finder and the windowed optimal parser: smaller output than the
+    reference's fast mode, and close to its normal mode (the tolerance the GPU tests enforce at size)."""
     data = o.corpus_lorem(1 << 20)
     base = len(o.orc_encode_block(data, o.OrcParams(1 << 23, 3, 0, 2, 273, 4, 56, 0, 0, 0)))
-    h8 = len(o.orc_encode_block(data, o.OrcParams(1 << 23, 3, 0, 2, 273, 4, 8, 0, 48, 0)))
-    opt = len(o.orc_encode_block(data, o.OrcParams(1 << 23, 3, 0, 2, 64, 4, 8, 0, 48, 1)))
-    assert opt < h8 <= base
+    exact_opt = len(o.orc_encode_block(data, o.OrcParams(1 << 23, 3, 0, 2, 64, 4, 8, 0, 0, 1)))
+    opt = len(o.orc_encode_block(data, o.OrcParams(1 << 23, 3, 0, 2, 64, 4, 1, 0, 30, 1)))
+    assert opt < exact_opt and opt < base
     if o.have_ref():
-        import ctypes as C2
         prm = o.OrcParams(1 << 23, 3, 0, 2, 64, 0x14, 0, 0, 0, 0)
         ref6 = len(o.ref_raw_encode(data, prm, mode=2))      # liblzma preset-6 options (BT4, normal)
-        assert opt <= ref6 * 1.10                            # stated tolerance for the device parser
+        assert opt <= ref6 * (1 + SIZE_TOLERANCE), (opt, ref6)
+
+
+SIZE_TOLERANCE = 0.03     # stated tolerance: device output <= 1.03 x liblzma at the same preset and block size
+
+
+def _elf_mix(n):
+    """x86-64 shared objects of the image, 1 MiB from each, in sorted order (present here and on the GPU box)."""
+    import glob, os
+    files = sorted(glob.glob("/usr/lib/x86_64-linux-gnu/*.so*"))
+    files = [f for f in files if os.path.isfile(f) and not os.path.islink(f) and os.path.getsize(f) > 65536]
+    out = bytearray()
+    for f in files:
+        with open(f, "rb") as fh:
+            out += fh.read(1 << 20)
+        if len(out) >= n:
+            break
+    return bytes(out[:n])
+
+
+@pytest.mark.parametrize("corpus,n", [("lorem", 4 << 20), ("text", 4 << 20), ("elf", 4 << 20)])
+def test_size_within_tolerance_of_reference_preset6(corpus, n):
+    """Oracle restatement of what the device runs for preset 6 (128 KiB spans) against the REAL liblzma at
+    preset 6 on the same Block: compressed size within the stated tolerance.  (The GPU test repeats this at
+    16 MiB through the product path.)"""
+    if not o.have_ref():
+        pytest.skip("oracle/_ref not built")
+    import xz_amd
+    if corpus == "lorem":
+        data = o.corpus_lorem(n)
+    elif corpus == "text":
+        data = xz_amd.corpus_text(n, seed=1000).tobytes()
+    else:
+        data = _elf_mix(n)
+        if len(data) < n:
+            pytest.skip("not enough ELF files on this box")
+    ours = len(o.orc_encode_block(data, o.OrcParams(1 << 23, 3, 0, 2, 64, 4, 1, 131072, 30, 1)))
+    ref = len(o.ref_raw_encode(data, o.OrcParams(1 << 23, 3, 0, 2, 64, 0x14, 0, 0, 0, 0), mode=2))
+    assert ours <= ref * (1 + SIZE_TOLERANCE), (corpus, ours, ref, ours / ref - 1)

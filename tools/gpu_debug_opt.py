@@ -11,8 +11,7 @@ data = o.corpus_lorem(max(n, 1))[:n] if n < 300000 else o.corpus_mixed(n, 5)
 opts = xz_amd.preset_options(preset, span_size=span)
 opts.gpu_parser = parser
 if depth2 >= 0:
-    opts.gpu_depth2 = depth2
-    if depth2: opts.gpu_depth = min(opts.gpu_depth, 8)
+    opts.gpu_sa_window = depth2
 enc = xz_amd.Encoder()
 prm = o.params_for_gpu_options(opts)
 enc.trace_enable(n + 64)

@@ -24,10 +24,10 @@ for case in range(ncases):
     opts = xz_amd.preset_options(preset)
     span = int(rng.choice([0, 0, 4096, 8192, 40000, 65536, 0xFFFFFFFF]))
     opts.span_size = span
-    if rng.random() < 0.3:
-        opts.gpu_parser = int(rng.integers(0, 2))
-    if rng.random() < 0.2 and opts.gpu_depth2:
-        opts.gpu_depth2 = int(rng.integers(1, 49)); opts.gpu_depth = int(rng.integers(1, 9))
+    if rng.random() < 0.3 and not opts.gpu_sa_window:
+        opts.gpu_parser = int(rng.integers(0, 2))       # exact finder with either parser
+    if rng.random() < 0.2 and opts.gpu_sa_window:
+        opts.gpu_sa_window = int(rng.integers(1, 31))
     if rng.random() < 0.2:
         opts.gpu_nice_len = int(rng.integers(max(4, opts.gpu_mf & 15), 274))
     if rng.random() < 0.15:
@@ -55,7 +55,7 @@ for case in range(ncases):
         want = o.orc_xz_stream(data, prm, bs, check=check) if "check" in o.orc_xz_stream.__code__.co_varnames else None
         if want is not None and o.first_diff(got, want) != -1:
             ok = False; msg += f" ORACLE@{o.first_diff(got, want)}"
-    print(f"case {case}: {'ok ' if ok else 'FAIL' + msg} kind={kind} n={n} preset={preset:#x} span={span:#x} parser={opts.gpu_parser} d={opts.gpu_depth}/{opts.gpu_depth2} "
+    print(f"case {case}: {'ok ' if ok else 'FAIL' + msg} kind={kind} n={n} preset={preset:#x} span={span:#x} parser={opts.gpu_parser} d={opts.gpu_depth}/{opts.gpu_sa_window} "
           f"nice={opts.gpu_nice_len} dict={opts.dict_size} lc/lp/pb={opts.lc}/{opts.lp}/{opts.pb} bcj={int(bcj)} bs={bs} check={check} out={len(got)}", flush=True)
     fails += 0 if ok else 1
 print(f"FUZZ seed {seed}: {ncases - fails} / {ncases} ok in {time.time()-t0:.0f} s")

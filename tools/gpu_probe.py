@@ -27,9 +27,7 @@ def run_case(enc, name, data, preset, block_size, span, trace_on_fail=True, pars
     if parser is not None:
         opts.gpu_parser = parser
     if depth2 is not None:
-        opts.gpu_depth2 = depth2
-        if depth2:
-            opts.gpu_depth = min(opts.gpu_depth, 8)
+        opts.gpu_sa_window = depth2
     t = torch.frombuffer(bytearray(data), dtype=torch.uint8).cuda() if data else torch.empty(0, dtype=torch.uint8, device="cuda")
     torch.cuda.synchronize()
     t0 = time.time()
@@ -107,14 +105,10 @@ def main():
     rnd = bytes(rng.integers(0, 256, size=200000, dtype=np.uint8))
     big = o.corpus_lorem(1 << 20)
     sandwich = big[:150000] + rnd[:120000] + big[:100000]
-    # new finder (HC4+H8 Pareto) with the fast parser
-    results.append(run_case(enc, "pareto-fast-lorem", lorem, 6, 1 << 20, W, parser=0))
-    results.append(run_case(enc, "pareto-fast-mixed", mixed, 6, 1 << 20, 65536, parser=0))
-    results.append(run_case(enc, "pareto-fast-sandwich", sandwich, 6, 1 << 20, 16384, parser=0))
     # exact HC4 finder + optimal parser
     results.append(run_case(enc, "exact-opt-lorem", lorem, 1, 1 << 20, W, parser=1))
     results.append(run_case(enc, "exact-opt-mixed", mixed, 2, 1 << 20, 65536, parser=1))
-    # preset 6 mapping: Pareto finder + optimal parser
+    # preset 6 mapping: suffix-neighbourhood finder + optimal parser
     results.append(run_case(enc, "p6-lorem-whole", lorem, 6, 1 << 20, W))
     results.append(run_case(enc, "p6-lorem-span", lorem, 6, 1 << 20, 0))
     results.append(run_case(enc, "p6-mixed", mixed, 6, 1 << 20, 0))

@@ -23,7 +23,7 @@ BCJ_X86 = 4
 class LzmaOptions(C.Structure):
     _fields_ = [(n, C.c_uint32) for n in (
         "dict_size", "lc", "lp", "pb", "mode", "nice_len", "mf", "depth",
-        "gpu_mf", "gpu_nice_len", "gpu_depth", "span_size", "gpu_depth2", "gpu_parser", "bcj")]
+        "gpu_mf", "gpu_nice_len", "gpu_depth", "span_size", "gpu_sa_window", "gpu_parser", "bcj")]
 
 
 class Stats(C.Structure):
@@ -73,6 +73,7 @@ def lib():
         l.xzamd_frame_index_footer.restype = C.c_uint64
         l.xzamd_frame_index_footer.argtypes = [C.c_void_p, C.c_uint64, C.c_int,
                                                C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_uint64]
+        l.xzamd_debug_fetch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint64]
         l.xzamd_trace_enable.argtypes = [C.c_void_p, C.c_uint32]
         l.xzamd_trace_read.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
         l.xzamd_corpus_lorem.argtypes = [C.c_void_p, C.c_uint64]
@@ -168,7 +169,13 @@ class Encoder:
         binfo = (BlockInfo * max(nblocks, 1))()
         out_size = C.c_uint64(0)
         nb = C.c_uint64(0)
-        stream = torch.cuda.current_stream(data.device).cuda_stream
+        cur = torch.cuda.current_stream(data.device)
+        stream = cur.cuda_stream
+        if stream == 0:
+            # The C ABI reads a NULL stream as "the context's own (non-blocking) stream", which is not ordered
+            # after work queued on torch's legacy default stream: make the input final first.  The library
+            # synchronises its stream before it returns, so the output is ordered for the caller either way.
+            cur.synchronize()
         rc = lib().xzamd_stream_encode_device(
             self._ctx, C.c_void_p(data.data_ptr()), n, bs, C.byref(opts), check,
             F_BLOCKS_ONLY if blocks_only else 0, C.c_void_p(out.data_ptr()), out.numel(),
@@ -178,7 +185,17 @@ class Encoder:
                              f"{lib().xzamd_last_error(self._ctx).decode()}")
         return out[: out_size.value], list(binfo)[: nb.value]
 
-    # debug hook used by the parity tests
+    # debug hooks used by the parity tests
+    def debug_fetch(self, what, count, dtype="uint32"):
+        """Copy a work buffer of the last batch to the host: 1 = suffix order, 2 = position -> slot,
+        3 = match-list records (8 x u32 per position), 4 = their u16 lengths."""
+        import numpy as np
+        buf = np.zeros(count, dtype=dtype)
+        rc = lib().xzamd_debug_fetch(self._ctx, what, C.c_void_p(buf.ctypes.data), C.c_uint64(buf.nbytes))
+        if rc != 0:
+            raise XzAmdError(f"debug_fetch({what}) failed: {rc}")
+        return buf
+
     def trace_enable(self, cap):
         if lib().xzamd_trace_enable(self._ctx, cap) != 0:
             raise XzAmdError("trace_enable failed")

@@ -18,17 +18,15 @@ typedef struct {
 	const uint32_t *sorted_pos;  /* slot -> pos | first_of_bucket << 31 */
 	const uint32_t *prev2;       /* distance to previous position with equal hash2, 0 = none */
 	const uint32_t *prev3;       /* same for hash3 (HC4 only) */
-	const uint32_t *rank8;       /* second chain family (8-byte context), NULL unless depth2 != 0 */
-	const uint32_t *sorted8;
 	uint8_t *scratch;            /* span s writes at scratch + s * span_cap */
 	uint64_t span_cap;
 	uint32_t *span_bytes;        /* out: bytes produced per span */
 	uint32_t *lit;               /* literal-coder probabilities: 6144 x u32 per span */
-	/* per-position match lists (parser != 0): 16 entries per position, written by xzk_find_matches */
-	const uint16_t *mlen;
+	/* per-position match lists (parser != 0), written by xzk_find_matches: 8 x u32 per position =
+	 * 7 entries sorted by length + trailer (count | len2 of the longest << 8 | len2 of the second << 16) */
+	const uint16_t *mlen;        /* 8 x u16 per position, lengths of the entries (list_packed == 0 only) */
 	const uint32_t *mdist;
-	const uint8_t *mcnt;
-	uint32_t list_packed;        /* 1: mdist holds length << 23 | distance-1 and mlen is unused (dict_size <= 8 MiB) */
+	uint32_t list_packed;        /* 1: entries are length << 23 | distance-1 and mlen is unused (dict_size <= 8 MiB) */
 	uint32_t *trace;             /* optional debug: 4 x u32 per symbol (span,pos,back,len) */
 	uint32_t *trace_count;
 	uint32_t trace_cap;
@@ -39,7 +37,7 @@ typedef struct {
 	uint32_t spans_per_block;
 	uint32_t dict_size, nice_len, depth, hash_bytes;
 	uint32_t lc, lp, pb;
-	uint32_t depth2;             /* 8-byte-chain candidates (0 = exact HC3/HC4 finder) */
+	uint32_t sa_window;          /* suffix-neighbourhood finder: slots examined on either side (0 = exact HC3/HC4 finder) */
 	uint32_t parser;             /* 0 = optimum_fast, 1 = windowed optimal parser */
 } xzamd_span_args;
 
@@ -59,8 +57,11 @@ int xzk_build_chains(const uint8_t *d_in, uint32_t n, uint32_t block_size, uint3
 		uint32_t *keys_a, uint32_t *keys_b, uint32_t *vals_a, uint32_t *vals_b,
 		void *sort_tmp, uint64_t sort_tmp_bytes,
 		uint32_t *rank, uint32_t *sorted_pos, uint32_t *prev2, uint32_t *prev3,
-		uint32_t *rank8, uint32_t *sorted8, void *stream);
-int xzk_find_matches(const xzamd_span_args *a, uint16_t *mlen, uint32_t *mdist, uint8_t *mcnt, void *stream);
+		uint32_t *prev4, uint32_t *prev8, uint64_t *key64_a, uint64_t *key64_b,
+		uint32_t *sa, uint32_t *sa_rank, void *stream);
+int xzk_sa_temp_bytes(uint32_t n, uint64_t *bytes);
+int xzk_find_matches(const xzamd_span_args *a, const uint32_t *sa, const uint32_t *sa_rank, const uint32_t *prev4,
+		const uint32_t *prev8, uint16_t *mlen, uint32_t *mdist, void *stream);
 int xzk_span_encode(const xzamd_span_args *a, uint32_t nspans, void *stream);
 /* x86 BCJ encoder: d_out = filtered copy of d_in, every Block filtered independently (simple/x86.c). */
 int xzk_x86_bcj(const uint8_t *d_in, uint8_t *d_out, uint32_t n, uint32_t block_size, uint32_t nblocks, void *stream);

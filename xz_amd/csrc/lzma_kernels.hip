@@ -31,6 +31,7 @@
 #include <hip/hip_runtime.h>
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
 #include <stdint.h>
 #include "kernels_api.h"
 
@@ -154,6 +155,106 @@ __global__ __launch_bounds__(256) void k_link_prev(const uint32_t* __restrict__ 
         uint32_t d = 0;
         if (i > 0 && keys[i - 1] == keys[i]) d = p - vals[i - 1];
         prev[p] = d;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Suffix order of every Block by its first 32 bytes (oracle: build_sa) -- the structure behind the
+// suffix-neighbourhood finder.  Order inside a Block: four 8-byte chunks compared as big-endian
+// numbers (bytes past the Block end read as zero, a chunk that starts past the end sorts lowest),
+// ties by position.  Built by stable LSD radix sorts (rocprim onesweep, HBM-bound):
+//   round 0   sort (chunk(p), p), then stably by Block number (so the slots of a Block are exactly
+//             its positions' range);
+//   round h   h = 8, 16: rank[p] = 1 + first slot of p's group of equal keys; sort by
+//             (rank[p], rank[p + h]) (0 = past the Block end): doubles the compared prefix.
+// Group starts come from a max-scan over "slot if the key differs from its left neighbour".
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_sa_chunk_keys(const uint8_t* __restrict__ in, uint32_t n, uint32_t block_size,
+        uint64_t* __restrict__ keys, uint32_t* __restrict__ vals)
+{
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < n; g += stride) {
+        const uint32_t b = g / block_size;
+        const uint32_t bend = min(n, (b + 1) * block_size);
+        const uint32_t avail = bend - g;
+        uint64_t v = 0;
+        if (avail >= 8) {
+            uint64_t t;
+            __builtin_memcpy(&t, in + g, 8);
+            v = __builtin_bswap64(t);
+        } else {
+            for (uint32_t i = 0; i < avail; ++i) v |= (uint64_t)in[g + i] << (56 - 8 * i);
+        }
+        keys[g] = v;
+        vals[g] = g;
+    }
+}
+
+// grp[i] = i where the 64-bit key differs from its left neighbour, else 0 (input of the max-scan)
+__global__ __launch_bounds__(256) void k_sa_flags64(const uint64_t* __restrict__ keys, uint32_t n, uint32_t* __restrict__ grp)
+{
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        grp[i] = (i != 0 && keys[i] != keys[i - 1]) ? i : 0u;
+}
+
+// round 0, second step: pack (position, chunk group) as the value, Block number as the key
+__global__ __launch_bounds__(256) void k_sa_block_keys(const uint32_t* __restrict__ pos, const uint32_t* __restrict__ grp,
+        uint32_t n, uint32_t block_size, uint32_t* __restrict__ bkeys, uint64_t* __restrict__ bvals)
+{
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint32_t p = pos[i];
+        bkeys[i] = p / block_size;
+        bvals[i] = (uint64_t)p | ((uint64_t)grp[i] << 32);
+    }
+}
+
+// after the Block sort: positions out, group flags from (Block, chunk group)
+__global__ __launch_bounds__(256) void k_sa_block_unpack(const uint32_t* __restrict__ bkeys, const uint64_t* __restrict__ bvals,
+        uint32_t n, uint32_t* __restrict__ pos, uint32_t* __restrict__ grp)
+{
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint64_t v = bvals[i];
+        pos[i] = (uint32_t)v;
+        const bool first = i == 0 || bkeys[i] != bkeys[i - 1] || (uint32_t)(bvals[i - 1] >> 32) != (uint32_t)(v >> 32);
+        grp[i] = (first && i != 0) ? i : 0u;
+    }
+}
+
+// rank[pos[i]] = group start + 1
+__global__ __launch_bounds__(256) void k_sa_scatter_rank(const uint32_t* __restrict__ pos, const uint32_t* __restrict__ grp,
+        uint32_t n, uint32_t* __restrict__ rank)
+{
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        rank[pos[i]] = grp[i] + 1;
+}
+
+// doubling key: (rank[p], rank[p + h]) with 0 for a second half that starts past the Block end
+__global__ __launch_bounds__(256) void k_sa_pair_keys(const uint32_t* __restrict__ pos, const uint32_t* __restrict__ grp,
+        const uint32_t* __restrict__ rank, uint32_t n, uint32_t block_size, uint32_t h, uint64_t* __restrict__ keys)
+{
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint32_t p = pos[i];
+        const uint32_t b = p / block_size;
+        const uint32_t bend = min(n, (b + 1) * block_size);
+        const uint32_t second = p + h < bend ? rank[p + h] : 0u;
+        keys[i] = ((uint64_t)(grp[i] + 1) << 32) | second;
+    }
+}
+
+// final: sa[i] = position of slot i, sa_rank[position] = slot
+__global__ __launch_bounds__(256) void k_sa_final(const uint32_t* __restrict__ pos, uint32_t n,
+        uint32_t* __restrict__ sa, uint32_t* __restrict__ sa_rank)
+{
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint32_t p = pos[i];
+        sa[i] = p;
+        sa_rank[p] = i;
     }
 }
 
@@ -315,18 +416,16 @@ struct Env {
     const uint32_t* __restrict__ sorted_pos;
     const uint32_t* __restrict__ prev2;
     const uint32_t* __restrict__ prev3;
-    const uint32_t* __restrict__ rank8;        // second chain family (8-byte context), PARETO only
-    const uint32_t* __restrict__ sorted8;
     uint32_t nice, depth, hb, cyclic;
-    uint32_t depth2, block_end;
+    uint32_t block_end;
     uint32_t n_last;                            // last valid byte offset of the batch (prefetch clamp)
-    // match lists written by k_find_t (LIST_K entries per position), read by the list-driven parser
+    // match lists written by k_find_sn / k_find_exact (one 32-byte record per position), read by the list-driven parser
     const uint16_t* __restrict__ mlen;
     const uint32_t* __restrict__ mdist;
-    const uint8_t* __restrict__ mcnt;
     uint32_t packed;                            // lists are one u32 per entry: length << 23 | distance-1 (dict <= 8 MiB)
 };
-constexpr uint32_t LIST_K = 16;               // entries kept per position (the LIST_K longest)
+constexpr uint32_t LIST_K = 7;                // entries kept per position (the LIST_K longest)
+constexpr uint32_t LIST_W = 8;                // words per position: LIST_K entries + trailer (count | len2 of the two longest)
 
 // ------------------------------------------------------------------------------------------
 // Software prefetch of the parse-independent per-position data.  Rounds mostly visit consecutive
@@ -334,7 +433,7 @@ constexpr uint32_t LIST_K = 16;               // entries kept per position (the 
 // wave works on position x the loads for x+1 (chain slots) and x+2 (rank / prev links) are already
 // in flight: two of the three dependent HBM round trips of a round leave the critical path.
 // ------------------------------------------------------------------------------------------
-struct PreA { uint32_t rk, d2, d3, rk8; };
+struct PreA { uint32_t rk, d2, d3; };
 struct Pre {
     uint32_t pos;       // position (a, ent) belong to; `an` belongs to pos + 1
     bool valid;
@@ -343,7 +442,6 @@ struct Pre {
     PreA an;
 };
 
-template <bool PARETO>
 __device__ __forceinline__ PreA load_a(const Env& e, uint32_t x)
 {
     x = x < e.n_last ? x : e.n_last;
@@ -351,42 +449,31 @@ __device__ __forceinline__ PreA load_a(const Env& e, uint32_t x)
     a.rk = e.rank[x];
     a.d2 = e.prev2[x];
     a.d3 = e.hb == 4 ? e.prev3[x] : 0;
-    a.rk8 = PARETO ? e.rank8[x] : 0;
     return a;
 }
 
-template <bool PARETO>
 __device__ __forceinline__ uint32_t load_ent(const Env& e, const PreA& a)
 {
     const uint32_t lane = threadIdx.x;
     uint32_t ent = 0x80000000u;                      // out of range == "bucket start"
-    if constexpr (!PARETO) {
-        const bool in_chain = lane >= 2 && lane <= 2 + e.depth;
-        if (in_chain && a.rk >= lane - 2) ent = e.sorted_pos[a.rk - (lane - 2)];
-    } else {
-        const uint32_t A = 3 + e.depth;
-        const bool in4 = lane >= 2 && lane <= 2 + e.depth;
-        const bool in8 = lane >= A && lane <= A + e.depth2;
-        if (in4 && a.rk >= lane - 2) ent = e.sorted_pos[a.rk - (lane - 2)];
-        if (in8 && a.rk8 >= lane - A) ent = e.sorted8[a.rk8 - (lane - A)];
-    }
+    const bool in_chain = lane >= 2 && lane <= 2 + e.depth;
+    if (in_chain && a.rk >= lane - 2) ent = e.sorted_pos[a.rk - (lane - 2)];
     return ent;
 }
 
-template <bool PARETO>
 __device__ __forceinline__ void fetch(const Env& e, Pre& P, uint32_t x, PreA& a, uint32_t& ent)
 {
     if (!(P.valid && P.pos == x)) {                  // cold start: two dependent round trips
-        P.a = load_a<PARETO>(e, x);
-        P.ent = load_ent<PARETO>(e, P.a);
-        P.an = load_a<PARETO>(e, x + 1);
+        P.a = load_a(e, x);
+        P.ent = load_ent(e, P.a);
+        P.an = load_a(e, x + 1);
     }
     a = P.a;
     ent = P.ent;
     const PreA an = P.an;                            // issued one round ago
     P.a = an;
-    P.ent = load_ent<PARETO>(e, an);                 // for x + 1, consumed next round
-    P.an = load_a<PARETO>(e, x + 2);
+    P.ent = load_ent(e, an);                         // for x + 1, consumed next round
+    P.an = load_a(e, x + 2);
     P.pos = x + 1;
     P.valid = true;
 }
@@ -397,7 +484,7 @@ __device__ __forceinline__ void do_round(const Env& e, Pre& P, uint32_t x, uint3
 {
     PreA pa;
     uint32_t pent;
-    fetch<false>(e, P, x, pa, pent);
+    fetch(e, P, x, pa, pent);
     const uint32_t lane = threadIdx.x;
     const uint32_t avail = end - x;
     const uint32_t buf_avail = avail < MATCH_LEN_MAX ? avail : MATCH_LEN_MAX;
@@ -710,16 +797,15 @@ __device__ __forceinline__ bool change_pair(uint32_t small_dist, uint32_t big_di
 }
 
 // ------------------------------------------------------------------------------------------
-// Second-generation match finder ("HC4+H8", the GPU successor of BT4) and the windowed optimal
-// parser.  Semantics are defined by oracle/lzma_fast_enc.c (find_pareto / optimum_window); the
-// code below is their wave-parallel form and must stay bit-exact with them.
+// Suffix-neighbourhood match finder (the GPU successor of BT4) and the windowed optimal parser.
+// Semantics are defined by oracle/lzma_fast_enc.c (build_sa / find_sn / optimum_window); the code
+// below is their wave-parallel form and must stay bit-exact with them.
 // ------------------------------------------------------------------------------------------
 #ifndef XZAMD_WMAX
 #define XZAMD_WMAX 232        /* LDS per wave <= 10 KiB -> 16 waves per CU */
 #endif
 constexpr uint32_t WMAX = XZAMD_WMAX;            // optimal-parser window: nodes 0..WMAX
 constexpr uint32_t PRICE_INF = 1u << 30;
-constexpr uint32_t H8_BITS = 22;
 
 #ifdef XZAMD_TIMING
 #define TM_BEGIN(v) const uint64_t v = __builtin_amdgcn_s_memtime()
@@ -751,6 +837,10 @@ struct Work {
 
 struct RoundL {
     uint32_t rp[4];     // list-driven parser: the four rep-match lengths
+    uint64_t rm[4];     // mismatch masks of the four rep sources over the 64-byte row at x (bit o: offset o differs or is past the end)
+    uint32_t cx;        // per lane: the row of text, lane = offset (lanes past the end hold byte 0 of the row)
+    uint32_t cr[4];     // per lane: the four rep sources' rows
+    uint32_t l2a, l2b;  // rep0 run behind the byte after the longest / second longest match (list trailer)
     uint32_t L;         // per lane; lanes 60..63 = rep lengths (in-kernel finders)
     uint32_t SL, SD;    // kept matches sorted by length: lane r holds entry r (length, zero-based distance)
     uint32_t cnt;       // number of entries
@@ -763,151 +853,37 @@ __device__ __forceinline__ uint32_t lane_scatter(uint32_t dst, uint32_t v)
     return (uint32_t)__builtin_amdgcn_ds_permute((int)(dst << 2), (int)v);
 }
 
-// Compact the exact finder's recorded lanes into the LDS list (already in ascending order).
-__device__ __forceinline__ void list_from_mask(const Work& w, const Round& R, RoundL& out)
-{
-    const uint32_t lane = threadIdx.x;
-    const uint64_t lt = (1ull << lane) - 1;
-    (void)w;
-    const uint32_t dst = ((R.mask >> lane) & 1) ? (uint32_t)__builtin_popcountll(R.mask & lt) : 63u;
-    out.SL = lane_scatter(dst, R.L);
-    out.SD = lane_scatter(dst, R.D);
-    out.L = R.L;
-    out.cnt = (uint32_t)__builtin_popcountll(R.mask);
-    out.longest = R.longest;
-}
-
-// find_pareto(): lanes 0 = hash2, 1 = hash3, 2 = own slot of the 4-byte chain, 3..2+d4 = 4-byte
-// chain, A = 3+d4 = own slot of the 8-byte chain, A+1..A+d8 = 8-byte chain, 60..63 = reps.
-template <bool REPS = true>
-__device__ __forceinline__ void do_round_pareto(const Env& e, const Work& w, Pre& P, uint32_t x, uint32_t end,
-        uint32_t r0, uint32_t r1, uint32_t r2, uint32_t r3, RoundL& R)
-{
-    PreA pa;
-    uint32_t pent;
-    fetch<true>(e, P, x, pa, pent);
-    const uint32_t lane = threadIdx.x;
-    const uint32_t avail = end - x;
-    const uint32_t buf_avail = avail < MATCH_LEN_MAX ? avail : MATCH_LEN_MAX;
-    uint32_t len_limit = avail;
-    bool mf_ok = true;
-    if (e.nice <= len_limit) len_limit = e.nice;
-    else if (len_limit < 4) mf_ok = false;
-
-    const uint32_t d4 = e.depth, d8 = e.depth2, A = 3 + d4;
-    uint32_t q = 0, lim = 0, minlen = 4;
-    bool valid = false;
-    if (mf_ok) {
-        const uint32_t d2 = pa.d2;
-        const uint32_t d3 = pa.d3;
-        const bool have8 = e.block_end - x >= 8;
-        if (lane == 0) {
-            minlen = 2;
-            if (d2 != 0 && d2 < e.cyclic) { q = x - d2; lim = len_limit; valid = true; }
-        } else if (lane == 1) {
-            minlen = 3;
-            if (d3 != 0 && d3 != d2 && d3 < e.cyclic) { q = x - d3; lim = len_limit; valid = true; }
-        }
-        const bool in4 = lane >= 2 && lane <= 2 + d4;
-        const bool in8 = have8 && lane >= A && lane <= A + d8;
-        uint32_t ent = pent;
-        if (!have8 && lane >= A) ent = 0x80000000u;
-        const uint64_t fl = __ballot((in4 || in8) && (ent >> 31));
-        const uint64_t flags4 = fl >> 2, flags8 = fl >> A;
-        const uint32_t qp = ent & 0x7FFFFFFFu;
-        if (in4 && lane >= 3) {
-            const uint32_t j = lane - 2;
-            if ((flags4 & ((1ull << j) - 1)) == 0 && x - qp < e.cyclic) { valid = true; q = qp; lim = len_limit; }
-        }
-        if (in8 && lane > A) {
-            const uint32_t j = lane - A;
-            if ((flags8 & ((1ull << j) - 1)) == 0 && x - qp < e.cyclic) { valid = true; q = qp; lim = len_limit; }
-        }
-    }
-    if (REPS && lane >= 60) {
-        const uint32_t rep = lane == 60 ? r0 : lane == 61 ? r1 : lane == 62 ? r2 : r3;
-        q = x - rep - 1;
-        lim = buf_avail;
-    }
-    const uint32_t L = lane_cmplen(e.in, q, x, lim);
-    R.L = L;
-    R.cnt = 0;
-    R.longest = 0;
-    if (!mf_ok) return;
-
-    const uint32_t dist = x - q;                        // delta (>= 1) for candidate lanes
-    const bool elig = valid && lane < 60 && L >= minlen;
-    const uint32_t Le = elig ? L : 0;
-    // within the 8-byte chain distances ascend strictly: exclusive prefix max
-    const bool lane8 = lane > A && lane <= A + d8;
-    const uint32_t P8 = prefix_max_incl(lane8 ? Le : 0);
-    uint32_t m = 0;
-    if (lane8) m = __shfl_up(P8, 1);                    // lane A holds 0
-    const uint64_t valid8 = __ballot(lane8 && valid);
-    // small set S = hash2, hash3, 4-byte chain: all-pairs against everybody
-    for (uint32_t s = 0; s <= 2 + d4; ++s) {
-        if (s == 2) continue;
-        const uint32_t Ls = lane_of(Le, s);
-        const uint32_t ds = lane_of(dist, s);
-        if (Ls != 0 && lane != s && (ds < dist || (ds == dist && s < lane)) && Ls > m) m = Ls;
-        // what the 8-byte chain contributes to s: its entries closer than s form a prefix
-        const uint32_t k = (uint32_t)__builtin_popcountll(__ballot(lane8 && valid && dist < ds) & valid8);
-        const uint32_t v = k ? lane_of(P8, A + k) : 0;
-        if (lane == s && v > m) m = v;
-    }
-    const bool keep = elig && L > m;
-    const uint64_t kmask = __ballot(keep);
-    const uint32_t cnt = (uint32_t)__builtin_popcountll(kmask);
-    R.cnt = cnt;
-    if (cnt == 0) return;
-    // rank by length (strictly increasing with distance among kept entries)
-    uint32_t rk = 0;
-    for (uint64_t mm = kmask; mm; mm &= mm - 1) {
-        const uint32_t k = (uint32_t)__builtin_ctzll(mm);
-        const uint32_t Lk = lane_of(L, k);
-        rk += (Lk < L) ? 1u : 0u;
-    }
-    (void)w;
-    const uint32_t dst = keep ? rk : 63u;
-    R.SL = lane_scatter(dst, L);
-    R.SD = lane_scatter(dst, dist - 1);
-    uint32_t longest = lane_of(R.SL, cnt - 1);
-    if (longest == e.nice) {
-        const uint32_t dd = lane_of(R.SD, cnt - 1);
-        longest = wave_cmplen(e.in, x, x - dd - 1, longest, buf_avail);
-    }
-    R.longest = longest;
-}
-
 // ---- list-driven rounds ------------------------------------------------------------------------
 // The match finder is parse independent (find and skip both insert), so k_find_t runs it for every
 // position of the batch as a separate, fully parallel kernel.  The parser then streams the lists:
 // positions are visited strictly in order, so the record of x+1 is always in flight while x is
 // priced.  Only the four rep-match lengths depend on the parse; lanes 60..63 measure them here.
-struct ListPre { uint32_t pos; bool valid; uint32_t sl, sd, cnt; };
+struct ListPre { uint32_t pos; bool valid; uint32_t sl, sd, tr; };
 
-
-__device__ __forceinline__ void lists_load(const Env& e, uint32_t x, uint32_t& sl, uint32_t& sd, uint32_t& cnt)
+// One 32-byte record per position (see k_find_sn): lanes 0..6 = entries, lane 7 = trailer.
+__device__ __forceinline__ void lists_load(const Env& e, uint32_t x, uint32_t& sl, uint32_t& sd, uint32_t& tr)
 {
     const uint32_t lane = threadIdx.x;
     x = x < e.n_last ? x : e.n_last;
-    const uint64_t base = (uint64_t)x * LIST_K;
-    sl = 0; sd = 0;
+    const uint64_t base = (uint64_t)x * LIST_W;
+    uint32_t v = 0;
+    if (lane < LIST_W) v = e.mdist[base + lane];
+    tr = v;                                        // lane LIST_K holds the trailer
     if (e.packed) {
-        if (lane < LIST_K) { const uint32_t v = e.mdist[base + lane]; sl = v >> 23; sd = v & 0x7FFFFFu; }
+        sl = v >> 23; sd = v & 0x7FFFFFu;
     } else {
-        if (lane < LIST_K) { sl = e.mlen[base + lane]; sd = e.mdist[base + lane]; }
+        sd = v;
+        sl = lane < LIST_K ? e.mlen[base + lane] : 0u;
     }
-    cnt = e.mcnt[x];
 }
 
 __device__ __forceinline__ void round_lists(const Env& e, ListPre& LP, uint32_t x, uint32_t end,
         uint32_t r0, uint32_t r1, uint32_t r2, uint32_t r3, RoundL& R)
 {
     const uint32_t lane = threadIdx.x;
-    if (!(LP.valid && LP.pos == x)) lists_load(e, x, LP.sl, LP.sd, LP.cnt);
-    const uint32_t sl = LP.sl, sd = LP.sd, cv = LP.cnt;
-    lists_load(e, x + 1, LP.sl, LP.sd, LP.cnt);
+    if (!(LP.valid && LP.pos == x)) lists_load(e, x, LP.sl, LP.sd, LP.tr);
+    const uint32_t sl = LP.sl, sd = LP.sd, tv = LP.tr;
+    lists_load(e, x + 1, LP.sl, LP.sd, LP.tr);
     LP.pos = x + 1;
     LP.valid = true;
     const uint32_t avail = end - x;
@@ -926,11 +902,16 @@ __device__ __forceinline__ void round_lists(const Env& e, ListPre& LP, uint32_t 
         R.rp[1] = m1 ? (uint32_t)__builtin_ctzll(m1) : wave_cmplen(e.in, x, x - r1 - 1, 64, buf_avail);
         R.rp[2] = m2 ? (uint32_t)__builtin_ctzll(m2) : wave_cmplen(e.in, x, x - r2 - 1, 64, buf_avail);
         R.rp[3] = m3 ? (uint32_t)__builtin_ctzll(m3) : wave_cmplen(e.in, x, x - r3 - 1, 64, buf_avail);
+        R.rm[0] = m0; R.rm[1] = m1; R.rm[2] = m2; R.rm[3] = m3;
+        R.cx = cx; R.cr[0] = c0; R.cr[1] = c1; R.cr[2] = c2; R.cr[3] = c3;
     }
-    const uint32_t cnt = uni(cv);
+    const uint32_t tr = lane_of(tv, LIST_K);
+    const uint32_t cnt = tr & 0xFFu;
     R.SL = sl;
     R.SD = sd;
     R.cnt = cnt;
+    R.l2a = (tr >> 8) & 0xFFu;
+    R.l2b = (tr >> 16) & 0xFFu;
     R.longest = cnt ? lane_of(sl, cnt - 1) : 0;
 }
 
@@ -1167,8 +1148,69 @@ __device__ __forceinline__ void relax_lengths(const Work& w, const LenTab& lt, u
     }
 }
 
+// ---- compound edges "X + literal + rep0" (lzma_encoder_optimum_normal.c:562-597, 635-687, 728-790) ----
+// Seven candidates per node, one lane each: lane 0 = "literal + rep0" (X empty), lanes 1..4 = rep0..rep3
+// at its full length, lanes 5 / 6 = the longest / second longest match of the list at its full length.
+// Geometry (lengths, target node) depends only on the round; it is fixed before any edge of the node
+// is relaxed so that the window end covers the targets.  The rep0 run behind the literal is limited to
+// the 64-byte row at x for lanes 0..4 (the rep compare masks) and comes from the list trailer for 5 / 6.
+struct Compound {
+    uint32_t L1, l2, T;     // per lane: length of X, rep0 run, target node (valid lanes)
+    uint32_t dist;          // per lane: distance X leaves in rep0 (lanes 1..6)
+    uint64_t mask;          // valid candidate lanes
+};
+
+__device__ __forceinline__ uint32_t mask_run_after(uint64_t m, uint32_t first)
+{
+    // equal bytes behind the mismatch at offset `first` inside the row (m: bit o = offset o differs / past the end)
+    const uint64_t rest = first >= 63 ? 0ull : (m >> (first + 1));
+    return rest ? (uint32_t)__builtin_ctzll(rest) : 63u - min(first, 63u);
+}
+
+__device__ __forceinline__ void compound_setup(const RoundL& RL, uint32_t j, uint32_t room, uint32_t buf_avail,
+        uint32_t r0, uint32_t r1, uint32_t r2, uint32_t r3, Compound& c)
+{
+    const uint32_t lane = threadIdx.x;
+    // uniform per-candidate geometry
+    uint32_t L1[7], l2[7];
+    bool ok[7];
+    L1[0] = 0;
+    ok[0] = RL.rp[0] == 0;                                     // rep0's byte differs here (buf_avail >= 1 inside a span)
+    l2[0] = ok[0] ? mask_run_after(RL.rm[0], 0) : 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t l = RL.rp[i];
+        L1[1 + i] = l;
+        ok[1 + i] = l >= 2 && l <= room && l < buf_avail && l < 64;
+        l2[1 + i] = ok[1 + i] ? mask_run_after(RL.rm[i], l) : 0;
+    }
+    const uint32_t cnt = RL.cnt;
+    L1[5] = cnt >= 1 ? RL.longest : 0;
+    L1[6] = cnt >= 2 ? lane_of(RL.SL, cnt >= 2 ? cnt - 2 : 0) : 0;
+    l2[5] = RL.l2a; l2[6] = RL.l2b;
+    ok[5] = cnt >= 1 && L1[5] >= 2 && L1[5] <= room && L1[5] <= 61;
+    ok[6] = cnt >= 2 && L1[6] >= 2 && L1[6] <= room && L1[6] <= 61;
+    const uint32_t dm0 = cnt >= 1 ? lane_of(RL.SD, cnt - 1) : 0, dm1 = cnt >= 2 ? lane_of(RL.SD, cnt - 2) : 0;
+    uint64_t m = 0;
+    uint32_t vL1 = 0, vl2 = 0, vT = 0;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+        const uint32_t T = j + L1[k] + 1 + l2[k];
+        const bool v = ok[k] && l2[k] >= 2 && T <= WMAX;
+        if (v) m |= 1ull << k;
+        vL1 = lane == (uint32_t)k ? L1[k] : vL1;
+        vl2 = lane == (uint32_t)k ? l2[k] : vl2;
+        vT = lane == (uint32_t)k ? T : vT;
+    }
+    c.L1 = vL1; c.l2 = vl2; c.T = vT;
+    c.dist = lane == 1 ? r0 : lane == 2 ? r1 : lane == 3 ? r2 : lane == 4 ? r3 : lane == 5 ? dm0 : dm1;
+    c.mask = m;
+}
+
 // One window of the optimal parser (oracle: optimum_window).  Returns with the chosen symbol path
-// stored as out-edges: node t -> (n_price[t] = back, out-len in n_info[t]); q_end = last node.
+// stored as out-edges: node t -> (n_price[t] = back, out-len in n_info[t]); q_end = last node to code
+// (a window cut by the node limit only commits the symbols that end WTAIL nodes before the cut).
+constexpr uint32_t WTAIL = 24;
 __device__ __forceinline__ bool optimum_window(const Env& e, const Work& w, ListPre& P, uint16_t* probs, const Lz& z, LenTab& lt,
         const uint8_t* __restrict__ in, uint32_t pos, uint32_t block_start, uint32_t span_end, bool cached,
         RoundL& RL, uint32_t& q_end)
@@ -1200,9 +1242,10 @@ __device__ __forceinline__ bool optimum_window(const Env& e, const Work& w, List
         w.n_info[0] = z.state << 9;
     }
     uint32_t n_end = 0, j = 0;
-    bool next_cached = false;
+    bool next_cached = false, forced = false;
     LitChunk lc;                          // lane = node - (j & ~63): the node's literal prices
     lc.v[0] = lc.v[1] = lc.v[2] = lc.v[3] = lc.v[4] = 0;
+    const uint32_t lmask = (0x100u << z.lp) - (0x100u >> z.lc);
     for (;;) {
         const uint32_t x = pos + j;
         uint32_t s, r0, r1, r2, r3, Pj;
@@ -1243,6 +1286,18 @@ __device__ __forceinline__ bool optimum_window(const Env& e, const Work& w, List
             }
         }
         const uint32_t room = WMAX - j;
+        const uint32_t avail = span_end - x;
+        const uint32_t buf_avail = avail < MATCH_LEN_MAX ? avail : MATCH_LEN_MAX;
+        // compound candidates: geometry now, prices after the plain edges
+        Compound cp;
+        compound_setup(RL, j, room, buf_avail, r0, r1, r2, r3, cp);
+        uint32_t cT_max = 0;
+        for (uint64_t mm = cp.mask; mm; mm &= mm - 1) cT_max = max(cT_max, lane_of(cp.T, (uint32_t)__builtin_ctzll(mm)));
+        // match byte of the literal behind a match candidate (lanes 5 / 6): the only load the compound
+        // literal prices need that the rep rows do not already hold
+        uint32_t c_mb = 0;
+        if (((cp.mask >> lane) & 1) && lane >= 5) c_mb = in[x + cp.L1 - cp.dist - 1];
+
         if (longest > room) longest = room;
         if (rl0 > room) rl0 = room;
         if (rl1 > room) rl1 = room;
@@ -1250,7 +1305,7 @@ __device__ __forceinline__ bool optimum_window(const Env& e, const Work& w, List
         if (rl3 > room) rl3 = room;
         const uint32_t rmax = max(max(rl0, rl1), max(rl2, rl3));
         const uint32_t reach = max(longest, rmax);
-        const uint32_t new_end = max(max(n_end, j + reach), j + 1);
+        const uint32_t new_end = max(max(max(n_end, j + reach), j + 1), cT_max);
         for (uint32_t tb = n_end + 1; tb <= new_end; tb += 64)
             if (tb + lane <= new_end) w.n_price[tb + lane] = PRICE_INF;
         n_end = new_end;
@@ -1261,11 +1316,41 @@ __device__ __forceinline__ bool optimum_window(const Env& e, const Work& w, List
         const uint32_t ci = s * 4 + ps;
         const uint32_t v01 = lane_of(c01, ci), v23 = lane_of(c23, ci), v45 = lane_of(c45, ci), v6 = lane_of(c6, ci);
         TM_END(w, 2, t_bits);
+
+        // compound literal prices: lane = candidate * 8 + bit (candidates 1..6), one gather of the eight
+        // probabilities each matched literal would use (literal_matched, lzma_encoder.c:23-41), issued
+        // here and summed after the plain edges
+        uint32_t cg_p = 0, cg_flip = 0;
+        const bool cg_any = (cp.mask & 0x7Eull) != 0;
+        if (cg_any) {
+            // bytes of the literal: cur / prev from the text row, match byte from the rep rows or c_mb
+            const uint32_t cl = lane < 7 ? cp.L1 : 0u;
+            const uint32_t cur_b = (uint32_t)__shfl((int)RL.cx, (int)cl);
+            const uint32_t prev_b = (uint32_t)__shfl((int)RL.cx, (int)(cl ? cl - 1 : 0));
+            const uint32_t m0b = (uint32_t)__shfl((int)RL.cr[0], (int)cl), m1b = (uint32_t)__shfl((int)RL.cr[1], (int)cl);
+            const uint32_t m2b = (uint32_t)__shfl((int)RL.cr[2], (int)cl), m3b = (uint32_t)__shfl((int)RL.cr[3], (int)cl);
+            const uint32_t mb_b = lane == 1 ? m0b : lane == 2 ? m1b : lane == 3 ? m2b : lane == 4 ? m3b : c_mb;
+            const uint32_t packed = cur_b | (mb_b << 8) | (prev_b << 16);
+            const uint32_t cand = lane >> 3, bit_i = lane & 7;
+            const uint32_t pk = (uint32_t)__shfl((int)packed, (int)cand);
+            const uint32_t cL = (uint32_t)__shfl((int)cp.L1, (int)cand);
+            const bool act = cand >= 1 && cand <= 6 && ((cp.mask >> cand) & 1);
+            const uint32_t cur = pk & 0xFFu, mb = (pk >> 8) & 0xFFu, prev = (pk >> 16) & 0xFFu;
+            const uint32_t up = upos + cL;
+            const uint32_t sub = 3u * ((((up << 8) + prev) & lmask) << z.lc);
+            const uint32_t pre = (0x100u | cur) >> (8 - bit_i);
+            const bool same = (mb >> (8 - bit_i)) == (cur >> (8 - bit_i));
+            const uint32_t idx = same ? 0x100u + (((mb >> (7 - bit_i)) & 1u) << 8) + pre : pre;
+            const uint32_t bit = (cur >> (7 - bit_i)) & 1u;
+            cg_flip = (0u - bit) & 0x7FFu;
+            if (act) cg_p = lit_load(z.lit + sub + idx);
+        }
+
         TM_BEGIN(t_lit);
         // literal and short rep -> node j+1
+        const uint32_t lp = lit_price(lc, j & 63, s, s < 7 ? 0u : uni(b_mb));
+        const uint32_t plit = Pj + (v01 & 0xFFFFu) + lp;
         {
-            const uint32_t lp = lit_price(lc, j & 63, s, s < 7 ? 0u : uni(b_mb));
-            const uint32_t plit = Pj + (v01 & 0xFFFFu) + lp;
             uint32_t best = uni(w.n_price[j + 1]), bb = 0, ns = 0;
             bool upd = false;
             if (plit < best) { best = plit; bb = LITERAL; upd = true; ns = s <= 3 ? 0 : (s <= 9 ? s - 3 : s - 6); }
@@ -1281,100 +1366,141 @@ __device__ __forceinline__ bool optimum_window(const Env& e, const Work& w, List
         }
         TM_END(w, 3, t_lit);
         TM_BEGIN(t_relax);
+        const uint32_t prep0 = Pj + (v23 & 0xFFFFu), prep1 = Pj + (v23 >> 16), prep2 = Pj + (v45 & 0xFFFFu), prep3 = Pj + (v45 >> 16);
+        const uint32_t pmatch = Pj + v6;
         if (reach >= 2) {
             relax_lengths(w, lt, ps & 3, RL.SL, RL.SD, j, reach, longest, RL.cnt, rl0, rl1, rl2, rl3,
-                    Pj + (v23 & 0xFFFFu), Pj + (v23 >> 16), Pj + (v45 & 0xFFFFu), Pj + (v45 >> 16), Pj + v6,
-                    s, r0, r1, r2, r3);
+                    prep0, prep1, prep2, prep3, pmatch, s, r0, r1, r2, r3);
             wave_sync();
         }
         TM_END(w, 4, t_relax);
+
+        if (cp.mask) {
+            // ---- price the compound candidates, lane = candidate ----
+            // length prices: LenTab holds length 2 + l + 64 * it in lane l (low half match, high half rep)
+            const uint32_t lo_ps = (ps & 3) == 0 ? lt.lo[0] : (ps & 3) == 1 ? lt.lo[1] : (ps & 3) == 2 ? lt.lo[2] : lt.lo[3];
+            const uint32_t i1 = lane < 7 && cp.L1 >= 2 ? cp.L1 - 2 : 0u;          // L1 <= 63: first pass of the table
+            const uint32_t t_lo = (uint32_t)__shfl((int)lo_ps, (int)(i1 & 63)), t_hi0 = (uint32_t)__shfl((int)lt.hi[0], (int)(i1 & 63));
+            const uint32_t lenX = i1 < 16 ? t_lo : t_hi0;                           // X's length price (match | rep << 16)
+            const uint32_t i2 = lane < 7 && cp.l2 >= 2 ? cp.l2 - 2 : 0u;            // l2 <= 127
+            const uint32_t psn = (upos + cp.L1 + 1) & pbm & 3;
+            const uint32_t u0 = (uint32_t)__shfl((int)lt.lo[0], (int)(i2 & 63)), u1 = (uint32_t)__shfl((int)lt.lo[1], (int)(i2 & 63));
+            const uint32_t u2 = (uint32_t)__shfl((int)lt.lo[2], (int)(i2 & 63)), u3 = (uint32_t)__shfl((int)lt.lo[3], (int)(i2 & 63));
+            const uint32_t h0v = (uint32_t)__shfl((int)lt.hi[0], (int)(i2 & 63)), h1v = (uint32_t)__shfl((int)lt.hi[1], (int)(i2 & 63));
+            const uint32_t ulo = psn == 0 ? u0 : psn == 1 ? u1 : psn == 2 ? u2 : u3;
+            const uint32_t len2p = (i2 < 16 ? ulo : i2 < 64 ? h0v : h1v) >> 16;     // rep length price of the rep0 run
+            // state chain: X -> literal -> long rep0
+            const bool isrep = lane >= 1 && lane <= 4;
+            const uint32_t sX = lane == 0 ? s : isrep ? (s < 7 ? 8u : 11u) : (s < 7 ? 7u : 10u);
+            const uint32_t sL = lane == 0 ? (s <= 3 ? 0u : (s <= 9 ? s - 3 : s - 6)) : isrep ? 5u : 4u;   // state after the literal
+            const uint32_t psl = (upos + cp.L1) & pbm & 3;
+            const uint32_t m0X = (uint32_t)__shfl((int)c01, (int)(sX * 4 + psl)) & 0xFFFFu;               // is_match = 0 before the literal
+            const uint32_t rafter = ((uint32_t)__shfl((int)c23, (int)(sL * 4 + psn)) & 0xFFFFu) + len2p;  // rep0 behind the literal
+            // price of X
+            uint32_t pX;
+            {
+                const uint32_t dist_m = cp.dist;
+                const uint32_t l = cp.L1;
+                const uint32_t ds = l < 6 ? (l >= 2 ? l - 2 : 0u) : 3u;
+                const uint32_t dnz = dist_m < 4 ? 4u : dist_m;
+                const uint32_t di = 31 - (uint32_t)__builtin_clz(dnz);
+                const uint32_t slot = dist_m < 4 ? dist_m : 2 * di + ((dnz >> (di - 1)) & 1);
+                const bool ism = lane == 5 || lane == 6;
+                const uint32_t p_dist = ism ? (uint32_t)w.dsp[ds * 64 + slot] + w.xt[dist_m < 128 ? dist_m : 128 + (dist_m & 15)] : 0u;
+                const uint32_t prep_i = lane == 1 ? prep0 : lane == 2 ? prep1 : lane == 3 ? prep2 : prep3;
+                pX = ism ? pmatch + (lenX & 0xFFFFu) + p_dist : prep_i + (lenX >> 16);
+            }
+            // matched-literal prices: sum the eight bit prices of each candidate's group of lanes
+            uint32_t litp = 0;
+            if (cg_any) {
+                uint32_t bp = w.ptab[(cg_p ^ cg_flip) >> 4];
+                const uint32_t cand = lane >> 3;
+                if (!(cand >= 1 && cand <= 6 && ((cp.mask >> cand) & 1))) bp = 0;
+                bp += (uint32_t)__shfl_xor((int)bp, 1);
+                bp += (uint32_t)__shfl_xor((int)bp, 2);
+                bp += (uint32_t)__shfl_xor((int)bp, 4);
+                litp = (uint32_t)__shfl((int)bp, (int)((lane < 7 ? lane : 0u) * 8));
+            }
+            const uint32_t cprice = lane == 0 ? plit + rafter : pX + m0X + litp + rafter;
+            // apply in candidate order (strict <, like every other edge)
+            for (uint64_t mm = cp.mask; mm; mm &= mm - 1) {
+                const uint32_t c = (uint32_t)__builtin_ctzll(mm);
+                const uint32_t T = lane_of(cp.T, c), pr = lane_of(cprice, c);
+                const uint32_t curp = uni(w.n_price[T]);
+                if (pr < curp) {
+                    const uint32_t cL = lane_of(cp.L1, c), cl2 = lane_of(cp.l2, c), cd = lane_of(cp.dist, c);
+                    const uint32_t kind = c == 0 ? 5u : c <= 4 ? c - 1 : 4u;
+                    uint4 nr;
+                    if (c == 0) nr = make_uint4(r0, r1, r2, r3);
+                    else if (c == 1) nr = make_uint4(r0, r1, r2, r3);
+                    else if (c == 2) nr = make_uint4(r1, r0, r2, r3);
+                    else if (c == 3) nr = make_uint4(r2, r0, r1, r3);
+                    else if (c == 4) nr = make_uint4(r3, r0, r1, r2);
+                    else nr = make_uint4(cd, r0, r1, r2);
+                    if (lane == 0) {
+                        w.n_price[T] = pr;
+                        w.n_info[T] = cL | (8u << 9) | (kind << 22) | (cl2 << 25);
+                        w.n_reps4[T] = nr;
+                    }
+                }
+                wave_sync();
+            }
+        }
         ++j;
-        if (j == n_end) break;
+        if (j == n_end) { forced = j >= WMAX; break; }
     }
     TM_BEGIN(t_back);
-    // backtrack from node j: turn in-edges into out-edges
+    // backtrack from node j: turn in-edges into out-edges.  A compound in-edge becomes three (two when
+    // X is empty) out-edges through its intermediate nodes.  `cut` = largest symbol boundary that lies
+    // at least WTAIL nodes before a forced window end, `first` = end of the first symbol.
     if (lane == 0) {
-        uint32_t t = j;
+        const uint32_t limit = j >= WTAIL ? j - WTAIL : 0;
+        uint32_t t = j, cut = 0, first = j;
         while (t > 0) {
             const uint32_t info = w.n_info[t];
-            const uint32_t ilen = info & 0x1FF, kind = (info >> 22) & 7;
+            const uint32_t ilen = info & 0x1FF, kind = (info >> 22) & 7, cl2 = info >> 25;
             const uint32_t bk = kind < 4 ? kind : kind == 4 ? w.n_reps4[t].x + 4 : LITERAL;
-            const uint32_t pv = t - ilen;
-            w.n_price[pv] = bk;
-            w.n_info[pv] = (w.n_info[pv] & 0x01C01FFFu) | (ilen << 13);     // keep in-len, state and in-edge kind of pv
+            const uint32_t pv = t - ilen - (cl2 ? 1 + cl2 : 0);
+            if (cut == 0 && t <= limit) cut = t;
+            first = t;
+            if (cl2) {
+                const uint32_t a = pv + ilen;                 // node of the literal, a + 1 = start of the rep0 run
+                w.n_price[a + 1] = 0;                          // rep0
+                w.n_info[a + 1] = cl2 << 13;
+                if (cut == 0 && a + 1 <= limit) cut = a + 1;
+                first = a + 1;
+                if (ilen) {
+                    w.n_price[a] = LITERAL;
+                    w.n_info[a] = 1u << 13;
+                    if (cut == 0 && a <= limit) cut = a;
+                    first = a;
+                    w.n_price[pv] = bk;
+                    w.n_info[pv] = (w.n_info[pv] & 0xFFC01FFFu) | (ilen << 13);
+                } else {
+                    w.n_price[pv] = LITERAL;                   // X empty: the literal leaves pv itself
+                    w.n_info[pv] = (w.n_info[pv] & 0xFFC01FFFu) | (1u << 13);
+                }
+            } else {
+                w.n_price[pv] = bk;
+                w.n_info[pv] = (w.n_info[pv] & 0xFFC01FFFu) | (ilen << 13);   // keep in-len, state, in-edge kind and len2 of pv
+            }
             t = pv;
         }
+        w.n_info[WMAX + 1] = (forced && pos + j < span_end) ? (cut ? cut : first) : j;   // spare word behind the node arrays
     }
     wave_sync();
+    q_end = uni(w.n_info[WMAX + 1]);
     TM_END(w, 5, t_back);
     TM_COUNT(w, 11);
-    q_end = j;
     return next_cached;
 }
 
-// optimum_fast over the LDS match list (oracle: optimum_fast()).  Returns `cached`.
-template <bool PARETO>
-__device__ __forceinline__ bool fast_parse_list(const Env& e, const Work& w, Pre& P, const Lz& z, uint32_t cur,
-        uint32_t span_end, bool cached, RoundL& RL, uint32_t& back, uint32_t& len)
-{
-    if (!cached) {
-        if constexpr (PARETO) do_round_pareto(e, w, P, cur, span_end, z.rep0, z.rep1, z.rep2, z.rep3, RL);
-    }
-    back = LITERAL; len = 1;
-    const uint32_t rem = span_end - cur;
-    const uint32_t buf_avail = rem < MATCH_LEN_MAX ? rem : MATCH_LEN_MAX;
-    uint32_t len_main = RL.longest;
-    uint32_t count = RL.cnt;
-    if (buf_avail < 2) return false;
-    uint32_t rep_len = 0, rep_index = 0;
-    for (uint32_t i = 0; i < 4; ++i) {
-        const uint32_t rl = lane_of(RL.L, 60 + i);
-        if (rl < 2) continue;
-        if (rl >= e.nice) { back = i; len = rl; return false; }
-        if (rl > rep_len) { rep_index = i; rep_len = rl; }
-    }
-    if (len_main >= e.nice) { back = lane_of(RL.SD, count - 1) + 4; len = len_main; return false; }
-    uint32_t back_main = 0;
-    if (len_main >= 2) {
-        back_main = lane_of(RL.SD, count - 1);
-        while (count > 1) {
-            const uint32_t l2 = lane_of(RL.SL, count - 2);
-            if (len_main != l2 + 1) break;
-            const uint32_t d2 = lane_of(RL.SD, count - 2);
-            if (!change_pair(d2, back_main)) break;
-            --count; len_main = l2; back_main = d2;
-        }
-        if (len_main == 2 && back_main >= 0x80) len_main = 1;
-    }
-    if (rep_len >= 2) {
-        if (rep_len + 1 >= len_main || (rep_len + 2 >= len_main && back_main > (1u << 9))
-                || (rep_len + 3 >= len_main && back_main > (1u << 15))) {
-            back = rep_index; len = rep_len;
-            return false;
-        }
-    }
-    if (len_main < 2 || buf_avail <= 2) return false;
-    if constexpr (PARETO) do_round_pareto(e, w, P, cur + 1, span_end, z.rep0, z.rep1, z.rep2, z.rep3, RL);
-    const uint32_t nl = RL.longest;
-    if (nl >= 2) {
-        const uint32_t new_dist = lane_of(RL.SD, RL.cnt - 1);
-        if ((nl >= len_main && new_dist < back_main) || (nl == len_main + 1 && !change_pair(back_main, new_dist))
-                || (nl > len_main + 1) || (nl + 1 >= len_main && len_main >= 3 && change_pair(new_dist, back_main)))
-            return true;
-    }
-    const uint32_t limit = len_main - 1 > 2 ? len_main - 1 : 2;
-    for (uint32_t i = 0; i < 4; ++i)
-        if (lane_of(RL.L, 60 + i) >= limit) return true;
-    back = back_main + 4;
-    len = len_main;
-    return false;
-}
-
 // ------------------------------------------------------------------------------------------
-// Span encoder: one wavefront per span.  PARETO selects the match finder (false = exact HC3/HC4
-// of the reference), OPT the parser (false = optimum_fast of the reference).
+// Span encoder: one wavefront per span.  FINDER 0 = exact HC3/HC4 of the reference evaluated inside
+// the kernel (fast parser), 2 = per-position match lists written by k_find_sn / k_find_exact;
+// OPT selects the parser (false = optimum_fast of the reference).
 // ------------------------------------------------------------------------------------------
-template <int FINDER, bool OPT>      // FINDER: 0 = exact HC3/HC4 in-kernel, 1 = HC4+H8 in-kernel, 2 = lists from k_find_t
+template <int FINDER, bool OPT>      // FINDER: 0 = exact HC3/HC4 in-kernel, 2 = lists from the batch finders
 #ifndef XZAMD_WAVES_FAST
 #define XZAMD_WAVES_FAST 4
 #endif
@@ -1385,7 +1511,6 @@ __global__ __launch_bounds__(64)
 __attribute__((amdgpu_waves_per_eu(OPT ? XZAMD_WAVES_OPT : XZAMD_WAVES_FAST, OPT ? XZAMD_WAVES_OPT : XZAMD_WAVES_FAST)))
 void k_span_encode_t(xzamd_span_args a)
 {
-    constexpr bool PARETO = FINDER == 1;
     constexpr bool LISTS = FINDER == 2;
     static_assert(!LISTS || OPT, "the fast parsers run with the in-kernel finders");
     // One LDS pool, carved by hand (a single __shared__ object: no aliasing or ordering surprises).
@@ -1419,15 +1544,14 @@ void k_span_encode_t(xzamd_span_args a)
 
     Env e;
     e.in = in; e.rank = a.rank; e.sorted_pos = a.sorted_pos; e.prev2 = a.prev2; e.prev3 = a.prev3;
-    e.rank8 = a.rank8; e.sorted8 = a.sorted8;
     e.nice = a.nice_len; e.depth = a.depth; e.hb = a.hash_bytes; e.cyclic = a.dict_size + 1;
-    e.depth2 = a.depth2; e.block_end = block_end; e.n_last = a.n - 1;
-    e.mlen = a.mlen; e.mdist = a.mdist; e.mcnt = a.mcnt; e.packed = a.list_packed;
+    e.block_end = block_end; e.n_last = a.n - 1;
+    e.mlen = a.mlen; e.mdist = a.mdist; e.packed = a.list_packed;
     ListPre LP;
-    LP.valid = false; LP.pos = 0; LP.sl = LP.sd = LP.cnt = 0;
+    LP.valid = false; LP.pos = 0; LP.sl = LP.sd = LP.tr = 0;
     Pre P;
     P.valid = false; P.pos = 0; P.ent = 0;
-    P.a.rk = P.a.d2 = P.a.d3 = P.a.rk8 = 0; P.an = P.a;
+    P.a.rk = P.a.d2 = P.a.d3 = 0; P.an = P.a;
 
     Work w{};
     if constexpr (OPT) {
@@ -1474,8 +1598,10 @@ void k_span_encode_t(xzamd_span_args a)
     Round R;            // exact path: cached find at `cur` when read_ahead == 1
     R.mask = 0; R.L = 0; R.D = 0; R.longest = 0;
     RoundL RL;
-    RL.L = 0; RL.SL = 0; RL.SD = 0; RL.cnt = 0; RL.longest = 0;
+    RL.L = 0; RL.SL = 0; RL.SD = 0; RL.cnt = 0; RL.longest = 0; RL.l2a = RL.l2b = 0; RL.cx = 0;
     RL.rp[0] = RL.rp[1] = RL.rp[2] = RL.rp[3] = 0;
+    RL.rm[0] = RL.rm[1] = RL.rm[2] = RL.rm[3] = 0;
+    RL.cr[0] = RL.cr[1] = RL.cr[2] = RL.cr[3] = 0;
     LenTab lt;
     uint32_t q_pos = 0, q_end = 0;  // pending path of the optimal parser (nodes in LDS)
     bool tables_valid = false;
@@ -1568,8 +1694,6 @@ void k_span_encode_t(xzamd_span_args a)
                     len = (uni(w.n_info[q_pos]) >> 13) & 0x1FF;
                     q_pos += len;
                 }
-            } else if constexpr (PARETO) {
-                cached = fast_parse_list<true>(e, w, P, z, cur, span_end, cached, RL, back, len);
             } else {
             // ---------------- lzma_lzma_optimum_fast (optimum_fast.c:20-169) ----------------
 #ifdef XZAMD_TIMING
@@ -1713,9 +1837,8 @@ void k_span_encode_t(xzamd_span_args a)
             // lzma2_encoder.c:205-214: store the chunk raw.  Fast parser: including the lookahead
             // byte; optimal parser: pending symbols are dropped and re-parsed after the reset.
             if constexpr (!OPT) {
-                const uint32_t ra = (PARETO ? (cached ? 1u : 0u) : read_ahead);
-                usize += ra;
-                cur += ra;
+                usize += read_ahead;
+                cur += read_ahead;
             }
             read_ahead = 0;
             cached = false;
@@ -1769,66 +1892,18 @@ void k_span_encode_t(xzamd_span_args a)
 }
 
 // ------------------------------------------------------------------------------------------
-// HC4+H8 finder, batch form (oracle: find_pareto + the LIST_K truncation of do_round).  Same lane
-// roles as do_round_pareto, but the Pareto filter is a sort instead of loops over candidates: the
-// scalar unit (one per CU, shared by all waves) is what the loop form saturates.
-//   key  = (distance-1) << 6 | lane          unique; invalid lanes get the largest keys
-//   rank = number of smaller keys: the 8-byte chain is already sorted (distances ascend along a
-//          chain), so a chain lane only counts the <= 10 hash2/hash3/4-byte-chain keys below it
-//          and one of those binary-searches the chain;
-//   one ds_permute puts (length, distance) in key order, a DPP max-scan finds the entries longer
-//   than everything closer, and the survivors are stored straight from their lanes.
+// Batch match finders: one wavefront per run of FIND_RUN consecutive positions.  Because find and
+// skip both insert (lz_encoder_mf.c:366-441), the matches of a position depend on the data only, so
+// they are computed for every position of the batch ahead of the (serial) parser, which streams
+// them.  Per position one 32-byte record: LIST_K entries sorted by length (length << 23 | distance-1
+// when the dictionary is <= 8 MiB, else distance-1 with the lengths in a u16 side array), the > nice_len
+// extension folded into the last one, and a trailer word
+//     count | len2(longest) << 8 | len2(second longest) << 16
+// where len2 = length of the rep0 run behind the byte that follows the match (the "match + literal +
+// rep0" edge of the parser, lzma_encoder_optimum_normal.c:728-790).
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t prefix_max_dpp(uint32_t v)
-{
-    // Hillis-Steele inside each row of 16 lanes, then the row totals (gfx9 row_bcast)
-    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false));   // row_shr:1
-    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, false));   // row_shr:2
-    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, false));   // row_shr:4
-    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, false));   // row_shr:8
-    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false));   // row_bcast:15 -> rows 1, 3
-    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false));   // row_bcast:31 -> rows 2, 3
-    return v;
-}
-
-// candidate of this lane at position x (lane roles as in do_round_pareto)
-struct Cand {
-    uint32_t q;          // candidate position (valid lanes)
-    uint32_t minlen;     // 2 / 3 / 4
-    bool valid;
-    uint32_t len_limit, buf_avail;     // uniform
-    bool mf_ok;                        // uniform: false = "pending", nothing is reported
-};
-
-__device__ __forceinline__ void cand_setup(const Env& e, Pre& P, uint32_t x, uint32_t end, Cand& c)
-{
-    PreA pa;
-    uint32_t pent;
-    fetch<true>(e, P, x, pa, pent);
-    const uint32_t lane = threadIdx.x;
-    const uint32_t avail = end - x;
-    c.buf_avail = avail < MATCH_LEN_MAX ? avail : MATCH_LEN_MAX;
-    c.len_limit = avail;
-    c.mf_ok = true;
-    if (e.nice <= c.len_limit) c.len_limit = e.nice;
-    else if (c.len_limit < 4) c.mf_ok = false;
-    const uint32_t d4 = e.depth, d8 = e.depth2, A = 3 + d4;
-    const uint32_t d2 = pa.d2, d3 = pa.d3;
-    const bool have8 = e.block_end - x >= 8;
-    const bool in4 = lane >= 2 && lane <= 2 + d4;
-    const bool in8 = have8 && lane >= A && lane <= A + d8;
-    const uint32_t ent = (!have8 && lane >= A) ? 0x80000000u : pent;
-    const uint64_t fl = __ballot((in4 || in8) && (ent >> 31));
-    const uint32_t qp = ent & 0x7FFFFFFFu;
-    const uint32_t jj = in4 ? lane - 2 : lane - A;                 // candidate number inside its chain
-    const uint64_t before = (in4 ? fl >> 2 : fl >> A) & ((1ull << (jj & 63)) - 1);
-    const bool chain_ok = (in4 || in8) && jj >= 1 && before == 0 && x - qp < e.cyclic;
-    const bool ok2 = lane == 0 && d2 != 0 && d2 < e.cyclic;
-    const bool ok3 = lane == 1 && d3 != 0 && d3 != d2 && d3 < e.cyclic;
-    c.valid = c.mf_ok && (chain_ok || ok2 || ok3);
-    c.q = lane == 0 ? x - d2 : lane == 1 ? x - d3 : qp;
-    c.minlen = lane == 0 ? 2u : lane == 1 ? 3u : 4u;
-}
+constexpr uint32_t FIND_RUN = 256;
+constexpr uint32_t LEN2_MAX = 127;
 
 // bytes matched inside one 16-byte trip (16 = all)
 __device__ __forceinline__ uint32_t match16(const uint4& a, const uint4& b)
@@ -1855,94 +1930,172 @@ __device__ __forceinline__ uint32_t lane_cmplen16_from(const uint8_t* __restrict
     return len;
 }
 
-// Pareto filter + store for one position, given every lane's match length L
-__device__ __forceinline__ void pareto_finish(const Env& e, uint32_t x, const Cand& c, uint32_t L,
-        uint16_t* __restrict__ mlen, uint32_t* __restrict__ mdist, uint8_t* __restrict__ mcnt)
+// inclusive prefix maximum inside each half (32 lanes) of the wavefront
+__device__ __forceinline__ uint32_t prefix_max_half(uint32_t v)
+{
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false));   // row_shr:1
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, false));   // row_shr:2
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, false));   // row_shr:4
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, false));   // row_shr:8
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false));   // row_bcast:15 -> rows 1, 3
+    return v;
+}
+
+struct SnArgs {
+    const uint8_t* __restrict__ in;
+    const uint32_t* __restrict__ sa;        // slot -> position (Block-major: the slots of a Block are its positions' range)
+    const uint32_t* __restrict__ sa_rank;   // position -> slot
+    const uint32_t* __restrict__ prev2;
+    const uint32_t* __restrict__ prev3;
+    const uint32_t* __restrict__ prev4;
+    const uint32_t* __restrict__ prev8;
+};
+
+// Suffix-neighbourhood finder (oracle: find_sn).  Lane roles for one position x with slot r:
+//   lanes  0..29   slots r-1 .. r-30   (left neighbours, nearest first)
+//   lanes 32..61   slots r+1 .. r+30   (right neighbours, nearest first)
+//   lane 30 / 31 / 62 / 63   nearest previous position with equal hash2 / hash3 / hash4 / 8-byte hash
+// A neighbour is eligible when it lies earlier in the same Block and inside the dictionary; it is a
+// candidate when it is more recent than every eligible neighbour nearer on its side ("recency
+// record": exactly the nodes BT4's descent would visit).  All candidates are compared with the text
+// at x in parallel (16 bytes per trip), filtered by the Pareto rule and stored sorted by length.
+__global__ __launch_bounds__(64) void k_find_sn(xzamd_span_args a, SnArgs sn, uint16_t* __restrict__ mlen,
+        uint32_t* __restrict__ mdist)
 {
     const uint32_t lane = threadIdx.x;
-    if (!c.mf_ok) {
-        if (lane == 0) mcnt[x] = 0;
-        return;
-    }
-    const uint32_t d4 = e.depth, d8 = e.depth2, A = 3 + d4;
-    const bool valid = c.valid;
-    const uint32_t Le = (valid && L >= c.minlen) ? L : 0u;
-    const uint32_t dist1 = x - c.q - 1;
-    const uint32_t key = valid ? ((dist1 << 6) | lane) : (0xFFFFFFC0u | lane);
-
-    // how many hash2 / hash3 / 4-byte-chain keys are smaller than mine
-    uint32_t cs = 0;
-    cs += lane_of(key, 0) < key ? 1u : 0u;
-    cs += lane_of(key, 1) < key ? 1u : 0u;
-    for (uint32_t sidx = 3; sidx <= 2 + d4; ++sidx) cs += lane_of(key, sidx) < key ? 1u : 0u;
-    // how many 8-byte-chain keys are smaller than mine (binary search over the sorted chain lanes)
-    const bool is8 = lane > A && lane <= A + d8;
-    const uint32_t n8 = (uint32_t)__builtin_popcountll(__ballot(is8 && valid));
-    uint32_t lo = 0, hi = n8;
-#pragma unroll
-    for (int it = 0; it < 6; ++it) {
-        const uint32_t mid = (lo + hi) >> 1;
-        const uint32_t km = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((A + 1 + mid) << 2), (int)key);
-        const bool act = lo < hi, lt = km < key;
-        lo = (act && lt) ? mid + 1 : lo;
-        hi = (act && !lt) ? mid : hi;
-    }
-    const uint32_t rank = !valid ? 63u : is8 ? (lane - (A + 1)) + cs : cs + lo;
-    const uint32_t n = (uint32_t)__builtin_popcountll(__ballot(valid));
-    uint32_t sL = lane_scatter(rank, Le);
-    const uint32_t sD = lane_scatter(rank, dist1);
-    sL = lane < n ? sL : 0u;
-    const uint32_t pm = prefix_max_dpp(sL);
-    uint32_t excl = (uint32_t)__shfl_up((int)pm, 1);
-    excl = lane == 0 ? 0u : excl;
-    const bool keep = sL > excl;
-    const uint64_t kmask = __ballot(keep);
-    const uint32_t cnt = (uint32_t)__builtin_popcountll(kmask);
-    if (cnt == 0) {
-        if (lane == 0) mcnt[x] = 0;
-        return;
-    }
-    const uint32_t top = 63 - (uint32_t)__builtin_clzll(kmask);
-    uint32_t longest = lane_of(sL, top);
-    if (longest == e.nice) {
-        const uint32_t dd = lane_of(sD, top);
-        longest = wave_cmplen(e.in, x, x - dd - 1, longest, c.buf_avail);
-    }
-    const uint32_t idx = __builtin_amdgcn_mbcnt_hi((uint32_t)(kmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)kmask, 0u));
-    const uint32_t drop = cnt > LIST_K ? cnt - LIST_K : 0;
-    if (keep && idx >= drop) {
-        const uint64_t o = (uint64_t)x * LIST_K + (idx - drop);
-        const uint32_t len = lane == top ? longest : sL;
-        if (e.packed) {
-            mdist[o] = (len << 23) | sD;
-        } else {
-            mlen[o] = (uint16_t)len;
-            mdist[o] = sD;
+    const uint32_t x0 = blockIdx.x * FIND_RUN;
+    if (x0 >= a.n) return;
+    const uint32_t x1 = min(a.n, x0 + FIND_RUN);
+    const uint8_t* __restrict__ in = sn.in;
+    const uint32_t W = a.sa_window;
+    const uint32_t cyclic = a.dict_size + 1;
+    const uint32_t nice = a.nice_len;
+    const uint32_t half = lane >> 5, k = lane & 31;
+    const bool win_lane = k < W;
+    uint32_t span_end = 0, block_start = 0, block_end = 0;
+    uint32_t RK = 0, P2 = 0, P3 = 0, P4 = 0, P8 = 0;     // lane = position - chunk start: per-position words of 64 positions
+    uint32_t wq_next = 0;                                 // this lane's neighbour for the NEXT position (prefetched)
+    bool pre_valid = false;
+    for (uint32_t x = x0; x < x1; ++x) {
+        const uint32_t i = (x - x0) & 63;
+        if (i == 0) {
+            const uint32_t xl = min(x + lane, a.n - 1);
+            RK = sn.sa_rank[xl]; P2 = sn.prev2[xl]; P3 = sn.prev3[xl]; P4 = sn.prev4[xl]; P8 = sn.prev8[xl];
         }
+        if (x >= span_end) {
+            const uint32_t blk = x / a.block_size;
+            block_start = blk * a.block_size;
+            block_end = min(a.n, block_start + a.block_size);
+            const uint64_t kk = (x - block_start) / a.span_size;
+            const uint64_t se = (uint64_t)block_start + (kk + 1) * a.span_size;
+            span_end = se < block_end ? (uint32_t)se : block_end;
+        }
+        // this lane's neighbour slot (the slots of a Block are exactly its positions' range)
+        const uint32_t r = lane_of(RK, i);
+        const int32_t slot = half ? (int32_t)(r + 1 + k) : (int32_t)r - 1 - (int32_t)k;
+        const bool inb = win_lane && slot >= (int32_t)block_start && slot < (int32_t)block_end;
+        uint32_t q = wq_next;
+        if (!pre_valid) q = inb ? sn.sa[slot] : 0u;
+        // prefetch the neighbours of x + 1 while x is being compared (its rank is in RK unless a new chunk starts)
+        pre_valid = i != 63 && x + 1 < x1;
+        if (pre_valid) {
+            const bool nb = x + 1 == block_end;                                  // x + 1 opens the next Block
+            const uint32_t bs2 = nb ? block_end : block_start;
+            const uint32_t be2 = nb ? min(a.n, block_end + a.block_size) : block_end;
+            const uint32_t rn = lane_of(RK, i + 1);
+            const int32_t sl2 = half ? (int32_t)(rn + 1 + k) : (int32_t)rn - 1 - (int32_t)k;
+            const bool ok2 = win_lane && sl2 >= (int32_t)bs2 && sl2 < (int32_t)be2;
+            wq_next = ok2 ? sn.sa[sl2] : 0u;
+        }
+        const uint32_t avail = span_end - x;
+        const uint32_t buf_avail = avail < MATCH_LEN_MAX ? avail : MATCH_LEN_MAX;
+        uint32_t len_limit = avail;
+        bool mf_ok = true;
+        if (nice <= len_limit) len_limit = nice;
+        else if (len_limit < 4) mf_ok = false;            // "pending": nothing is reported (lz_encoder_mf.c:190-201)
+        const uint64_t rec_base = (uint64_t)x * LIST_W;
+        if (!mf_ok) {
+            if (lane == 0) mdist[rec_base + LIST_K] = 0;
+            continue;
+        }
+        // recency records of both sides
+        const bool elig = inb && q < x && x - q < cyclic;
+        const uint32_t v = elig ? q + 1 : 0u;
+        const uint32_t pm = prefix_max_half(v);
+        uint32_t ex = (uint32_t)__shfl_up((int)pm, 1);
+        ex = k == 0 ? 0u : ex;
+        bool valid = elig && v > ex;
+        uint32_t minlen = 4;
+        // the four hash candidates sit in the lanes the windows never use
+        {
+            const uint32_t d2 = lane_of(P2, i), d3 = lane_of(P3, i), d4 = lane_of(P4, i), d8 = lane_of(P8, i);
+            const uint32_t dh = lane == 30 ? d2 : lane == 31 ? d3 : lane == 62 ? d4 : d8;
+            if (k >= 30) {
+                valid = dh != 0 && dh < cyclic;
+                q = x - dh;
+                minlen = lane == 30 ? 2u : lane == 31 ? 3u : 4u;
+            }
+        }
+        const uint32_t L = lane_cmplen16_from(in, valid ? q : 0u, x, 0, valid ? len_limit : 0u);
+        const bool ok = valid && L >= minlen;
+        const uint32_t dist = x - q;                        // delta >= 1 on ok lanes
+        // Pareto set: drop a candidate when another one is closer and at least as long (duplicates: the
+        // lower lane stays)
+        bool dom = false;
+        for (uint64_t mm = __ballot(ok); mm; mm &= mm - 1) {
+            const uint32_t jl = (uint32_t)__builtin_ctzll(mm);
+            const uint32_t dj = lane_of(dist, jl), Lj = lane_of(L, jl);
+            dom = dom || (dj < dist && Lj >= L) || (dj == dist && jl < lane);
+        }
+        const bool keep = ok && !dom;
+        const uint64_t kmask = __ballot(keep);
+        const uint32_t cnt = (uint32_t)__builtin_popcountll(kmask);
+        if (cnt == 0) {
+            if (lane == 0) mdist[rec_base + LIST_K] = 0;
+            continue;
+        }
+        // kept entries have distinct lengths, increasing with distance: rank by length
+        uint32_t rk = 0;
+        for (uint64_t mm = kmask; mm; mm &= mm - 1) {
+            const uint32_t kl = (uint32_t)__builtin_ctzll(mm);
+            rk += lane_of(L, kl) < L ? 1u : 0u;
+        }
+        const uint64_t topm = __ballot(keep && rk + 1 == cnt);
+        const uint32_t top = (uint32_t)__builtin_ctzll(topm);
+        uint32_t longest = lane_of(L, top);
+        if (longest == nice)
+            longest = wave_cmplen(in, x, x - lane_of(dist, top), longest, buf_avail);
+        const uint32_t len_out = lane == top ? longest : L;
+        // rep0 run behind the byte after the match, for the two longest entries
+        uint32_t l2 = 0;
+        if (keep && rk + 2 >= cnt && len_out + 1 < avail) {
+            const uint32_t lim = min(avail, len_out + 1 + LEN2_MAX);
+            l2 = lane_cmplen16_from(in, q, x, len_out + 1, lim) - (len_out + 1);
+        }
+        const uint32_t l2a = lane_of(l2, top);
+        uint32_t l2b = 0;
+        if (cnt >= 2) {
+            const uint64_t secm = __ballot(keep && rk + 2 == cnt);
+            l2b = lane_of(l2, (uint32_t)__builtin_ctzll(secm));
+        }
+        const uint32_t drop = cnt > LIST_K ? cnt - LIST_K : 0;
+        if (keep && rk >= drop) {
+            const uint64_t o = rec_base + (rk - drop);
+            if (a.list_packed) {
+                mdist[o] = (len_out << 23) | (dist - 1);
+            } else {
+                mlen[o] = (uint16_t)len_out;
+                mdist[o] = dist - 1;
+            }
+        }
+        if (lane == top) mdist[rec_base + LIST_K] = (cnt - drop) | (l2a << 8) | (l2b << 16);
     }
-    if (lane == 0) mcnt[x] = (uint8_t)(cnt - drop);
 }
 
-__device__ __forceinline__ void find_pareto_store(const Env& e, Pre& P, uint32_t x, uint32_t end,
-        uint16_t* __restrict__ mlen, uint32_t* __restrict__ mdist, uint8_t* __restrict__ mcnt)
-{
-    Cand c;
-    cand_setup(e, P, x, end, c);
-    const uint32_t L = lane_cmplen16_from(e.in, c.valid ? c.q : 0u, x, 0, c.valid ? c.len_limit : 0u);
-    pareto_finish(e, x, c, L, mlen, mdist, mcnt);
-}
-
-// ------------------------------------------------------------------------------------------
-// Batch match finder: one wavefront per run of FIND_RUN consecutive positions, lanes = candidates
-// (the same round as above, without the rep lanes).  Writes, per position, the kept matches sorted
-// by length -- at most the LIST_K longest -- with the > nice_len extension folded into the last one.
-// No LDS, no dependence between runs: occupancy is bounded by registers only.
-// ------------------------------------------------------------------------------------------
-constexpr uint32_t FIND_RUN = 256;
-
-template <bool PARETO>
-__global__ __launch_bounds__(64) void k_find_t(xzamd_span_args a, uint16_t* __restrict__ mlen,
-        uint32_t* __restrict__ mdist, uint8_t* __restrict__ mcnt)
+// Exact HC3/HC4 finder in list form (optimal parser over the reference's match finder; test
+// configuration).  Same record layout, len2 = 0.
+__global__ __launch_bounds__(64) void k_find_exact(xzamd_span_args a, uint16_t* __restrict__ mlen,
+        uint32_t* __restrict__ mdist)
 {
     const uint32_t lane = threadIdx.x;
     const uint32_t x0 = blockIdx.x * FIND_RUN;
@@ -1950,14 +2103,12 @@ __global__ __launch_bounds__(64) void k_find_t(xzamd_span_args a, uint16_t* __re
     const uint32_t x1 = min(a.n, x0 + FIND_RUN);
     Env e;
     e.in = a.in; e.rank = a.rank; e.sorted_pos = a.sorted_pos; e.prev2 = a.prev2; e.prev3 = a.prev3;
-    e.rank8 = a.rank8; e.sorted8 = a.sorted8;
     e.nice = a.nice_len; e.depth = a.depth; e.hb = a.hash_bytes; e.cyclic = a.dict_size + 1;
-    e.depth2 = a.depth2; e.block_end = 0; e.n_last = a.n - 1;
-    e.mlen = nullptr; e.mdist = nullptr; e.mcnt = nullptr; e.packed = a.list_packed;
+    e.block_end = 0; e.n_last = a.n - 1;
+    e.mlen = nullptr; e.mdist = nullptr; e.packed = a.list_packed;
     Pre P;
     P.valid = false; P.pos = 0; P.ent = 0;
-    P.a.rk = P.a.d2 = P.a.d3 = P.a.rk8 = 0; P.an = P.a;
-    Work w{};
+    P.a.rk = P.a.d2 = P.a.d3 = 0; P.an = P.a;
     uint32_t span_end = 0;
     for (uint32_t x = x0; x < x1; ++x) {
         if (x >= span_end) {
@@ -1969,31 +2120,25 @@ __global__ __launch_bounds__(64) void k_find_t(xzamd_span_args a, uint16_t* __re
             span_end = se < block_end ? (uint32_t)se : block_end;
             e.block_end = block_end;
         }
-        if constexpr (PARETO) {
-            find_pareto_store(e, P, x, span_end, mlen, mdist, mcnt);
-            continue;
-        }
-        RoundL RL;
-        RL.SL = 0; RL.SD = 0;
-        {
-            Round R;
-            do_round<false>(e, P, x, span_end, 0, 0, 0, 0, R);
-            list_from_mask(w, R, RL);
-        }
-        const uint32_t cnt = RL.cnt;
+        Round R;
+        do_round<false>(e, P, x, span_end, 0, 0, 0, 0, R);
+        const uint64_t lt = (1ull << lane) - 1;
+        const bool rec = (R.mask >> lane) & 1;
+        const uint32_t idx = (uint32_t)__builtin_popcountll(R.mask & lt);
+        const uint32_t cnt = (uint32_t)__builtin_popcountll(R.mask);
         const uint32_t drop = cnt > LIST_K ? cnt - LIST_K : 0;
-        uint32_t len = RL.SL;
-        if (lane + 1 == cnt) len = RL.longest;
-        if (lane >= drop && lane < cnt) {
-            const uint64_t o = (uint64_t)x * LIST_K + (lane - drop);
+        const uint64_t rec_base = (uint64_t)x * LIST_W;
+        if (rec && idx >= drop) {
+            const uint32_t len = idx + 1 == cnt ? R.longest : R.L;
+            const uint64_t o = rec_base + (idx - drop);
             if (e.packed) {
-                mdist[o] = (len << 23) | RL.SD;
+                mdist[o] = (len << 23) | R.D;
             } else {
                 mlen[o] = (uint16_t)len;
-                mdist[o] = RL.SD;
+                mdist[o] = R.D;
             }
         }
-        if (lane == 0) mcnt[x] = (uint8_t)(cnt - drop);
+        if (lane == 0) mdist[rec_base + LIST_K] = cnt - drop;
     }
 }
 
@@ -2242,13 +2387,45 @@ int xzk_sort_temp_bytes(uint32_t n, uint32_t end_bit, uint64_t* bytes)
     return (int)e;
 }
 
-// Builds rank/sorted_pos/prev2/prev3 for a batch.  keys_a/keys_b/vals_a/vals_b: n u32 each.
+// temporary storage the suffix-order build needs (largest of its three primitives)
+int xzk_sa_temp_bytes(uint32_t n, uint64_t* bytes)
+{
+    size_t best = 0, sz = 0;
+    {
+        rocprim::double_buffer<uint64_t> k(nullptr, nullptr);
+        rocprim::double_buffer<uint32_t> v(nullptr, nullptr);
+        hipError_t e = rocprim::radix_sort_pairs(nullptr, sz, k, v, (size_t)n, 0u, 64u, (hipStream_t)0);
+        if (e != hipSuccess) return (int)e;
+        best = sz > best ? sz : best;
+    }
+    {
+        rocprim::double_buffer<uint32_t> k(nullptr, nullptr);
+        rocprim::double_buffer<uint64_t> v(nullptr, nullptr);
+        hipError_t e = rocprim::radix_sort_pairs(nullptr, sz, k, v, (size_t)n, 0u, 32u, (hipStream_t)0);
+        if (e != hipSuccess) return (int)e;
+        best = sz > best ? sz : best;
+    }
+    {
+        hipError_t e = rocprim::inclusive_scan(nullptr, sz, (uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)n,
+                rocprim::maximum<uint32_t>(), (hipStream_t)0);
+        if (e != hipSuccess) return (int)e;
+        best = sz > best ? sz : best;
+    }
+    *bytes = best;
+    return 0;
+}
+
+// Builds the match-finder structure of a batch.
+//   exact finder (sa == NULL):   rank / sorted_pos (main chain), prev2, prev3
+//   suffix-neighbourhood finder: prev2, prev3, prev4, prev8 and the suffix order sa / sa_rank
+// keys_a/keys_b/vals_a/vals_b: n u32 each; key64_a/key64_b: n u64 each (sa != NULL only).
 int xzk_build_chains(const uint8_t* d_in, uint32_t n, uint32_t block_size, uint32_t nblocks,
         uint32_t hash_bytes, uint32_t hash_mask, uint32_t hash_bits,
         uint32_t* keys_a, uint32_t* keys_b, uint32_t* vals_a, uint32_t* vals_b,
         void* sort_tmp, uint64_t sort_tmp_bytes,
         uint32_t* rank, uint32_t* sorted_pos, uint32_t* prev2, uint32_t* prev3,
-        uint32_t* rank8, uint32_t* sorted8, void* stream_)
+        uint32_t* prev4, uint32_t* prev8, uint64_t* key64_a, uint64_t* key64_b,
+        uint32_t* sa, uint32_t* sa_rank, void* stream_)
 {
     hipStream_t st = (hipStream_t)stream_;
     const uint32_t g = grid_for(n, 256, 256 * 16);
@@ -2259,7 +2436,7 @@ int xzk_build_chains(const uint8_t* d_in, uint32_t n, uint32_t block_size, uint3
     for (int w = 0; w < 4; ++w) {
         const uint32_t which = which_list[w];
         if (which == 3 && hash_bytes != 4) continue;
-        if (which == 8 && rank8 == nullptr) continue;
+        if (which == 8 && sa == nullptr) continue;
         const uint32_t kbits = which == 2 ? 10u : (which == 3 ? 16u : (which == 8 ? H8_BITS_K : hash_bits));
         hipLaunchKernelGGL(k_hash_keys, dim3(g), dim3(256), 0, st, d_in, n, block_size, nblocks, hash_bytes,
                 hash_mask, hash_bits, which, keys_a, vals_a);
@@ -2276,22 +2453,89 @@ int xzk_build_chains(const uint8_t* d_in, uint32_t n, uint32_t block_size, uint3
         else if (which == 3)
             hipLaunchKernelGGL(k_link_prev, dim3(g), dim3(256), 0, st, kb.current(), vb.current(), n, prev3);
         else if (which == 8)
-            hipLaunchKernelGGL(k_link_main, dim3(g), dim3(256), 0, st, kb.current(), vb.current(), n, sorted8, rank8);
+            hipLaunchKernelGGL(k_link_prev, dim3(g), dim3(256), 0, st, kb.current(), vb.current(), n, prev8);
+        else if (sa != nullptr)
+            hipLaunchKernelGGL(k_link_prev, dim3(g), dim3(256), 0, st, kb.current(), vb.current(), n, prev4);
         else
             hipLaunchKernelGGL(k_link_main, dim3(g), dim3(256), 0, st, kb.current(), vb.current(), n, sorted_pos, rank);
     }
+    if (sa == nullptr) return (int)hipGetLastError();
+
+    // ---- suffix order ----
+    uint32_t* grp = keys_a;                       // group-start scan buffer (the hash sorts above are done with it)
+    hipError_t e;
+    size_t need = 0;
+    // round 0: chunk sort
+    hipLaunchKernelGGL(k_sa_chunk_keys, dim3(g), dim3(256), 0, st, d_in, n, block_size, key64_a, vals_a);
+    rocprim::double_buffer<uint64_t> k64(key64_a, key64_b);
+    rocprim::double_buffer<uint32_t> pv(vals_a, vals_b);
+    e = rocprim::radix_sort_pairs(nullptr, need, k64, pv, (size_t)n, 0u, 64u, st);
+    if (e != hipSuccess) return (int)e;
+    if (need > tb) return (int)hipErrorOutOfMemory;
+    e = rocprim::radix_sort_pairs(sort_tmp, tb, k64, pv, (size_t)n, 0u, 64u, st);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(k_sa_flags64, dim3(g), dim3(256), 0, st, k64.current(), n, grp);
+    e = rocprim::inclusive_scan(nullptr, need, grp, grp, (size_t)n, rocprim::maximum<uint32_t>(), st);
+    if (e != hipSuccess) return (int)e;
+    if (need > tb) return (int)hipErrorOutOfMemory;
+    e = rocprim::inclusive_scan(sort_tmp, tb, grp, grp, (size_t)n, rocprim::maximum<uint32_t>(), st);
+    if (e != hipSuccess) return (int)e;
+    uint32_t* pos = pv.current();
+    uint32_t* pos_alt = pv.alternate();
+    if (nblocks > 1) {
+        // stable sort by Block number; values = (position, chunk group), the chunk keys are dead now
+        uint32_t* bk_a = keys_b;
+        uint32_t* bk_b = pos_alt;
+        uint64_t* bv_a = k64.alternate();
+        uint64_t* bv_b = k64.current();
+        hipLaunchKernelGGL(k_sa_block_keys, dim3(g), dim3(256), 0, st, pos, grp, n, block_size, bk_a, bv_a);
+        rocprim::double_buffer<uint32_t> bk(bk_a, bk_b);
+        rocprim::double_buffer<uint64_t> bv(bv_a, bv_b);
+        e = rocprim::radix_sort_pairs(nullptr, need, bk, bv, (size_t)n, 0u, bb, st);
+        if (e != hipSuccess) return (int)e;
+        if (need > tb) return (int)hipErrorOutOfMemory;
+        e = rocprim::radix_sort_pairs(sort_tmp, tb, bk, bv, (size_t)n, 0u, bb, st);
+        if (e != hipSuccess) return (int)e;
+        // positions go back to `pos` (vals buffer that held them before; its content is dead)
+        hipLaunchKernelGGL(k_sa_block_unpack, dim3(g), dim3(256), 0, st, bk.current(), bv.current(), n, pos, grp);
+        // pos_alt may have been used as a key buffer: both vals buffers are free for reuse below except `pos`
+        e = rocprim::inclusive_scan(sort_tmp, tb, grp, grp, (size_t)n, rocprim::maximum<uint32_t>(), st);
+        if (e != hipSuccess) return (int)e;
+    }
+    // doubling rounds
+    for (uint32_t h = 8; h <= 16; h *= 2) {
+        hipLaunchKernelGGL(k_sa_scatter_rank, dim3(g), dim3(256), 0, st, pos, grp, n, sa_rank);
+        hipLaunchKernelGGL(k_sa_pair_keys, dim3(g), dim3(256), 0, st, pos, grp, sa_rank, n, block_size, h, key64_a);
+        rocprim::double_buffer<uint64_t> kk(key64_a, key64_b);
+        rocprim::double_buffer<uint32_t> vv(pos, pos_alt);
+        e = rocprim::radix_sort_pairs(sort_tmp, tb, kk, vv, (size_t)n, 0u, 64u, st);
+        if (e != hipSuccess) return (int)e;
+        pos = vv.current();
+        pos_alt = vv.alternate();
+        if (h == 8) {
+            hipLaunchKernelGGL(k_sa_flags64, dim3(g), dim3(256), 0, st, kk.current(), n, grp);
+            e = rocprim::inclusive_scan(sort_tmp, tb, grp, grp, (size_t)n, rocprim::maximum<uint32_t>(), st);
+            if (e != hipSuccess) return (int)e;
+        }
+    }
+    hipLaunchKernelGGL(k_sa_final, dim3(g), dim3(256), 0, st, pos, n, sa, sa_rank);
     return (int)hipGetLastError();
 }
 
-int xzk_find_matches(const xzamd_span_args* a, uint16_t* mlen, uint32_t* mdist, uint8_t* mcnt, void* stream_)
+int xzk_find_matches(const xzamd_span_args* a, const uint32_t* sa, const uint32_t* sa_rank, const uint32_t* prev4,
+        const uint32_t* prev8, uint16_t* mlen, uint32_t* mdist, void* stream_)
 {
     hipStream_t st = (hipStream_t)stream_;
     const uint32_t runs = (a->n + FIND_RUN - 1) / FIND_RUN;
     if (runs == 0) return 0;
-    if (a->depth2)
-        hipLaunchKernelGGL((k_find_t<true>), dim3(runs), dim3(64), 0, st, *a, mlen, mdist, mcnt);
-    else
-        hipLaunchKernelGGL((k_find_t<false>), dim3(runs), dim3(64), 0, st, *a, mlen, mdist, mcnt);
+    if (a->sa_window) {
+        if (!sa || !sa_rank || !prev4 || !prev8 || a->sa_window > 30) return (int)hipErrorInvalidValue;
+        SnArgs sn;
+        sn.in = a->in; sn.sa = sa; sn.sa_rank = sa_rank; sn.prev2 = a->prev2; sn.prev3 = a->prev3; sn.prev4 = prev4; sn.prev8 = prev8;
+        hipLaunchKernelGGL(k_find_sn, dim3(runs), dim3(64), 0, st, *a, sn, mlen, mdist);
+    } else {
+        hipLaunchKernelGGL(k_find_exact, dim3(runs), dim3(64), 0, st, *a, mlen, mdist);
+    }
     return (int)hipGetLastError();
 }
 
@@ -2299,12 +2543,11 @@ int xzk_span_encode(const xzamd_span_args* a, uint32_t nspans, void* stream_)
 {
     hipStream_t st = (hipStream_t)stream_;
     if (a->parser) {
-        if ((!a->mlen && !a->list_packed) || !a->mdist || !a->mcnt) return (int)hipErrorInvalidValue;
+        if ((!a->mlen && !a->list_packed) || !a->mdist) return (int)hipErrorInvalidValue;
         hipLaunchKernelGGL((k_span_encode_t<2, true>), dim3(nspans), dim3(64), 0, st, *a);
-    } else if (a->depth2 == 0) {
-        hipLaunchKernelGGL((k_span_encode_t<0, false>), dim3(nspans), dim3(64), 0, st, *a);
     } else {
-        hipLaunchKernelGGL((k_span_encode_t<1, false>), dim3(nspans), dim3(64), 0, st, *a);
+        if (a->sa_window) return (int)hipErrorInvalidValue;      // the fast parser runs on the exact finder only
+        hipLaunchKernelGGL((k_span_encode_t<0, false>), dim3(nspans), dim3(64), 0, st, *a);
     }
     return (int)hipGetLastError();
 }

@@ -213,21 +213,21 @@ int xzamd_lzma_preset(xzamd_lzma_options *o, uint32_t preset)
 		else { o->nice_len = 273; o->depth = 512; }
 	}
 	/* Device mapping.  Fast-mode HC3/HC4 chains run exactly as requested.
-	 * BT4/normal chains (presets 4-9, -e) have no parallel equivalent: the
-	 * device runs its two-family hash-chain successor (<= 56 candidates per
-	 * wavefront round) and its own windowed optimal parser (DESIGN.md "what
-	 * differs from the reference"). */
+	 * BT4/normal chains (presets 4-9, -e): BT4 relinks its tree at every
+	 * insert, i.e. is sequential per Block; the device runs its parallel
+	 * successor, the suffix-neighbourhood finder (the recency records of the
+	 * 32-byte-prefix suffix order are the nodes BT4's descent visits), and a
+	 * windowed form of the optimal parser. */
 	if (o->mf == XZAMD_MF_HC3 || o->mf == XZAMD_MF_HC4) {
 		o->gpu_mf = o->mf;
 		o->gpu_nice_len = o->nice_len;
 		o->gpu_depth = o->depth;
 	} else {
-		/* BT4 + normal mode -> HC4+H8 Pareto finder + windowed optimal parser */
-		uint32_t ref_depth = o->depth ? o->depth : 16 + o->nice_len / 2;   /* lz_encoder.c:359-365 */
+		/* BT4 + normal mode -> suffix-neighbourhood finder + windowed optimal parser */
 		o->gpu_mf = XZAMD_MF_HC4;
 		o->gpu_nice_len = o->nice_len;
-		o->gpu_depth = 8;
-		o->gpu_depth2 = ref_depth > 48 ? 48 : ref_depth;
+		o->gpu_depth = 1;
+		o->gpu_sa_window = XZAMD_SA_WINDOW_MAX;
 		o->gpu_parser = 1;
 	}
 	o->span_size = XZAMD_SPAN_DEFAULT;
@@ -257,8 +257,8 @@ struct xzamd_ctx {
 	char err[256];
 	char err_msg_buf[200];
 	/* device buffers */
-	dbuf keys_a, keys_b, vals_a, vals_b, rank, sorted_pos, prev2, prev3, rank8, sorted8, sort_tmp;
-	dbuf scratch, span_bytes, strip_crc, block_crc, segs, lits, trace, errw, litp, mlen, mdist, mcnt, bcj;
+	dbuf keys_a, keys_b, vals_a, vals_b, rank, sorted_pos, prev2, prev3, prev4, prev8, key64_a, key64_b, sa, sa_rank, sort_tmp;
+	dbuf scratch, span_bytes, strip_crc, block_crc, segs, lits, trace, errw, litp, mlen, mdist, bcj;
 	/* pinned host buffers */
 	dbuf h_span_bytes, h_block_crc, h_segs, h_lits;
 	void *ev[10];
@@ -333,8 +333,9 @@ void xzamd_ctx_destroy(xzamd_ctx *c)
 		return;
 	xzk_set_device(c->device);
 	dbuf *d[] = { &c->keys_a, &c->keys_b, &c->vals_a, &c->vals_b, &c->rank, &c->sorted_pos,
-		&c->prev2, &c->prev3, &c->rank8, &c->sorted8, &c->sort_tmp, &c->scratch, &c->span_bytes, &c->strip_crc,
-		&c->block_crc, &c->segs, &c->lits, &c->trace, &c->errw, &c->litp, &c->mlen, &c->mdist, &c->mcnt, &c->bcj };
+		&c->prev2, &c->prev3, &c->prev4, &c->prev8, &c->key64_a, &c->key64_b, &c->sa, &c->sa_rank, &c->sort_tmp,
+		&c->scratch, &c->span_bytes, &c->strip_crc,
+		&c->block_crc, &c->segs, &c->lits, &c->trace, &c->errw, &c->litp, &c->mlen, &c->mdist, &c->bcj };
 	for (size_t i = 0; i < sizeof(d) / sizeof(d[0]); ++i)
 		if (d[i]->p) xzk_free(d[i]->p);
 	dbuf *h[] = { &c->h_span_bytes, &c->h_block_crc, &c->h_segs, &c->h_lits };
@@ -370,6 +371,20 @@ int xzamd_trace_enable(xzamd_ctx *c, uint32_t cap)
 	c->trace_cap = cap;
 	c->trace_on = 1;
 	if (xzk_memset(c->trace.p, 0, 16, c->own_stream) || xzk_sync(c->own_stream))
+		return XZAMD_DEVICE_ERROR;
+	return XZAMD_OK;
+}
+
+int xzamd_debug_fetch(xzamd_ctx *c, int what, void *out, uint64_t bytes)
+{
+	if (!c || !out)
+		return XZAMD_PROG_ERROR;
+	const dbuf *b = what == XZAMD_DEBUG_SA ? &c->sa : what == XZAMD_DEBUG_SA_RANK ? &c->sa_rank
+			: what == XZAMD_DEBUG_LISTS ? &c->mdist : what == XZAMD_DEBUG_LIST_LENS ? &c->mlen : NULL;
+	if (!b || !b->p || b->cap < bytes)
+		return XZAMD_PROG_ERROR;
+	xzk_set_device(c->device);
+	if (xzk_d2h(out, b->p, bytes, c->own_stream) || xzk_sync(c->own_stream))
 		return XZAMD_DEVICE_ERROR;
 	return XZAMD_OK;
 }
@@ -450,11 +465,18 @@ static int batch_geometry(xzamd_ctx *c, const xzamd_lzma_options *opt, uint64_t 
 	uint32_t bb = 0;
 	while ((1u << bb) < g->nb + 1) ++bb;
 	const uint32_t bits[4] = { 10 + bb, 16 + bb, hbits + bb, 22 + bb };
-	for (int i = 0; i < (opt->gpu_depth2 ? 4 : 3); ++i) {
+	for (int i = 0; i < (opt->gpu_sa_window ? 4 : 3); ++i) {
 		uint64_t sbytes = 0;
 		int e = xzk_sort_temp_bytes(g->n, bits[i], &sbytes);
 		if (e)
 			return fail(c, XZAMD_DEVICE_ERROR, "rocprim temp size", e);
+		if (sbytes > g->sort_bytes) g->sort_bytes = sbytes;
+	}
+	if (opt->gpu_sa_window) {
+		uint64_t sbytes = 0;
+		int e = xzk_sa_temp_bytes(g->n, &sbytes);
+		if (e)
+			return fail(c, XZAMD_DEVICE_ERROR, "rocprim temp size (suffix order)", e);
 		if (sbytes > g->sort_bytes) g->sort_bytes = sbytes;
 	}
 	return XZAMD_OK;
@@ -468,8 +490,12 @@ static int launch_chains(xzamd_ctx *c, const xzamd_lzma_options *opt, const uint
 			(uint32_t *)c->vals_b.p, c->sort_tmp.p, g->sort_bytes,
 			(uint32_t *)c->rank.p, (uint32_t *)c->sorted_pos.p, (uint32_t *)c->prev2.p,
 			(uint32_t *)c->prev3.p,
-			opt->gpu_depth2 ? (uint32_t *)c->rank8.p : NULL,
-			opt->gpu_depth2 ? (uint32_t *)c->sorted8.p : NULL, st);
+			opt->gpu_sa_window ? (uint32_t *)c->prev4.p : NULL,
+			opt->gpu_sa_window ? (uint32_t *)c->prev8.p : NULL,
+			opt->gpu_sa_window ? (uint64_t *)c->key64_a.p : NULL,
+			opt->gpu_sa_window ? (uint64_t *)c->key64_b.p : NULL,
+			opt->gpu_sa_window ? (uint32_t *)c->sa.p : NULL,
+			opt->gpu_sa_window ? (uint32_t *)c->sa_rank.p : NULL, st);
 	return e ? fail(c, XZAMD_DEVICE_ERROR, "build_chains", e) : XZAMD_OK;
 }
 
@@ -493,8 +519,8 @@ int xzamd_stream_encode_device(xzamd_ctx *c,
 	if (opt->lc + opt->lp > 3 || opt->pb > 4)
 		return fail(c, XZAMD_OPTIONS_ERROR, "lc+lp <= 3 and pb <= 4 required (LDS model size)", 0);
 	if ((opt->gpu_mf != XZAMD_MF_HC3 && opt->gpu_mf != XZAMD_MF_HC4)
-			|| opt->gpu_depth < 1 || opt->gpu_depth + opt->gpu_depth2 > 56
-			|| (opt->gpu_depth2 && opt->gpu_mf != XZAMD_MF_HC4) || opt->gpu_parser > 1
+			|| opt->gpu_depth < 1 || opt->gpu_depth > 56 || opt->gpu_sa_window > XZAMD_SA_WINDOW_MAX
+			|| (opt->gpu_sa_window && (opt->gpu_mf != XZAMD_MF_HC4 || !opt->gpu_parser)) || opt->gpu_parser > 1
 			|| opt->gpu_nice_len < opt->gpu_mf || opt->gpu_nice_len > 273
 			|| opt->dict_size < 4096 || opt->dict_size > (1u << 30))
 		return fail(c, XZAMD_OPTIONS_ERROR, "unsupported match finder options for the device path", 0);
@@ -515,7 +541,7 @@ int xzamd_stream_encode_device(xzamd_ctx *c,
 	const uint32_t hmask = hash_mask_for(opt->dict_size, hb);
 	uint32_t hbits = 0;
 	while ((1ull << hbits) <= hmask) ++hbits;
-	const uint32_t kbits_max = (opt->gpu_depth2 && hbits < 22) ? 22 : hbits;   /* widest sort key family */
+	const uint32_t kbits_max = (opt->gpu_sa_window && hbits < 22) ? 22 : hbits;   /* widest 32-bit sort key family */
 	uint32_t span = opt->span_size == XZAMD_SPAN_DEFAULT ? (opt->gpu_parser ? DEFAULT_SPAN_OPT : DEFAULT_SPAN) : opt->span_size;
 	if (span > block_size) span = (uint32_t)block_size;
 	if (span < 4096)
@@ -523,14 +549,11 @@ int xzamd_stream_encode_device(xzamd_ctx *c,
 	const uint32_t spb = (uint32_t)((block_size + span - 1) / span);
 	const uint64_t span_cap = ((uint64_t)span + (span >> 3) + 4096 + 15) & ~15ull;
 
-	/* Match lists of the optimal parser: 16 x u32 (length << 23 | distance-1) per position when
-	 * distances fit 23 bits, else 16 x (u16 + u32). */
+	/* Match lists of the optimal parser: 8 x u32 per position (7 entries length << 23 | distance-1 and a
+	 * trailer) when distances fit 23 bits, else 8 x u32 distances + 8 x u16 lengths. */
 	const int list_packed = opt->gpu_parser && opt->dict_size <= (1u << 23);
-	/* batch = whole Blocks, n < 2^31, (nblocks+1) << hbits < 2^32.  The 96-byte list format keeps
-	 * the batch at 1 GiB (HBM footprint ~140 B per input byte). */
+	/* batch = whole Blocks, n < 2^31, (nblocks+1) << hbits < 2^32 */
 	uint64_t batch_bytes = c->batch_bytes;
-	if (opt->gpu_parser && !list_packed && batch_bytes > (1ull << 30))
-		batch_bytes = 1ull << 30;
 	uint64_t max_blocks = batch_bytes / block_size;
 	if (max_blocks == 0) max_blocks = 1;
 	const uint64_t key_blocks = (1ull << (32 - kbits_max)) - 2;
@@ -593,9 +616,14 @@ int xzamd_stream_encode_device(xzamd_ctx *c,
 		if (r_) { rc = r_; goto done; } } while (0)
 		GROW(keys_a, 4ull * n, 0); GROW(keys_b, 4ull * n, 0);
 		GROW(vals_a, 4ull * n, 0); GROW(vals_b, 4ull * n, 0);
-		GROW(rank, 4ull * n, 0); GROW(sorted_pos, 4ull * n, 0);
 		GROW(prev2, 4ull * n, 0); GROW(prev3, 4ull * n, 0);
-		if (opt->gpu_depth2) { GROW(rank8, 4ull * n, 0); GROW(sorted8, 4ull * n, 0); }
+		if (opt->gpu_sa_window) {
+			GROW(prev4, 4ull * n, 0); GROW(prev8, 4ull * n, 0);
+			GROW(key64_a, 8ull * n, 0); GROW(key64_b, 8ull * n, 0);
+			GROW(sa, 4ull * n, 0); GROW(sa_rank, 4ull * n, 0);
+		} else {
+			GROW(rank, 4ull * n, 0); GROW(sorted_pos, 4ull * n, 0);
+		}
 		GROW(sort_tmp, sort_bytes + 256, 0);
 		GROW(scratch, span_cap * nspans, 0);
 		GROW(span_bytes, 4ull * nspans, 0);
@@ -604,9 +632,9 @@ int xzamd_stream_encode_device(xzamd_ctx *c,
 		GROW(errw, 256, 0);
 		GROW(litp, (uint64_t)nspans * 6144ull * 4ull, 0);
 		if (opt->gpu_parser) {
-			/* per-position match lists: 16 x (u16 len + u32 dist) + count */
-			if (!list_packed) GROW(mlen, 32ull * n, 0);
-			GROW(mdist, 64ull * n, 0); GROW(mcnt, (uint64_t)n, 0);
+			/* per-position match lists: 8 x u32 (7 entries + trailer), + 8 x u16 lengths when not packed */
+			if (!list_packed) GROW(mlen, 16ull * n, 0);
+			GROW(mdist, 32ull * n, 0);
 		}
 		GROW(h_span_bytes, 4ull * nspans, 1);
 		GROW(h_block_crc, 8ull * nb, 1);
@@ -649,9 +677,7 @@ int xzamd_stream_encode_device(xzamd_ctx *c,
 			a.sorted_pos = (const uint32_t *)c->sorted_pos.p;
 			a.prev2 = (const uint32_t *)c->prev2.p;
 			a.prev3 = (const uint32_t *)c->prev3.p;
-			a.rank8 = opt->gpu_depth2 ? (const uint32_t *)c->rank8.p : NULL;
-			a.sorted8 = opt->gpu_depth2 ? (const uint32_t *)c->sorted8.p : NULL;
-			a.depth2 = opt->gpu_depth2;
+			a.sa_window = opt->gpu_sa_window;
 			a.parser = opt->gpu_parser;
 			a.scratch = (uint8_t *)c->scratch.p;
 			a.span_cap = span_cap;
@@ -679,8 +705,8 @@ int xzamd_stream_encode_device(xzamd_ctx *c,
 				a.mlen = list_packed ? NULL : (const uint16_t *)c->mlen.p;
 				a.list_packed = (uint32_t)list_packed;
 				a.mdist = (const uint32_t *)c->mdist.p;
-				a.mcnt = (const uint8_t *)c->mcnt.p;
-				e = xzk_find_matches(&a, list_packed ? NULL : (uint16_t *)c->mlen.p, (uint32_t *)c->mdist.p, (uint8_t *)c->mcnt.p, st);
+				e = xzk_find_matches(&a, (const uint32_t *)c->sa.p, (const uint32_t *)c->sa_rank.p, (const uint32_t *)c->prev4.p,
+						(const uint32_t *)c->prev8.p, list_packed ? NULL : (uint16_t *)c->mlen.p, (uint32_t *)c->mdist.p, st);
 				if (e) { rc = fail(c, XZAMD_DEVICE_ERROR, "find_matches launch", e); goto done; }
 				xzk_event_record(c->ev[5], st);
 			}

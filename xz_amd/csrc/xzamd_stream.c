@@ -192,12 +192,13 @@ static lzma_ret parse_options(const lzma_mt *o, xzamd_lzma_options *opt, uint64_
 			opt->gpu_depth = d > 56 ? 56 : d;
 			opt->gpu_parser = l->mode == LZMA_MODE_NORMAL ? 1 : 0;
 		} else if (l->mf == LZMA_MF_BT2 || l->mf == LZMA_MF_BT3 || l->mf == LZMA_MF_BT4) {
-			uint32_t rd = l->depth ? l->depth : 16 + l->nice_len / 2;
+			/* binary-tree finders -> suffix-neighbourhood finder + windowed optimal parser (the device has
+			 * no fast parser for it: LZMA_MODE_FAST with a BT finder gets the optimal parser too) */
 			opt->gpu_mf = XZAMD_MF_HC4;
 			opt->gpu_nice_len = l->nice_len < 4 ? 4 : l->nice_len;
-			opt->gpu_depth = 8;
-			opt->gpu_depth2 = rd > 48 ? 48 : rd;
-			opt->gpu_parser = l->mode == LZMA_MODE_NORMAL ? 1 : 0;
+			opt->gpu_depth = 1;
+			opt->gpu_sa_window = XZAMD_SA_WINDOW_MAX;
+			opt->gpu_parser = 1;
 		} else {
 			return LZMA_OPTIONS_ERROR;
 		}
@@ -278,12 +279,12 @@ uint64_t lzma_stream_encoder_mt_memusage(const lzma_mt *options)
 	uint64_t maxb = (1ull << 30) / bs;
 	if (maxb == 0) maxb = 1;
 	const uint64_t stage = maxb * bs;
-	/* host: staging + output queue; device: input + output, 40 B/byte of sort buffers and chain tables
-	 * (48 with the 8-byte chain family), span scratch, and for the optimal parser the match lists
-	 * (65 B/byte packed, 97 B/byte for dictionaries above 8 MiB) */
-	uint64_t per_byte = 2 + 2 + (opt.gpu_depth2 ? 48 : 40) + 2;
+	/* host: staging + output queue; device: input + output, 32 B/byte of sort buffers and chain tables
+	 * (56 with the suffix-order build), span scratch, and for the optimal parser the match lists
+	 * (32 B/byte packed, 48 B/byte for dictionaries above 8 MiB) */
+	uint64_t per_byte = 2 + 2 + (opt.gpu_sa_window ? 56 : 32) + 2;
 	if (opt.gpu_parser)
-		per_byte += opt.dict_size <= (1u << 23) ? 65 : 97;
+		per_byte += opt.dict_size <= (1u << 23) ? 32 : 48;
 	return stage * per_byte;
 }
 
