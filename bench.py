@@ -10,10 +10,14 @@ CRC64, assembly into a complete .xz Stream) over the batch already resident in H
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-N>1: weak scaling -- every rank encodes its own shard of Blocks on its own GPU (no data-path
-collective), then the encoded Blocks are gathered to rank 0 over RCCL (send/recv of
-variable-length byte tensors + the 16-byte Index records) and rank 0 frames the Stream.  The gather
-is inside the timed region.  Prints ONE JSON line on rank 0.
+`python bench.py --gpus N` with N > 1 spawns its own N ranks (torch.distributed.run, one process per
+GPU).  Every rank encodes its own shard of Blocks on its own GPU (no data-path collective), then the
+encoded Blocks are gathered to rank 0 over RCCL (send/recv of variable-length byte tensors + the 16-byte
+Index records) and rank 0 frames the Stream.  The gather is inside the timed region.
+--scaling weak (default): --size-mib per GPU; --scaling strong: --size-mib in total, whole Blocks dealt
+to the ranks in order (north_star's 4 GiB on 8 GPUs).  Prints ONE JSON line on rank 0, with `roofline`,
+`cpu_baseline` (reference liblzma -T0 on the host cores, bounded wall time) and `host_to_host` (the same
+job through lzma_code on host buffers, PCIe inclusive).
 """
 import argparse
 import json
@@ -91,23 +95,124 @@ def corpus_elf(n, rank):
     return out
 
 
-def cpu_baseline(sample, preset, bcj=False):
-    """Reference liblzma (oracle/_ref, the real 5.8.3 sources) MT encoder on the host cores, timed on a
-    bounded sample of the same workload.  Test infrastructure used as a reported baseline only."""
+def cpu_limits():
+    """What the host offers: CPUs in the affinity mask, the cgroup CPU quota (cpu.max), hardware threads."""
+    info = {"os_cpu_count": os.cpu_count()}
+    try:
+        info["sched_getaffinity"] = len(os.sched_getaffinity(0))
+    except Exception:  # noqa: BLE001
+        info["sched_getaffinity"] = None
+    quota = None
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                quota = None if txt[0] == "max" else float(txt[0]) / float(txt[1])
+            else:
+                q = float(txt[0])
+                per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                quota = None if q < 0 else q / per
+            info["cgroup_cpu_max"] = " ".join(txt)
+            break
+        except Exception:  # noqa: BLE001
+            continue
+    info["cgroup_quota_cpus"] = quota
+    return info
+
+
+def cpu_baseline(host, preset, bcj, block_size, seconds=20.0):
+    """Reference liblzma (oracle/_ref, the real 5.8.3 sources) on the host cores, beside the GPU number.
+    `xz -T0`-equivalent: lzma_stream_encoder_mt with threads = lzma_cputhreads() over the WHOLE input of
+    rank 0 (every worker has a Block to chew on), timed for a bounded wall time: value = input bytes the
+    workers processed (lzma_get_progress) / wall.  Plus the -T1 per-core figure and the host's CPU limits.
+    Test infrastructure used as a reported baseline only."""
+    import ctypes as C
     try:
         import _oracle as o
         if not o.have_ref():
-            return None, None
-        cores = int(o.ref().ref_cputhreads())
-        t0 = time.time()
-        enc = (o.ref_encode_mt_x86 if bcj else o.ref_encode_mt)(sample, preset, threads=max(cores, 1), block_size=0)
-        dt = time.time() - t0
-        return {"value": round(len(sample) / dt / 1e6, 2), "unit": "MB/s", "cores": cores, "kind": "reference",
-                "sample": f"first {len(sample) >> 20} MiB of rank 0's input, liblzma 5.8.3 lzma_stream_encoder_mt "
-                          f"preset {preset & 31}{'e' if preset >> 31 else ''}{' + x86 BCJ' if bcj else ''} threads={cores} default block size, {dt:.1f} s wall",
-                "ratio": round(len(enc) / max(len(sample), 1), 5)}, enc
+            return None
+        f = o.ref().ref_encode_mt_timed
+        f.restype = C.c_int
+        f.argtypes = [C.c_void_p, C.c_size_t, C.c_uint32, C.c_int, C.c_uint32, C.c_uint64, C.c_double,
+                      C.POINTER(C.c_uint64), C.POINTER(C.c_double), C.POINTER(C.c_uint32)]
+        pin, el, th = C.c_uint64(), C.c_double(), C.c_uint32()
+        lim = cpu_limits()
+        r = f(host.ctypes.data, host.size, preset, 1 if bcj else 0, 0, 0, seconds, C.byref(pin), C.byref(el), C.byref(th))
+        if r != 1:
+            return {"value": None, "unit": "MB/s", "cores": 0, "kind": "reference", "sample": f"lzma_code failed: {r}"}
+        nblocks = (host.size + block_size - 1) // block_size
+        busy = min(int(th.value), int(nblocks))
+        mt = pin.value / el.value / 1e6
+        pin1, el1, th1 = C.c_uint64(), C.c_double(), C.c_uint32()
+        f(host.ctypes.data, host.size, preset, 1 if bcj else 0, 1, 0, min(seconds, 6.0), C.byref(pin1), C.byref(el1), C.byref(th1))
+        t1 = pin1.value / max(el1.value, 1e-9) / 1e6
+        return {"value": round(mt, 2), "unit": "MB/s", "cores": busy, "kind": "reference",
+                "sample": (f"liblzma 5.8.3 lzma_stream_encoder_mt preset {preset & 31}{'e' if preset >> 31 else ''}{' + x86 BCJ' if bcj else ''}, "
+                           f"threads={int(th.value)} (lzma_cputhreads, as xz -T0), whole {host.size >> 20} MiB input of rank 0 on offer = {nblocks} Blocks "
+                           f"-> {busy} busy workers, timed {el.value:.1f} s wall, {pin.value >> 20} MiB processed (lzma_get_progress)"),
+                "per_core_T1": round(t1, 3), "scaling_vs_T1": round(mt / t1, 1) if t1 > 0 else None,
+                "host": lim}
     except Exception as e:  # noqa: BLE001
-        return {"value": None, "unit": "MB/s", "cores": 0, "kind": "reference", "sample": f"failed: {e}"}, None
+        return {"value": None, "unit": "MB/s", "cores": 0, "kind": "reference", "sample": f"failed: {e}"}
+
+
+def reference_ratio(sample, preset, bcj, block_size):
+    """Compressed size of the reference MT encoder on a few Blocks of the input (the ratio baseline)."""
+    import _oracle as o
+    nb = max(1, (len(sample) + block_size - 1) // block_size)
+    enc = (o.ref_encode_mt_x86 if bcj else o.ref_encode_mt)(sample, preset, threads=min(nb, 8), block_size=block_size)
+    return len(enc)
+
+
+def host_to_host(host, preset, block_size, reps=2):
+    """The SURVEY 8(d) end-to-end number: lzma_stream_encoder_mt + lzma_code(LZMA_FINISH) of libxz_amd.so on
+    HOST buffers -- staging copy, H2D, device encode, D2H of the Stream all inside the timed region."""
+    import ctypes as C
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from bench_lzma_code import Mt, Stream
+    L = xz_amd.lib()
+    n = host.size
+    out = np.empty(n // 2 + (1 << 20), dtype=np.uint8)
+    best = None
+    for _ in range(reps):
+        s = Stream()
+        m = Mt(threads=1, preset=preset, check=4, block_size=block_size)
+        if L.lzma_stream_encoder_mt(C.byref(s), C.byref(m)) != 0:
+            return None
+        s.next_in = host.ctypes.data
+        s.avail_in = n
+        s.next_out = out.ctypes.data
+        s.avail_out = out.size
+        t0 = time.perf_counter()
+        rc = L.lzma_code(C.byref(s), 3)
+        while rc == 0:
+            rc = L.lzma_code(C.byref(s), 3)
+        dt = time.perf_counter() - t0
+        total_out = s.total_out
+        L.lzma_end(C.byref(s))
+        if rc != 1:
+            return {"value": None, "error": int(rc)}
+        if best is None or dt < best[0]:
+            best = (dt, total_out)
+    return {"value": round(n / best[0] / 1e6, 2), "unit": "MB/s", "bytes": int(n), "ms": round(best[0] * 1e3, 1),
+            "ratio": round(best[1] / n, 5),
+            "what": "lzma_stream_encoder_mt + lzma_code(LZMA_FINISH) of libxz_amd.so, input and output in host RAM "
+                    "(staging, H2D, device encode, D2H inside the timed region), best of %d" % reps}
+
+
+def relaunch_under_torchrun(args_list, n):
+    """`python bench.py --gpus N` with N > 1: spawn the N ranks ourselves (one process per GPU, RCCL)."""
+    import socket
+    import subprocess
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + args_list
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -115,43 +220,63 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--size-mib", type=int, default=4096, help="input MiB per GPU")
+    ap.add_argument("--size-mib", type=int, default=4096, help="input MiB per GPU (weak) or in total (strong)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak: --size-mib per GPU; strong: --size-mib in total, whole Blocks dealt to the ranks in order")
     ap.add_argument("--preset", type=lambda v: int(v, 0), default=6, help="0-9, | 0x80000000 for -e")
     ap.add_argument("--span-kib", type=int, default=0, help="0 = library default")
     ap.add_argument("--block-mib", type=int, default=0, help="0 = lzma_mt_block_size of the preset (BASELINE configs[1]: 16)")
     ap.add_argument("--parser", choices=["default", "fast", "optimal"], default="default",
                     help="device parser override (default: what the preset maps to)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-to-host", action="store_true")
     ap.add_argument("--bcj", action="store_true", help="chain {x86 BCJ, LZMA2} (SURVEY.md 8d config C5)")
     ap.add_argument("--corpus", choices=["text", "elf"], default="text",
                     help="text: seeded synthetic enwik-style text (the headline workload); elf: the x86-64 shared "
                          "objects present on the box, concatenated and cycled (config C5's input)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(relaunch_under_torchrun(sys.argv[1:], args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=dev)
+        assert dist.get_world_size() == args.gpus
 
-    n = args.size_mib << 20
     opts = xz_amd.preset_options(args.preset)
-    if args.span_kib:
-        opts.span_size = args.span_kib << 10
     if args.parser != "default":
         opts.gpu_parser = 1 if args.parser == "optimal" else 0
+        if not opts.gpu_parser:
+            opts.gpu_sa_window = 0
     block_size = (args.block_mib << 20) if args.block_mib else xz_amd.mt_block_size(opts)
+    total = args.size_mib << 20
+    if args.scaling == "strong":
+        nblocks = (total + block_size - 1) // block_size
+        lo, hi = parallel.shard_blocks(nblocks, rank, world)
+        n = min(total, hi * block_size) - lo * block_size if hi > lo else 0
+    else:
+        n = total
+    if args.span_kib:
+        opts.span_size = args.span_kib << 10
+    elif args.scaling == "strong" and opts.gpu_parser and n:
+        # one wavefront per span: keep >= 3 rounds of the 4096 wave slots per GPU when the shard gets small
+        span = 131072
+        while span > 16384 and n // span < 3 * 4096:
+            span //= 2
+        opts.span_size = span
 
     if args.bcj:
         opts.bcj = xz_amd.BCJ_X86
-    host = corpus_elf(n, rank) if args.corpus == "elf" else xz_amd.corpus_text(n, seed=1000 + rank)
+    host = corpus_elf(max(n, 1), rank) if args.corpus == "elf" else xz_amd.corpus_text(max(n, 1), seed=1000 + rank)
+    host = host[:n]
     data = torch.from_numpy(host).to(dev)
     enc = xz_amd.Encoder(local_rank)
     out_buf = torch.empty(xz_amd.lib().xzamd_stream_buffer_bound(n, block_size) + 64, dtype=torch.uint8, device=dev)
@@ -177,7 +302,7 @@ def main():
     for _ in range(args.steps):
         out, binfo = step()
         st = enc.stats()
-        enc_ms += st.ms_encode - st.ms_find      # the span kernel alone (k_find_t is timed separately)
+        enc_ms += st.ms_encode - st.ms_find      # the span kernel alone (the finder is timed separately)
         launches += st.encode_launches
     torch.cuda.synchronize()
     if world > 1:
@@ -190,7 +315,8 @@ def main():
         elapsed = float(tmax.item())
 
     st = enc.stats()
-    total_in = n * world * args.steps
+    job_bytes = total if args.scaling == "strong" else total * world
+    total_in = job_bytes * args.steps
     value = total_in / elapsed / 1e6
     # roofline of the dominant kernel (k_span_encode): algorithmic bytes = uncompressed in +
     # compressed out per launch, divided by its HIP-event time on its own stream.
@@ -208,24 +334,26 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 2),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "u8",
             "data": "synthetic" if args.corpus == "text" else "x86-64 ELF shared objects of the box, concatenated/cycled",
             "config": {
                 "workload": f"preset -{args.preset & 31}{'e' if args.preset >> 31 else ''} options (dict {opts.dict_size >> 20} MiB, {block_size >> 20} MiB Blocks, "
                             f"CRC64{', x86 BCJ + LZMA2' if args.bcj else ''}), {args.size_mib} MiB "
-                            f"{'synthetic enwik-style text' if args.corpus == 'text' else 'ELF shared objects'} per GPU, input resident in HBM, "
+                            f"{'synthetic enwik-style text' if args.corpus == 'text' else 'ELF shared objects'} "
+                            f"{'per GPU' if args.scaling == 'weak' else 'in total, whole Blocks dealt to the ranks in order'}, input resident in HBM, "
                             f"output = complete .xz Stream in HBM",
+                "world_size": world,
                 "device_match_finder": ((f"suffix-neighbourhood finder (32-byte-prefix suffix order, {opts.gpu_sa_window} slots per side + hash2/3/4/8)"
                                          if opts.gpu_sa_window else f"HC{opts.gpu_mf & 15} depth {opts.gpu_depth} (sort-built chains)")
                                         + f", nice {opts.gpu_nice_len}"),
                 "device_parser": ("windowed optimal parser (232-node DP, exact prices, compound edges) over per-position match lists" if opts.gpu_parser
                                   else "lzma_lzma_optimum_fast semantics (greedy + 1-byte lazy)"),
                 "span_kib": (opts.span_size or (131072 if opts.gpu_parser else 65536)) >> 10,
-                "parallelism": f"{world} x (one wavefront per span, {int(st.spans)} spans per GPU)",
+                "parallelism": f"{world} x (one wavefront per span, {int(st.spans)} spans on rank 0)",
             },
-            "ratio": {"ours": round(local_out_bytes / n, 5)},
+            "ratio": {"ours": round(local_out_bytes / max(n, 1), 5)},
             "roofline": {
                 "bound": "hbm",
                 "kernel": span_kernel_name(opts),
@@ -244,31 +372,33 @@ def main():
                                    "crc": round(st.ms_crc, 2), "assemble": round(st.ms_assemble, 2),
                                    "total": round(st.ms_total, 2)},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and n:
+            import _oracle as o
+            # ratio vs the reference on the same Blocks + bit-exact round trip through the REAL reference decoder
             try:
-                import _oracle as o
-                cores = int(o.ref().ref_cputhreads()) if o.have_ref() else 1
-            except Exception:  # noqa: BLE001
-                cores = 1
-            sample_n = min(n, min(max(1, cores), 32) * block_size)
-            cb, ref_enc = cpu_baseline(host[:sample_n], args.preset, args.bcj)
-            if cb is not None:
-                res["cpu_baseline"] = cb
-                # our ratio on the same sample + bit-exact round trip of that output through the
-                # REAL reference decoder (first 64 MiB only: the CPU decoder is the slow side)
-                try:
-                    import _oracle as o
+                if o.have_ref():
+                    sample_n = min(n, 4 * block_size)
+                    ref_size = reference_ratio(host[:sample_n], args.preset, args.bcj, block_size)
                     s_out, _ = enc.encode(data[:sample_n], opts=opts, block_size=block_size)
+                    res["ratio"]["sample_mib"] = sample_n >> 20
                     res["ratio"]["ours_on_sample"] = round(s_out.numel() / sample_n, 5)
-                    if cb.get("ratio"):
-                        res["ratio"][f"reference_xz_T0_{args.preset & 31}{'e' if args.preset >> 31 else ''}_on_sample"] = cb["ratio"]
-                        res["ratio"]["size_vs_reference_pct"] = round(100.0 * (s_out.numel() / sample_n / cb["ratio"] - 1), 2)
+                    res["ratio"][f"reference_xz_{args.preset & 31}{'e' if args.preset >> 31 else ''}_on_sample"] = round(ref_size / sample_n, 5)
+                    res["ratio"]["size_vs_reference_pct"] = round(100.0 * (s_out.numel() / ref_size - 1), 2)
                     vn = min(sample_n, 64 << 20)
                     v_out, _ = enc.encode(data[:vn], opts=opts, block_size=block_size)
                     rr, dec = o.ref_decode(v_out.cpu().numpy().tobytes(), vn + 16)
                     res["roundtrip_reference_decoder"] = bool(rr == 1 and dec == host[:vn].tobytes())
+            except Exception as e:  # noqa: BLE001
+                res["roundtrip_reference_decoder"] = f"failed: {e}"
+            if not args.no_host_to_host and not args.bcj:
+                try:
+                    res["host_to_host"] = host_to_host(host[:min(n, 2 << 30)], args.preset, block_size)
                 except Exception as e:  # noqa: BLE001
-                    res["roundtrip_reference_decoder"] = f"failed: {e}"
+                    res["host_to_host"] = {"value": None, "error": str(e)}
+            if not args.no_cpu_baseline:
+                cb = cpu_baseline(host, args.preset, args.bcj, block_size)
+                if cb is not None:
+                    res["cpu_baseline"] = cb
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()

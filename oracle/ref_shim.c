@@ -114,6 +114,79 @@ int ref_encode_mt_x86(const uint8_t *in, size_t in_size, uint32_t preset,
 	return (int)r;
 }
 
+/* Steady-state throughput of the reference MT encoder: feed `in` through lzma_code(LZMA_RUN) in 4 MiB
+ * slices (output discarded) until `seconds` of wall time have passed or the input is used up, then report
+ * how many input bytes the workers have actually processed (lzma_get_progress) and the wall time.  With
+ * threads = 0 the library's own count (lzma_cputhreads) is used, as `xz -T0` does.  The bench uses it so
+ * that the whole input is on offer (every worker has a Block) without waiting minutes for the last one. */
+#include <time.h>
+static double now_s(void)
+{
+	struct timespec ts;
+	clock_gettime(CLOCK_MONOTONIC, &ts);
+	return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+int ref_encode_mt_timed(const uint8_t *in, size_t in_size, uint32_t preset, int x86,
+		uint32_t threads, uint64_t block_size, double seconds,
+		uint64_t *processed_in, double *elapsed, uint32_t *threads_used)
+{
+	lzma_options_lzma opt;
+	if (lzma_lzma_preset(&opt, preset))
+		return (int)LZMA_OPTIONS_ERROR;
+	lzma_filter f[3];
+	int nf = 0;
+	if (x86) { f[nf].id = LZMA_FILTER_X86; f[nf].options = NULL; ++nf; }
+	f[nf].id = LZMA_FILTER_LZMA2; f[nf].options = &opt; ++nf;
+	f[nf].id = LZMA_VLI_UNKNOWN; f[nf].options = NULL;
+	if (threads == 0)
+		threads = lzma_cputhreads();
+	if (threads == 0)
+		threads = 1;
+	lzma_stream strm = LZMA_STREAM_INIT;
+	lzma_mt mt;
+	memset(&mt, 0, sizeof(mt));
+	mt.threads = threads;
+	mt.block_size = block_size;
+	mt.filters = f;
+	mt.check = LZMA_CHECK_CRC64;
+	mt.timeout = 100;
+	lzma_ret r = lzma_stream_encoder_mt(&strm, &mt);
+	if (r != LZMA_OK)
+		return (int)r;
+	const size_t ocap = 8u << 20;
+	uint8_t *obuf = (uint8_t *)malloc(ocap);
+	if (!obuf) { lzma_end(&strm); return (int)LZMA_MEM_ERROR; }
+	const double t0 = now_s();
+	size_t off = 0;
+	strm.next_in = in;
+	strm.avail_in = 0;
+	for (;;) {
+		if (strm.avail_in == 0 && off < in_size) {
+			size_t k = in_size - off < (4u << 20) ? in_size - off : (4u << 20);
+			strm.next_in = in + off;
+			strm.avail_in = k;
+			off += k;
+		}
+		strm.next_out = obuf;
+		strm.avail_out = ocap;
+		const int finishing = off >= in_size && strm.avail_in == 0;
+		r = lzma_code(&strm, finishing ? LZMA_FINISH : LZMA_RUN);
+		if (r != LZMA_OK)
+			break;
+		if (now_s() - t0 >= seconds)
+			break;
+	}
+	uint64_t pin = 0, pout = 0;
+	lzma_get_progress(&strm, &pin, &pout);
+	*elapsed = now_s() - t0;
+	*processed_in = pin;
+	*threads_used = threads;
+	lzma_end(&strm);
+	free(obuf);
+	return (r == LZMA_OK || r == LZMA_STREAM_END) ? 1 : (int)r;
+}
+
 /* The x86 BCJ encoder's output for one buffer (= one Block: fresh filter state, start offset 0):
  * raw-encode with {x86, LZMA2}, raw-decode with {LZMA2} only.  out must hold in_size bytes. */
 int ref_x86_filter(const uint8_t *in, size_t in_size, uint8_t *out)

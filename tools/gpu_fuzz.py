@@ -40,6 +40,7 @@ for case in range(ncases):
     if opts.span_size not in (0, 0xFFFFFFFF) and opts.span_size > bs: opts.span_size = 4096
     check = int(rng.choice([0, 1, 4]))
     t = torch.frombuffer(bytearray(data), dtype=torch.uint8).cuda()
+    enc.trace_enable(n + 64)
     try:
         out, _ = enc.encode(t, opts=opts, block_size=bs, check=check)
     except Exception as e:  # noqa: BLE001
@@ -55,6 +56,27 @@ for case in range(ncases):
         want = o.orc_xz_stream(data, prm, bs, check=check) if "check" in o.orc_xz_stream.__code__.co_varnames else None
         if want is not None and o.first_diff(got, want) != -1:
             ok = False; msg += f" ORACLE@{o.first_diff(got, want)}"
+    gs, gcnt = enc.trace_read(n + 64)
+    if not ok and not bcj and len(gs):
+        # first differing LZMA symbol, Block by Block (device trace: span, offset in Block, back, len)
+        prm = o.params_for_gpu_options(opts)
+        sp = prm.span_size if prm.span_size else bs
+        spb = (bs + sp - 1) // sp
+        order = np.lexsort((gs[:, 1], gs[:, 0])); gs = gs[order]
+        for b0 in range(0, n, bs):
+            blk = data[b0:b0 + bs]
+            _, osym, _ = o.orc_encode_block(blk, prm, want_trace=True)
+            b = b0 // bs
+            g = gs[(gs[:, 0] >= b * spb) & (gs[:, 0] < (b + 1) * spb)][:, 1:]
+            if len(osym) and len(g) and osym[0][0] == 0 and g[0][0] != 0:
+                osym = osym[1:]
+            k = min(len(g), len(osym))
+            dd = np.nonzero((g[:k] != osym[:k]).any(axis=1))[0]
+            if len(dd) or len(g) != len(osym):
+                i = int(dd[0]) if len(dd) else k
+                msg += (f" | block {b}: symbol #{i} gpu {g[i].tolist() if i < len(g) else None} oracle {osym[i].tolist() if i < len(osym) else None}"
+                        f" prev {g[max(i - 3, 0):i].tolist()} ctx {blk[int(osym[min(i, len(osym) - 1)][0]):int(osym[min(i, len(osym) - 1)][0]) + 16]!r}")
+                break
     print(f"case {case}: {'ok ' if ok else 'FAIL' + msg} kind={kind} n={n} preset={preset:#x} span={span:#x} parser={opts.gpu_parser} d={opts.gpu_depth}/{opts.gpu_sa_window} "
           f"nice={opts.gpu_nice_len} dict={opts.dict_size} lc/lp/pb={opts.lc}/{opts.lp}/{opts.pb} bcj={int(bcj)} bs={bs} check={check} out={len(got)}", flush=True)
     fails += 0 if ok else 1

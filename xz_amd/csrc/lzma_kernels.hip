@@ -1675,9 +1675,11 @@ void k_span_encode_t(xzamd_span_args a)
                         back = sb; len = sl;
                         cached = false;
                         q_pos = q_end = 0;
-                    } else if (RL.cnt == 0 && RL.rp[0] == 0 && RL.rp[1] < 2 && RL.rp[2] < 2 && RL.rp[3] < 2) {
+                    } else if (RL.cnt == 0 && RL.rp[0] == 0 && RL.rp[1] < 2 && RL.rp[2] < 2 && RL.rp[3] < 2
+                            && mask_run_after(RL.rm[0], 0) < 2) {
                         // nothing but a literal can leave node 0 (no match, no rep of two bytes, not even
-                        // a short rep): the window would be that literal (incompressible data lives here)
+                        // a short rep, no "literal + rep0" compound): the window would be that literal
+                        // (incompressible data lives here)
                         cached = false;
                         q_pos = q_end = 0;
                     } else {
