@@ -174,6 +174,7 @@ def host_to_host(host, preset, block_size, reps=2):
     n = host.size
     out = np.empty(n // 2 + (1 << 20), dtype=np.uint8)
     best = None
+    os.environ["XZAMD_SPAN_AUTO"] = "1"          # same span policy as the device-resident number
     for _ in range(reps):
         s = Stream()
         m = Mt(threads=1, preset=preset, check=4, block_size=block_size)
@@ -264,14 +265,9 @@ def main():
         n = min(total, hi * block_size) - lo * block_size if hi > lo else 0
     else:
         n = total
-    if args.span_kib:
-        opts.span_size = args.span_kib << 10
-    elif args.scaling == "strong" and opts.gpu_parser and n:
-        # one wavefront per span: keep >= 3 rounds of the 4096 wave slots per GPU when the shard gets small
-        span = 131072
-        while span > 16384 and n // span < 3 * 4096:
-            span //= 2
-        opts.span_size = span
+    # span size: derived by the library from the batch geometry and the GPU's wave slots (full rounds of
+    # wavefronts per launch, between half the default and the default span) unless given
+    opts.span_size = (args.span_kib << 10) if args.span_kib else xz_amd.SPAN_AUTO
 
     if args.bcj:
         opts.bcj = xz_amd.BCJ_X86
@@ -350,7 +346,7 @@ def main():
                                         + f", nice {opts.gpu_nice_len}"),
                 "device_parser": ("windowed optimal parser (232-node DP, exact prices, compound edges) over per-position match lists" if opts.gpu_parser
                                   else "lzma_lzma_optimum_fast semantics (greedy + 1-byte lazy)"),
-                "span_kib": (opts.span_size or (131072 if opts.gpu_parser else 65536)) >> 10,
+                "span_bytes": int(st.span_size),
                 "parallelism": f"{world} x (one wavefront per span, {int(st.spans)} spans on rank 0)",
             },
             "ratio": {"ours": round(local_out_bytes / max(n, 1), 5)},
@@ -368,6 +364,7 @@ def main():
                 "launches": launches,
             },
             "stage_ms_last_step": {"chains": round(st.ms_chains, 2), "find": round(st.ms_find, 2),
+                                   "find_under_previous_span": round(st.ms_find_overlapped, 2),
                                    "span_encode": round(st.ms_encode - st.ms_find, 2),
                                    "crc": round(st.ms_crc, 2), "assemble": round(st.ms_assemble, 2),
                                    "total": round(st.ms_total, 2)},
@@ -379,6 +376,7 @@ def main():
                 if o.have_ref():
                     sample_n = min(n, 4 * block_size)
                     ref_size = reference_ratio(host[:sample_n], args.preset, args.bcj, block_size)
+                    opts.span_size = int(st.span_size)        # the span size the timed run used
                     s_out, _ = enc.encode(data[:sample_n], opts=opts, block_size=block_size)
                     res["ratio"]["sample_mib"] = sample_n >> 20
                     res["ratio"]["ours_on_sample"] = round(s_out.numel() / sample_n, 5)

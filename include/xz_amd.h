@@ -63,6 +63,9 @@ typedef struct xzamd_ctx xzamd_ctx;
  * for fast-mode HC3/HC4 chains (presets 0-3). */
 #define XZAMD_SPAN_WHOLE_BLOCK 0xFFFFFFFFu
 #define XZAMD_SPAN_DEFAULT 0u
+/* Span size derived from the batch geometry and the GPU's wave slots (full rounds of wavefronts per
+ * launch; between half the default and the default).  The size used is reported in xzamd_stats. */
+#define XZAMD_SPAN_AUTO 1u
 
 /* LZMA2 options: the encoder-relevant subset of lzma_options_lzma
  * (api/lzma/lzma12.h:216-525) plus the GPU span size. */
@@ -121,6 +124,8 @@ typedef struct {
 	float ms_total;              /* first launch -> last kernel done */
 	uint32_t encode_launches;
 	float ms_find;               /* the k_find part of ms_encode */
+	uint32_t span_size;          /* bytes per span the last encode used */
+	float ms_find_overlapped;    /* k_find of batches whose structure + lists were made underneath the previous span kernel */
 } xzamd_stats;
 void xzamd_get_stats(const xzamd_ctx *ctx, xzamd_stats *out);
 

@@ -66,7 +66,7 @@
 #define WMAX 232u                 /* optimal-parser window (nodes 0..WMAX); sized so the GPU's node arrays +
                                    * model + price tables fit 10 KiB of LDS per wavefront */
 #ifndef WTAIL
-#define WTAIL 24u
+#define WTAIL 16u
 #endif
 #define WTAIL_                 /* symbols ending less than WTAIL nodes before a forced window cut are re-parsed */
 #ifndef LIST_K

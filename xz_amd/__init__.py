@@ -16,6 +16,7 @@ MF_HC3, MF_HC4, MF_BT4 = 0x03, 0x04, 0x14
 PRESET_EXTREME = 0x80000000
 SPAN_WHOLE_BLOCK = 0xFFFFFFFF
 SPAN_DEFAULT = 0
+SPAN_AUTO = 1
 F_BLOCKS_ONLY = 1
 BCJ_X86 = 4
 
@@ -31,7 +32,7 @@ class Stats(C.Structure):
                 ("spans", C.c_uint64), ("batches", C.c_uint64), ("blocks_stored", C.c_uint64),
                 ("ms_chains", C.c_float), ("ms_encode", C.c_float), ("ms_crc", C.c_float),
                 ("ms_assemble", C.c_float), ("ms_total", C.c_float), ("encode_launches", C.c_uint32),
-                ("ms_find", C.c_float)]
+                ("ms_find", C.c_float), ("span_size", C.c_uint32), ("ms_find_overlapped", C.c_float)]
 
 
 class BlockInfo(C.Structure):

@@ -82,6 +82,7 @@ int xzk_sync(void *stream);
 int xzk_set_device(int dev);
 int xzk_get_device(int *dev);
 int xzk_device_count(int *n);
+int xzk_cu_count(int dev, int *cus);
 int xzk_stream_create(void **stream);
 int xzk_stream_create_low(void **stream);      /* lowest priority of the device */
 int xzk_stream_wait_event(void *stream, void *ev);

@@ -838,8 +838,6 @@ struct Work {
 struct RoundL {
     uint32_t rp[4];     // list-driven parser: the four rep-match lengths
     uint64_t rm[4];     // mismatch masks of the four rep sources over the 64-byte row at x (bit o: offset o differs or is past the end)
-    uint32_t cx;        // per lane: the row of text, lane = offset (lanes past the end hold byte 0 of the row)
-    uint32_t cr[4];     // per lane: the four rep sources' rows
     uint32_t l2a, l2b;  // rep0 run behind the byte after the longest / second longest match (list trailer)
     uint32_t L;         // per lane; lanes 60..63 = rep lengths (in-kernel finders)
     uint32_t SL, SD;    // kept matches sorted by length: lane r holds entry r (length, zero-based distance)
@@ -903,7 +901,6 @@ __device__ __forceinline__ void round_lists(const Env& e, ListPre& LP, uint32_t 
         R.rp[2] = m2 ? (uint32_t)__builtin_ctzll(m2) : wave_cmplen(e.in, x, x - r2 - 1, 64, buf_avail);
         R.rp[3] = m3 ? (uint32_t)__builtin_ctzll(m3) : wave_cmplen(e.in, x, x - r3 - 1, 64, buf_avail);
         R.rm[0] = m0; R.rm[1] = m1; R.rm[2] = m2; R.rm[3] = m3;
-        R.cx = cx; R.cr[0] = c0; R.cr[1] = c1; R.cr[2] = c2; R.cr[3] = c3;
     }
     const uint32_t tr = lane_of(tv, LIST_K);
     const uint32_t cnt = tr & 0xFFu;
@@ -1210,7 +1207,7 @@ __device__ __forceinline__ void compound_setup(const RoundL& RL, uint32_t j, uin
 // One window of the optimal parser (oracle: optimum_window).  Returns with the chosen symbol path
 // stored as out-edges: node t -> (n_price[t] = back, out-len in n_info[t]); q_end = last node to code
 // (a window cut by the node limit only commits the symbols that end WTAIL nodes before the cut).
-constexpr uint32_t WTAIL = 24;
+constexpr uint32_t WTAIL = 16;
 __device__ __forceinline__ bool optimum_window(const Env& e, const Work& w, ListPre& P, uint16_t* probs, const Lz& z, LenTab& lt,
         const uint8_t* __restrict__ in, uint32_t pos, uint32_t block_start, uint32_t span_end, bool cached,
         RoundL& RL, uint32_t& q_end)
@@ -1288,15 +1285,30 @@ __device__ __forceinline__ bool optimum_window(const Env& e, const Work& w, List
         const uint32_t room = WMAX - j;
         const uint32_t avail = span_end - x;
         const uint32_t buf_avail = avail < MATCH_LEN_MAX ? avail : MATCH_LEN_MAX;
-        // compound candidates: geometry now, prices after the plain edges
+        // compound candidates: geometry now, prices after the plain edges.  A cheap necessary condition first
+        // (two equal bytes behind the first mismatch of a rep source, or a run recorded with the list): text
+        // rarely has any, and then none of the compound code runs.
         Compound cp;
-        compound_setup(RL, j, room, buf_avail, r0, r1, r2, r3, cp);
+        cp.mask = 0; cp.L1 = cp.l2 = cp.T = cp.dist = 0;
+        {
+            bool any = (RL.l2a | RL.l2b) >= 2;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint64_t m = RL.rm[i];
+                const uint64_t after = m ? (m >> 1) >> (uint32_t)__builtin_ctzll(m) : 1ull;      // bits behind the first mismatch
+                any = any || (after & 3ull) == 0;
+            }
+            if (any) compound_setup(RL, j, room, buf_avail, r0, r1, r2, r3, cp);
+        }
         uint32_t cT_max = 0;
         for (uint64_t mm = cp.mask; mm; mm &= mm - 1) cT_max = max(cT_max, lane_of(cp.T, (uint32_t)__builtin_ctzll(mm)));
-        // match byte of the literal behind a match candidate (lanes 5 / 6): the only load the compound
-        // literal prices need that the rep rows do not already hold
-        uint32_t c_mb = 0;
-        if (((cp.mask >> lane) & 1) && lane >= 5) c_mb = in[x + cp.L1 - cp.dist - 1];
+        // the three bytes each compound literal needs (lane = candidate 1..6): the byte itself, its
+        // predecessor (literal context) and the match byte X leaves behind
+        uint32_t c_bytes = 0;
+        if (((cp.mask >> lane) & 1) && lane >= 1) {
+            const uint8_t* pl = in + x + cp.L1;
+            c_bytes = (uint32_t)pl[0] | ((uint32_t)*(pl - cp.dist - 1) << 8) | ((uint32_t)*(pl - 1) << 16);
+        }
 
         if (longest > room) longest = room;
         if (rl0 > room) rl0 = room;
@@ -1320,17 +1332,11 @@ __device__ __forceinline__ bool optimum_window(const Env& e, const Work& w, List
         // compound literal prices: lane = candidate * 8 + bit (candidates 1..6), one gather of the eight
         // probabilities each matched literal would use (literal_matched, lzma_encoder.c:23-41), issued
         // here and summed after the plain edges
+        TM_BEGIN(t_cg);
         uint32_t cg_p = 0, cg_flip = 0;
         const bool cg_any = (cp.mask & 0x7Eull) != 0;
         if (cg_any) {
-            // bytes of the literal: cur / prev from the text row, match byte from the rep rows or c_mb
-            const uint32_t cl = lane < 7 ? cp.L1 : 0u;
-            const uint32_t cur_b = (uint32_t)__shfl((int)RL.cx, (int)cl);
-            const uint32_t prev_b = (uint32_t)__shfl((int)RL.cx, (int)(cl ? cl - 1 : 0));
-            const uint32_t m0b = (uint32_t)__shfl((int)RL.cr[0], (int)cl), m1b = (uint32_t)__shfl((int)RL.cr[1], (int)cl);
-            const uint32_t m2b = (uint32_t)__shfl((int)RL.cr[2], (int)cl), m3b = (uint32_t)__shfl((int)RL.cr[3], (int)cl);
-            const uint32_t mb_b = lane == 1 ? m0b : lane == 2 ? m1b : lane == 3 ? m2b : lane == 4 ? m3b : c_mb;
-            const uint32_t packed = cur_b | (mb_b << 8) | (prev_b << 16);
+            const uint32_t packed = c_bytes;
             const uint32_t cand = lane >> 3, bit_i = lane & 7;
             const uint32_t pk = (uint32_t)__shfl((int)packed, (int)cand);
             const uint32_t cL = (uint32_t)__shfl((int)cp.L1, (int)cand);
@@ -1345,6 +1351,7 @@ __device__ __forceinline__ bool optimum_window(const Env& e, const Work& w, List
             cg_flip = (0u - bit) & 0x7FFu;
             if (act) cg_p = lit_load(z.lit + sub + idx);
         }
+        TM_END(w, 15, t_cg);
 
         TM_BEGIN(t_lit);
         // literal and short rep -> node j+1
@@ -1375,7 +1382,9 @@ __device__ __forceinline__ bool optimum_window(const Env& e, const Work& w, List
         }
         TM_END(w, 4, t_relax);
 
+        TM_BEGIN(t_cp);
         if (cp.mask) {
+            TM_COUNT(w, 13);
             // ---- price the compound candidates, lane = candidate ----
             // length prices: LenTab holds length 2 + l + 64 * it in lane l (low half match, high half rep)
             const uint32_t lo_ps = (ps & 3) == 0 ? lt.lo[0] : (ps & 3) == 1 ? lt.lo[1] : (ps & 3) == 2 ? lt.lo[2] : lt.lo[3];
@@ -1446,6 +1455,7 @@ __device__ __forceinline__ bool optimum_window(const Env& e, const Work& w, List
                 wave_sync();
             }
         }
+        TM_END(w, 14, t_cp);
         ++j;
         if (j == n_end) { forced = j >= WMAX; break; }
     }
@@ -1598,10 +1608,9 @@ void k_span_encode_t(xzamd_span_args a)
     Round R;            // exact path: cached find at `cur` when read_ahead == 1
     R.mask = 0; R.L = 0; R.D = 0; R.longest = 0;
     RoundL RL;
-    RL.L = 0; RL.SL = 0; RL.SD = 0; RL.cnt = 0; RL.longest = 0; RL.l2a = RL.l2b = 0; RL.cx = 0;
+    RL.L = 0; RL.SL = 0; RL.SD = 0; RL.cnt = 0; RL.longest = 0; RL.l2a = RL.l2b = 0;
     RL.rp[0] = RL.rp[1] = RL.rp[2] = RL.rp[3] = 0;
     RL.rm[0] = RL.rm[1] = RL.rm[2] = RL.rm[3] = 0;
-    RL.cr[0] = RL.cr[1] = RL.cr[2] = RL.cr[3] = 0;
     LenTab lt;
     uint32_t q_pos = 0, q_end = 0;  // pending path of the optimal parser (nodes in LDS)
     bool tables_valid = false;
@@ -1882,7 +1891,9 @@ void k_span_encode_t(xzamd_span_args a)
             unsigned long long* g = reinterpret_cast<unsigned long long*>(a.err + 16);
             for (int i = 0; i < 12; ++i) atomicAdd(g + i, tm_lds[i]);
             atomicMax(g + 12, tm_lds[8]);
-            atomicMax(g + 13, (1ull << 62) - tm_lds[8]);
+            atomicAdd(g + 13, tm_lds[13]);
+            atomicAdd(g + 14, tm_lds[14]);
+            atomicAdd(g + 15, tm_lds[15]);
         }
     }
     if (lane == 0 && span == 0 && a.err) {
@@ -1961,6 +1972,34 @@ struct SnArgs {
 // candidate when it is more recent than every eligible neighbour nearer on its side ("recency
 // record": exactly the nodes BT4's descent would visit).  All candidates are compared with the text
 // at x in parallel (16 bytes per trip), filtered by the Pareto rule and stored sorted by length.
+//
+// A position is a chain of dependent memory round trips (rank -> suffix-order window -> candidate
+// text), so the loop is software pipelined three deep: while position x is compared and filtered, the
+// first 16 bytes of every candidate of x + 1 and the window of x + 2 are already in flight.
+struct Geo { uint32_t bs, be, se; };          // Block start / end and span end of a position
+
+__device__ __forceinline__ void geo_init(Geo& g, uint32_t p, const xzamd_span_args& a)
+{
+    const uint32_t blk = p / a.block_size;
+    g.bs = blk * a.block_size;
+    g.be = min(a.n, g.bs + a.block_size);
+    const uint64_t kk = (p - g.bs) / a.span_size;
+    const uint64_t se = (uint64_t)g.bs + (kk + 1) * a.span_size;
+    g.se = se < g.be ? (uint32_t)se : g.be;
+}
+
+// g describes position p - 1 (or p); make it describe p
+__device__ __forceinline__ void geo_advance(Geo& g, uint32_t p, const xzamd_span_args& a)
+{
+    if (p >= g.se && p < a.n) {
+        if (p >= g.be) { g.bs = g.be; g.be = min(a.n, g.bs + a.block_size); g.se = g.bs; }
+        const uint64_t se = (uint64_t)g.se + a.span_size;
+        g.se = se < g.be ? (uint32_t)se : g.be;
+    }
+}
+
+constexpr uint32_t SN_NONE = 0xFFFFFFFFu;     // "no neighbour in this lane" (positions are < 2^31)
+
 __global__ __launch_bounds__(64) void k_find_sn(xzamd_span_args a, SnArgs sn, uint16_t* __restrict__ mlen,
         uint32_t* __restrict__ mdist)
 {
@@ -1974,123 +2013,161 @@ __global__ __launch_bounds__(64) void k_find_sn(xzamd_span_args a, SnArgs sn, ui
     const uint32_t nice = a.nice_len;
     const uint32_t half = lane >> 5, k = lane & 31;
     const bool win_lane = k < W;
-    uint32_t span_end = 0, block_start = 0, block_end = 0;
-    uint32_t RK = 0, P2 = 0, P3 = 0, P4 = 0, P8 = 0;     // lane = position - chunk start: per-position words of 64 positions
-    uint32_t wq_next = 0;                                 // this lane's neighbour for the NEXT position (prefetched)
-    bool pre_valid = false;
-    for (uint32_t x = x0; x < x1; ++x) {
-        const uint32_t i = (x - x0) & 63;
-        if (i == 0) {
-            const uint32_t xl = min(x + lane, a.n - 1);
-            RK = sn.sa_rank[xl]; P2 = sn.prev2[xl]; P3 = sn.prev3[xl]; P4 = sn.prev4[xl]; P8 = sn.prev8[xl];
-        }
-        if (x >= span_end) {
-            const uint32_t blk = x / a.block_size;
-            block_start = blk * a.block_size;
-            block_end = min(a.n, block_start + a.block_size);
-            const uint64_t kk = (x - block_start) / a.span_size;
-            const uint64_t se = (uint64_t)block_start + (kk + 1) * a.span_size;
-            span_end = se < block_end ? (uint32_t)se : block_end;
-        }
-        // this lane's neighbour slot (the slots of a Block are exactly its positions' range)
-        const uint32_t r = lane_of(RK, i);
+    const uint32_t n_last = a.n - 1;
+
+    // per-position words of the current and the next 64 positions (lane = position - chunk start)
+    uint32_t RKc, P2c, P3c, P4c, P8c, RKn, P2n, P3n, P4n, P8n;
+    {
+        const uint32_t xa = min(x0 + lane, n_last), xb = min(x0 + 64 + lane, n_last);
+        RKc = sn.sa_rank[xa]; P2c = sn.prev2[xa]; P3c = sn.prev3[xa]; P4c = sn.prev4[xa]; P8c = sn.prev8[xa];
+        RKn = sn.sa_rank[xb]; P2n = sn.prev2[xb]; P3n = sn.prev3[xb]; P4n = sn.prev4[xb]; P8n = sn.prev8[xb];
+    }
+    uint32_t chunk = x0;                                   // first position of RKc
+    auto word = [&](uint32_t c, uint32_t nx, uint32_t idx) -> uint32_t {
+        return idx < 64 ? lane_of(c, idx) : lane_of(nx, idx - 64);
+    };
+    // neighbour of this lane for position p (slot bounds = the Block's position range)
+    auto window = [&](uint32_t p, const Geo& g) -> uint32_t {
+        const uint32_t r = word(RKc, RKn, p - chunk);
         const int32_t slot = half ? (int32_t)(r + 1 + k) : (int32_t)r - 1 - (int32_t)k;
-        const bool inb = win_lane && slot >= (int32_t)block_start && slot < (int32_t)block_end;
-        uint32_t q = wq_next;
-        if (!pre_valid) q = inb ? sn.sa[slot] : 0u;
-        // prefetch the neighbours of x + 1 while x is being compared (its rank is in RK unless a new chunk starts)
-        pre_valid = i != 63 && x + 1 < x1;
-        if (pre_valid) {
-            const bool nb = x + 1 == block_end;                                  // x + 1 opens the next Block
-            const uint32_t bs2 = nb ? block_end : block_start;
-            const uint32_t be2 = nb ? min(a.n, block_end + a.block_size) : block_end;
-            const uint32_t rn = lane_of(RK, i + 1);
-            const int32_t sl2 = half ? (int32_t)(rn + 1 + k) : (int32_t)rn - 1 - (int32_t)k;
-            const bool ok2 = win_lane && sl2 >= (int32_t)bs2 && sl2 < (int32_t)be2;
-            wq_next = ok2 ? sn.sa[sl2] : 0u;
-        }
-        const uint32_t avail = span_end - x;
-        const uint32_t buf_avail = avail < MATCH_LEN_MAX ? avail : MATCH_LEN_MAX;
-        uint32_t len_limit = avail;
-        bool mf_ok = true;
-        if (nice <= len_limit) len_limit = nice;
-        else if (len_limit < 4) mf_ok = false;            // "pending": nothing is reported (lz_encoder_mf.c:190-201)
-        const uint64_t rec_base = (uint64_t)x * LIST_W;
-        if (!mf_ok) {
-            if (lane == 0) mdist[rec_base + LIST_K] = 0;
-            continue;
-        }
-        // recency records of both sides
-        const bool elig = inb && q < x && x - q < cyclic;
-        const uint32_t v = elig ? q + 1 : 0u;
+        const bool inb = win_lane && slot >= (int32_t)g.bs && slot < (int32_t)g.be;
+        return inb ? sn.sa[slot] : SN_NONE;
+    };
+    // candidate of this lane for position p given its neighbour wq: position q, validity, minimum length
+    auto candidate = [&](uint32_t p, uint32_t wq, uint32_t& q, bool& valid) {
+        const bool elig = wq != SN_NONE && wq < p && p - wq < cyclic;
+        const uint32_t v = elig ? wq + 1 : 0u;
         const uint32_t pm = prefix_max_half(v);
         uint32_t ex = (uint32_t)__shfl_up((int)pm, 1);
         ex = k == 0 ? 0u : ex;
-        bool valid = elig && v > ex;
-        uint32_t minlen = 4;
-        // the four hash candidates sit in the lanes the windows never use
-        {
-            const uint32_t d2 = lane_of(P2, i), d3 = lane_of(P3, i), d4 = lane_of(P4, i), d8 = lane_of(P8, i);
+        valid = elig && v > ex;
+        q = elig ? wq : 0u;
+        if (k >= 30) {                                      // the four hash candidates sit in the lanes the windows never use
+            const uint32_t idx = p - chunk;
+            const uint32_t d2 = word(P2c, P2n, idx), d3 = word(P3c, P3n, idx), d4 = word(P4c, P4n, idx), d8 = word(P8c, P8n, idx);
             const uint32_t dh = lane == 30 ? d2 : lane == 31 ? d3 : lane == 62 ? d4 : d8;
-            if (k >= 30) {
-                valid = dh != 0 && dh < cyclic;
-                q = x - dh;
-                minlen = lane == 30 ? 2u : lane == 31 ? 3u : 4u;
+            valid = dh != 0 && dh < cyclic;
+            q = valid ? p - dh : 0u;
+        }
+    };
+    auto load16 = [&](uint32_t off) -> uint4 {
+        uint4 v;
+        __builtin_memcpy(&v, in + off, 16);
+        return v;
+    };
+
+    Geo g0, g1, g2;
+    geo_init(g0, x0, a);
+    g1 = g0; geo_advance(g1, x0 + 1, a);
+    g2 = g1; geo_advance(g2, x0 + 2, a);
+    // prologue: window of x0 and x0 + 1, candidates + first compare trip of x0
+    uint32_t w1 = x0 + 1 < x1 ? window(x0 + 1, g1) : SN_NONE;
+    uint32_t q0; bool v0;
+    candidate(x0, window(x0, g0), q0, v0);
+    bool pf0 = x0 + 16 <= a.n;                             // the 16-byte prefetch of this position stays inside the batch
+    uint4 A0 = make_uint4(0, 0, 0, 0), B0 = A0;
+    if (pf0) { A0 = load16(q0); B0 = load16(x0); }
+
+    for (uint32_t x = x0; x < x1; ++x) {
+        // stage 0: window of x + 2
+        uint32_t w2 = SN_NONE;
+        if (x + 2 < x1) w2 = window(x + 2, g2);
+        // stage 1: candidates of x + 1 and their first 16 bytes
+        uint32_t q1 = 0; bool v1 = false, pf1 = false;
+        uint4 A1 = A0, B1 = B0;
+        if (x + 1 < x1) {
+            candidate(x + 1, w1, q1, v1);
+            pf1 = x + 1 + 16 <= a.n;
+            if (pf1) { A1 = load16(q1); B1 = load16(x + 1); }
+        }
+        // stage 2: position x
+        {
+            const uint32_t q = q0;
+            const bool valid = v0;
+            const uint32_t avail = g0.se - x;
+            const uint32_t buf_avail = avail < MATCH_LEN_MAX ? avail : MATCH_LEN_MAX;
+            uint32_t len_limit = avail;
+            bool mf_ok = true;
+            if (nice <= len_limit) len_limit = nice;
+            else if (len_limit < 4) mf_ok = false;            // "pending": nothing is reported (lz_encoder_mf.c:190-201)
+            const uint64_t rec_base = (uint64_t)x * LIST_W;
+            uint64_t kmask = 0;
+            uint32_t L = 0, dist = 0;
+            bool keep = false;
+            if (mf_ok) {
+                const uint32_t lim = valid ? len_limit : 0u;
+                if (pf0) {
+                    const uint32_t m = match16(A0, B0);
+                    L = m < lim ? m : lim;
+                    if (m == 16 && lim > 16) L = lane_cmplen16_from(in, q, x, 16, lim);
+                } else {
+                    L = lane_cmplen16_from(in, q, x, 0, lim);
+                }
+                const uint32_t minlen = lane == 30 ? 2u : lane == 31 ? 3u : 4u;
+                const bool ok = valid && L >= minlen;
+                dist = x - q;                                   // delta >= 1 on ok lanes
+                // Pareto set: drop a candidate when another one is closer and at least as long (duplicates:
+                // the lower lane stays)
+                bool dom = false;
+                for (uint64_t mm = __ballot(ok); mm; mm &= mm - 1) {
+                    const uint32_t jl = (uint32_t)__builtin_ctzll(mm);
+                    const uint32_t dj = lane_of(dist, jl), Lj = lane_of(L, jl);
+                    dom = dom || (dj < dist && Lj >= L) || (dj == dist && jl < lane);
+                }
+                keep = ok && !dom;
+                kmask = __ballot(keep);
             }
-        }
-        const uint32_t L = lane_cmplen16_from(in, valid ? q : 0u, x, 0, valid ? len_limit : 0u);
-        const bool ok = valid && L >= minlen;
-        const uint32_t dist = x - q;                        // delta >= 1 on ok lanes
-        // Pareto set: drop a candidate when another one is closer and at least as long (duplicates: the
-        // lower lane stays)
-        bool dom = false;
-        for (uint64_t mm = __ballot(ok); mm; mm &= mm - 1) {
-            const uint32_t jl = (uint32_t)__builtin_ctzll(mm);
-            const uint32_t dj = lane_of(dist, jl), Lj = lane_of(L, jl);
-            dom = dom || (dj < dist && Lj >= L) || (dj == dist && jl < lane);
-        }
-        const bool keep = ok && !dom;
-        const uint64_t kmask = __ballot(keep);
-        const uint32_t cnt = (uint32_t)__builtin_popcountll(kmask);
-        if (cnt == 0) {
-            if (lane == 0) mdist[rec_base + LIST_K] = 0;
-            continue;
-        }
-        // kept entries have distinct lengths, increasing with distance: rank by length
-        uint32_t rk = 0;
-        for (uint64_t mm = kmask; mm; mm &= mm - 1) {
-            const uint32_t kl = (uint32_t)__builtin_ctzll(mm);
-            rk += lane_of(L, kl) < L ? 1u : 0u;
-        }
-        const uint64_t topm = __ballot(keep && rk + 1 == cnt);
-        const uint32_t top = (uint32_t)__builtin_ctzll(topm);
-        uint32_t longest = lane_of(L, top);
-        if (longest == nice)
-            longest = wave_cmplen(in, x, x - lane_of(dist, top), longest, buf_avail);
-        const uint32_t len_out = lane == top ? longest : L;
-        // rep0 run behind the byte after the match, for the two longest entries
-        uint32_t l2 = 0;
-        if (keep && rk + 2 >= cnt && len_out + 1 < avail) {
-            const uint32_t lim = min(avail, len_out + 1 + LEN2_MAX);
-            l2 = lane_cmplen16_from(in, q, x, len_out + 1, lim) - (len_out + 1);
-        }
-        const uint32_t l2a = lane_of(l2, top);
-        uint32_t l2b = 0;
-        if (cnt >= 2) {
-            const uint64_t secm = __ballot(keep && rk + 2 == cnt);
-            l2b = lane_of(l2, (uint32_t)__builtin_ctzll(secm));
-        }
-        const uint32_t drop = cnt > LIST_K ? cnt - LIST_K : 0;
-        if (keep && rk >= drop) {
-            const uint64_t o = rec_base + (rk - drop);
-            if (a.list_packed) {
-                mdist[o] = (len_out << 23) | (dist - 1);
+            const uint32_t cnt = (uint32_t)__builtin_popcountll(kmask);
+            if (cnt == 0) {
+                if (lane == 0) mdist[rec_base + LIST_K] = 0;
             } else {
-                mlen[o] = (uint16_t)len_out;
-                mdist[o] = dist - 1;
+                // kept entries have distinct lengths, increasing with distance: rank by length
+                uint32_t rk = 0;
+                for (uint64_t mm = kmask; mm; mm &= mm - 1) {
+                    const uint32_t kl = (uint32_t)__builtin_ctzll(mm);
+                    rk += lane_of(L, kl) < L ? 1u : 0u;
+                }
+                const uint64_t topm = __ballot(keep && rk + 1 == cnt);
+                const uint32_t top = (uint32_t)__builtin_ctzll(topm);
+                uint32_t longest = lane_of(L, top);
+                if (longest == nice)
+                    longest = wave_cmplen(in, x, x - lane_of(dist, top), longest, buf_avail);
+                const uint32_t len_out = lane == top ? longest : L;
+                // rep0 run behind the byte after the match, for the two longest entries
+                uint32_t l2 = 0;
+                if (keep && rk + 2 >= cnt && len_out + 1 < avail) {
+                    const uint32_t lim2 = min(avail, len_out + 1 + LEN2_MAX);
+                    l2 = lane_cmplen16_from(in, q, x, len_out + 1, lim2) - (len_out + 1);
+                }
+                const uint32_t l2a = lane_of(l2, top);
+                uint32_t l2b = 0;
+                if (cnt >= 2) {
+                    const uint64_t secm = __ballot(keep && rk + 2 == cnt);
+                    l2b = lane_of(l2, (uint32_t)__builtin_ctzll(secm));
+                }
+                const uint32_t drop = cnt > LIST_K ? cnt - LIST_K : 0;
+                if (keep && rk >= drop) {
+                    const uint64_t o = rec_base + (rk - drop);
+                    if (a.list_packed) {
+                        mdist[o] = (len_out << 23) | (dist - 1);
+                    } else {
+                        mlen[o] = (uint16_t)len_out;
+                        mdist[o] = dist - 1;
+                    }
+                }
+                if (lane == top) mdist[rec_base + LIST_K] = (cnt - drop) | (l2a << 8) | (l2b << 16);
             }
         }
-        if (lane == top) mdist[rec_base + LIST_K] = (cnt - drop) | (l2a << 8) | (l2b << 16);
+        // shift the pipeline
+        q0 = q1; v0 = v1; pf0 = pf1; A0 = A1; B0 = B1;
+        w1 = w2;
+        g0 = g1; g1 = g2; geo_advance(g2, x + 3, a);
+        if (x + 1 - chunk == 64) {                              // x + 1 opens the next chunk of per-position words
+            chunk += 64;
+            RKc = RKn; P2c = P2n; P3c = P3n; P4c = P4n; P8c = P8n;
+            const uint32_t xb = min(chunk + 64 + lane, n_last);
+            RKn = sn.sa_rank[xb]; P2n = sn.prev2[xb]; P3n = sn.prev3[xb]; P4n = sn.prev4[xb]; P8n = sn.prev8[xb];
+        }
     }
 }
 
@@ -2609,6 +2686,7 @@ int xzk_sync(void* st) { return (int)hipStreamSynchronize((hipStream_t)st); }
 int xzk_set_device(int dev) { return (int)hipSetDevice(dev); }
 int xzk_get_device(int* dev) { return (int)hipGetDevice(dev); }
 int xzk_device_count(int* n) { return (int)hipGetDeviceCount(n); }
+int xzk_cu_count(int dev, int* cus) { return (int)hipDeviceGetAttribute(cus, hipDeviceAttributeMultiprocessorCount, dev); }
 int xzk_stream_create(void** st) { return (int)hipStreamCreateWithFlags((hipStream_t*)st, hipStreamNonBlocking); }
 // lowest-priority stream of the device (work on it only fills slots the caller's stream leaves free)
 int xzk_stream_create_low(void** st)

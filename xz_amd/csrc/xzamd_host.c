@@ -252,13 +252,14 @@ struct xzamd_ctx {
 	int device;
 	void *own_stream;
 	void *lo_stream;             /* lowest priority: the next batch's chain build runs here, under the span kernel */
-	void *ev_lo[4];              /* find done (hi), chains begin / end (lo), input ready (hi) */
+	void *ev_lo[2][4];           /* per list buffer: find done (hi), chains begin / end (lo), prefetched find done (lo) */
 	uint64_t batch_bytes;
+	uint32_t wave_slots;         /* span wavefronts resident at once (CUs x 16) */
 	char err[256];
 	char err_msg_buf[200];
 	/* device buffers */
 	dbuf keys_a, keys_b, vals_a, vals_b, rank, sorted_pos, prev2, prev3, prev4, prev8, key64_a, key64_b, sa, sa_rank, sort_tmp;
-	dbuf scratch, span_bytes, strip_crc, block_crc, segs, lits, trace, errw, litp, mlen, mdist, bcj;
+	dbuf scratch, span_bytes, strip_crc, block_crc, segs, lits, trace, errw, litp, mlen, mdist, mlen2, mdist2, bcj;
 	/* pinned host buffers */
 	dbuf h_span_bytes, h_block_crc, h_segs, h_lits;
 	void *ev[10];
@@ -315,11 +316,16 @@ int xzamd_ctx_create(xzamd_ctx **out, int device)
 	c->device = device;
 	if (xzk_stream_create(&c->own_stream)) { free(c); return XZAMD_DEVICE_ERROR; }
 	if (xzk_stream_create_low(&c->lo_stream)) c->lo_stream = NULL;      /* no overlap then */
-	for (int i = 0; i < 4; ++i)
-		if (xzk_event_create(&c->ev_lo[i])) { c->ev_lo[i] = NULL; c->lo_stream = NULL; }
+	for (int i = 0; i < 8; ++i)
+		if (xzk_event_create(&c->ev_lo[i >> 2][i & 3])) { c->ev_lo[i >> 2][i & 3] = NULL; c->lo_stream = NULL; }
 	for (int i = 0; i < 10; ++i)
 		if (xzk_event_create(&c->ev[i])) { free(c); return XZAMD_DEVICE_ERROR; }
 	c->batch_bytes = DEFAULT_BATCH;
+	{
+		int cus = 0;
+		if (xzk_cu_count(device, &cus) || cus <= 0) cus = 256;
+		c->wave_slots = (uint32_t)cus * 16u;       /* the span kernels run 4 waves per SIMD = 16 per CU */
+	}
 	const char *env = getenv("XZAMD_BATCH_MIB");
 	if (env && atoll(env) > 0)
 		xzamd_ctx_set_batch_bytes(c, (uint64_t)atoll(env) << 20);
@@ -335,7 +341,7 @@ void xzamd_ctx_destroy(xzamd_ctx *c)
 	dbuf *d[] = { &c->keys_a, &c->keys_b, &c->vals_a, &c->vals_b, &c->rank, &c->sorted_pos,
 		&c->prev2, &c->prev3, &c->prev4, &c->prev8, &c->key64_a, &c->key64_b, &c->sa, &c->sa_rank, &c->sort_tmp,
 		&c->scratch, &c->span_bytes, &c->strip_crc,
-		&c->block_crc, &c->segs, &c->lits, &c->trace, &c->errw, &c->litp, &c->mlen, &c->mdist, &c->bcj };
+		&c->block_crc, &c->segs, &c->lits, &c->trace, &c->errw, &c->litp, &c->mlen, &c->mdist, &c->mlen2, &c->mdist2, &c->bcj };
 	for (size_t i = 0; i < sizeof(d) / sizeof(d[0]); ++i)
 		if (d[i]->p) xzk_free(d[i]->p);
 	dbuf *h[] = { &c->h_span_bytes, &c->h_block_crc, &c->h_segs, &c->h_lits };
@@ -343,8 +349,8 @@ void xzamd_ctx_destroy(xzamd_ctx *c)
 		if (h[i]->p) xzk_host_free(h[i]->p);
 	for (int i = 0; i < 10; ++i)
 		if (c->ev[i]) xzk_event_destroy(c->ev[i]);
-	for (int i = 0; i < 4; ++i)
-		if (c->ev_lo[i]) xzk_event_destroy(c->ev_lo[i]);
+	for (int i = 0; i < 8; ++i)
+		if (c->ev_lo[i >> 2][i & 3]) xzk_event_destroy(c->ev_lo[i >> 2][i & 3]);
 	if (c->lo_stream) xzk_stream_destroy(c->lo_stream);
 	if (c->own_stream) xzk_stream_destroy(c->own_stream);
 	free(c);
@@ -542,12 +548,11 @@ int xzamd_stream_encode_device(xzamd_ctx *c,
 	uint32_t hbits = 0;
 	while ((1ull << hbits) <= hmask) ++hbits;
 	const uint32_t kbits_max = (opt->gpu_sa_window && hbits < 22) ? 22 : hbits;   /* widest 32-bit sort key family */
-	uint32_t span = opt->span_size == XZAMD_SPAN_DEFAULT ? (opt->gpu_parser ? DEFAULT_SPAN_OPT : DEFAULT_SPAN) : opt->span_size;
+	const uint32_t span0 = opt->gpu_parser ? DEFAULT_SPAN_OPT : DEFAULT_SPAN;
+	uint32_t span = (opt->span_size == XZAMD_SPAN_DEFAULT || opt->span_size == XZAMD_SPAN_AUTO) ? span0 : opt->span_size;
 	if (span > block_size) span = (uint32_t)block_size;
 	if (span < 4096)
 		return fail(c, XZAMD_OPTIONS_ERROR, "span_size must be >= 4096", 0);
-	const uint32_t spb = (uint32_t)((block_size + span - 1) / span);
-	const uint64_t span_cap = ((uint64_t)span + (span >> 3) + 4096 + 15) & ~15ull;
 
 	/* Match lists of the optimal parser: 8 x u32 per position (7 entries length << 23 | distance-1 and a
 	 * trailer) when distances fit 23 bits, else 8 x u32 distances + 8 x u16 lengths. */
@@ -570,12 +575,31 @@ int xzamd_stream_encode_device(xzamd_ctx *c,
 		max_blocks = (total_blocks + nbatch - 1) / nbatch;
 	}
 	if (nblocks_out) *nblocks_out = total_blocks;
+	if (opt->span_size == XZAMD_SPAN_AUTO && total_blocks) {
+		/* One wavefront per span and spans of about equal cost: a launch runs in rounds of `wave_slots`
+		 * spans.  Size the spans so that the rounds of a batch are full: between half the default and
+		 * the default span. */
+		const uint64_t nbb = total_blocks < max_blocks ? total_blocks : max_blocks;
+		const uint64_t spb0 = (block_size + span - 1) / span;
+		const uint64_t rounds = (nbb * spb0 + c->wave_slots - 1) / c->wave_slots;
+		uint64_t spb_new = rounds * c->wave_slots / nbb;
+		if (spb_new > spb0) {
+			uint64_t sp = (block_size + spb_new - 1) / spb_new;
+			sp = (sp + 15) & ~15ull;
+			if (sp < span / 2) sp = span / 2;
+			if (sp < 4096) sp = 4096;
+			if (sp < span) span = (uint32_t)sp;
+		}
+	}
+	const uint32_t spb = (uint32_t)((block_size + span - 1) / span);
+	const uint64_t span_cap = ((uint64_t)span + (span >> 3) + 4096 + 15) & ~15ull;
 	const uint64_t bound = xzamd_block_buffer_bound(block_size);
 	const int x86 = opt->bcj == XZAMD_BCJ_X86;
 	const uint32_t hs_fixed = block_header_size(bound, block_size, x86);
 	const uint8_t dbyte = dict_size_byte(opt->dict_size);
 
 	memset(&c->stats, 0, sizeof(c->stats));
+	c->stats.span_size = span;
 	uint64_t opos = 0;
 	uint8_t small[64];
 	uint64_t *rec_unp = NULL, *rec_unc = NULL;
@@ -596,7 +620,7 @@ int xzamd_stream_encode_device(xzamd_ctx *c,
 	int rc = XZAMD_OK;
 	/* chain-build overlap: more than one batch, no BCJ copy to double-buffer, not disabled */
 	const int overlap = c->lo_stream != NULL && !x86 && total_blocks > max_blocks && getenv("XZAMD_NO_OVERLAP") == NULL;
-	int prefetched = 0, chains_on_lo = 0;
+	int prefetched = 0, chains_on_lo = 0, lists_cur = 0, find_on_lo = 0;
 	uint64_t prefetched_b0 = 0;
 	xzk_event_record(c->ev[8], st);
 	for (uint64_t b0 = 0; b0 < total_blocks && rc == XZAMD_OK; ) {
@@ -635,6 +659,11 @@ int xzamd_stream_encode_device(xzamd_ctx *c,
 			/* per-position match lists: 8 x u32 (7 entries + trailer), + 8 x u16 lengths when not packed */
 			if (!list_packed) GROW(mlen, 16ull * n, 0);
 			GROW(mdist, 32ull * n, 0);
+			if (overlap) {
+				/* second list buffer: the next batch's finder runs underneath this batch's span kernel */
+				if (!list_packed) GROW(mlen2, 16ull * n, 0);
+				GROW(mdist2, 32ull * n, 0);
+			}
 		}
 		GROW(h_span_bytes, 4ull * nspans, 1);
 		GROW(h_block_crc, 8ull * nb, 1);
@@ -659,12 +688,17 @@ int xzamd_stream_encode_device(xzamd_ctx *c,
 		/* 1. match-finder structure: built on the caller's stream, unless the previous iteration already
 		 * started it on the low-priority stream underneath its span kernel */
 		if (prefetched && prefetched_b0 == b0) {
-			if (xzk_stream_wait_event(st, c->ev_lo[2])) { rc = fail(c, XZAMD_DEVICE_ERROR, "wait chains", 1); goto done; }
+			/* chains AND match lists of this batch were produced on the low-priority stream (into the other
+			 * list buffer) while the previous span kernel ran */
+			lists_cur ^= 1;
+			if (xzk_stream_wait_event(st, c->ev_lo[lists_cur][3])) { rc = fail(c, XZAMD_DEVICE_ERROR, "wait chains", 1); goto done; }
 			chains_on_lo = 1;
+			find_on_lo = 1;
 		} else {
 			rc = launch_chains(c, opt, enc_in, &g, block_size, hb, hmask, hbits, st);
 			if (rc != XZAMD_OK) goto done;
 			chains_on_lo = 0;
+			find_on_lo = 0;
 		}
 		prefetched = 0;
 		xzk_event_record(c->ev[1], st);
@@ -700,28 +734,42 @@ int xzamd_stream_encode_device(xzamd_ctx *c,
 			a.hash_bytes = hb;
 			a.lc = opt->lc; a.lp = opt->lp; a.pb = opt->pb;
 			int e = 0;
+			uint16_t *const ml_cur = list_packed ? NULL : (uint16_t *)(lists_cur ? c->mlen2.p : c->mlen.p);
+			uint32_t *const md_cur = (uint32_t *)(lists_cur ? c->mdist2.p : c->mdist.p);
 			if (opt->gpu_parser) {
-				/* 2a. batch match finder -> lists the parser streams */
-				a.mlen = list_packed ? NULL : (const uint16_t *)c->mlen.p;
+				/* 2a. batch match finder -> lists the parser streams (unless already made on the low-priority stream) */
+				a.mlen = ml_cur;
 				a.list_packed = (uint32_t)list_packed;
-				a.mdist = (const uint32_t *)c->mdist.p;
-				e = xzk_find_matches(&a, (const uint32_t *)c->sa.p, (const uint32_t *)c->sa_rank.p, (const uint32_t *)c->prev4.p,
-						(const uint32_t *)c->prev8.p, list_packed ? NULL : (uint16_t *)c->mlen.p, (uint32_t *)c->mdist.p, st);
-				if (e) { rc = fail(c, XZAMD_DEVICE_ERROR, "find_matches launch", e); goto done; }
+				a.mdist = md_cur;
+				if (!find_on_lo) {
+					e = xzk_find_matches(&a, (const uint32_t *)c->sa.p, (const uint32_t *)c->sa_rank.p, (const uint32_t *)c->prev4.p,
+							(const uint32_t *)c->prev8.p, ml_cur, md_cur, st);
+					if (e) { rc = fail(c, XZAMD_DEVICE_ERROR, "find_matches launch", e); goto done; }
+				}
 				xzk_event_record(c->ev[5], st);
 			}
-			/* The chain arrays are free once the finder is done (the fast kernels read them, so they
-			 * keep them): build the NEXT batch's chains now, on the lowest-priority stream.  The span
-			 * kernel takes every slot it can use; the sorts fill what its tail leaves idle. */
+			/* The chain arrays are free once the finder is done (the fast kernels read them, so they keep
+			 * them): build the NEXT batch's chains and match lists now, on the lowest-priority stream, into
+			 * the other list buffer.  The span kernel takes every slot it can use; the sorts and the finder
+			 * fill what its rounds leave idle. */
 			if (overlap && opt->gpu_parser && b0 + nb < total_blocks) {
 				batch_geo g2;
 				if (batch_geometry(c, opt, b0 + nb, total_blocks, max_blocks, block_size, in_size, hbits, &g2) == XZAMD_OK
 						&& g2.n <= n && g2.sort_bytes + 256 <= c->sort_tmp.cap) {
-					int e2 = xzk_event_record(c->ev_lo[0], st);
-					if (!e2) e2 = xzk_stream_wait_event(c->lo_stream, c->ev_lo[0]);
-					if (!e2) e2 = xzk_event_record(c->ev_lo[1], c->lo_stream);
+					xzamd_span_args a2 = a;
+					a2.in = d_in + g2.in_off;
+					a2.n = g2.n;
+					uint16_t *const ml_nx = list_packed ? NULL : (uint16_t *)(lists_cur ? c->mlen.p : c->mlen2.p);
+					uint32_t *const md_nx = (uint32_t *)(lists_cur ? c->mdist.p : c->mdist2.p);
+					void **evn = c->ev_lo[lists_cur ^ 1];
+					int e2 = xzk_event_record(evn[0], st);
+					if (!e2) e2 = xzk_stream_wait_event(c->lo_stream, evn[0]);
+					if (!e2) e2 = xzk_event_record(evn[1], c->lo_stream);
 					if (!e2 && launch_chains(c, opt, d_in + g2.in_off, &g2, block_size, hb, hmask, hbits, c->lo_stream) != XZAMD_OK) e2 = 1;
-					if (!e2) e2 = xzk_event_record(c->ev_lo[2], c->lo_stream);
+					if (!e2) e2 = xzk_event_record(evn[2], c->lo_stream);
+					if (!e2) e2 = xzk_find_matches(&a2, (const uint32_t *)c->sa.p, (const uint32_t *)c->sa_rank.p, (const uint32_t *)c->prev4.p,
+							(const uint32_t *)c->prev8.p, ml_nx, md_nx, c->lo_stream);
+					if (!e2) e2 = xzk_event_record(evn[3], c->lo_stream);
 					if (e2) { rc = fail(c, XZAMD_DEVICE_ERROR, "chain prefetch", e2); goto done; }
 					prefetched = 1;
 					prefetched_b0 = b0 + nb;
@@ -753,12 +801,12 @@ int xzamd_stream_encode_device(xzamd_ctx *c,
 				const uint64_t *t = (const uint64_t *)(herr + 16);
 				if (t[8])
 					fprintf(stderr, "[timing opt, Mcycles summed over spans] total %llu | derive %llu round %llu bits %llu lit %llu relax %llu "
-							"backtrack %llu encode %llu refresh %llu | nodes %llu symbols %llu windows %llu | span max %llu min %llu Mcyc\n",
+							"backtrack %llu encode %llu refresh %llu | nodes %llu symbols %llu windows %llu | span max %llu Mcyc | compound nodes %llu price %llu gather %llu\n",
 							(unsigned long long)(t[8] >> 20), (unsigned long long)(t[0] >> 20), (unsigned long long)(t[1] >> 20),
 							(unsigned long long)(t[2] >> 20), (unsigned long long)(t[3] >> 20), (unsigned long long)(t[4] >> 20),
 							(unsigned long long)(t[5] >> 20), (unsigned long long)(t[6] >> 20), (unsigned long long)(t[7] >> 20),
 							(unsigned long long)t[9], (unsigned long long)t[10], (unsigned long long)t[11],
-							(unsigned long long)(t[12] >> 20), (unsigned long long)(((1ull << 62) - t[13]) >> 20));
+							(unsigned long long)(t[12] >> 20), (unsigned long long)t[13], (unsigned long long)(t[14] >> 20), (unsigned long long)(t[15] >> 20));
 			}
 			if (herr[0]) {
 				snprintf(c->err_msg_buf, sizeof(c->err_msg_buf),
@@ -847,10 +895,12 @@ int xzamd_stream_encode_device(xzamd_ctx *c,
 			if (e) { rc = fail(c, XZAMD_DEVICE_ERROR, "assemble", e); goto done; }
 		}
 		float ms;
-		if (chains_on_lo) { if (!xzk_event_elapsed_ms(c->ev_lo[1], c->ev_lo[2], &ms)) c->stats.ms_chains += ms; }
-		else if (!xzk_event_elapsed_ms(c->ev[0], c->ev[1], &ms)) c->stats.ms_chains += ms;
+		if (chains_on_lo) {
+			if (!xzk_event_elapsed_ms(c->ev_lo[lists_cur][1], c->ev_lo[lists_cur][2], &ms)) c->stats.ms_chains += ms;
+			if (!xzk_event_elapsed_ms(c->ev_lo[lists_cur][2], c->ev_lo[lists_cur][3], &ms)) c->stats.ms_find_overlapped += ms;
+		} else if (!xzk_event_elapsed_ms(c->ev[0], c->ev[1], &ms)) c->stats.ms_chains += ms;
 		if (!xzk_event_elapsed_ms(c->ev[1], c->ev[2], &ms)) c->stats.ms_encode += ms;
-		if (opt->gpu_parser && !xzk_event_elapsed_ms(c->ev[1], c->ev[5], &ms)) c->stats.ms_find += ms;
+		if (opt->gpu_parser && !find_on_lo && !xzk_event_elapsed_ms(c->ev[1], c->ev[5], &ms)) c->stats.ms_find += ms;
 		if (!xzk_event_elapsed_ms(c->ev[2], c->ev[3], &ms)) c->stats.ms_crc += ms;
 		if (!xzk_event_elapsed_ms(c->ev[3], c->ev[4], &ms)) c->stats.ms_assemble += ms;
 		c->stats.blocks += nb;

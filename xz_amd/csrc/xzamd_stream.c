@@ -207,6 +207,11 @@ static lzma_ret parse_options(const lzma_mt *o, xzamd_lzma_options *opt, uint64_
 	} else if (xzamd_lzma_preset(opt, o->preset)) {
 		return LZMA_OPTIONS_ERROR;
 	}
+	{
+		const char *au = getenv("XZAMD_SPAN_AUTO");
+		if (au && *au == '1')
+			opt->span_size = XZAMD_SPAN_AUTO;
+	}
 	const char *env = getenv("XZAMD_SPAN_KIB");
 	if (env && atoi(env) > 0)
 		opt->span_size = (uint32_t)atoi(env) << 10;
