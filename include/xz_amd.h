@@ -82,16 +82,17 @@ typedef struct {
 	uint32_t gpu_depth;  /* candidates taken from the main (3/4-byte hash) chain (exact finder only) */
 	uint32_t span_size;  /* bytes per independently coded span; XZAMD_SPAN_* */
 	uint32_t gpu_sa_window; /* 0 = exact HC3/HC4 semantics of the reference; else the suffix-neighbourhood
-	                        finder (the BT4 successor): recency records among this many slots (<= 30) on
+	                        finder (the BT4 successor): recency records among this many slots (<= 5) on
 	                        either side of a position in 32-byte-prefix suffix order, plus the nearest
-	                        equal hash2/hash3/hash4/hash8; needs gpu_mf = HC4 and gpu_parser = 1 */
+	                        equal hash2/hash3/hash4 and equal 8 / 16 bytes; needs gpu_mf = HC4 and
+	                        gpu_parser = 1 */
 	uint32_t gpu_parser; /* 0 = lzma_lzma_optimum_fast semantics, 1 = windowed optimal parser (232-node DP over
 	                        per-position match lists incl. the reference's compound edges; needs pb <= 2,
 	                        else XZAMD_OPTIONS_ERROR) */
 	uint32_t bcj;        /* 0 = chain {LZMA2}; XZAMD_BCJ_X86 = chain {x86 BCJ, LZMA2} (simple/x86.c, start offset 0) */
 } xzamd_lzma_options;
 #define XZAMD_BCJ_X86 4u    /* LZMA_FILTER_X86, api/lzma/bcj.h:20 */
-#define XZAMD_SA_WINDOW_MAX 30u
+#define XZAMD_SA_WINDOW_MAX 5u
 
 /* lzma_lzma_preset() (lzma/lzma_encoder_presets.c:17-63) + the device mapping.
  * Returns nonzero for an invalid preset. */

@@ -41,9 +41,10 @@
  *                    nearer in suffix order.  We therefore sort all positions of
  *                    the Block by their first 32 bytes (8-byte chunks, two
  *                    rank-doubling rounds, ties by position) and take, for each
- *                    position, the records among the sa_window slots to the left
- *                    and to the right of its own slot, plus the nearest previous
- *                    position with equal hash2 / hash3 / hash4 / 8-byte hash.  All candidates
+ *                    position, the records among the sa_window (<= 5) slots to the
+ *                    left and to the right of its own slot, plus the nearest
+ *                    previous position with equal hash2 / hash3 / hash4 and with
+ *                    the same 8 / 16 bytes (by-products of the sort rounds).  All candidates
  *                    are merged by the Pareto rule "longer than everything
  *                    closer"; the LIST_K longest survive.
  *   parser == 1      price-based forward dynamic program over a bounded window
@@ -73,7 +74,8 @@
 #define LIST_K 7u
 #endif
 #define LIST_K_                 /* matches kept per position (the LIST_K longest) */
-#define SA_WMAX 30u               /* widest suffix-order window per side (60 records + 4 hash candidates = 64 lanes) */
+#define SA_WMAX 5u                /* widest suffix-order window per side: the GPU gives every position 16 lanes
+                                   * (5 + 5 neighbours, hash2/3/4, prev8, prev16) and four positions to a wavefront */
 #define LEN2_MAX 127u             /* cap of the rep0 run of a compound edge */
 #define PRICE_INF (1u << 30)
 
@@ -116,7 +118,9 @@ typedef struct {
 	/* parse-independent chain links (0 = none) */
 	uint32_t *prev2, *prev3;    /* delta to the previous position with equal hash2 / hash3 */
 	uint32_t *son;              /* main chain: previous position + 1 */
-	uint32_t *prev4, *prev8;    /* delta to the previous position with equal hash4 / 8-byte hash (sa_window != 0) */
+	uint32_t *prev4;            /* delta to the previous position with equal hash4 (sa_window != 0) */
+	uint32_t *prev8, *prev16;   /* delta to the previous position with the same 8 / 16 bytes: by-products of the
+	                             * suffix-order build (left neighbour inside the group of equal keys) */
 	uint32_t *sa, *sa_rank;     /* suffix-neighbourhood finder: slot -> position, position -> slot */
 	uint32_t span_end;          /* exclusive end for avail computations */
 	/* result of the last find */
@@ -166,14 +170,6 @@ static const uint32_t *crc_table0(void)
 	return t;
 }
 
-#define H8_BITS 22
-static uint32_t hash8_of(const uint8_t *p)
-{
-	uint64_t v;
-	memcpy(&v, p, 8);            /* little-endian hosts only, like the GPU */
-	return (uint32_t)((v * 0x9E3779B185EBCA87ull) >> (64 - H8_BITS));
-}
-
 static uint32_t cmplen(const uint8_t *a, const uint8_t *b, uint32_t len, uint32_t limit)
 {
 	/* common/memcmplen.h:47: first `len` bytes are known equal */
@@ -192,8 +188,7 @@ static int build_links(enc *e)
 	uint32_t *head2 = (uint32_t *)calloc(1024, 4);
 	uint32_t *head3 = (uint32_t *)calloc(65536, 4);
 	uint32_t *headm = (uint32_t *)calloc((size_t)e->hash_mask + 1, 4);
-	uint32_t *head8 = e->prev8 ? (uint32_t *)calloc((size_t)1 << H8_BITS, 4) : NULL;
-	if (!head2 || !head3 || !headm || (e->prev8 && !head8))
+	if (!head2 || !head3 || !headm)
 		return -1;
 	for (uint32_t p = 0; p < n; ++p) {
 		const uint8_t *cur = e->in + p;
@@ -216,13 +211,8 @@ static int build_links(enc *e)
 		if (e->prev4)
 			e->prev4[p] = headm[h] ? p + 1 - headm[h] : 0;
 		headm[h] = p + 1;
-		if (head8 && n - p >= 8) {
-			const uint32_t h8 = hash8_of(cur);
-			e->prev8[p] = head8[h8] ? p + 1 - head8[h8] : 0;
-			head8[h8] = p + 1;
-		}
 	}
-	free(head2); free(head3); free(headm); free(head8);
+	free(head2); free(head3); free(headm);
 	return 0;
 }
 
@@ -270,11 +260,15 @@ static int build_sa(enc *e)
 	}
 	for (uint32_t h = 8; ; h *= 2) {
 		radix_sort_u64(key, sa, key2, val2, n);
-		/* rank = 1 + first slot of the group */
+		/* rank = 1 + first slot of the group; inside a group positions ascend, so the left neighbour of a
+		 * group member is the nearest earlier position with the same 8 (round 0) / 16 (round 1) bytes */
 		uint32_t g = 0;
+		uint32_t *prevx = h == 8 ? e->prev8 : (h == 16 ? e->prev16 : NULL);
 		for (uint32_t i = 0; i < n; ++i) {
 			if (i && key[i] != key[i - 1]) g = i;
 			rk[sa[i]] = g + 1;
+			if (prevx)
+				prevx[sa[i]] = g != i ? sa[i] - sa[i - 1] : 0;
 		}
 		if (h == 32)
 			break;
@@ -402,9 +396,9 @@ static void find_sn(enc *e, uint32_t p)
 	else if (len_limit < 4)
 		return;
 
-	/* candidates: nearest equal hash2 / hash3 / hash4 / 8-byte hash, then the recency records of both sides */
+	/* candidates: nearest equal hash2 / hash3 / hash4 / 8 bytes / 16 bytes, then the recency records of both sides */
 	uint32_t cd[64], cl[64], nc = 0;
-	const uint32_t d2 = e->prev2[p], d3 = e->prev3[p], d4 = e->prev4[p], d8 = e->prev8[p];
+	const uint32_t d2 = e->prev2[p], d3 = e->prev3[p], d4 = e->prev4[p], d8 = e->prev8[p], d16 = e->prev16[p];
 	if (d2 && d2 < e->cyclic_size) {
 		uint32_t L = cmplen(cur - d2, cur, 0, len_limit);
 		if (L >= 2) { cd[nc] = d2; cl[nc] = L; ++nc; }
@@ -420,6 +414,10 @@ static void find_sn(enc *e, uint32_t p)
 	if (d8 && d8 < e->cyclic_size) {
 		uint32_t L = cmplen(cur - d8, cur, 0, len_limit);
 		if (L >= 4) { cd[nc] = d8; cl[nc] = L; ++nc; }
+	}
+	if (d16 && d16 < e->cyclic_size) {
+		uint32_t L = cmplen(cur - d16, cur, 0, len_limit);
+		if (L >= 4) { cd[nc] = d16; cl[nc] = L; ++nc; }
 	}
 	const uint32_t r = e->sa_rank[p];
 	for (int side = 0; side < 2; ++side) {
@@ -1336,7 +1334,7 @@ static uint32_t hash_mask_for(uint32_t dict_size, uint32_t hash_bytes)
 static void enc_free(enc *e)
 {
 	if (!e) return;
-	free(e->prev2); free(e->prev3); free(e->son); free(e->prev4); free(e->prev8); free(e->sa); free(e->sa_rank); free(e->cbuf); free(e->nodes); free(e);
+	free(e->prev2); free(e->prev3); free(e->son); free(e->prev4); free(e->prev8); free(e->prev16); free(e->sa); free(e->sa_rank); free(e->cbuf); free(e->nodes); free(e);
 }
 
 static enc *enc_new(const uint8_t *in, uint32_t n, const orc_enc_params *p)
@@ -1357,13 +1355,14 @@ static enc *enc_new(const uint8_t *in, uint32_t n, const orc_enc_params *p)
 	if (p->sa_window) {
 		e->prev4 = (uint32_t *)calloc((size_t)n + 1, 4);
 		e->prev8 = (uint32_t *)calloc((size_t)n + 1, 4);
+		e->prev16 = (uint32_t *)calloc((size_t)n + 1, 4);
 		e->sa = (uint32_t *)calloc((size_t)n + 1, 4);
 		e->sa_rank = (uint32_t *)calloc((size_t)n + 1, 4);
 	}
 	e->cbuf = (uint8_t *)malloc(1 << 17);
 	e->nodes = (node *)calloc(WMAX + MATCH_LEN_MAX + 2, sizeof(node));
 	if (!e->prev2 || !e->prev3 || !e->son || !e->cbuf || !e->nodes
-			|| (p->sa_window && (!e->prev4 || !e->prev8 || !e->sa || !e->sa_rank))
+			|| (p->sa_window && (!e->prev4 || !e->prev8 || !e->prev16 || !e->sa || !e->sa_rank))
 			|| build_links(e) || (p->sa_window && build_sa(e))) {
 		enc_free(e);
 		return NULL;

@@ -119,8 +119,8 @@ typedef struct {
 	uint32_t span_size; /* 0 = whole Block is one span (== reference);
 	                       else independent state-reset spans (GPU mode) */
 	uint32_t sa_window; /* 0 = exact HC3/HC4; else the suffix-neighbourhood finder: recency records among
-	                       `sa_window` (<= 30) slots on either side in 32-byte-prefix suffix order, plus the
-	                       nearest equal hash2/hash3/hash4 (`depth` unused) */
+	                       `sa_window` (<= 5) slots on either side in 32-byte-prefix suffix order, plus the
+	                       nearest equal hash2/hash3/hash4 and equal 8 / 16 bytes (`depth` unused) */
 	uint32_t parser;    /* 0 = optimum_fast (reference); 1 = windowed optimal parser (ours) */
 } orc_enc_params;
 

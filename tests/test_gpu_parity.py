@@ -81,7 +81,7 @@ def test_span_mode_identical_to_oracle(enc, preset, span):
     (2, 1, None, 65536),      # exact HC4 finder with the windowed optimal parser
     (1, 1, None, 0xFFFFFFFF),
     (6, None, None, 0xFFFFFFFF),
-    (6, None, 7, 8192),       # narrow suffix-order window
+    (6, None, 2, 8192),       # narrow suffix-order window
     (4, None, None, 0), (5, None, None, 4096), (7, None, None, 0),
     (3 | 0x80000000, None, None, 0),
 ])
@@ -116,7 +116,7 @@ def test_suffix_order_and_match_lists_identical_to_oracle(enc):
              "runs": (b"a" * 70000 + b"ab" * 30000 + bytes(range(256)) * 300)[:200000],
              "text": xz_amd.corpus_text(250000, seed=3).tobytes()}
     for name, data in cases.items():
-        for bs, span, window in ((1 << 20, 0, None), (65536, 8192, None), (100000, 0xFFFFFFFF, 5)):
+        for bs, span, window in ((1 << 20, 0, None), (65536, 8192, None), (100000, 0xFFFFFFFF, 3)):
             opts = xz_amd.preset_options(6, span_size=span)
             if window is not None:
                 opts.gpu_sa_window = window

@@ -107,7 +107,7 @@ def test_parse_trace_consistency():
 
 
 # ---- OUR definitions (GPU successor of BT4 + windowed optimal parser): CPU-side sanity ----------
-@pytest.mark.parametrize("depth2,parser,span", [(30, 1, 0), (0, 1, 65536), (30, 1, 131072), (24, 1, 4096), (1, 1, 8192)])
+@pytest.mark.parametrize("depth2,parser,span", [(5, 1, 0), (0, 1, 65536), (5, 1, 131072), (3, 1, 4096), (1, 1, 8192)])
 def test_sn_finder_and_optimal_parser_roundtrip(depth2, parser, span):
     for name, data in _edge_inputs().items():
         if len(data) > 400000:
@@ -129,7 +129,7 @@ def test_optimal_parser_beats_fast_parser():
     data = o.corpus_lorem(1 << 20)
     base = len(o.orc_encode_block(data, o.OrcParams(1 << 23, 3, 0, 2, 273, 4, 56, 0, 0, 0)))
     exact_opt = len(o.orc_encode_block(data, o.OrcParams(1 << 23, 3, 0, 2, 64, 4, 8, 0, 0, 1)))
-    opt = len(o.orc_encode_block(data, o.OrcParams(1 << 23, 3, 0, 2, 64, 4, 1, 0, 30, 1)))
+    opt = len(o.orc_encode_block(data, o.OrcParams(1 << 23, 3, 0, 2, 64, 4, 1, 0, 5, 1)))
     assert opt < exact_opt and opt < base
     if o.have_ref():
         prm = o.OrcParams(1 << 23, 3, 0, 2, 64, 0x14, 0, 0, 0, 0)
@@ -170,6 +170,6 @@ def test_size_within_tolerance_of_reference_preset6(corpus, n):
         data = _elf_mix(n)
         if len(data) < n:
             pytest.skip("not enough ELF files on this box")
-    ours = len(o.orc_encode_block(data, o.OrcParams(1 << 23, 3, 0, 2, 64, 4, 1, 131072, 30, 1)))
+    ours = len(o.orc_encode_block(data, o.OrcParams(1 << 23, 3, 0, 2, 64, 4, 1, 131072, 5, 1)))
     ref = len(o.ref_raw_encode(data, o.OrcParams(1 << 23, 3, 0, 2, 64, 0x14, 0, 0, 0, 0), mode=2))
     assert ours <= ref * (1 + SIZE_TOLERANCE), (corpus, ours, ref, ours / ref - 1)

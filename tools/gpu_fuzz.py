@@ -27,7 +27,7 @@ for case in range(ncases):
     if rng.random() < 0.3 and not opts.gpu_sa_window:
         opts.gpu_parser = int(rng.integers(0, 2))       # exact finder with either parser
     if rng.random() < 0.2 and opts.gpu_sa_window:
-        opts.gpu_sa_window = int(rng.integers(1, 31))
+        opts.gpu_sa_window = int(rng.integers(1, 6))
     if rng.random() < 0.2:
         opts.gpu_nice_len = int(rng.integers(max(4, opts.gpu_mf & 15), 274))
     if rng.random() < 0.15:

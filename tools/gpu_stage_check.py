@@ -109,7 +109,7 @@ def main():
     res = []
     res.append(check(enc, "tiny", lorem[:5000], 6, 1 << 20, W))
     res.append(check(enc, "lorem-whole", lorem, 6, 1 << 20, W))
-    res.append(check(enc, "lorem-w5", lorem, 6, 1 << 20, W, window=5))
+    res.append(check(enc, "lorem-w2", lorem, 6, 1 << 20, W, window=2))
     res.append(check(enc, "mixed-whole", mixed, 6, 1 << 20, W))
     res.append(check(enc, "text-whole", text, 6, 1 << 20, W))
     res.append(check(enc, "text-span", text, 6, 1 << 20, 0))

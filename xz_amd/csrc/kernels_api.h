@@ -57,11 +57,11 @@ int xzk_build_chains(const uint8_t *d_in, uint32_t n, uint32_t block_size, uint3
 		uint32_t *keys_a, uint32_t *keys_b, uint32_t *vals_a, uint32_t *vals_b,
 		void *sort_tmp, uint64_t sort_tmp_bytes,
 		uint32_t *rank, uint32_t *sorted_pos, uint32_t *prev2, uint32_t *prev3,
-		uint32_t *prev4, uint32_t *prev8, uint64_t *key64_a, uint64_t *key64_b,
+		uint32_t *prev4, uint32_t *prev8, uint32_t *prev16, uint64_t *key64_a, uint64_t *key64_b,
 		uint32_t *sa, uint32_t *sa_rank, void *stream);
 int xzk_sa_temp_bytes(uint32_t n, uint64_t *bytes);
 int xzk_find_matches(const xzamd_span_args *a, const uint32_t *sa, const uint32_t *sa_rank, const uint32_t *prev4,
-		const uint32_t *prev8, uint16_t *mlen, uint32_t *mdist, void *stream);
+		const uint32_t *prev8, const uint32_t *prev16, uint16_t *mlen, uint32_t *mdist, void *stream);
 int xzk_span_encode(const xzamd_span_args *a, uint32_t nspans, void *stream);
 /* x86 BCJ encoder: d_out = filtered copy of d_in, every Block filtered independently (simple/x86.c). */
 int xzk_x86_bcj(const uint8_t *d_in, uint8_t *d_out, uint32_t n, uint32_t block_size, uint32_t nblocks, void *stream);

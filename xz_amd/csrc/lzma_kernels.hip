@@ -40,7 +40,6 @@ namespace {
 constexpr uint32_t MATCH_LEN_MAX = 273;
 constexpr uint32_t LITERAL = 0xFFFFFFFFu;
 constexpr uint32_t NO_DELTA = 0xFFFFFFFFu;
-constexpr uint32_t H8_BITS_K = 22;      // key bits of the 8-byte-context chain family
 
 // Probability model layout (u16 each), 7990 entries at lc+lp<=... we size for lc+lp <= 3
 // (8 literal coders = 6144) which covers every preset (lc=3, lp=0).  Same order as the oracle.
@@ -102,8 +101,8 @@ __global__ __launch_bounds__(256) void k_hash_keys(const uint8_t* __restrict__ i
     __shared__ uint32_t T[256];
     T[threadIdx.x] = crc_t0(threadIdx.x);
     __syncthreads();
-    const uint32_t kbits = which == 2 ? 10u : (which == 3 ? 16u : (which == 8 ? H8_BITS_K : hash_bits));
-    const uint32_t need = which == 8 ? 8u : hash_bytes;
+    const uint32_t kbits = which == 2 ? 10u : (which == 3 ? 16u : hash_bits);
+    const uint32_t need = hash_bytes;
     const uint32_t stride = gridDim.x * blockDim.x;
     for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < n; g += stride) {
         const uint32_t b = g / block_size;
@@ -114,11 +113,7 @@ __global__ __launch_bounds__(256) void k_hash_keys(const uint8_t* __restrict__ i
             const uint32_t c0 = in[g], c1 = in[g + 1], c2 = in[g + 2];
             const uint32_t temp = T[c0] ^ c1;
             uint32_t h;
-            if (which == 8) {
-                uint64_t v;
-                __builtin_memcpy(&v, in + g, 8);
-                h = (uint32_t)((v * 0x9E3779B185EBCA87ull) >> (64 - H8_BITS_K));
-            } else if (which == 2) h = temp & 0x3FF;
+            if (which == 2) h = temp & 0x3FF;
             else if (which == 3) h = (temp ^ (c2 << 8)) & 0xFFFF;
             else if (hash_bytes == 3) h = (temp ^ (c2 << 8)) & hash_mask;
             else h = (temp ^ (c2 << 8) ^ (T[in[g + 3]] << 5)) & hash_mask;
@@ -220,6 +215,18 @@ __global__ __launch_bounds__(256) void k_sa_block_unpack(const uint32_t* __restr
         pos[i] = (uint32_t)v;
         const bool first = i == 0 || bkeys[i] != bkeys[i - 1] || (uint32_t)(bvals[i - 1] >> 32) != (uint32_t)(v >> 32);
         grp[i] = (first && i != 0) ? i : 0u;
+    }
+}
+
+// By-product of a sort round: inside a group of equal keys positions ascend, so the left neighbour of a
+// group member is the nearest earlier position with the same 8 (round 0) / 16 (round 1) bytes.
+__global__ __launch_bounds__(256) void k_sa_prev(const uint32_t* __restrict__ pos, const uint32_t* __restrict__ grp,
+        uint32_t n, uint32_t* __restrict__ prev)
+{
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint32_t p = pos[i];
+        prev[p] = grp[i] != i ? p - pos[i - 1] : 0u;
     }
 }
 
@@ -1104,6 +1111,7 @@ __device__ __forceinline__ void relax_lengths(const Work& w, const LenTab& lt, u
     const uint32_t lane = threadIdx.x;
     const uint32_t info_rep = (s < 7 ? 8u : 11u) << 9, info_match = (s < 7 ? 7u : 10u) << 9;
     const uint32_t lo_ps = PS == 0 ? lt.lo[0] : PS == 1 ? lt.lo[1] : PS == 2 ? lt.lo[2] : lt.lo[3];
+    const uint32_t SLx = lane + 1 < cnt ? SL : 0xFFFFu;      // list lengths with everything from the last entry on = infinity
     // not unrolled: one pass covers 64 lengths and is all that nearly every node needs; five copies of
     // the body would only cost instruction-cache space
 #pragma unroll 1
@@ -1111,7 +1119,8 @@ __device__ __forceinline__ void relax_lengths(const Work& w, const LenTab& lt, u
         if (2 + 64u * it > reach) break;
         const uint32_t l = 2 + lane + 64u * it;
         uint32_t idx_m = 0;                       // first entry whose length reaches l (or the last one)
-        for (uint32_t k = 0; k + 1 < cnt; ++k) idx_m += (lane_of(SL, k) < l) ? 1u : 0u;
+#pragma unroll
+        for (uint32_t k = 0; k + 1 < LIST_K; ++k) idx_m += (lane_of(SLx, k) < l) ? 1u : 0u;   // entries >= cnt-1 hold "infinity"
         const uint32_t dist_m = __shfl(SD, idx_m);
         const uint32_t cur = w.n_price[j + l];
         const uint32_t hv = it == 0 ? lt.hi[0] : it == 1 ? lt.hi[1] : it == 2 ? lt.hi[2] : it == 3 ? lt.hi[3] : lt.hi[4];
@@ -1292,11 +1301,13 @@ __device__ __forceinline__ bool optimum_window(const Env& e, const Work& w, List
         cp.mask = 0; cp.L1 = cp.l2 = cp.T = cp.dist = 0;
         {
             bool any = (RL.l2a | RL.l2b) >= 2;
+            // rep i qualifies only when it runs >= 2 bytes and ends inside the row, rep0 also when its first byte
+            // differs (the "literal + rep0" case): most rep sources of a text node fail on their first byte
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const uint64_t m = RL.rm[i];
-                const uint64_t after = m ? (m >> 1) >> (uint32_t)__builtin_ctzll(m) : 1ull;      // bits behind the first mismatch
-                any = any || (after & 3ull) == 0;
+                const uint32_t l = RL.rp[i];
+                if ((l >= 2 && l < 62) || (i == 0 && l == 0))
+                    any = any || ((RL.rm[i] >> (l + 1)) & 3ull) == 0;
             }
             if (any) compound_setup(RL, j, room, buf_avail, r0, r1, r2, r3, cp);
         }
@@ -1310,11 +1321,13 @@ __device__ __forceinline__ bool optimum_window(const Env& e, const Work& w, List
             c_bytes = (uint32_t)pl[0] | ((uint32_t)*(pl - cp.dist - 1) << 8) | ((uint32_t)*(pl - 1) << 16);
         }
 
-        if (longest > room) longest = room;
-        if (rl0 > room) rl0 = room;
-        if (rl1 > room) rl1 = room;
-        if (rl2 > room) rl2 = room;
-        if (rl3 > room) rl3 = room;
+        if (room < MATCH_LEN_MAX) {                 // only the last nodes of a window can reach past its end
+            if (longest > room) longest = room;
+            if (rl0 > room) rl0 = room;
+            if (rl1 > room) rl1 = room;
+            if (rl2 > room) rl2 = room;
+            if (rl3 > room) rl3 = room;
+        }
         const uint32_t rmax = max(max(rl0, rl1), max(rl2, rl3));
         const uint32_t reach = max(longest, rmax);
         const uint32_t new_end = max(max(max(n_end, j + reach), j + 1), cT_max);
@@ -1962,92 +1975,117 @@ struct SnArgs {
     const uint32_t* __restrict__ prev3;
     const uint32_t* __restrict__ prev4;
     const uint32_t* __restrict__ prev8;
+    const uint32_t* __restrict__ prev16;
 };
+constexpr uint32_t SN_WMAX = 5;
 
-// Suffix-neighbourhood finder (oracle: find_sn).  Lane roles for one position x with slot r:
-//   lanes  0..29   slots r-1 .. r-30   (left neighbours, nearest first)
-//   lanes 32..61   slots r+1 .. r+30   (right neighbours, nearest first)
-//   lane 30 / 31 / 62 / 63   nearest previous position with equal hash2 / hash3 / hash4 / 8-byte hash
-// A neighbour is eligible when it lies earlier in the same Block and inside the dictionary; it is a
-// candidate when it is more recent than every eligible neighbour nearer on its side ("recency
-// record": exactly the nodes BT4's descent would visit).  All candidates are compared with the text
-// at x in parallel (16 bytes per trip), filtered by the Pareto rule and stored sorted by length.
-//
-// A position is a chain of dependent memory round trips (rank -> suffix-order window -> candidate
-// text), so the loop is software pipelined three deep: while position x is compared and filtered, the
-// first 16 bytes of every candidate of x + 1 and the window of x + 2 are already in flight.
-struct Geo { uint32_t bs, be, se; };          // Block start / end and span end of a position
-
-__device__ __forceinline__ void geo_init(Geo& g, uint32_t p, const xzamd_span_args& a)
-{
-    const uint32_t blk = p / a.block_size;
-    g.bs = blk * a.block_size;
-    g.be = min(a.n, g.bs + a.block_size);
-    const uint64_t kk = (p - g.bs) / a.span_size;
-    const uint64_t se = (uint64_t)g.bs + (kk + 1) * a.span_size;
-    g.se = se < g.be ? (uint32_t)se : g.be;
-}
-
-// g describes position p - 1 (or p); make it describe p
-__device__ __forceinline__ void geo_advance(Geo& g, uint32_t p, const xzamd_span_args& a)
-{
-    if (p >= g.se && p < a.n) {
-        if (p >= g.be) { g.bs = g.be; g.be = min(a.n, g.bs + a.block_size); g.se = g.bs; }
-        const uint64_t se = (uint64_t)g.se + a.span_size;
-        g.se = se < g.be ? (uint32_t)se : g.be;
-    }
-}
-
+// Suffix-neighbourhood finder (oracle: find_sn).  Both hot kernels of this path are bound by instruction
+// issue, not by memory, so the finder gives a position only the lanes it can use: a wavefront works on FOUR
+// positions at once, one per DPP row of 16 lanes, and everything "uniform per position" lives in vector
+// registers (the scalar unit only runs the loop).  Lane roles inside a row, t = lane & 15, slot r = own slot:
+//   t =  0..4   slots r-1 .. r-5   (left neighbours, nearest first)
+//   t =  5..9   slots r+1 .. r+5   (right neighbours, nearest first)
+//   t = 10 / 11 / 12   nearest previous position with equal hash2 / hash3 / hash4
+//   t = 13 / 14        nearest previous position with the same 8 / 16 bytes (by-products of the sort rounds)
+// A neighbour is eligible when it lies earlier in the same Block and inside the dictionary; it is a candidate
+// when it is more recent than every eligible neighbour nearer on its side ("recency record": exactly the
+// nodes BT4's descent would visit).  All candidates are compared with the text at x in parallel (16 bytes per
+// trip) and filtered by the Pareto rule with all-pairs compares inside the row (15 DPP row rotations).
+// Row r of the wavefront at x0 owns positions x0 + 64 r .. x0 + 64 r + 63.  The loop is software pipelined
+// three deep: while position i is compared and filtered, the first 16 bytes of every candidate of i + 1 and
+// the window of i + 2 are in flight.
 constexpr uint32_t SN_NONE = 0xFFFFFFFFu;     // "no neighbour in this lane" (positions are < 2^31)
+constexpr uint32_t ROW_RUN = FIND_RUN / 4;    // positions per row
+
+template <int N>
+__device__ __forceinline__ uint32_t row_ror(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x120 + N, 0xF, 0xF, false);    // row_ror:N
+}
+template <int N>
+__device__ __forceinline__ uint32_t row_shr(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x110 + N, 0xF, 0xF, false);    // row_shr:N, 0 shifted in
+}
+
+// one all-pairs step: partner = the lane N places away (inside the row)
+template <int N>
+__device__ __forceinline__ void pareto_step(uint32_t dist, uint32_t Lok, uint32_t t, bool& dom, uint32_t& rank)
+{
+    const uint32_t dj = row_ror<N>(dist), Lj = row_ror<N>(Lok), tj = row_ror<N>(t);
+    const bool before = Lj != 0 && (dj < dist || (dj == dist && tj < t));      // partner is a candidate and sorts before me
+    dom = dom || (before && (Lj >= Lok || dj == dist));
+    rank += before ? 1u : 0u;
+}
+template <int N>
+__device__ __forceinline__ void count_step(uint32_t key, uint32_t t, uint32_t& idx)
+{
+    const uint32_t kj = row_ror<N>(key), tj = row_ror<N>(t);
+    idx += (kj < key || (kj == key && tj < t)) ? 1u : 0u;
+}
 
 __global__ __launch_bounds__(64) void k_find_sn(xzamd_span_args a, SnArgs sn, uint16_t* __restrict__ mlen,
         uint32_t* __restrict__ mdist)
 {
     const uint32_t lane = threadIdx.x;
-    const uint32_t x0 = blockIdx.x * FIND_RUN;
-    if (x0 >= a.n) return;
-    const uint32_t x1 = min(a.n, x0 + FIND_RUN);
+    const uint32_t t = lane & 15, row = lane >> 4;
+    const uint32_t xr0 = blockIdx.x * FIND_RUN + row * ROW_RUN;          // first position of this row
     const uint8_t* __restrict__ in = sn.in;
     const uint32_t W = a.sa_window;
     const uint32_t cyclic = a.dict_size + 1;
     const uint32_t nice = a.nice_len;
-    const uint32_t half = lane >> 5, k = lane & 31;
-    const bool win_lane = k < W;
-    const uint32_t n_last = a.n - 1;
+    const uint32_t n = a.n;
+    // lane roles
+    const bool left = t < 5, right = t >= 5 && t < 10;
+    const uint32_t k = left ? t : t - 5;
+    const bool win_lane = (left || right) && k < W;
+    const bool hash_lane = t >= 10 && t < 15;
+    const uint32_t* __restrict__ hp = t == 10 ? sn.prev2 : t == 11 ? sn.prev3 : t == 12 ? sn.prev4 : t == 13 ? sn.prev8 : sn.prev16;
+    const uint32_t minlen = t == 10 ? 2u : t == 11 ? 3u : 4u;
+    // masks for the prefix maximum inside a side (the right side must not look into the left one)
+    const bool sh1 = t != 0 && t != 5, sh2 = (left && t >= 2) || (right && t >= 7), sh4 = (left && t >= 4) || (right && t >= 9);
 
-    // per-position words of the current and the next 64 positions (lane = position - chunk start)
-    uint32_t RKc, P2c, P3c, P4c, P8c, RKn, P2n, P3n, P4n, P8n;
+    // geometry of the row's current position (per lane, equal inside a row): Block start / end, span end
+    uint32_t g_bs, g_be, g_se;
     {
-        const uint32_t xa = min(x0 + lane, n_last), xb = min(x0 + 64 + lane, n_last);
-        RKc = sn.sa_rank[xa]; P2c = sn.prev2[xa]; P3c = sn.prev3[xa]; P4c = sn.prev4[xa]; P8c = sn.prev8[xa];
-        RKn = sn.sa_rank[xb]; P2n = sn.prev2[xb]; P3n = sn.prev3[xb]; P4n = sn.prev4[xb]; P8n = sn.prev8[xb];
+        const uint32_t p = xr0 < n ? xr0 : 0u;
+        const uint32_t blk = p / a.block_size;
+        g_bs = blk * a.block_size;
+        g_be = min(n, g_bs + a.block_size);
+        const uint64_t kk = (p - g_bs) / a.span_size;
+        const uint64_t se = (uint64_t)g_bs + (kk + 1) * a.span_size;
+        g_se = se < g_be ? (uint32_t)se : g_be;
     }
-    uint32_t chunk = x0;                                   // first position of RKc
-    auto word = [&](uint32_t c, uint32_t nx, uint32_t idx) -> uint32_t {
-        return idx < 64 ? lane_of(c, idx) : lane_of(nx, idx - 64);
+    auto geo_next = [&](uint32_t& bs, uint32_t& be, uint32_t& se, uint32_t p) {      // (bs, be, se) of p - 1 -> of p
+        const bool nb = p >= be, ns = p >= se;
+        const uint32_t bs2 = nb ? be : bs;
+        const uint32_t be2 = nb ? min(n, be + a.block_size) : be;
+        const uint32_t base = nb ? bs2 : se;
+        const uint64_t se2 = (uint64_t)base + a.span_size;
+        se = ns ? (se2 < be2 ? (uint32_t)se2 : be2) : se;
+        bs = bs2; be = be2;
     };
-    // neighbour of this lane for position p (slot bounds = the Block's position range)
-    auto window = [&](uint32_t p, const Geo& g) -> uint32_t {
-        const uint32_t r = word(RKc, RKn, p - chunk);
-        const int32_t slot = half ? (int32_t)(r + 1 + k) : (int32_t)r - 1 - (int32_t)k;
-        const bool inb = win_lane && slot >= (int32_t)g.bs && slot < (int32_t)g.be;
+    auto clampp = [&](uint32_t p) -> uint32_t { return p < n ? p : n - 1; };
+    // neighbour of this lane for position p with rank r inside Block [bs, be)
+    auto window = [&](uint32_t r, uint32_t bs, uint32_t be, bool live) -> uint32_t {
+        const int32_t slot = right ? (int32_t)(r + 1 + k) : (int32_t)r - 1 - (int32_t)k;
+        const bool inb = live && win_lane && slot >= (int32_t)bs && slot < (int32_t)be;
         return inb ? sn.sa[slot] : SN_NONE;
     };
-    // candidate of this lane for position p given its neighbour wq: position q, validity, minimum length
-    auto candidate = [&](uint32_t p, uint32_t wq, uint32_t& q, bool& valid) {
+    auto candidate = [&](uint32_t p, uint32_t wq, uint32_t hw, uint32_t& q, bool& valid) {
         const bool elig = wq != SN_NONE && wq < p && p - wq < cyclic;
         const uint32_t v = elig ? wq + 1 : 0u;
-        const uint32_t pm = prefix_max_half(v);
-        uint32_t ex = (uint32_t)__shfl_up((int)pm, 1);
-        ex = k == 0 ? 0u : ex;
+        uint32_t pm = v;
+        { const uint32_t o = row_shr<1>(pm); pm = max(pm, sh1 ? o : 0u); }
+        { const uint32_t o = row_shr<2>(pm); pm = max(pm, sh2 ? o : 0u); }
+        { const uint32_t o = row_shr<4>(pm); pm = max(pm, sh4 ? o : 0u); }
+        const uint32_t o1 = row_shr<1>(pm);
+        const uint32_t ex = sh1 ? o1 : 0u;
         valid = elig && v > ex;
         q = elig ? wq : 0u;
-        if (k >= 30) {                                      // the four hash candidates sit in the lanes the windows never use
-            const uint32_t idx = p - chunk;
-            const uint32_t d2 = word(P2c, P2n, idx), d3 = word(P3c, P3n, idx), d4 = word(P4c, P4n, idx), d8 = word(P8c, P8n, idx);
-            const uint32_t dh = lane == 30 ? d2 : lane == 31 ? d3 : lane == 62 ? d4 : d8;
-            valid = dh != 0 && dh < cyclic;
-            q = valid ? p - dh : 0u;
+        if (hash_lane) {
+            valid = hw != 0 && hw < cyclic && hw <= p;
+            q = valid ? p - hw : 0u;
         }
     };
     auto load16 = [&](uint32_t off) -> uint4 {
@@ -2056,118 +2094,120 @@ __global__ __launch_bounds__(64) void k_find_sn(xzamd_span_args a, SnArgs sn, ui
         return v;
     };
 
-    Geo g0, g1, g2;
-    geo_init(g0, x0, a);
-    g1 = g0; geo_advance(g1, x0 + 1, a);
-    g2 = g1; geo_advance(g2, x0 + 2, a);
-    // prologue: window of x0 and x0 + 1, candidates + first compare trip of x0
-    uint32_t w1 = x0 + 1 < x1 ? window(x0 + 1, g1) : SN_NONE;
+    // ---- prologue: positions i = 0, 1, 2 of the row
+    const uint32_t xend = min(n, xr0 + ROW_RUN);                          // this row's positions: [xr0, xend)
+    uint32_t g1_bs = g_bs, g1_be = g_be, g1_se = g_se;                    // geometry of x + 1
+    geo_next(g1_bs, g1_be, g1_se, xr0 + 1);
+    uint32_t g2_bs = g1_bs, g2_be = g1_be, g2_se = g1_se;                 // geometry of x + 2
+    geo_next(g2_bs, g2_be, g2_se, xr0 + 2);
+    uint32_t rk1 = sn.sa_rank[clampp(xr0 + 1)];
+    uint32_t rk2 = sn.sa_rank[clampp(xr0 + 2)];
+    uint32_t hw1 = hash_lane ? hp[clampp(xr0 + 1)] : 0u;
+    uint32_t w1 = window(rk1, g1_bs, g1_be, xr0 + 1 < xend);
     uint32_t q0; bool v0;
-    candidate(x0, window(x0, g0), q0, v0);
-    bool pf0 = x0 + 16 <= a.n;                             // the 16-byte prefetch of this position stays inside the batch
+    {
+        const uint32_t rk0 = sn.sa_rank[clampp(xr0)];
+        const uint32_t hw0 = hash_lane ? hp[clampp(xr0)] : 0u;
+        candidate(xr0, window(rk0, g_bs, g_be, xr0 < xend), hw0, q0, v0);
+        if (!(xr0 < xend)) v0 = false;
+    }
+    bool pf0 = xr0 + 16 <= n;
     uint4 A0 = make_uint4(0, 0, 0, 0), B0 = A0;
-    if (pf0) { A0 = load16(q0); B0 = load16(x0); }
+    if (pf0) { A0 = load16(q0); B0 = load16(xr0); }
 
-    for (uint32_t x = x0; x < x1; ++x) {
-        // stage 0: window of x + 2
-        uint32_t w2 = SN_NONE;
-        if (x + 2 < x1) w2 = window(x + 2, g2);
+    for (uint32_t i = 0; i < ROW_RUN; ++i) {
+        const uint32_t x = xr0 + i;
+        if (__builtin_amdgcn_readfirstlane((int)(blockIdx.x * FIND_RUN + i)) >= (int)n) break;   // every row is past the end
+        // stage 0: window of x + 2 (its rank arrived last iteration), rank of x + 3, hash word of x + 2
+        const uint32_t w2 = window(rk2, g2_bs, g2_be, x + 2 < xend);
+        const uint32_t rk3 = sn.sa_rank[clampp(x + 3)];
+        const uint32_t hw2 = hash_lane ? hp[clampp(x + 2)] : 0u;
         // stage 1: candidates of x + 1 and their first 16 bytes
-        uint32_t q1 = 0; bool v1 = false, pf1 = false;
+        uint32_t q1; bool v1;
+        candidate(x + 1, w1, hw1, q1, v1);
+        if (!(x + 1 < xend)) { v1 = false; q1 = 0; }
+        const bool pf1 = x + 1 + 16 <= n;
         uint4 A1 = A0, B1 = B0;
-        if (x + 1 < x1) {
-            candidate(x + 1, w1, q1, v1);
-            pf1 = x + 1 + 16 <= a.n;
-            if (pf1) { A1 = load16(q1); B1 = load16(x + 1); }
-        }
+        if (pf1) { A1 = load16(q1); B1 = load16(x + 1); }
         // stage 2: position x
-        {
+        if (x < xend) {
             const uint32_t q = q0;
             const bool valid = v0;
-            const uint32_t avail = g0.se - x;
+            const uint32_t avail = g_se - x;
             const uint32_t buf_avail = avail < MATCH_LEN_MAX ? avail : MATCH_LEN_MAX;
-            uint32_t len_limit = avail;
-            bool mf_ok = true;
-            if (nice <= len_limit) len_limit = nice;
-            else if (len_limit < 4) mf_ok = false;            // "pending": nothing is reported (lz_encoder_mf.c:190-201)
+            const uint32_t len_limit = nice <= avail ? nice : avail;
+            const bool mf_ok = nice <= avail || avail >= 4;    // "pending": nothing is reported (lz_encoder_mf.c:190-201)
             const uint64_t rec_base = (uint64_t)x * LIST_W;
-            uint64_t kmask = 0;
-            uint32_t L = 0, dist = 0;
-            bool keep = false;
-            if (mf_ok) {
-                const uint32_t lim = valid ? len_limit : 0u;
-                if (pf0) {
-                    const uint32_t m = match16(A0, B0);
-                    L = m < lim ? m : lim;
-                    if (m == 16 && lim > 16) L = lane_cmplen16_from(in, q, x, 16, lim);
-                } else {
-                    L = lane_cmplen16_from(in, q, x, 0, lim);
-                }
-                const uint32_t minlen = lane == 30 ? 2u : lane == 31 ? 3u : 4u;
-                const bool ok = valid && L >= minlen;
-                dist = x - q;                                   // delta >= 1 on ok lanes
-                // Pareto set: drop a candidate when another one is closer and at least as long (duplicates:
-                // the lower lane stays)
-                bool dom = false;
-                for (uint64_t mm = __ballot(ok); mm; mm &= mm - 1) {
-                    const uint32_t jl = (uint32_t)__builtin_ctzll(mm);
-                    const uint32_t dj = lane_of(dist, jl), Lj = lane_of(L, jl);
-                    dom = dom || (dj < dist && Lj >= L) || (dj == dist && jl < lane);
-                }
-                keep = ok && !dom;
-                kmask = __ballot(keep);
-            }
-            const uint32_t cnt = (uint32_t)__builtin_popcountll(kmask);
-            if (cnt == 0) {
-                if (lane == 0) mdist[rec_base + LIST_K] = 0;
+            const uint32_t lim = (valid && mf_ok) ? len_limit : 0u;
+            uint32_t L;
+            if (pf0) {
+                const uint32_t m = match16(A0, B0);
+                L = m < lim ? m : lim;
+                if (m == 16 && lim > 16) L = lane_cmplen16_from(in, q, x, 16, lim);
             } else {
-                // kept entries have distinct lengths, increasing with distance: rank by length
-                uint32_t rk = 0;
-                for (uint64_t mm = kmask; mm; mm &= mm - 1) {
-                    const uint32_t kl = (uint32_t)__builtin_ctzll(mm);
-                    rk += lane_of(L, kl) < L ? 1u : 0u;
+                L = lane_cmplen16_from(in, q, x, 0, lim);
+            }
+            const bool ok = lim != 0 && L >= minlen;
+            const uint32_t dist = x - q;                        // delta >= 1 on ok lanes
+            const uint32_t Lok = ok ? L : 0u;
+            // Pareto set inside the row: drop a candidate when another one sorts before it (closer, or the same
+            // position in a lower lane) and is at least as long; rank = candidates sorting before me
+            bool dom = false;
+            uint32_t rank = 0;
+            pareto_step<1>(dist, Lok, t, dom, rank); pareto_step<2>(dist, Lok, t, dom, rank); pareto_step<3>(dist, Lok, t, dom, rank);
+            pareto_step<4>(dist, Lok, t, dom, rank); pareto_step<5>(dist, Lok, t, dom, rank); pareto_step<6>(dist, Lok, t, dom, rank);
+            pareto_step<7>(dist, Lok, t, dom, rank); pareto_step<8>(dist, Lok, t, dom, rank); pareto_step<9>(dist, Lok, t, dom, rank);
+            pareto_step<10>(dist, Lok, t, dom, rank); pareto_step<11>(dist, Lok, t, dom, rank); pareto_step<12>(dist, Lok, t, dom, rank);
+            pareto_step<13>(dist, Lok, t, dom, rank); pareto_step<14>(dist, Lok, t, dom, rank); pareto_step<15>(dist, Lok, t, dom, rank);
+            const bool keep = ok && !dom;
+            // index among the kept entries in distance (= length) order, and their number
+            const uint32_t key = keep ? rank : 0xFFu;
+            uint32_t kidx = 0;
+            count_step<1>(key, t, kidx); count_step<2>(key, t, kidx); count_step<3>(key, t, kidx); count_step<4>(key, t, kidx);
+            count_step<5>(key, t, kidx); count_step<6>(key, t, kidx); count_step<7>(key, t, kidx); count_step<8>(key, t, kidx);
+            count_step<9>(key, t, kidx); count_step<10>(key, t, kidx); count_step<11>(key, t, kidx); count_step<12>(key, t, kidx);
+            count_step<13>(key, t, kidx); count_step<14>(key, t, kidx); count_step<15>(key, t, kidx);
+            const uint64_t kmask = __ballot(keep);
+            const uint32_t cnt = (uint32_t)__builtin_popcount((uint32_t)(kmask >> (lane & 48)) & 0xFFFFu);
+            const bool top = keep && kidx + 1 == cnt, second = keep && kidx + 2 == cnt;
+            uint32_t len_out = L;
+            if (top && L == nice) len_out = lane_cmplen16_from(in, q, x, L, buf_avail);      // > nice_len extension
+            // rep0 run behind the byte after the match, for the two longest entries
+            uint32_t l2 = 0;
+            if ((top || second) && len_out + 1 < avail) {
+                const uint32_t lim2 = min(avail, len_out + 1 + LEN2_MAX);
+                l2 = lane_cmplen16_from(in, q, x, len_out + 1, lim2) - (len_out + 1);
+            }
+            const uint32_t drop = cnt > LIST_K ? cnt - LIST_K : 0;
+            if (keep && kidx >= drop) {
+                const uint64_t o = rec_base + (kidx - drop);
+                if (a.list_packed) {
+                    mdist[o] = (len_out << 23) | (dist - 1);
+                } else {
+                    mlen[o] = (uint16_t)len_out;
+                    mdist[o] = dist - 1;
                 }
-                const uint64_t topm = __ballot(keep && rk + 1 == cnt);
-                const uint32_t top = (uint32_t)__builtin_ctzll(topm);
-                uint32_t longest = lane_of(L, top);
-                if (longest == nice)
-                    longest = wave_cmplen(in, x, x - lane_of(dist, top), longest, buf_avail);
-                const uint32_t len_out = lane == top ? longest : L;
-                // rep0 run behind the byte after the match, for the two longest entries
-                uint32_t l2 = 0;
-                if (keep && rk + 2 >= cnt && len_out + 1 < avail) {
-                    const uint32_t lim2 = min(avail, len_out + 1 + LEN2_MAX);
-                    l2 = lane_cmplen16_from(in, q, x, len_out + 1, lim2) - (len_out + 1);
+            }
+            // trailer: count | len2(longest) << 8 | len2(second) << 16, written bytewise by the lanes that know
+            uint8_t* tr = reinterpret_cast<uint8_t*>(mdist + rec_base + LIST_K);
+            if (cnt == 0) {
+                if (t == 0) mdist[rec_base + LIST_K] = 0;
+            } else {
+                if (top) {
+                    *reinterpret_cast<uint16_t*>(tr) = (uint16_t)((cnt - drop) | (l2 << 8));
+                    tr[3] = 0;
+                    if (cnt == 1) tr[2] = 0;
                 }
-                const uint32_t l2a = lane_of(l2, top);
-                uint32_t l2b = 0;
-                if (cnt >= 2) {
-                    const uint64_t secm = __ballot(keep && rk + 2 == cnt);
-                    l2b = lane_of(l2, (uint32_t)__builtin_ctzll(secm));
-                }
-                const uint32_t drop = cnt > LIST_K ? cnt - LIST_K : 0;
-                if (keep && rk >= drop) {
-                    const uint64_t o = rec_base + (rk - drop);
-                    if (a.list_packed) {
-                        mdist[o] = (len_out << 23) | (dist - 1);
-                    } else {
-                        mlen[o] = (uint16_t)len_out;
-                        mdist[o] = dist - 1;
-                    }
-                }
-                if (lane == top) mdist[rec_base + LIST_K] = (cnt - drop) | (l2a << 8) | (l2b << 16);
+                if (second) tr[2] = (uint8_t)l2;
             }
         }
         // shift the pipeline
         q0 = q1; v0 = v1; pf0 = pf1; A0 = A1; B0 = B1;
-        w1 = w2;
-        g0 = g1; g1 = g2; geo_advance(g2, x + 3, a);
-        if (x + 1 - chunk == 64) {                              // x + 1 opens the next chunk of per-position words
-            chunk += 64;
-            RKc = RKn; P2c = P2n; P3c = P3n; P4c = P4n; P8c = P8n;
-            const uint32_t xb = min(chunk + 64 + lane, n_last);
-            RKn = sn.sa_rank[xb]; P2n = sn.prev2[xb]; P3n = sn.prev3[xb]; P4n = sn.prev4[xb]; P8n = sn.prev8[xb];
-        }
+        w1 = w2; hw1 = hw2;
+        rk2 = rk3;
+        g_bs = g1_bs; g_be = g1_be; g_se = g1_se;
+        g1_bs = g2_bs; g1_be = g2_be; g1_se = g2_se;
+        geo_next(g2_bs, g2_be, g2_se, x + 3);
     }
 }
 
@@ -2496,14 +2536,15 @@ int xzk_sa_temp_bytes(uint32_t n, uint64_t* bytes)
 
 // Builds the match-finder structure of a batch.
 //   exact finder (sa == NULL):   rank / sorted_pos (main chain), prev2, prev3
-//   suffix-neighbourhood finder: prev2, prev3, prev4, prev8 and the suffix order sa / sa_rank
+//   suffix-neighbourhood finder: prev2, prev3, prev4, the suffix order sa / sa_rank and its by-products
+//                                prev8 / prev16 (nearest earlier position with the same 8 / 16 bytes)
 // keys_a/keys_b/vals_a/vals_b: n u32 each; key64_a/key64_b: n u64 each (sa != NULL only).
 int xzk_build_chains(const uint8_t* d_in, uint32_t n, uint32_t block_size, uint32_t nblocks,
         uint32_t hash_bytes, uint32_t hash_mask, uint32_t hash_bits,
         uint32_t* keys_a, uint32_t* keys_b, uint32_t* vals_a, uint32_t* vals_b,
         void* sort_tmp, uint64_t sort_tmp_bytes,
         uint32_t* rank, uint32_t* sorted_pos, uint32_t* prev2, uint32_t* prev3,
-        uint32_t* prev4, uint32_t* prev8, uint64_t* key64_a, uint64_t* key64_b,
+        uint32_t* prev4, uint32_t* prev8, uint32_t* prev16, uint64_t* key64_a, uint64_t* key64_b,
         uint32_t* sa, uint32_t* sa_rank, void* stream_)
 {
     hipStream_t st = (hipStream_t)stream_;
@@ -2511,12 +2552,11 @@ int xzk_build_chains(const uint8_t* d_in, uint32_t n, uint32_t block_size, uint3
     uint32_t bb = 0;
     while ((1u << bb) < nblocks + 1) ++bb;
     size_t tb = sort_tmp_bytes;
-    const uint32_t which_list[4] = { 2u, 3u, 0u, 8u };
-    for (int w = 0; w < 4; ++w) {
+    const uint32_t which_list[3] = { 2u, 3u, 0u };
+    for (int w = 0; w < 3; ++w) {
         const uint32_t which = which_list[w];
         if (which == 3 && hash_bytes != 4) continue;
-        if (which == 8 && sa == nullptr) continue;
-        const uint32_t kbits = which == 2 ? 10u : (which == 3 ? 16u : (which == 8 ? H8_BITS_K : hash_bits));
+        const uint32_t kbits = which == 2 ? 10u : (which == 3 ? 16u : hash_bits);
         hipLaunchKernelGGL(k_hash_keys, dim3(g), dim3(256), 0, st, d_in, n, block_size, nblocks, hash_bytes,
                 hash_mask, hash_bits, which, keys_a, vals_a);
         rocprim::double_buffer<uint32_t> kb(keys_a, keys_b);
@@ -2531,8 +2571,6 @@ int xzk_build_chains(const uint8_t* d_in, uint32_t n, uint32_t block_size, uint3
             hipLaunchKernelGGL(k_link_prev, dim3(g), dim3(256), 0, st, kb.current(), vb.current(), n, prev2);
         else if (which == 3)
             hipLaunchKernelGGL(k_link_prev, dim3(g), dim3(256), 0, st, kb.current(), vb.current(), n, prev3);
-        else if (which == 8)
-            hipLaunchKernelGGL(k_link_prev, dim3(g), dim3(256), 0, st, kb.current(), vb.current(), n, prev8);
         else if (sa != nullptr)
             hipLaunchKernelGGL(k_link_prev, dim3(g), dim3(256), 0, st, kb.current(), vb.current(), n, prev4);
         else
@@ -2583,6 +2621,7 @@ int xzk_build_chains(const uint8_t* d_in, uint32_t n, uint32_t block_size, uint3
     }
     // doubling rounds
     for (uint32_t h = 8; h <= 16; h *= 2) {
+        hipLaunchKernelGGL(k_sa_prev, dim3(g), dim3(256), 0, st, pos, grp, n, h == 8 ? prev8 : prev16);
         hipLaunchKernelGGL(k_sa_scatter_rank, dim3(g), dim3(256), 0, st, pos, grp, n, sa_rank);
         hipLaunchKernelGGL(k_sa_pair_keys, dim3(g), dim3(256), 0, st, pos, grp, sa_rank, n, block_size, h, key64_a);
         rocprim::double_buffer<uint64_t> kk(key64_a, key64_b);
@@ -2602,15 +2641,16 @@ int xzk_build_chains(const uint8_t* d_in, uint32_t n, uint32_t block_size, uint3
 }
 
 int xzk_find_matches(const xzamd_span_args* a, const uint32_t* sa, const uint32_t* sa_rank, const uint32_t* prev4,
-        const uint32_t* prev8, uint16_t* mlen, uint32_t* mdist, void* stream_)
+        const uint32_t* prev8, const uint32_t* prev16, uint16_t* mlen, uint32_t* mdist, void* stream_)
 {
     hipStream_t st = (hipStream_t)stream_;
     const uint32_t runs = (a->n + FIND_RUN - 1) / FIND_RUN;
     if (runs == 0) return 0;
     if (a->sa_window) {
-        if (!sa || !sa_rank || !prev4 || !prev8 || a->sa_window > 30) return (int)hipErrorInvalidValue;
+        if (!sa || !sa_rank || !prev4 || !prev8 || !prev16 || a->sa_window > SN_WMAX) return (int)hipErrorInvalidValue;
         SnArgs sn;
         sn.in = a->in; sn.sa = sa; sn.sa_rank = sa_rank; sn.prev2 = a->prev2; sn.prev3 = a->prev3; sn.prev4 = prev4; sn.prev8 = prev8;
+        sn.prev16 = prev16;
         hipLaunchKernelGGL(k_find_sn, dim3(runs), dim3(64), 0, st, *a, sn, mlen, mdist);
     } else {
         hipLaunchKernelGGL(k_find_exact, dim3(runs), dim3(64), 0, st, *a, mlen, mdist);

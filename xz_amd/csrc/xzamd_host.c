@@ -258,7 +258,7 @@ struct xzamd_ctx {
 	char err[256];
 	char err_msg_buf[200];
 	/* device buffers */
-	dbuf keys_a, keys_b, vals_a, vals_b, rank, sorted_pos, prev2, prev3, prev4, prev8, key64_a, key64_b, sa, sa_rank, sort_tmp;
+	dbuf keys_a, keys_b, vals_a, vals_b, rank, sorted_pos, prev2, prev3, prev4, prev8, prev16, key64_a, key64_b, sa, sa_rank, sort_tmp;
 	dbuf scratch, span_bytes, strip_crc, block_crc, segs, lits, trace, errw, litp, mlen, mdist, mlen2, mdist2, bcj;
 	/* pinned host buffers */
 	dbuf h_span_bytes, h_block_crc, h_segs, h_lits;
@@ -339,7 +339,7 @@ void xzamd_ctx_destroy(xzamd_ctx *c)
 		return;
 	xzk_set_device(c->device);
 	dbuf *d[] = { &c->keys_a, &c->keys_b, &c->vals_a, &c->vals_b, &c->rank, &c->sorted_pos,
-		&c->prev2, &c->prev3, &c->prev4, &c->prev8, &c->key64_a, &c->key64_b, &c->sa, &c->sa_rank, &c->sort_tmp,
+		&c->prev2, &c->prev3, &c->prev4, &c->prev8, &c->prev16, &c->key64_a, &c->key64_b, &c->sa, &c->sa_rank, &c->sort_tmp,
 		&c->scratch, &c->span_bytes, &c->strip_crc,
 		&c->block_crc, &c->segs, &c->lits, &c->trace, &c->errw, &c->litp, &c->mlen, &c->mdist, &c->mlen2, &c->mdist2, &c->bcj };
 	for (size_t i = 0; i < sizeof(d) / sizeof(d[0]); ++i)
@@ -470,8 +470,8 @@ static int batch_geometry(xzamd_ctx *c, const xzamd_lzma_options *opt, uint64_t 
 	g->sort_bytes = 0;
 	uint32_t bb = 0;
 	while ((1u << bb) < g->nb + 1) ++bb;
-	const uint32_t bits[4] = { 10 + bb, 16 + bb, hbits + bb, 22 + bb };
-	for (int i = 0; i < (opt->gpu_sa_window ? 4 : 3); ++i) {
+	const uint32_t bits[3] = { 10 + bb, 16 + bb, hbits + bb };
+	for (int i = 0; i < 3; ++i) {
 		uint64_t sbytes = 0;
 		int e = xzk_sort_temp_bytes(g->n, bits[i], &sbytes);
 		if (e)
@@ -498,6 +498,7 @@ static int launch_chains(xzamd_ctx *c, const xzamd_lzma_options *opt, const uint
 			(uint32_t *)c->prev3.p,
 			opt->gpu_sa_window ? (uint32_t *)c->prev4.p : NULL,
 			opt->gpu_sa_window ? (uint32_t *)c->prev8.p : NULL,
+			opt->gpu_sa_window ? (uint32_t *)c->prev16.p : NULL,
 			opt->gpu_sa_window ? (uint64_t *)c->key64_a.p : NULL,
 			opt->gpu_sa_window ? (uint64_t *)c->key64_b.p : NULL,
 			opt->gpu_sa_window ? (uint32_t *)c->sa.p : NULL,
@@ -547,7 +548,7 @@ int xzamd_stream_encode_device(xzamd_ctx *c,
 	const uint32_t hmask = hash_mask_for(opt->dict_size, hb);
 	uint32_t hbits = 0;
 	while ((1ull << hbits) <= hmask) ++hbits;
-	const uint32_t kbits_max = (opt->gpu_sa_window && hbits < 22) ? 22 : hbits;   /* widest 32-bit sort key family */
+	const uint32_t kbits_max = hbits;   /* widest 32-bit sort key family */
 	const uint32_t span0 = opt->gpu_parser ? DEFAULT_SPAN_OPT : DEFAULT_SPAN;
 	uint32_t span = (opt->span_size == XZAMD_SPAN_DEFAULT || opt->span_size == XZAMD_SPAN_AUTO) ? span0 : opt->span_size;
 	if (span > block_size) span = (uint32_t)block_size;
@@ -642,7 +643,7 @@ int xzamd_stream_encode_device(xzamd_ctx *c,
 		GROW(vals_a, 4ull * n, 0); GROW(vals_b, 4ull * n, 0);
 		GROW(prev2, 4ull * n, 0); GROW(prev3, 4ull * n, 0);
 		if (opt->gpu_sa_window) {
-			GROW(prev4, 4ull * n, 0); GROW(prev8, 4ull * n, 0);
+			GROW(prev4, 4ull * n, 0); GROW(prev8, 4ull * n, 0); GROW(prev16, 4ull * n, 0);
 			GROW(key64_a, 8ull * n, 0); GROW(key64_b, 8ull * n, 0);
 			GROW(sa, 4ull * n, 0); GROW(sa_rank, 4ull * n, 0);
 		} else {
@@ -743,7 +744,7 @@ int xzamd_stream_encode_device(xzamd_ctx *c,
 				a.mdist = md_cur;
 				if (!find_on_lo) {
 					e = xzk_find_matches(&a, (const uint32_t *)c->sa.p, (const uint32_t *)c->sa_rank.p, (const uint32_t *)c->prev4.p,
-							(const uint32_t *)c->prev8.p, ml_cur, md_cur, st);
+							(const uint32_t *)c->prev8.p, (const uint32_t *)c->prev16.p, ml_cur, md_cur, st);
 					if (e) { rc = fail(c, XZAMD_DEVICE_ERROR, "find_matches launch", e); goto done; }
 				}
 				xzk_event_record(c->ev[5], st);
@@ -768,7 +769,7 @@ int xzamd_stream_encode_device(xzamd_ctx *c,
 					if (!e2 && launch_chains(c, opt, d_in + g2.in_off, &g2, block_size, hb, hmask, hbits, c->lo_stream) != XZAMD_OK) e2 = 1;
 					if (!e2) e2 = xzk_event_record(evn[2], c->lo_stream);
 					if (!e2) e2 = xzk_find_matches(&a2, (const uint32_t *)c->sa.p, (const uint32_t *)c->sa_rank.p, (const uint32_t *)c->prev4.p,
-							(const uint32_t *)c->prev8.p, ml_nx, md_nx, c->lo_stream);
+							(const uint32_t *)c->prev8.p, (const uint32_t *)c->prev16.p, ml_nx, md_nx, c->lo_stream);
 					if (!e2) e2 = xzk_event_record(evn[3], c->lo_stream);
 					if (e2) { rc = fail(c, XZAMD_DEVICE_ERROR, "chain prefetch", e2); goto done; }
 					prefetched = 1;
