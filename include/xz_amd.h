@@ -97,6 +97,10 @@ typedef struct {
 /* lzma_lzma_preset() (lzma/lzma_encoder_presets.c:17-63) + the device mapping.
  * Returns nonzero for an invalid preset. */
 int xzamd_lzma_preset(xzamd_lzma_options *opt, uint32_t preset);
+/* NULL when the device path runs this option set, else the reason it does not (static string). */
+const char *xzamd_options_check(const xzamd_lzma_options *opt);
+/* Give back the device / pinned buffers lzma_end() keeps parked for the next stream of the process. */
+void xzamd_release_parked(void);
 /* lzma_mt_block_size() for a plain LZMA2 chain (lzma2_encoder.c:403-413). */
 uint64_t xzamd_mt_block_size(const xzamd_lzma_options *opt);
 /* lzma_block_buffer_bound64() (common/block_buffer_encoder.c:55-69). */

@@ -16,9 +16,10 @@
  *   lzma_get_progress                replaces common/common.c:406
  *
  * Behavioural notes (INTEGRATION.md has the full list):
- *   - lzma_mt.threads is validated like the reference but only sizes nothing:
- *     parallelism comes from the GPU; lzma_mt.timeout is accepted and ignored
- *     (lzma_code may block while a device batch runs).
+ *   - lzma_mt.threads caps the number of worker threads = GPUs used (one worker per visible GPU);
+ *     lzma_mt.timeout bounds the time a lzma_code call waits for the workers (0 = no limit), a call
+ *     that returns because of it returns LZMA_OK like the reference (stream_encoder_mt.c:667-713);
+ *     LZMA_FULL_BARRIER returns once the input has been handed over (:803-807).
  *   - filters: {LZMA2} and {x86 BCJ, LZMA2} chains; LZMA_SYNC_FLUSH is unsupported exactly like the
  *     reference MT encoder (stream_encoder_mt.c:1201-1205).
  *   - check: LZMA_CHECK_NONE, LZMA_CHECK_CRC32 and LZMA_CHECK_CRC64 (the xz default); others
@@ -140,6 +141,11 @@ uint64_t lzma_stream_encoder_mt_memusage(const lzma_mt *options);
 lzma_ret lzma_code(lzma_stream *strm, lzma_action action);
 void lzma_end(lzma_stream *strm);
 void lzma_get_progress(lzma_stream *strm, uint64_t *progress_in, uint64_t *progress_out);
+/* common/filter_encoder.c:270 (block size a chain asks for), hardware_cputhreads.c (here: visible GPUs = the
+ * workers lzma_mt.threads can be given), stream_encoder_mt.c:914-950 (new chain between Blocks). */
+uint64_t lzma_mt_block_size(const lzma_filter *filters);
+uint32_t lzma_cputhreads(void);
+lzma_ret lzma_filters_update(lzma_stream *strm, const lzma_filter *filters);
 
 /* One-shot buffer API (common/stream_buffer_encoder.c:43-141, common/easy_buffer_encoder.c:16-27), same
  * return codes (LZMA_BUF_ERROR and *out_pos untouched if the output does not fit).  Unlike the reference,

@@ -3,6 +3,7 @@
 Bars: byte-identical to liblzma 5.8.3's MT encoder for presets 0-3 when one span covers a Block;
 byte-identical to the oracle's span-mode restatement otherwise; bit-exact round trip always."""
 import hashlib
+import os
 
 import numpy as np
 import pytest
@@ -544,3 +545,122 @@ def test_lzma_code_semantics(tmp_path):
     L.lzma_end(C.byref(s))
     assert not s.internal
     L.lzma_end(C.byref(s))      # idempotent
+
+
+def test_lzma_code_worker_pipeline_timeout_barrier_and_filters_update(monkeypatch):
+    """The front end deals batches of Blocks ("jobs") to one worker thread per GPU and drains them in order:
+    many small jobs (XZAMD_BATCH_MIB=1) must give the same Stream as one big batch; lzma_mt.timeout makes a
+    call return LZMA_OK while the workers are busy (stream_encoder_mt.c:667-713) without tripping the
+    LZMA_BUF_ERROR rule; LZMA_FULL_BARRIER returns as soon as the input is handed over (:803-807);
+    lzma_filters_update between Blocks changes the chain from the next Block on (:914-950); and the two
+    helper exports answer (filter_encoder.c:270, hardware_cputhreads.c)."""
+    import ctypes as C
+    import xz_amd
+    sys_path = os.path.join(o.ROOT, "tools")
+    import sys
+    if sys_path not in sys.path:
+        sys.path.insert(0, sys_path)
+    from bench_lzma_code import Mt, Stream
+    L = xz_amd.lib()
+    OK, STREAM_END = 0, 1
+    RUN, FULL_FLUSH, FINISH, BARRIER = 0, 2, 3, 4
+    data = o.corpus_mixed(6 << 20, 33)
+    ib = C.create_string_buffer(data, len(data))
+    ob = C.create_string_buffer(len(data) + (1 << 20))
+
+    def run(timeout, chunk):
+        s = Stream()
+        m = Mt(threads=4, preset=1, check=4, block_size=1 << 18, timeout=timeout)
+        assert L.lzma_stream_encoder_mt(C.byref(s), C.byref(m)) == OK
+        s.next_out = C.cast(ob, C.c_void_p).value
+        s.avail_out = len(ob)
+        pos = 0
+        oks = 0
+        while pos < len(data):
+            k = min(chunk, len(data) - pos)
+            s.next_in = C.cast(ib, C.c_void_p).value + pos
+            s.avail_in = k
+            while s.avail_in:
+                assert L.lzma_code(C.byref(s), RUN) == OK
+            pos += k
+        r = L.lzma_code(C.byref(s), FINISH)
+        while r == OK:
+            oks += 1
+            assert oks < 100000
+            r = L.lzma_code(C.byref(s), FINISH)
+        assert r == STREAM_END
+        got = ob.raw[: s.total_out]
+        L.lzma_end(C.byref(s))
+        return got, oks
+
+    monkeypatch.setenv("XZAMD_BATCH_MIB", "1")
+    small, _ = run(0, 300000)
+    timed, oks = run(1, 1 << 20)             # 1 ms: FINISH returns LZMA_OK (often without progress) until the jobs are done
+    monkeypatch.delenv("XZAMD_BATCH_MIB")
+    big, _ = run(0, len(data))
+    assert small == big and timed == big
+    r, dec, nb = o.orc_xz_decode(big, len(data) + 16)
+    assert r == 0 and dec == data and nb == 24
+
+    # FULL_BARRIER: STREAM_END without waiting; the output arrives with the following calls
+    s = Stream()
+    m = Mt(threads=1, preset=1, check=4, block_size=1 << 18)
+    assert L.lzma_stream_encoder_mt(C.byref(s), C.byref(m)) == OK
+    s.next_in = C.cast(ib, C.c_void_p).value
+    s.avail_in = 1 << 20
+    s.next_out = C.cast(ob, C.c_void_p).value
+    s.avail_out = len(ob)
+    assert L.lzma_code(C.byref(s), BARRIER) == STREAM_END and s.avail_in == 0
+    # new chain between Blocks: preset-0 options for the rest
+    class Filter(C.Structure):
+        _fields_ = [("id", C.c_uint64), ("options", C.c_void_p)]
+    class OptLzma(C.Structure):
+        _fields_ = [("dict_size", C.c_uint32), ("preset_dict", C.c_void_p), ("preset_dict_size", C.c_uint32),
+                    ("lc", C.c_uint32), ("lp", C.c_uint32), ("pb", C.c_uint32), ("mode", C.c_int),
+                    ("nice_len", C.c_uint32), ("mf", C.c_int), ("depth", C.c_uint32), ("pad", C.c_uint8 * 64)]
+    ol = OptLzma(dict_size=1 << 18, lc=3, lp=0, pb=2, mode=1, nice_len=128, mf=3, depth=4)
+    fl = (Filter * 2)(Filter(0x21, C.cast(C.pointer(ol), C.c_void_p)), Filter(2**64 - 1, None))
+    assert L.lzma_filters_update(C.byref(s), fl) == OK
+    s.next_in = C.cast(ib, C.c_void_p).value + (1 << 20)
+    s.avail_in = 1 << 20
+    r = L.lzma_code(C.byref(s), FINISH)
+    while r == OK:
+        r = L.lzma_code(C.byref(s), FINISH)
+    assert r == STREAM_END
+    got = ob.raw[: s.total_out]
+    L.lzma_end(C.byref(s))
+    r, dec, nb = o.orc_xz_decode(got, (2 << 20) + 16)
+    assert r == 0 and dec == data[: 2 << 20] and nb == 8
+    if o.have_ref():
+        rr, rdec = o.ref_decode(got, (2 << 20) + 16)
+        assert rr == 1 and rdec == data[: 2 << 20]
+    # a chain in the middle of a Block is refused
+    s = Stream()
+    assert L.lzma_stream_encoder_mt(C.byref(s), C.byref(m)) == OK
+    s.next_in = C.cast(ib, C.c_void_p).value; s.avail_in = 1000
+    s.next_out = C.cast(ob, C.c_void_p).value; s.avail_out = len(ob)
+    assert L.lzma_code(C.byref(s), RUN) == OK
+    assert L.lzma_filters_update(C.byref(s), fl) == 11
+    L.lzma_end(C.byref(s))
+    L.lzma_mt_block_size.restype = C.c_uint64
+    assert L.lzma_mt_block_size(fl) == 1 << 20
+    ol.dict_size = 8 << 20
+    assert L.lzma_mt_block_size(fl) == 24 << 20
+    assert L.lzma_cputhreads() >= 1
+    # an option set outside the device path is refused at init (a preload client then stays on the CPU library)
+    ol.dict_size = 1 << 20; ol.pb = 4; ol.mode = 2; ol.mf = 0x14
+    mm = Mt(threads=1, check=4, filters=C.cast(fl, C.c_void_p))
+    assert L.lzma_stream_encoder_mt(C.byref(s), C.byref(mm)) == 8
+    ol.pb = 2; ol.lc = 4; ol.lp = 0; ol.mode = 1; ol.mf = 4; ol.depth = 8
+    assert L.lzma_stream_encoder_mt(C.byref(s), C.byref(mm)) == 0       # lc + lp = 4 runs on the device
+    s.next_in = C.cast(ib, C.c_void_p).value; s.avail_in = 500000
+    s.next_out = C.cast(ob, C.c_void_p).value; s.avail_out = len(ob)
+    r = L.lzma_code(C.byref(s), FINISH)
+    while r == OK:
+        r = L.lzma_code(C.byref(s), FINISH)
+    assert r == STREAM_END
+    got = ob.raw[: s.total_out]
+    L.lzma_end(C.byref(s))
+    r, dec, nb = o.orc_xz_decode(got, 500016)
+    assert r == 0 and dec == data[:500000]
+    L.xzamd_release_parked()

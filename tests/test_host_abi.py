@@ -3,6 +3,7 @@ headers declare, and its host-side helpers (presets, sizes, framing) agree with 
 import ctypes as C
 import os
 import re
+import subprocess
 
 import numpy as np
 import pytest
@@ -113,3 +114,74 @@ def test_preload_library_exports_the_interposed_symbols():
     L = C.CDLL(pre)
     for sym in ("lzma_stream_encoder_mt", "lzma_code", "lzma_end", "lzma_get_progress"):
         assert hasattr(L, sym), sym
+
+
+REF_API = "/root/reference/src/liblzma/api"
+
+
+def _real_header_dir():
+    """The REAL liblzma headers: the reference tree's (dev container) or the system's liblzma-dev."""
+    if os.path.exists(os.path.join(REF_API, "lzma.h")):
+        return REF_API
+    if os.path.exists("/usr/include/lzma.h"):
+        return "/usr/include"
+    return None
+
+
+def test_client_compiles_against_the_real_lzma_h_and_links(tmp_path, product_lib):
+    """examples/compress_mt.c compiled against the real <lzma.h> (no -DUSE_XZ_AMD) and linked against
+    libxz_amd.so only: every liblzma symbol it uses must come from the drop-in library."""
+    inc = _real_header_dir()
+    if inc is None:
+        pytest.skip("no real lzma.h on this box")
+    exe = str(tmp_path / "compress_mt_real")
+    subprocess.run(["gcc", "-O2", "-I" + inc, os.path.join(ROOT, "examples", "compress_mt.c"), "-o", exe,
+                    "-L" + os.path.join(ROOT, "xz_amd"), "-lxz_amd", "-Wl,-rpath," + os.path.join(ROOT, "xz_amd"),
+                    "-Wl,--no-undefined"], check=True)
+    undefined = subprocess.run(["nm", "-D", "--undefined-only", exe], capture_output=True, text=True).stdout
+    assert "lzma_stream_encoder_mt" in undefined and "lzma_code" in undefined
+
+
+def test_struct_layouts_equal_the_real_headers(tmp_path):
+    """sizeof / offsetof of every struct that crosses the boundary, compiled once against the real <lzma.h>
+    and once against include/xz_amd_lzma.h: must be identical (catches drift of the ABI restatement)."""
+    inc = _real_header_dir()
+    if inc is None:
+        pytest.skip("no real lzma.h on this box")
+    src = tmp_path / "probe.c"
+    src.write_text(r'''
+#ifdef USE_XZ_AMD
+#include "xz_amd_lzma.h"
+#else
+#include <lzma.h>
+#endif
+#include <stddef.h>
+#include <stdio.h>
+#define O(T, f) printf(#T "." #f " %zu\n", offsetof(T, f))
+int main(void)
+{
+    printf("lzma_stream %zu\nlzma_mt %zu\nlzma_options_lzma %zu\nlzma_filter %zu\nlzma_options_bcj %zu\nlzma_allocator %zu\n",
+           sizeof(lzma_stream), sizeof(lzma_mt), sizeof(lzma_options_lzma), sizeof(lzma_filter),
+           sizeof(lzma_options_bcj), sizeof(lzma_allocator));
+    O(lzma_stream, next_in); O(lzma_stream, avail_in); O(lzma_stream, total_in); O(lzma_stream, next_out);
+    O(lzma_stream, avail_out); O(lzma_stream, total_out); O(lzma_stream, allocator); O(lzma_stream, internal);
+    O(lzma_stream, reserved_ptr1); O(lzma_stream, reserved_ptr4); O(lzma_stream, reserved_int2);
+    O(lzma_stream, reserved_int3); O(lzma_stream, reserved_enum1); O(lzma_stream, reserved_enum2);
+    O(lzma_mt, flags); O(lzma_mt, threads); O(lzma_mt, block_size); O(lzma_mt, timeout); O(lzma_mt, preset);
+    O(lzma_mt, filters); O(lzma_mt, check);
+    O(lzma_options_lzma, dict_size); O(lzma_options_lzma, preset_dict); O(lzma_options_lzma, preset_dict_size);
+    O(lzma_options_lzma, lc); O(lzma_options_lzma, lp); O(lzma_options_lzma, pb); O(lzma_options_lzma, mode);
+    O(lzma_options_lzma, nice_len); O(lzma_options_lzma, mf); O(lzma_options_lzma, depth);
+    O(lzma_filter, id); O(lzma_filter, options); O(lzma_options_bcj, start_offset);
+    printf("enums %d %d %d %d %d %d %d %d\n", (int)LZMA_STREAM_END, (int)LZMA_BUF_ERROR, (int)LZMA_PROG_ERROR,
+           (int)LZMA_FULL_BARRIER, (int)LZMA_CHECK_CRC64, (int)LZMA_MODE_NORMAL, (int)LZMA_MF_BT4, (int)LZMA_FINISH);
+    printf("ids %llx %llx\n", (unsigned long long)LZMA_FILTER_LZMA2, (unsigned long long)LZMA_FILTER_X86);
+    return 0;
+}
+''')
+    outs = []
+    for flags in (["-I" + inc], ["-DUSE_XZ_AMD", "-I" + os.path.join(ROOT, "include")]):
+        exe = str(tmp_path / ("probe" + str(len(outs))))
+        subprocess.run(["gcc", "-O1", *flags, str(src), "-o", exe], check=True)
+        outs.append(subprocess.run([exe], capture_output=True, text=True, check=True).stdout)
+    assert outs[0] == outs[1], "\n".join(l for l in outs[0].splitlines() if l not in outs[1].splitlines())

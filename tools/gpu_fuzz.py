@@ -33,7 +33,7 @@ for case in range(ncases):
     if rng.random() < 0.15:
         opts.dict_size = int(rng.choice([4096, 65536, 1 << 20, 3 << 20]))
     if rng.random() < 0.15 and not opts.gpu_parser:
-        lc = int(rng.integers(0, 4)); opts.lc = lc; opts.lp = int(rng.integers(0, 4 - lc)); opts.pb = int(rng.integers(0, 5))
+        lc = int(rng.integers(0, 5)); opts.lc = lc; opts.lp = int(rng.integers(0, 5 - lc)); opts.pb = int(rng.integers(0, 5))
     bcj = rng.random() < 0.2
     if bcj: opts.bcj = xz_amd.BCJ_X86
     bs = int(rng.choice([1 << 20, 200000, 65537, 1 << 16]))

@@ -57,12 +57,12 @@ int xzk_build_chains(const uint8_t *d_in, uint32_t n, uint32_t block_size, uint3
 		uint32_t *keys_a, uint32_t *keys_b, uint32_t *vals_a, uint32_t *vals_b,
 		void *sort_tmp, uint64_t sort_tmp_bytes,
 		uint32_t *rank, uint32_t *sorted_pos, uint32_t *prev2, uint32_t *prev3,
-		uint32_t *prev4, uint32_t *prev8, uint32_t *prev16, uint64_t *key64_a, uint64_t *key64_b,
+		uint32_t *prev4, uint64_t *rp8, uint64_t *rp16, uint64_t *key64_a, uint64_t *key64_b,
 		uint32_t *sa, uint32_t *sa_rank, void *stream);
 int xzk_sa_temp_bytes(uint32_t n, uint64_t *bytes);
 int xzk_find_matches(const xzamd_span_args *a, const uint32_t *sa, const uint32_t *sa_rank, const uint32_t *prev4,
-		const uint32_t *prev8, const uint32_t *prev16, uint16_t *mlen, uint32_t *mdist, void *stream);
-int xzk_span_encode(const xzamd_span_args *a, uint32_t nspans, void *stream);
+		const uint64_t *rp8, const uint64_t *rp16, uint16_t *mlen, uint32_t *mdist, void *stream);
+int xzk_span_encode(const xzamd_span_args *a, uint32_t nspans, uint32_t waves, uint32_t *counter, void *stream);
 /* x86 BCJ encoder: d_out = filtered copy of d_in, every Block filtered independently (simple/x86.c). */
 int xzk_x86_bcj(const uint8_t *d_in, uint8_t *d_out, uint32_t n, uint32_t block_size, uint32_t nblocks, void *stream);
 /* Block checks: CRC64 (crc32 = 0) or CRC32 (crc32 = 1, zero-extended into d_block_crc). */

@@ -218,37 +218,30 @@ __global__ __launch_bounds__(256) void k_sa_block_unpack(const uint32_t* __restr
     }
 }
 
-// By-product of a sort round: inside a group of equal keys positions ascend, so the left neighbour of a
-// group member is the nearest earlier position with the same 8 (round 0) / 16 (round 1) bytes.
-__global__ __launch_bounds__(256) void k_sa_prev(const uint32_t* __restrict__ pos, const uint32_t* __restrict__ grp,
-        uint32_t n, uint32_t* __restrict__ prev)
+// rk[pos[i]] = (group start + 1, distance to the left neighbour inside the group or 0).  The second word is
+// a by-product of the sort round: inside a group of equal keys positions ascend, so the left neighbour of a
+// group member is the nearest earlier position with the same 8 (round 0) / 16 (round 1) bytes.  One 8-byte
+// scatter instead of two 4-byte ones: a scattered store costs a 64-byte sector whatever it carries.
+__global__ __launch_bounds__(256) void k_sa_scatter_rank(const uint32_t* __restrict__ pos, const uint32_t* __restrict__ grp,
+        uint32_t n, uint2* __restrict__ rk)
 {
     const uint32_t stride = gridDim.x * blockDim.x;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const uint32_t p = pos[i];
-        prev[p] = grp[i] != i ? p - pos[i - 1] : 0u;
+        const uint32_t p = pos[i], g = grp[i];
+        rk[p] = make_uint2(g + 1, g != i ? p - pos[i - 1] : 0u);
     }
-}
-
-// rank[pos[i]] = group start + 1
-__global__ __launch_bounds__(256) void k_sa_scatter_rank(const uint32_t* __restrict__ pos, const uint32_t* __restrict__ grp,
-        uint32_t n, uint32_t* __restrict__ rank)
-{
-    const uint32_t stride = gridDim.x * blockDim.x;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
-        rank[pos[i]] = grp[i] + 1;
 }
 
 // doubling key: (rank[p], rank[p + h]) with 0 for a second half that starts past the Block end
 __global__ __launch_bounds__(256) void k_sa_pair_keys(const uint32_t* __restrict__ pos, const uint32_t* __restrict__ grp,
-        const uint32_t* __restrict__ rank, uint32_t n, uint32_t block_size, uint32_t h, uint64_t* __restrict__ keys)
+        const uint2* __restrict__ rank, uint32_t n, uint32_t block_size, uint32_t h, uint64_t* __restrict__ keys)
 {
     const uint32_t stride = gridDim.x * blockDim.x;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         const uint32_t p = pos[i];
         const uint32_t b = p / block_size;
         const uint32_t bend = min(n, (b + 1) * block_size);
-        const uint32_t second = p + h < bend ? rank[p + h] : 0u;
+        const uint32_t second = p + h < bend ? rank[p + h].x : 0u;
         keys[i] = ((uint64_t)(grp[i] + 1) << 32) | second;
     }
 }
@@ -1530,9 +1523,7 @@ template <int FINDER, bool OPT>      // FINDER: 0 = exact HC3/HC4 in-kernel, 2 =
 #ifndef XZAMD_WAVES_OPT
 #define XZAMD_WAVES_OPT 4
 #endif
-__global__ __launch_bounds__(64)
-__attribute__((amdgpu_waves_per_eu(OPT ? XZAMD_WAVES_OPT : XZAMD_WAVES_FAST, OPT ? XZAMD_WAVES_OPT : XZAMD_WAVES_FAST)))
-void k_span_encode_t(xzamd_span_args a)
+__device__ __forceinline__ void span_encode_one(const xzamd_span_args& a, const uint32_t span)
 {
     constexpr bool LISTS = FINDER == 2;
     static_assert(!LISTS || OPT, "the fast parsers run with the in-kernel finders");
@@ -1551,7 +1542,6 @@ void k_span_encode_t(xzamd_span_args a)
 #endif
     uint16_t* const probs = reinterpret_cast<uint16_t*>(pool);
     const uint32_t lane = threadIdx.x;
-    const uint32_t span = blockIdx.x;
     const uint32_t blk = span / a.spans_per_block;
     const uint32_t k = span - blk * a.spans_per_block;
     const uint32_t block_start = blk * a.block_size;
@@ -1608,7 +1598,8 @@ void k_span_encode_t(xzamd_span_args a)
     Lz z;
     z.lc = a.lc; z.lp = a.lp; z.pb = a.pb;
     z.cnt_len = z.cnt_match = z.cnt_align = 0;
-    z.lit = a.lit + (uint64_t)span * 6144u;
+    const uint32_t lit_size = 0x300u << (a.lc + a.lp);       // literal coders of this span (lc + lp <= 4)
+    z.lit = a.lit + (uint64_t)span * lit_size;
     RC rc;
     rc.cpos = 0; rc.out = outp; rc.reset();
 
@@ -1640,7 +1631,7 @@ void k_span_encode_t(xzamd_span_args a)
             {
                 uint4* l4 = reinterpret_cast<uint4*>(z.lit);
                 const uint4 v = make_uint4(1024u, 1024u, 1024u, 1024u);
-                for (uint32_t i = lane; i < 6144 / 4; i += 64) l4[i] = v;
+                for (uint32_t i = lane; i < lit_size / 4; i += 64) l4[i] = v;
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
             wave_sync();
@@ -1917,6 +1908,28 @@ void k_span_encode_t(xzamd_span_args a)
 #endif
 }
 
+// Persistent form: a launch has at most as many wavefronts as the GPU holds at once (the host passes the
+// count); each pulls span numbers from a counter until none is left, so a launch is not a sequence of rounds
+// of equally long spans and fewer resident wavefronts can be asked for (leaving room for other streams).
+template <int FINDER, bool OPT>
+__global__ __launch_bounds__(64)
+__attribute__((amdgpu_waves_per_eu(OPT ? XZAMD_WAVES_OPT : XZAMD_WAVES_FAST, OPT ? XZAMD_WAVES_OPT : XZAMD_WAVES_FAST)))
+void k_span_encode_t(xzamd_span_args a, uint32_t nspans, uint32_t* __restrict__ counter)
+{
+    for (;;) {
+        uint32_t s = blockIdx.x;            // counter == nullptr: one wavefront per span
+        if (counter != nullptr) {
+            if (threadIdx.x == 0) s = atomicAdd(counter, 1u);
+            s = uni(s);
+        }
+        if (s >= nspans) break;
+        span_encode_one<FINDER, OPT>(a, s);
+        if (counter == nullptr) break;
+        __builtin_amdgcn_s_waitcnt(0);      // this span's stores are out before the LDS pool is reused
+        wave_sync();
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // Batch match finders: one wavefront per run of FIND_RUN consecutive positions.  Because find and
 // skip both insert (lz_encoder_mf.c:366-441), the matches of a position depend on the data only, so
@@ -1974,8 +1987,8 @@ struct SnArgs {
     const uint32_t* __restrict__ prev2;
     const uint32_t* __restrict__ prev3;
     const uint32_t* __restrict__ prev4;
-    const uint32_t* __restrict__ prev8;
-    const uint32_t* __restrict__ prev16;
+    const uint32_t* __restrict__ prev8;     // stride 2 (interleaved with the round's rank)
+    const uint32_t* __restrict__ prev16;    // stride 2
 };
 constexpr uint32_t SN_WMAX = 5;
 
@@ -2041,6 +2054,7 @@ __global__ __launch_bounds__(64) void k_find_sn(xzamd_span_args a, SnArgs sn, ui
     const bool win_lane = (left || right) && k < W;
     const bool hash_lane = t >= 10 && t < 15;
     const uint32_t* __restrict__ hp = t == 10 ? sn.prev2 : t == 11 ? sn.prev3 : t == 12 ? sn.prev4 : t == 13 ? sn.prev8 : sn.prev16;
+    const uint32_t hstride = t >= 13 ? 2u : 1u;
     const uint32_t minlen = t == 10 ? 2u : t == 11 ? 3u : 4u;
     // masks for the prefix maximum inside a side (the right side must not look into the left one)
     const bool sh1 = t != 0 && t != 5, sh2 = (left && t >= 2) || (right && t >= 7), sh4 = (left && t >= 4) || (right && t >= 9);
@@ -2102,12 +2116,12 @@ __global__ __launch_bounds__(64) void k_find_sn(xzamd_span_args a, SnArgs sn, ui
     geo_next(g2_bs, g2_be, g2_se, xr0 + 2);
     uint32_t rk1 = sn.sa_rank[clampp(xr0 + 1)];
     uint32_t rk2 = sn.sa_rank[clampp(xr0 + 2)];
-    uint32_t hw1 = hash_lane ? hp[clampp(xr0 + 1)] : 0u;
+    uint32_t hw1 = hash_lane ? hp[hstride * clampp(xr0 + 1)] : 0u;
     uint32_t w1 = window(rk1, g1_bs, g1_be, xr0 + 1 < xend);
     uint32_t q0; bool v0;
     {
         const uint32_t rk0 = sn.sa_rank[clampp(xr0)];
-        const uint32_t hw0 = hash_lane ? hp[clampp(xr0)] : 0u;
+        const uint32_t hw0 = hash_lane ? hp[hstride * clampp(xr0)] : 0u;
         candidate(xr0, window(rk0, g_bs, g_be, xr0 < xend), hw0, q0, v0);
         if (!(xr0 < xend)) v0 = false;
     }
@@ -2121,7 +2135,7 @@ __global__ __launch_bounds__(64) void k_find_sn(xzamd_span_args a, SnArgs sn, ui
         // stage 0: window of x + 2 (its rank arrived last iteration), rank of x + 3, hash word of x + 2
         const uint32_t w2 = window(rk2, g2_bs, g2_be, x + 2 < xend);
         const uint32_t rk3 = sn.sa_rank[clampp(x + 3)];
-        const uint32_t hw2 = hash_lane ? hp[clampp(x + 2)] : 0u;
+        const uint32_t hw2 = hash_lane ? hp[hstride * clampp(x + 2)] : 0u;
         // stage 1: candidates of x + 1 and their first 16 bytes
         uint32_t q1; bool v1;
         candidate(x + 1, w1, hw1, q1, v1);
@@ -2537,14 +2551,15 @@ int xzk_sa_temp_bytes(uint32_t n, uint64_t* bytes)
 // Builds the match-finder structure of a batch.
 //   exact finder (sa == NULL):   rank / sorted_pos (main chain), prev2, prev3
 //   suffix-neighbourhood finder: prev2, prev3, prev4, the suffix order sa / sa_rank and its by-products
-//                                prev8 / prev16 (nearest earlier position with the same 8 / 16 bytes)
+//                                rp8 / rp16: per position (rank of the round, distance to the nearest earlier
+//                                position with the same 8 / 16 bytes)
 // keys_a/keys_b/vals_a/vals_b: n u32 each; key64_a/key64_b: n u64 each (sa != NULL only).
 int xzk_build_chains(const uint8_t* d_in, uint32_t n, uint32_t block_size, uint32_t nblocks,
         uint32_t hash_bytes, uint32_t hash_mask, uint32_t hash_bits,
         uint32_t* keys_a, uint32_t* keys_b, uint32_t* vals_a, uint32_t* vals_b,
         void* sort_tmp, uint64_t sort_tmp_bytes,
         uint32_t* rank, uint32_t* sorted_pos, uint32_t* prev2, uint32_t* prev3,
-        uint32_t* prev4, uint32_t* prev8, uint32_t* prev16, uint64_t* key64_a, uint64_t* key64_b,
+        uint32_t* prev4, uint64_t* rp8, uint64_t* rp16, uint64_t* key64_a, uint64_t* key64_b,
         uint32_t* sa, uint32_t* sa_rank, void* stream_)
 {
     hipStream_t st = (hipStream_t)stream_;
@@ -2621,9 +2636,9 @@ int xzk_build_chains(const uint8_t* d_in, uint32_t n, uint32_t block_size, uint3
     }
     // doubling rounds
     for (uint32_t h = 8; h <= 16; h *= 2) {
-        hipLaunchKernelGGL(k_sa_prev, dim3(g), dim3(256), 0, st, pos, grp, n, h == 8 ? prev8 : prev16);
-        hipLaunchKernelGGL(k_sa_scatter_rank, dim3(g), dim3(256), 0, st, pos, grp, n, sa_rank);
-        hipLaunchKernelGGL(k_sa_pair_keys, dim3(g), dim3(256), 0, st, pos, grp, sa_rank, n, block_size, h, key64_a);
+        uint2* rkx = reinterpret_cast<uint2*>(h == 8 ? rp8 : rp16);
+        hipLaunchKernelGGL(k_sa_scatter_rank, dim3(g), dim3(256), 0, st, pos, grp, n, rkx);
+        hipLaunchKernelGGL(k_sa_pair_keys, dim3(g), dim3(256), 0, st, pos, grp, rkx, n, block_size, h, key64_a);
         rocprim::double_buffer<uint64_t> kk(key64_a, key64_b);
         rocprim::double_buffer<uint32_t> vv(pos, pos_alt);
         e = rocprim::radix_sort_pairs(sort_tmp, tb, kk, vv, (size_t)n, 0u, 64u, st);
@@ -2641,16 +2656,17 @@ int xzk_build_chains(const uint8_t* d_in, uint32_t n, uint32_t block_size, uint3
 }
 
 int xzk_find_matches(const xzamd_span_args* a, const uint32_t* sa, const uint32_t* sa_rank, const uint32_t* prev4,
-        const uint32_t* prev8, const uint32_t* prev16, uint16_t* mlen, uint32_t* mdist, void* stream_)
+        const uint64_t* rp8, const uint64_t* rp16, uint16_t* mlen, uint32_t* mdist, void* stream_)
 {
     hipStream_t st = (hipStream_t)stream_;
     const uint32_t runs = (a->n + FIND_RUN - 1) / FIND_RUN;
     if (runs == 0) return 0;
     if (a->sa_window) {
-        if (!sa || !sa_rank || !prev4 || !prev8 || !prev16 || a->sa_window > SN_WMAX) return (int)hipErrorInvalidValue;
+        if (!sa || !sa_rank || !prev4 || !rp8 || !rp16 || a->sa_window > SN_WMAX) return (int)hipErrorInvalidValue;
         SnArgs sn;
-        sn.in = a->in; sn.sa = sa; sn.sa_rank = sa_rank; sn.prev2 = a->prev2; sn.prev3 = a->prev3; sn.prev4 = prev4; sn.prev8 = prev8;
-        sn.prev16 = prev16;
+        sn.in = a->in; sn.sa = sa; sn.sa_rank = sa_rank; sn.prev2 = a->prev2; sn.prev3 = a->prev3; sn.prev4 = prev4;
+        sn.prev8 = reinterpret_cast<const uint32_t*>(rp8) + 1;        // second word of each (rank, distance) pair
+        sn.prev16 = reinterpret_cast<const uint32_t*>(rp16) + 1;
         hipLaunchKernelGGL(k_find_sn, dim3(runs), dim3(64), 0, st, *a, sn, mlen, mdist);
     } else {
         hipLaunchKernelGGL(k_find_exact, dim3(runs), dim3(64), 0, st, *a, mlen, mdist);
@@ -2658,15 +2674,21 @@ int xzk_find_matches(const xzamd_span_args* a, const uint32_t* sa, const uint32_
     return (int)hipGetLastError();
 }
 
-int xzk_span_encode(const xzamd_span_args* a, uint32_t nspans, void* stream_)
+// waves = 0: one wavefront per span; else a persistent launch of min(waves, nspans) wavefronts that pull
+// span numbers from *counter (must be zero at launch).
+int xzk_span_encode(const xzamd_span_args* a, uint32_t nspans, uint32_t waves, uint32_t* counter, void* stream_)
 {
     hipStream_t st = (hipStream_t)stream_;
+    if (nspans == 0) return 0;
+    const bool persist = waves != 0 && counter != nullptr && waves < nspans;
+    const uint32_t grid = persist ? waves : nspans;
+    uint32_t* cnt = persist ? counter : nullptr;
     if (a->parser) {
         if ((!a->mlen && !a->list_packed) || !a->mdist) return (int)hipErrorInvalidValue;
-        hipLaunchKernelGGL((k_span_encode_t<2, true>), dim3(nspans), dim3(64), 0, st, *a);
+        hipLaunchKernelGGL((k_span_encode_t<2, true>), dim3(grid), dim3(64), 0, st, *a, nspans, cnt);
     } else {
         if (a->sa_window) return (int)hipErrorInvalidValue;      // the fast parser runs on the exact finder only
-        hipLaunchKernelGGL((k_span_encode_t<0, false>), dim3(nspans), dim3(64), 0, st, *a);
+        hipLaunchKernelGGL((k_span_encode_t<0, false>), dim3(grid), dim3(64), 0, st, *a, nspans, cnt);
     }
     return (int)hipGetLastError();
 }

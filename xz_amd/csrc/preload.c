@@ -8,7 +8,7 @@
  * stream (SURVEY.md 8b "What calls it", option 2):
  *   lzma_stream_encoder_mt  -> libxz_amd.so (falls back to the real liblzma if there is no GPU or the
  *                              options are outside the device path)
- *   lzma_code / lzma_end / lzma_get_progress
+ *   lzma_code / lzma_end / lzma_get_progress / lzma_filters_update
  *                           -> libxz_amd.so for streams it created (tagged lzma_internal), the real
  *                              liblzma (dlsym RTLD_NEXT) for all others (decoders, single-threaded
  *                              encoder, ...)
@@ -32,6 +32,7 @@ typedef lzma_ret (*enc_mt_fn)(lzma_stream *, const lzma_mt *);
 typedef lzma_ret (*code_fn)(lzma_stream *, lzma_action);
 typedef void (*end_fn)(lzma_stream *);
 typedef void (*progress_fn)(lzma_stream *, uint64_t *, uint64_t *);
+typedef lzma_ret (*fupd_fn)(lzma_stream *, const lzma_filter *);
 
 static struct {
 	int tried;
@@ -40,6 +41,7 @@ static struct {
 	code_fn code;
 	end_fn end;
 	progress_fn progress;
+	fupd_fn fupd;
 } gpu;
 
 static int verbose(void) { const char *v = getenv("XZ_AMD_VERBOSE"); return v && *v && *v != '0'; }
@@ -75,6 +77,7 @@ static void gpu_load(void)
 	gpu.code = (code_fn)dlsym(h, "lzma_code");
 	gpu.end = (end_fn)dlsym(h, "lzma_end");
 	gpu.progress = (progress_fn)dlsym(h, "lzma_get_progress");
+	gpu.fupd = (fupd_fn)dlsym(h, "lzma_filters_update");
 	if (gpu.enc_mt && gpu.code && gpu.end && gpu.progress)
 		gpu.h = h;
 	else
@@ -148,4 +151,14 @@ void lzma_get_progress(lzma_stream *strm, uint64_t *progress_in, uint64_t *progr
 		real = (progress_fn)dlsym(RTLD_NEXT, "lzma_get_progress");
 	if (real)
 		real(strm, progress_in, progress_out);
+}
+
+lzma_ret lzma_filters_update(lzma_stream *strm, const lzma_filter *filters)
+{
+	static fupd_fn real;
+	if (is_ours(strm) && gpu.h && gpu.fupd)
+		return gpu.fupd(strm, filters);
+	if (!real)
+		real = (fupd_fn)dlsym(RTLD_NEXT, "lzma_filters_update");
+	return real ? real(strm, filters) : LZMA_PROG_ERROR;
 }

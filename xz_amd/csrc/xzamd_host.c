@@ -255,6 +255,7 @@ struct xzamd_ctx {
 	void *ev_lo[2][4];           /* per list buffer: find done (hi), chains begin / end (lo), prefetched find done (lo) */
 	uint64_t batch_bytes;
 	uint32_t wave_slots;         /* span wavefronts resident at once (CUs x 16) */
+	uint32_t span_waves;         /* != 0: persistent span kernel with this many wavefronts */
 	char err[256];
 	char err_msg_buf[200];
 	/* device buffers */
@@ -325,6 +326,10 @@ int xzamd_ctx_create(xzamd_ctx **out, int device)
 		int cus = 0;
 		if (xzk_cu_count(device, &cus) || cus <= 0) cus = 256;
 		c->wave_slots = (uint32_t)cus * 16u;       /* the span kernels run 4 waves per SIMD = 16 per CU */
+		/* XZAMD_SPAN_WAVES_PER_CU = k: persistent span kernel with k wavefronts per CU (k < 16 leaves
+		 * register space for the low-priority stream's kernels); 0 / unset: one wavefront per span */
+		const char *pw = getenv("XZAMD_SPAN_WAVES_PER_CU");
+		c->span_waves = (pw && atoi(pw) > 0) ? (uint32_t)cus * (uint32_t)atoi(pw) : 0;
 	}
 	const char *env = getenv("XZAMD_BATCH_MIB");
 	if (env && atoll(env) > 0)
@@ -368,6 +373,26 @@ const char *xzamd_last_error(const xzamd_ctx *c) { return c ? c->err : "no conte
 int xzamd_ctx_device(const xzamd_ctx *c) { return c ? c->device : -1; }
 void xzamd_get_stats(const xzamd_ctx *c, xzamd_stats *out) { *out = c->stats; }
 const char *xzamd_version(void) { return "xz_amd 0.1 (gfx950)"; }
+
+/* The one place that says which LZMA2 option sets the device path runs (used by the batch entry point and
+ * by lzma_stream_encoder_mt, so an unsupported set is refused at init, not mid-stream).  NULL = fine. */
+const char *xzamd_options_check(const xzamd_lzma_options *opt)
+{
+	if (opt->lc > 4 || opt->lp > 4 || opt->lc + opt->lp > 4 || opt->pb > 4)
+		return "lc + lp <= 4 and pb <= 4 required (lzma_encoder.c:440-470)";
+	if ((opt->gpu_mf != XZAMD_MF_HC3 && opt->gpu_mf != XZAMD_MF_HC4)
+			|| opt->gpu_depth < 1 || opt->gpu_depth > 56 || opt->gpu_sa_window > XZAMD_SA_WINDOW_MAX
+			|| (opt->gpu_sa_window && (opt->gpu_mf != XZAMD_MF_HC4 || !opt->gpu_parser)) || opt->gpu_parser > 1
+			|| opt->gpu_nice_len < (opt->gpu_mf & 0x0F) || opt->gpu_nice_len > 273)
+		return "unsupported match finder options for the device path";
+	if (opt->dict_size < 4096 || opt->dict_size > (1u << 30))
+		return "dict_size must be 4 KiB .. 1 GiB on the device path";
+	if (opt->bcj != 0 && opt->bcj != XZAMD_BCJ_X86)
+		return "only the x86 BCJ filter is supported in front of LZMA2";
+	if (opt->gpu_parser && opt->pb > 2)
+		return "the optimal parser's price tables cover pb <= 2";
+	return NULL;
+}
 
 int xzamd_trace_enable(xzamd_ctx *c, uint32_t cap)
 {
@@ -497,8 +522,8 @@ static int launch_chains(xzamd_ctx *c, const xzamd_lzma_options *opt, const uint
 			(uint32_t *)c->rank.p, (uint32_t *)c->sorted_pos.p, (uint32_t *)c->prev2.p,
 			(uint32_t *)c->prev3.p,
 			opt->gpu_sa_window ? (uint32_t *)c->prev4.p : NULL,
-			opt->gpu_sa_window ? (uint32_t *)c->prev8.p : NULL,
-			opt->gpu_sa_window ? (uint32_t *)c->prev16.p : NULL,
+			opt->gpu_sa_window ? (uint64_t *)c->prev8.p : NULL,
+			opt->gpu_sa_window ? (uint64_t *)c->prev16.p : NULL,
 			opt->gpu_sa_window ? (uint64_t *)c->key64_a.p : NULL,
 			opt->gpu_sa_window ? (uint64_t *)c->key64_b.p : NULL,
 			opt->gpu_sa_window ? (uint32_t *)c->sa.p : NULL,
@@ -523,18 +548,11 @@ int xzamd_stream_encode_device(xzamd_ctx *c,
 		return fail(c, XZAMD_PROG_ERROR, "check id out of range", 0);
 	if (cbytes == 0xFFFFFFFFu)
 		return fail(c, XZAMD_UNSUPPORTED_CHECK, "only CRC32/CRC64/none are supported", 0);
-	if (opt->lc + opt->lp > 3 || opt->pb > 4)
-		return fail(c, XZAMD_OPTIONS_ERROR, "lc+lp <= 3 and pb <= 4 required (LDS model size)", 0);
-	if ((opt->gpu_mf != XZAMD_MF_HC3 && opt->gpu_mf != XZAMD_MF_HC4)
-			|| opt->gpu_depth < 1 || opt->gpu_depth > 56 || opt->gpu_sa_window > XZAMD_SA_WINDOW_MAX
-			|| (opt->gpu_sa_window && (opt->gpu_mf != XZAMD_MF_HC4 || !opt->gpu_parser)) || opt->gpu_parser > 1
-			|| opt->gpu_nice_len < opt->gpu_mf || opt->gpu_nice_len > 273
-			|| opt->dict_size < 4096 || opt->dict_size > (1u << 30))
-		return fail(c, XZAMD_OPTIONS_ERROR, "unsupported match finder options for the device path", 0);
-	if (opt->bcj != 0 && opt->bcj != XZAMD_BCJ_X86)
-		return fail(c, XZAMD_OPTIONS_ERROR, "only the x86 BCJ filter is supported in front of LZMA2", 0);
-	if (opt->gpu_parser && opt->pb > 2)
-		return fail(c, XZAMD_OPTIONS_ERROR, "the optimal parser's price tables cover pb <= 2", 0);
+	{
+		const char *why = xzamd_options_check(opt);
+		if (why)
+			return fail(c, XZAMD_OPTIONS_ERROR, why, 0);
+	}
 	if (block_size == 0)
 		block_size = xzamd_mt_block_size(opt);
 	if (block_size >= (1ull << 31))
@@ -643,7 +661,7 @@ int xzamd_stream_encode_device(xzamd_ctx *c,
 		GROW(vals_a, 4ull * n, 0); GROW(vals_b, 4ull * n, 0);
 		GROW(prev2, 4ull * n, 0); GROW(prev3, 4ull * n, 0);
 		if (opt->gpu_sa_window) {
-			GROW(prev4, 4ull * n, 0); GROW(prev8, 4ull * n, 0); GROW(prev16, 4ull * n, 0);
+			GROW(prev4, 4ull * n, 0); GROW(prev8, 8ull * n, 0); GROW(prev16, 8ull * n, 0);   /* prev8/16: (rank, distance) pairs */
 			GROW(key64_a, 8ull * n, 0); GROW(key64_b, 8ull * n, 0);
 			GROW(sa, 4ull * n, 0); GROW(sa_rank, 4ull * n, 0);
 		} else {
@@ -655,7 +673,7 @@ int xzamd_stream_encode_device(xzamd_ctx *c,
 		GROW(strip_crc, 8ull * spb_crc * nb, 0);
 		GROW(block_crc, 8ull * nb, 0);
 		GROW(errw, 256, 0);
-		GROW(litp, (uint64_t)nspans * 6144ull * 4ull, 0);
+		GROW(litp, (uint64_t)nspans * (0x300ull << (opt->lc + opt->lp)) * 4ull, 0);
 		if (opt->gpu_parser) {
 			/* per-position match lists: 8 x u32 (7 entries + trailer), + 8 x u16 lengths when not packed */
 			if (!list_packed) GROW(mlen, 16ull * n, 0);
@@ -744,7 +762,7 @@ int xzamd_stream_encode_device(xzamd_ctx *c,
 				a.mdist = md_cur;
 				if (!find_on_lo) {
 					e = xzk_find_matches(&a, (const uint32_t *)c->sa.p, (const uint32_t *)c->sa_rank.p, (const uint32_t *)c->prev4.p,
-							(const uint32_t *)c->prev8.p, (const uint32_t *)c->prev16.p, ml_cur, md_cur, st);
+							(const uint64_t *)c->prev8.p, (const uint64_t *)c->prev16.p, ml_cur, md_cur, st);
 					if (e) { rc = fail(c, XZAMD_DEVICE_ERROR, "find_matches launch", e); goto done; }
 				}
 				xzk_event_record(c->ev[5], st);
@@ -769,14 +787,14 @@ int xzamd_stream_encode_device(xzamd_ctx *c,
 					if (!e2 && launch_chains(c, opt, d_in + g2.in_off, &g2, block_size, hb, hmask, hbits, c->lo_stream) != XZAMD_OK) e2 = 1;
 					if (!e2) e2 = xzk_event_record(evn[2], c->lo_stream);
 					if (!e2) e2 = xzk_find_matches(&a2, (const uint32_t *)c->sa.p, (const uint32_t *)c->sa_rank.p, (const uint32_t *)c->prev4.p,
-							(const uint32_t *)c->prev8.p, (const uint32_t *)c->prev16.p, ml_nx, md_nx, c->lo_stream);
+							(const uint64_t *)c->prev8.p, (const uint64_t *)c->prev16.p, ml_nx, md_nx, c->lo_stream);
 					if (!e2) e2 = xzk_event_record(evn[3], c->lo_stream);
 					if (e2) { rc = fail(c, XZAMD_DEVICE_ERROR, "chain prefetch", e2); goto done; }
 					prefetched = 1;
 					prefetched_b0 = b0 + nb;
 				}
 			}
-			e = xzk_span_encode(&a, nspans, st);
+			e = xzk_span_encode(&a, nspans, c->span_waves, (uint32_t *)c->errw.p + 60, st);
 			if (e) { rc = fail(c, XZAMD_DEVICE_ERROR, "span_encode launch", e); goto done; }
 		}
 		xzk_event_record(c->ev[2], st);

@@ -11,12 +11,22 @@
  *   lzma_get_progress       <- common/common.c:406 / stream_encoder_mt.c:1004-1024
  *   lzma_stream_encoder_mt_memusage <- stream_encoder_mt.c:1231
  *
+ *   lzma_filters_update     <- stream_encoder_mt.c:914-950 (between Blocks only)
+ *   lzma_mt_block_size, lzma_cputhreads <- filter_encoder.c:270, hardware_cputhreads.c
+ *
  * stream_encode_mt() (:717-883) copies caller input into per-worker Block
- * buffers and hands them to threads; here the caller's bytes are copied into a
- * pinned host staging buffer holding a batch of Blocks, one batch at a time is
- * uploaded, encoded by xzamd_stream_encode_device(BLOCKS_ONLY) and downloaded
- * into an ordered output buffer (the lzma_outq equivalent), and the Index
- * records are kept on the host until LZMA_FINISH.
+ * buffers and hands them to worker threads (get_thread :540-597,
+ * stream_encode_in :599-665), results come back through an ordered output
+ * queue (outqueue.c:182-260).  Same shape here with a GPU per worker: the
+ * caller's bytes are copied into a pinned staging buffer holding a batch of
+ * whole Blocks ("job"); full jobs are dealt in order to one worker thread per
+ * visible GPU (own xzamd_ctx each), which uploads, encodes
+ * (xzamd_stream_encode_device, BLOCKS_ONLY) and downloads into the job's pinned
+ * output buffer; the calling thread drains finished jobs strictly in order,
+ * keeps the Index records, and fills the next job meanwhile (staging, H2D,
+ * encode and D2H of consecutive batches overlap).  lzma_mt.timeout bounds the
+ * time a call may wait for the workers, LZMA_FULL_BARRIER returns once the
+ * input is handed over (:803-807).
  */
 #include "../../include/xz_amd.h"
 #include "../../include/xz_amd_lzma.h"
@@ -29,9 +39,37 @@
 
 #define LZMA_THREADS_MAX 16384
 #define XZAMD_MAGIC 0x585A414D44474655ull
+#define MAX_DEVS 16
+#define MAX_JOBS (MAX_DEVS + 1)
+
+#include <errno.h>
+#include <time.h>
 
 enum iseq { ISEQ_RUN, ISEQ_SYNC_FLUSH, ISEQ_FULL_FLUSH, ISEQ_FINISH, ISEQ_FULL_BARRIER, ISEQ_END, ISEQ_ERROR };
 enum sseq { SEQ_HEADER, SEQ_BLOCKS, SEQ_TAIL, SEQ_DONE };
+enum jstate { J_FREE, J_FILLING, J_QUEUED, J_RUNNING, J_DONE };
+
+/* One batch of whole Blocks on its way through a worker. */
+typedef struct {
+	enum jstate state;
+	uint64_t seq;
+	uint8_t *stage; uint64_t stage_len, stage_cap;       /* pinned: caller bytes */
+	uint8_t *out; uint64_t out_len, out_pos, out_cap;     /* pinned: encoded Blocks */
+	xzamd_block_info *binfo; uint64_t binfo_cap, nblocks;
+	xzamd_lzma_options opt;                               /* options in force when the job was queued */
+	lzma_ret err;
+} job;
+
+/* One GPU: context + device buffers, driven by one worker thread. */
+typedef struct {
+	int device;
+	xzamd_ctx *ctx;
+	void *d_in; uint64_t d_in_cap;
+	void *d_out; uint64_t d_out_cap;
+	pthread_t thr;
+	int started;
+	struct lzma_internal_s *owner;
+} devslot;
 
 struct lzma_internal_s {
 	uint64_t magic;
@@ -39,20 +77,24 @@ struct lzma_internal_s {
 	size_t avail_in;
 	int allow_buf_error;
 	/* encoder */
-	xzamd_ctx *ctx;
 	xzamd_lzma_options opt;
 	uint64_t block_size;
 	int check;
+	uint32_t timeout_ms;
 	enum sseq sseq;
-	/* staging of caller input (pinned) */
-	uint8_t *stage; uint64_t stage_len, stage_cap, stage_max;
-	void *d_in; uint64_t d_in_cap;
-	void *d_out; uint64_t d_out_cap;
-	/* ordered output (pinned) */
-	uint8_t *outq; uint64_t outq_pos, outq_len, outq_cap;
+	uint64_t stage_max;
+	/* workers */
+	devslot dev[MAX_DEVS]; int ndev;
+	job jobs[MAX_JOBS]; int njobs;
+	int fill;                    /* job being filled by the calling thread, -1 = none */
+	uint64_t next_seq, drain_seq;
+	pthread_mutex_t mu;
+	pthread_cond_t cv_work, cv_done;
+	int shutdown, mu_ok;
+	/* small framing pieces (Stream Header, Index + Footer) */
+	uint8_t *tailbuf; uint64_t tail_pos, tail_len, tail_cap;
 	/* Index records */
 	uint64_t *rec; uint64_t nrec, rec_cap;
-	xzamd_block_info *binfo; uint64_t binfo_cap;
 	uint64_t progress_in, progress_out;
 	const lzma_allocator *allocator;
 };
@@ -83,71 +125,243 @@ static lzma_ret map_rc(int rc)
 	}
 }
 
-/* One parked set of device/pinned resources: hipMalloc of the work buffers (tens of GiB for a 1 GiB
- * batch) and hipHostMalloc of the staging area cost seconds, so lzma_end() parks them and the next
- * lzma_stream_encoder_mt() of the process picks them up instead of allocating again. */
+/* Parked resources: hipMalloc of the work buffers (tens of GiB for a 1 GiB batch) and hipHostMalloc of the
+ * staging areas cost seconds, so lzma_end() parks them (one set per device, a pool of pinned buffers) and
+ * the next lzma_stream_encoder_mt() of the process picks them up.  xzamd_release_parked() / a library
+ * destructor give them back; XZAMD_NO_PARK=1 disables parking. */
 static struct {
 	pthread_mutex_t mu;
-	int full;
-	xzamd_ctx *ctx;
-	uint8_t *stage; uint64_t stage_cap;
-	uint8_t *outq; uint64_t outq_cap;
-	void *d_in; uint64_t d_in_cap;
-	void *d_out; uint64_t d_out_cap;
-} g_park = { PTHREAD_MUTEX_INITIALIZER, 0, NULL, NULL, 0, NULL, 0, NULL, 0, NULL, 0 };
+	struct { int full; xzamd_ctx *ctx; void *d_in, *d_out; uint64_t d_in_cap, d_out_cap; } dev[MAX_DEVS];
+	struct { uint8_t *p; uint64_t cap; } pinned[2 * MAX_JOBS];
+} g_park = { .mu = PTHREAD_MUTEX_INITIALIZER };
 
-static int park_resources(lzma_internal *in)
+static int parking_enabled(void)
 {
-	int parked = 0;
-	pthread_mutex_lock(&g_park.mu);
-	if (!g_park.full && in->ctx) {
-		g_park.ctx = in->ctx;
-		g_park.stage = in->stage; g_park.stage_cap = in->stage_cap;
-		g_park.outq = in->outq; g_park.outq_cap = in->outq_cap;
-		g_park.d_in = in->d_in; g_park.d_in_cap = in->d_in_cap;
-		g_park.d_out = in->d_out; g_park.d_out_cap = in->d_out_cap;
-		g_park.full = 1;
-		parked = 1;
-	}
-	pthread_mutex_unlock(&g_park.mu);
-	return parked;
+	const char *e = getenv("XZAMD_NO_PARK");
+	return !(e && *e == '1');
 }
 
-static int unpark_resources(lzma_internal *in)
+static void park_pinned(uint8_t *p, uint64_t cap)
 {
-	int got = 0, dev = -1;
-	if (xzk_get_device(&dev))
-		return 0;
-	pthread_mutex_lock(&g_park.mu);
-	if (g_park.full && xzamd_ctx_device(g_park.ctx) == dev) {
-		in->ctx = g_park.ctx;
-		in->stage = g_park.stage; in->stage_cap = g_park.stage_cap;
-		in->outq = g_park.outq; in->outq_cap = g_park.outq_cap;
-		in->d_in = g_park.d_in; in->d_in_cap = g_park.d_in_cap;
-		in->d_out = g_park.d_out; in->d_out_cap = g_park.d_out_cap;
-		g_park.full = 0;
-		got = 1;
+	if (!p) return;
+	if (parking_enabled()) {
+		pthread_mutex_lock(&g_park.mu);
+		for (int i = 0; i < 2 * MAX_JOBS; ++i)
+			if (!g_park.pinned[i].p) {
+				g_park.pinned[i].p = p; g_park.pinned[i].cap = cap;
+				pthread_mutex_unlock(&g_park.mu);
+				return;
+			}
+		pthread_mutex_unlock(&g_park.mu);
 	}
+	xzk_host_free(p);
+}
+
+static uint8_t *unpark_pinned(uint64_t want, uint64_t *cap)
+{
+	uint8_t *p = NULL;
+	pthread_mutex_lock(&g_park.mu);
+	for (int i = 0; i < 2 * MAX_JOBS; ++i)
+		if (g_park.pinned[i].p && g_park.pinned[i].cap >= want) {
+			p = g_park.pinned[i].p; *cap = g_park.pinned[i].cap;
+			g_park.pinned[i].p = NULL; g_park.pinned[i].cap = 0;
+			break;
+		}
+	pthread_mutex_unlock(&g_park.mu);
+	return p;
+}
+
+void xzamd_release_parked(void)
+{
+	pthread_mutex_lock(&g_park.mu);
+	for (int i = 0; i < MAX_DEVS; ++i)
+		if (g_park.dev[i].full) {
+			xzk_set_device(xzamd_ctx_device(g_park.dev[i].ctx));
+			if (g_park.dev[i].d_in) xzk_free(g_park.dev[i].d_in);
+			if (g_park.dev[i].d_out) xzk_free(g_park.dev[i].d_out);
+			xzamd_ctx_destroy(g_park.dev[i].ctx);
+			memset(&g_park.dev[i], 0, sizeof(g_park.dev[i]));
+		}
+	for (int i = 0; i < 2 * MAX_JOBS; ++i)
+		if (g_park.pinned[i].p) {
+			xzk_host_free(g_park.pinned[i].p);
+			g_park.pinned[i].p = NULL; g_park.pinned[i].cap = 0;
+		}
+	pthread_mutex_unlock(&g_park.mu);
+}
+
+static void park_dev(devslot *d)
+{
+	if (!d->ctx) return;
+	if (parking_enabled()) {
+		pthread_mutex_lock(&g_park.mu);
+		for (int i = 0; i < MAX_DEVS; ++i)
+			if (!g_park.dev[i].full) {
+				g_park.dev[i].full = 1; g_park.dev[i].ctx = d->ctx;
+				g_park.dev[i].d_in = d->d_in; g_park.dev[i].d_in_cap = d->d_in_cap;
+				g_park.dev[i].d_out = d->d_out; g_park.dev[i].d_out_cap = d->d_out_cap;
+				pthread_mutex_unlock(&g_park.mu);
+				d->ctx = NULL; d->d_in = d->d_out = NULL;
+				return;
+			}
+		pthread_mutex_unlock(&g_park.mu);
+	}
+	xzk_set_device(d->device);
+	if (d->d_in) xzk_free(d->d_in);
+	if (d->d_out) xzk_free(d->d_out);
+	xzamd_ctx_destroy(d->ctx);
+	d->ctx = NULL; d->d_in = d->d_out = NULL;
+}
+
+static int unpark_dev(devslot *d, int device)
+{
+	int got = 0;
+	pthread_mutex_lock(&g_park.mu);
+	for (int i = 0; i < MAX_DEVS; ++i)
+		if (g_park.dev[i].full && xzamd_ctx_device(g_park.dev[i].ctx) == device) {
+			d->ctx = g_park.dev[i].ctx;
+			d->d_in = g_park.dev[i].d_in; d->d_in_cap = g_park.dev[i].d_in_cap;
+			d->d_out = g_park.dev[i].d_out; d->d_out_cap = g_park.dev[i].d_out_cap;
+			memset(&g_park.dev[i], 0, sizeof(g_park.dev[i]));
+			got = 1;
+			break;
+		}
 	pthread_mutex_unlock(&g_park.mu);
 	return got;
+}
+
+static lzma_ret grow_pinned(uint8_t **buf, uint64_t *cap, uint64_t keep, uint64_t want)
+{
+	if (*cap >= want)
+		return LZMA_OK;
+	uint64_t ncap = 0;
+	uint8_t *p = unpark_pinned(want, &ncap);
+	if (!p) {
+		void *q = NULL;
+		if (xzk_host_alloc(&q, want))
+			return LZMA_MEM_ERROR;
+		p = (uint8_t *)q;
+		ncap = want;
+	}
+	if (*buf) {
+		if (keep) memcpy(p, *buf, keep);
+		park_pinned(*buf, *cap);
+	}
+	*buf = p;
+	*cap = ncap;
+	return LZMA_OK;
+}
+
+/* worker_encode() x nblocks (stream_encoder_mt.c:219-361) for one job on one GPU. */
+static lzma_ret run_job(lzma_internal *in, devslot *d, job *j)
+{
+	const uint64_t n = j->stage_len;
+	const uint64_t nb = (n + in->block_size - 1) / in->block_size;
+	const uint64_t bound = xzamd_stream_buffer_bound(n, in->block_size);
+	if (xzk_set_device(d->device))
+		return LZMA_PROG_ERROR;
+	if (d->d_in_cap < n) {
+		if (d->d_in) xzk_free(d->d_in);
+		d->d_in = NULL; d->d_in_cap = 0;
+		if (xzk_malloc(&d->d_in, n)) return LZMA_MEM_ERROR;
+		d->d_in_cap = n;
+	}
+	if (d->d_out_cap < bound) {
+		if (d->d_out) xzk_free(d->d_out);
+		d->d_out = NULL; d->d_out_cap = 0;
+		if (xzk_malloc(&d->d_out, bound)) return LZMA_MEM_ERROR;
+		d->d_out_cap = bound;
+	}
+	if (j->binfo_cap < nb) {
+		free(j->binfo);
+		j->binfo = (xzamd_block_info *)malloc(nb * sizeof(xzamd_block_info));
+		if (!j->binfo) { j->binfo_cap = 0; return LZMA_MEM_ERROR; }
+		j->binfo_cap = nb;
+	}
+	lzma_ret r = grow_pinned(&j->out, &j->out_cap, 0, bound);
+	if (r != LZMA_OK) return r;
+	if (xzk_h2d(d->d_in, j->stage, n, NULL) || xzk_sync(NULL))
+		return LZMA_PROG_ERROR;
+	uint64_t out_size = 0, nblocks = 0;
+	int rc = xzamd_stream_encode_device(d->ctx, d->d_in, n, in->block_size, &j->opt, in->check,
+			XZAMD_F_BLOCKS_ONLY, d->d_out, d->d_out_cap, &out_size, j->binfo, j->binfo_cap,
+			&nblocks, NULL);
+	if (rc != XZAMD_OK)
+		return map_rc(rc);
+	if (xzk_d2h(j->out, d->d_out, out_size, NULL) || xzk_sync(NULL))
+		return LZMA_PROG_ERROR;
+	j->out_len = out_size;
+	j->out_pos = 0;
+	j->nblocks = nblocks;
+	return LZMA_OK;
+}
+
+/* Worker thread: takes the oldest queued job (jobs are dealt strictly in order, stream_encode_in
+ * :599-665), runs it on its GPU, reports it done. */
+static void *worker_main(void *arg)
+{
+	devslot *d = (devslot *)arg;
+	lzma_internal *in = d->owner;
+	pthread_mutex_lock(&in->mu);
+	for (;;) {
+		int pick = -1;
+		for (int i = 0; i < in->njobs; ++i)
+			if (in->jobs[i].state == J_QUEUED && (pick < 0 || in->jobs[i].seq < in->jobs[pick].seq))
+				pick = i;
+		if (pick < 0) {
+			if (in->shutdown)
+				break;
+			pthread_cond_wait(&in->cv_work, &in->mu);
+			continue;
+		}
+		job *j = &in->jobs[pick];
+		j->state = J_RUNNING;
+		pthread_mutex_unlock(&in->mu);
+		const lzma_ret r = run_job(in, d, j);
+		pthread_mutex_lock(&in->mu);
+		j->err = r;
+		j->state = J_DONE;
+		in->progress_in += j->stage_len;
+		pthread_cond_broadcast(&in->cv_done);
+	}
+	pthread_mutex_unlock(&in->mu);
+	return NULL;
 }
 
 static void internal_free(lzma_internal *in)
 {
 	if (!in) return;
 	const lzma_allocator *a = in->allocator;
-	if (park_resources(in)) {
-		in->ctx = NULL; in->stage = NULL; in->outq = NULL; in->d_in = NULL; in->d_out = NULL;
+	if (in->mu_ok) {
+		pthread_mutex_lock(&in->mu);
+		in->shutdown = 1;
+		/* abandon what is still queued; running jobs finish */
+		for (int i = 0; i < in->njobs; ++i)
+			if (in->jobs[i].state == J_QUEUED) in->jobs[i].state = J_FREE;
+		pthread_cond_broadcast(&in->cv_work);
+		pthread_mutex_unlock(&in->mu);
+		for (int i = 0; i < in->ndev; ++i)
+			if (in->dev[i].started) pthread_join(in->dev[i].thr, NULL);
+		pthread_cond_destroy(&in->cv_work);
+		pthread_cond_destroy(&in->cv_done);
+		pthread_mutex_destroy(&in->mu);
 	}
-	if (in->stage) xzk_host_free(in->stage);
-	if (in->outq) xzk_host_free(in->outq);
-	if (in->d_in) xzk_free(in->d_in);
-	if (in->d_out) xzk_free(in->d_out);
+	for (int i = 0; i < in->ndev; ++i)
+		park_dev(&in->dev[i]);
+	for (int i = 0; i < in->njobs; ++i) {
+		park_pinned(in->jobs[i].stage, in->jobs[i].stage_cap);
+		park_pinned(in->jobs[i].out, in->jobs[i].out_cap);
+		free(in->jobs[i].binfo);
+	}
+	if (in->tailbuf) a_free(a, in->tailbuf);
 	if (in->rec) a_free(a, in->rec);
-	if (in->binfo) a_free(a, in->binfo);
-	if (in->ctx) xzamd_ctx_destroy(in->ctx);
 	in->magic = 0;
 	a_free(a, in);
+}
+
+__attribute__((destructor)) static void xzamd_stream_fini(void)
+{
+	xzamd_release_parked();
 }
 
 /* get_options(): stream_encoder_mt.c:956-1000 */
@@ -207,6 +421,8 @@ static lzma_ret parse_options(const lzma_mt *o, xzamd_lzma_options *opt, uint64_
 	} else if (xzamd_lzma_preset(opt, o->preset)) {
 		return LZMA_OPTIONS_ERROR;
 	}
+	if (xzamd_options_check(opt) != NULL)
+		return LZMA_OPTIONS_ERROR;      /* refused at init: a preload client then stays on the CPU library */
 	{
 		const char *au = getenv("XZAMD_SPAN_AUTO");
 		if (au && *au == '1')
@@ -242,6 +458,9 @@ lzma_ret lzma_stream_encoder_mt(lzma_stream *strm, const lzma_mt *options)
 			internal_free(strm->internal);
 		strm->internal = NULL;
 	}
+	int ndev_all = 0, cur = 0;
+	if (xzk_device_count(&ndev_all) || ndev_all <= 0 || xzk_get_device(&cur))
+		return LZMA_PROG_ERROR;      /* no GPU: the product path never falls back to the CPU */
 	lzma_internal *in = (lzma_internal *)a_alloc(strm->allocator, sizeof(*in));
 	if (!in)
 		return LZMA_MEM_ERROR;
@@ -251,23 +470,62 @@ lzma_ret lzma_stream_encoder_mt(lzma_stream *strm, const lzma_mt *options)
 	in->opt = opt;
 	in->block_size = block_size;
 	in->check = check;
+	in->timeout_ms = options->timeout;
 	in->sequence = ISEQ_RUN;
 	in->sseq = SEQ_HEADER;
-	if (!unpark_resources(in)) {
-		int rc = xzamd_ctx_create(&in->ctx, -1);
-		if (rc) {
-			internal_free(in);
-			return rc == XZAMD_MEM_ERROR ? LZMA_MEM_ERROR : LZMA_PROG_ERROR;
-		}
+	in->fill = -1;
+	/* one worker per visible GPU, the current device first; never more workers than lzma_mt.threads
+	 * (XZAMD_DEVICES=n caps it further) */
+	int ndev = ndev_all;
+	if ((uint32_t)ndev > options->threads) ndev = (int)options->threads;
+	if (ndev > MAX_DEVS) ndev = MAX_DEVS;
+	{
+		const char *e = getenv("XZAMD_DEVICES");
+		if (e && atoi(e) > 0 && atoi(e) < ndev) ndev = atoi(e);
 	}
-	/* batch = whole Blocks, at most the context's device batch */
-	uint64_t maxb = (1ull << 30) / block_size;
+	for (int i = 0; i < ndev; ++i) {
+		devslot *d = &in->dev[i];
+		d->device = (cur + i) % ndev_all;
+		d->owner = in;
+		if (!unpark_dev(d, d->device)) {
+			int rc = xzamd_ctx_create(&d->ctx, d->device);
+			if (rc) {
+				in->ndev = i;
+				xzk_set_device(cur);
+				internal_free(in);
+				return rc == XZAMD_MEM_ERROR ? LZMA_MEM_ERROR : LZMA_PROG_ERROR;
+			}
+		}
+		in->ndev = i + 1;
+	}
+	xzk_set_device(cur);
+	in->njobs = in->ndev + 1;        /* one job is filled while every GPU works on one */
+	/* batch = whole Blocks; several GPUs or a known-small input do not need the full GiB */
+	uint64_t batch = 1ull << 30;
 	const char *env = getenv("XZAMD_BATCH_MIB");
 	if (env && atoll(env) > 0)
-		maxb = ((uint64_t)atoll(env) << 20) / block_size;
+		batch = (uint64_t)atoll(env) << 20;
+	uint64_t maxb = batch / block_size;
 	if (maxb == 0) maxb = 1;
 	if (maxb * block_size >= (1ull << 31)) maxb = ((1ull << 31) - 1) / block_size;
 	in->stage_max = maxb * block_size;
+	if (pthread_mutex_init(&in->mu, NULL)) { internal_free(in); return LZMA_MEM_ERROR; }
+	pthread_cond_init(&in->cv_work, NULL);
+	{
+		pthread_condattr_t ca;
+		pthread_condattr_init(&ca);
+		pthread_condattr_setclock(&ca, CLOCK_MONOTONIC);
+		pthread_cond_init(&in->cv_done, &ca);
+		pthread_condattr_destroy(&ca);
+	}
+	in->mu_ok = 1;
+	for (int i = 0; i < in->ndev; ++i) {
+		if (pthread_create(&in->dev[i].thr, NULL, worker_main, &in->dev[i])) {
+			internal_free(in);
+			return LZMA_MEM_ERROR;
+		}
+		in->dev[i].started = 1;
+	}
 	strm->internal = in;
 	strm->total_in = 0;
 	strm->total_out = 0;
@@ -285,181 +543,291 @@ uint64_t lzma_stream_encoder_mt_memusage(const lzma_mt *options)
 	if (maxb == 0) maxb = 1;
 	const uint64_t stage = maxb * bs;
 	/* host: staging + output queue; device: input + output, 32 B/byte of sort buffers and chain tables
-	 * (56 with the suffix-order build), span scratch, and for the optimal parser the match lists
-	 * (32 B/byte packed, 48 B/byte for dictionaries above 8 MiB) */
-	uint64_t per_byte = 2 + 2 + (opt.gpu_sa_window ? 56 : 32) + 2;
+	 * (64 with the suffix-order build), span scratch, and for the optimal parser the match lists
+	 * (2 x 32 B/byte packed, 2 x 48 B/byte for dictionaries above 8 MiB) */
+	uint64_t per_byte = 2 + 2 + (opt.gpu_sa_window ? 64 : 32) + 2;
 	if (opt.gpu_parser)
-		per_byte += opt.dict_size <= (1u << 23) ? 32 : 48;
+		per_byte += opt.dict_size <= (1u << 23) ? 64 : 96;
 	return stage * per_byte;
 }
 
-static lzma_ret grow_pinned(uint8_t **buf, uint64_t *cap, uint64_t keep, uint64_t want)
+uint64_t lzma_mt_block_size(const lzma_filter *filters)
 {
-	if (*cap >= want)
-		return LZMA_OK;
-	void *p = NULL;
-	if (xzk_host_alloc(&p, want))
-		return LZMA_MEM_ERROR;
-	if (*buf) {
-		if (keep) memcpy(p, *buf, keep);
-		xzk_host_free(*buf);
+	/* filter_encoder.c:270-292: the largest block size any filter of the chain asks for; only LZMA2 does
+	 * (lzma2_encoder.c:403-413: max(3 x dict_size, 1 MiB)).  0 = unsupported chain. */
+	if (filters == NULL)
+		return 0;
+	uint64_t max = 0;
+	for (size_t i = 0; filters[i].id != LZMA_VLI_UNKNOWN; ++i) {
+		if (i >= 4)
+			return 0;
+		if (filters[i].id == LZMA_FILTER_LZMA2) {
+			const lzma_options_lzma *l = (const lzma_options_lzma *)filters[i].options;
+			if (l == NULL || l->dict_size < 4096 || l->dict_size > (1u << 30) + (1u << 29))
+				return 0;
+			uint64_t b = (uint64_t)l->dict_size * 3;
+			if (b < (1u << 20)) b = 1u << 20;
+			if (b > max) max = b;
+		} else if (filters[i].id != LZMA_FILTER_X86) {
+			return 0;
+		}
 	}
-	*buf = (uint8_t *)p;
-	*cap = want;
-	return LZMA_OK;
+	return max;
 }
 
-/* Encode everything staged (whole Blocks, last one possibly short) and append the result to the
- * output queue.  worker_encode() x nblocks (stream_encoder_mt.c:219-361) in one device batch. */
-static lzma_ret flush_stage(lzma_internal *in)
+uint32_t lzma_cputhreads(void)
 {
-	if (in->stage_len == 0)
-		return LZMA_OK;
-	const uint64_t n = in->stage_len;
-	const uint64_t nb = (n + in->block_size - 1) / in->block_size;
-	const uint64_t bound = xzamd_stream_buffer_bound(n, in->block_size);
-	if (in->d_in_cap < n) {
-		if (in->d_in) xzk_free(in->d_in);
-		in->d_in = NULL; in->d_in_cap = 0;
-		if (xzk_malloc(&in->d_in, n)) return LZMA_MEM_ERROR;
-		in->d_in_cap = n;
-	}
-	if (in->d_out_cap < bound) {
-		if (in->d_out) xzk_free(in->d_out);
-		in->d_out = NULL; in->d_out_cap = 0;
-		if (xzk_malloc(&in->d_out, bound)) return LZMA_MEM_ERROR;
-		in->d_out_cap = bound;
-	}
-	if (in->binfo_cap < nb) {
-		if (in->binfo) a_free(in->allocator, in->binfo);
-		in->binfo = (xzamd_block_info *)a_alloc(in->allocator, nb * sizeof(xzamd_block_info));
-		if (!in->binfo) { in->binfo_cap = 0; return LZMA_MEM_ERROR; }
-		in->binfo_cap = nb;
-	}
-	if (in->nrec + nb > in->rec_cap) {
-		uint64_t nc = in->rec_cap ? in->rec_cap * 2 : 256;
-		while (nc < in->nrec + nb) nc *= 2;
-		uint64_t *nr = (uint64_t *)a_alloc(in->allocator, nc * 2 * sizeof(uint64_t));
-		if (!nr) return LZMA_MEM_ERROR;
-		if (in->rec) { memcpy(nr, in->rec, in->nrec * 2 * sizeof(uint64_t)); a_free(in->allocator, in->rec); }
-		in->rec = nr;
-		in->rec_cap = nc;
-	}
-	/* pending output must have been drained (we only flush when the queue is empty) */
-	lzma_ret r = grow_pinned(&in->outq, &in->outq_cap, 0, bound);
-	if (r != LZMA_OK) return r;
-
-	if (xzk_h2d(in->d_in, in->stage, n, NULL) || xzk_sync(NULL))
-		return LZMA_PROG_ERROR;
-	uint64_t out_size = 0, nblocks = 0;
-	int rc = xzamd_stream_encode_device(in->ctx, in->d_in, n, in->block_size, &in->opt, in->check,
-			XZAMD_F_BLOCKS_ONLY, in->d_out, in->d_out_cap, &out_size, in->binfo, in->binfo_cap,
-			&nblocks, NULL);
-	if (rc != XZAMD_OK)
-		return map_rc(rc);
-	if (xzk_d2h(in->outq, in->d_out, out_size, NULL) || xzk_sync(NULL))
-		return LZMA_PROG_ERROR;
-	in->outq_pos = 0;
-	in->outq_len = out_size;
-	for (uint64_t i = 0; i < nblocks; ++i) {
-		in->rec[2 * (in->nrec + i)] = in->binfo[i].unpadded_size;
-		in->rec[2 * (in->nrec + i) + 1] = in->binfo[i].uncompressed_size;
-	}
-	in->nrec += nblocks;
-	in->progress_in += n;
-	in->stage_len = 0;
-	return LZMA_OK;
+	/* hardware_cputhreads.c: "threads" that make sense for lzma_mt.threads = the number of workers this
+	 * library can run = visible GPUs (0 when that cannot be determined, like the reference) */
+	int n = 0;
+	if (xzk_device_count(&n) || n < 0)
+		return 0;
+	return (uint32_t)n;
 }
 
-static void drain(lzma_internal *in, uint8_t *out, size_t *out_pos, size_t out_size)
+/* true when every job has been drained */
+static int all_drained(const lzma_internal *in)
 {
-	uint64_t n = in->outq_len - in->outq_pos;
-	if (n > out_size - *out_pos) n = out_size - *out_pos;
-	if (n) {
-		memcpy(out + *out_pos, in->outq + in->outq_pos, n);
-		in->outq_pos += n;
-		*out_pos += n;
-		in->progress_out += n;
-	}
+	return in->drain_seq == in->next_seq && (in->fill < 0 || in->jobs[in->fill].stage_len == 0);
 }
 
-/* stream_encode_mt(): stream_encoder_mt.c:717-883 */
+static void queue_fill_job(lzma_internal *in)
+{
+	job *j = &in->jobs[in->fill];
+	j->opt = in->opt;
+	pthread_mutex_lock(&in->mu);
+	j->seq = in->next_seq++;
+	j->state = J_QUEUED;
+	pthread_cond_signal(&in->cv_work);
+	pthread_mutex_unlock(&in->mu);
+	in->fill = -1;
+}
+
+/* Wait until the job to drain next is done or a job slot is free (what = 0), or until job `drain_seq`
+ * is done (what = 1).  Returns 0 when the condition holds, 1 on timeout (wait_for_work :667-713). */
+static int wait_workers(lzma_internal *in, int what, const struct timespec *deadline)
+{
+	int rc = 0;
+	pthread_mutex_lock(&in->mu);
+	for (;;) {
+		int ok = 0;
+		for (int i = 0; i < in->njobs; ++i) {
+			const job *j = &in->jobs[i];
+			if (j->state == J_DONE && j->seq == in->drain_seq) ok = 1;
+			if (what == 0 && j->state == J_FREE) ok = 1;
+		}
+		if (ok) break;
+		if (deadline) {
+			if (pthread_cond_timedwait(&in->cv_done, &in->mu, deadline) == ETIMEDOUT) { rc = 1; break; }
+		} else {
+			pthread_cond_wait(&in->cv_done, &in->mu);
+		}
+	}
+	pthread_mutex_unlock(&in->mu);
+	return rc;
+}
+
+/* stream_encode_mt(): stream_encoder_mt.c:717-883.  *timed_out is set when the call returns LZMA_OK only
+ * because lzma_mt.timeout expired (common.c:332-335: that return does not count towards LZMA_BUF_ERROR). */
 static lzma_ret stream_code(lzma_internal *in, const uint8_t *inb, size_t *in_pos, size_t in_size,
-		uint8_t *out, size_t *out_pos, size_t out_size, lzma_action action)
+		uint8_t *out, size_t *out_pos, size_t out_size, lzma_action action, int *timed_out)
 {
+	struct timespec dl, *deadline = NULL;
+	if (in->timeout_ms) {
+		clock_gettime(CLOCK_MONOTONIC, &dl);
+		dl.tv_sec += in->timeout_ms / 1000;
+		dl.tv_nsec += (long)(in->timeout_ms % 1000) * 1000000L;
+		if (dl.tv_nsec >= 1000000000L) { dl.tv_sec += 1; dl.tv_nsec -= 1000000000L; }
+		deadline = &dl;
+	}
 	for (;;) {
 		switch (in->sseq) {
 		case SEQ_HEADER: {
-			lzma_ret r = grow_pinned(&in->outq, &in->outq_cap, 0, 4096);
-			if (r != LZMA_OK) return r;
-			in->outq_len = xzamd_frame_header(in->outq, in->check);
-			in->outq_pos = 0;
+			if (in->tail_cap < 64) {
+				in->tailbuf = (uint8_t *)a_alloc(in->allocator, 64);
+				if (!in->tailbuf) return LZMA_MEM_ERROR;
+				in->tail_cap = 64;
+			}
+			in->tail_len = xzamd_frame_header(in->tailbuf, in->check);
+			in->tail_pos = 0;
 			in->sseq = SEQ_BLOCKS;
 			break;
 		}
 		case SEQ_BLOCKS: {
-			drain(in, out, out_pos, out_size);
-			if (in->outq_pos < in->outq_len)
-				return LZMA_OK;             /* output full */
-			/* take input (stream_encode_in: :599-664) */
-			while (*in_pos < in_size) {
-				if (in->stage_len == in->stage_max)
+			/* 0. Stream Header bytes */
+			if (in->tail_pos < in->tail_len) {
+				uint64_t k = in->tail_len - in->tail_pos;
+				if (k > out_size - *out_pos) k = out_size - *out_pos;
+				memcpy(out + *out_pos, in->tailbuf + in->tail_pos, k);
+				in->tail_pos += k; *out_pos += k; in->progress_out += k;
+				if (in->tail_pos < in->tail_len)
+					return LZMA_OK;
+			}
+			/* 1. drain finished jobs in order (lzma_outq_read, outqueue.c:182-260) */
+			for (;;) {
+				job *dj = NULL;
+				pthread_mutex_lock(&in->mu);
+				for (int i = 0; i < in->njobs; ++i)
+					if (in->jobs[i].state == J_DONE && in->jobs[i].seq == in->drain_seq)
+						dj = &in->jobs[i];
+				pthread_mutex_unlock(&in->mu);
+				if (!dj)
 					break;
-				if (in->stage_len == in->stage_cap) {
+				if (dj->err != LZMA_OK)
+					return dj->err;
+				uint64_t k = dj->out_len - dj->out_pos;
+				if (k > out_size - *out_pos) k = out_size - *out_pos;
+				if (k) {
+					memcpy(out + *out_pos, dj->out + dj->out_pos, k);
+					dj->out_pos += k; *out_pos += k; in->progress_out += k;
+				}
+				if (dj->out_pos < dj->out_len)
+					return LZMA_OK;             /* output full */
+				/* Index records of this batch (lzma_index_append, :722) */
+				if (in->nrec + dj->nblocks > in->rec_cap) {
+					uint64_t nc = in->rec_cap ? in->rec_cap * 2 : 256;
+					while (nc < in->nrec + dj->nblocks) nc *= 2;
+					uint64_t *nr = (uint64_t *)a_alloc(in->allocator, nc * 2 * sizeof(uint64_t));
+					if (!nr) return LZMA_MEM_ERROR;
+					if (in->rec) { memcpy(nr, in->rec, in->nrec * 2 * sizeof(uint64_t)); a_free(in->allocator, in->rec); }
+					in->rec = nr;
+					in->rec_cap = nc;
+				}
+				for (uint64_t i = 0; i < dj->nblocks; ++i) {
+					in->rec[2 * (in->nrec + i)] = dj->binfo[i].unpadded_size;
+					in->rec[2 * (in->nrec + i) + 1] = dj->binfo[i].uncompressed_size;
+				}
+				in->nrec += dj->nblocks;
+				pthread_mutex_lock(&in->mu);
+				dj->state = J_FREE;
+				dj->stage_len = 0;
+				++in->drain_seq;
+				pthread_mutex_unlock(&in->mu);
+			}
+			/* 2. take input (stream_encode_in: :599-664) */
+			while (*in_pos < in_size) {
+				if (in->fill < 0) {
+					pthread_mutex_lock(&in->mu);
+					for (int i = 0; i < in->njobs && in->fill < 0; ++i)
+						if (in->jobs[i].state == J_FREE) { in->fill = i; in->jobs[i].state = J_FILLING; in->jobs[i].stage_len = 0; }
+					pthread_mutex_unlock(&in->mu);
+					if (in->fill < 0)
+						break;                   /* every job is with a worker or waits to be drained */
+				}
+				job *j = &in->jobs[in->fill];
+				if (j->stage_len == j->stage_cap) {
 					/* second growth step goes straight to the full batch: each step is a pinned allocation + copy */
-					uint64_t nc = in->stage_cap ? in->stage_max : in->block_size;
+					uint64_t nc = j->stage_cap ? in->stage_max : in->block_size;
 					if (nc < (1u << 20)) nc = 1u << 20;
 					if (nc > in->stage_max) nc = in->stage_max;
-					lzma_ret r = grow_pinned(&in->stage, &in->stage_cap, in->stage_len, nc);
+					lzma_ret r = grow_pinned(&j->stage, &j->stage_cap, j->stage_len, nc);
 					if (r != LZMA_OK) return r;
 				}
-				uint64_t room = in->stage_cap - in->stage_len;
+				uint64_t room = (j->stage_cap < in->stage_max ? j->stage_cap : in->stage_max) - j->stage_len;
 				uint64_t take = in_size - *in_pos;
 				if (take > room) take = room;
-				memcpy(in->stage + in->stage_len, inb + *in_pos, take);
-				in->stage_len += take;
+				memcpy(j->stage + j->stage_len, inb + *in_pos, take);
+				j->stage_len += take;
 				*in_pos += take;
+				if (j->stage_len == in->stage_max)
+					queue_fill_job(in);
 			}
 			const int input_done = *in_pos == in_size;
-			if (in->stage_len == in->stage_max || (input_done && action != LZMA_RUN && in->stage_len)) {
-				lzma_ret r = flush_stage(in);
-				if (r != LZMA_OK) return r;
-				break;                       /* drain, then continue */
-			}
-			if (!input_done)
+			if (input_done && action != LZMA_RUN && in->fill >= 0 && in->jobs[in->fill].stage_len)
+				queue_fill_job(in);
+			if (!input_done) {
+				/* no free job: wait for a worker (or for room to drain) */
+				int drainable = 0;
+				pthread_mutex_lock(&in->mu);
+				for (int i = 0; i < in->njobs; ++i)
+					if (in->jobs[i].state == J_DONE && in->jobs[i].seq == in->drain_seq) drainable = 1;
+				pthread_mutex_unlock(&in->mu);
+				if (drainable) {
+					if (*out_pos == out_size) return LZMA_OK;
+					break;
+				}
+				if (wait_workers(in, 0, deadline)) { *timed_out = 1; return LZMA_OK; }
 				break;
+			}
 			if (action == LZMA_RUN)
 				return LZMA_OK;             /* :796-801 */
-			/* all input handed over and encoded, queue empty */
-			if (action == LZMA_FULL_FLUSH || action == LZMA_FULL_BARRIER)
-				return LZMA_STREAM_END;     /* :803-823 */
+			if (action == LZMA_FULL_BARRIER)
+				return LZMA_STREAM_END;     /* :803-807: the input is handed over, no waiting */
+			if (!all_drained(in)) {
+				/* LZMA_FULL_FLUSH / LZMA_FINISH wait for the output queue to empty (:809-823) */
+				if (*out_pos == out_size) return LZMA_OK;
+				if (wait_workers(in, 1, deadline)) { *timed_out = 1; return LZMA_OK; }
+				break;
+			}
+			if (action == LZMA_FULL_FLUSH)
+				return LZMA_STREAM_END;
 			/* LZMA_FINISH: Index + Stream Footer (:842-883) */
 			{
 				const uint64_t cap = 64 + in->nrec * 18;
-				lzma_ret r = grow_pinned(&in->outq, &in->outq_cap, 0, cap);
-				if (r != LZMA_OK) return r;
+				if (in->tail_cap < cap) {
+					if (in->tailbuf) a_free(in->allocator, in->tailbuf);
+					in->tailbuf = (uint8_t *)a_alloc(in->allocator, cap);
+					if (!in->tailbuf) { in->tail_cap = 0; return LZMA_MEM_ERROR; }
+					in->tail_cap = cap;
+				}
 				uint64_t *unp = (uint64_t *)a_alloc(in->allocator, (in->nrec + 1) * 2 * sizeof(uint64_t));
 				if (!unp) return LZMA_MEM_ERROR;
 				uint64_t *unc = unp + in->nrec + 1;
 				for (uint64_t i = 0; i < in->nrec; ++i) { unp[i] = in->rec[2 * i]; unc[i] = in->rec[2 * i + 1]; }
-				in->outq_len = xzamd_frame_index_footer(in->outq, in->outq_cap, in->check, unp, unc, in->nrec);
-				in->outq_pos = 0;
+				in->tail_len = xzamd_frame_index_footer(in->tailbuf, in->tail_cap, in->check, unp, unc, in->nrec);
+				in->tail_pos = 0;
 				a_free(in->allocator, unp);
-				if (in->outq_len == 0) return LZMA_PROG_ERROR;
+				if (in->tail_len == 0) return LZMA_PROG_ERROR;
 				in->sseq = SEQ_TAIL;
 			}
 			break;
 		}
-		case SEQ_TAIL:
-			drain(in, out, out_pos, out_size);
-			if (in->outq_pos < in->outq_len)
+		case SEQ_TAIL: {
+			uint64_t k = in->tail_len - in->tail_pos;
+			if (k > out_size - *out_pos) k = out_size - *out_pos;
+			memcpy(out + *out_pos, in->tailbuf + in->tail_pos, k);
+			in->tail_pos += k; *out_pos += k; in->progress_out += k;
+			if (in->tail_pos < in->tail_len)
 				return LZMA_OK;
 			in->sseq = SEQ_DONE;
 			return LZMA_STREAM_END;
+		}
 		case SEQ_DONE:
 			return LZMA_STREAM_END;
 		}
 	}
+}
+
+lzma_ret lzma_filters_update(lzma_stream *strm, const lzma_filter *filters)
+{
+	/* common.c / stream_encoder_mt.c:914-950: the MT encoder takes a new chain only between Blocks: at
+	 * the very start or right after LZMA_FULL_FLUSH / LZMA_FULL_BARRIER, and it applies from the next
+	 * Block on.  Jobs already dealt keep the options they were queued with. */
+	if (strm == NULL || strm->internal == NULL || strm->internal->magic != XZAMD_MAGIC)
+		return LZMA_PROG_ERROR;
+	lzma_internal *in = strm->internal;
+	if (in->sequence != ISEQ_RUN)
+		return LZMA_PROG_ERROR;
+	if (in->fill >= 0 && in->jobs[in->fill].stage_len % in->block_size != 0)
+		return LZMA_PROG_ERROR;      /* in the middle of a Block */
+	lzma_mt mt;
+	memset(&mt, 0, sizeof(mt));
+	mt.threads = 1;
+	mt.filters = filters;
+	mt.block_size = in->block_size;
+	mt.check = (lzma_check)in->check;
+	xzamd_lzma_options opt;
+	uint64_t bs = 0;
+	int check = 0;
+	lzma_ret r = parse_options(&mt, &opt, &bs, &check);
+	if (r != LZMA_OK)
+		return r;
+	if (xzamd_block_buffer_bound(in->block_size) == 0)
+		return LZMA_OPTIONS_ERROR;
+	if (in->fill >= 0 && in->jobs[in->fill].stage_len)
+		queue_fill_job(in);          /* whole Blocks staged so far go out with the old chain */
+	in->opt = opt;
+	return LZMA_OK;
 }
 
 lzma_ret lzma_code(lzma_stream *strm, lzma_action action)
@@ -497,14 +865,17 @@ lzma_ret lzma_code(lzma_stream *strm, lzma_action action)
 		return LZMA_PROG_ERROR;
 	}
 	size_t in_pos = 0, out_pos = 0;
+	int timed_out = 0;
 	lzma_ret ret = stream_code(in, strm->next_in, &in_pos, strm->avail_in,
-			strm->next_out, &out_pos, strm->avail_out, action);
+			strm->next_out, &out_pos, strm->avail_out, action, &timed_out);
 	if (in_pos) { strm->next_in += in_pos; strm->avail_in -= in_pos; strm->total_in += in_pos; }
 	if (out_pos) { strm->next_out += out_pos; strm->avail_out -= out_pos; strm->total_out += out_pos; }
 	in->avail_in = strm->avail_in;
 	switch (ret) {
 	case LZMA_OK:
-		if (out_pos == 0 && in_pos == 0) {
+		if (timed_out) {
+			in->allow_buf_error = 0;        /* common.c:332-335 */
+		} else if (out_pos == 0 && in_pos == 0) {
 			if (in->allow_buf_error) ret = LZMA_BUF_ERROR;
 			else in->allow_buf_error = 1;
 		} else {
@@ -540,8 +911,11 @@ void lzma_end(lzma_stream *strm)
 void lzma_get_progress(lzma_stream *strm, uint64_t *progress_in, uint64_t *progress_out)
 {
 	if (strm && strm->internal && strm->internal->magic == XZAMD_MAGIC) {
-		*progress_in = strm->internal->progress_in;
-		*progress_out = strm->internal->progress_out;
+		lzma_internal *in = strm->internal;
+		pthread_mutex_lock(&in->mu);
+		*progress_in = in->progress_in;
+		pthread_mutex_unlock(&in->mu);
+		*progress_out = in->progress_out;
 	} else if (strm) {
 		*progress_in = strm->total_in;
 		*progress_out = strm->total_out;
