@@ -390,6 +390,10 @@ def main():
                 res["roundtrip_reference_decoder"] = f"failed: {e}"
             if not args.no_host_to_host and not args.bcj:
                 try:
+                    # the front end owns its own device context: give the device-resident one's work buffers back first
+                    del data, out_buf, out
+                    enc.close()
+                    torch.cuda.empty_cache()
                     res["host_to_host"] = host_to_host(host[:min(n, 2 << 30)], args.preset, block_size)
                 except Exception as e:  # noqa: BLE001
                     res["host_to_host"] = {"value": None, "error": str(e)}

@@ -51,6 +51,13 @@ def lib():
             raise RuntimeError(
                 f"{LIB_PATH} is missing: build it with `make -C xz_amd/csrc` "
                 "(there is no CPU fallback for the encoder)")
+        try:
+            # torch brings its own copy of the HIP runtime; when libxz_amd.so (linked against /opt/rocm) is
+            # loaded first, a later `import torch` puts a second runtime into the process and device
+            # initialisation fails.  Loading torch first makes the linker reuse its runtime for ours.
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         l = C.CDLL(LIB_PATH)
         l.xzamd_lzma_preset.argtypes = [C.POINTER(LzmaOptions), C.c_uint32]
         l.xzamd_mt_block_size.restype = C.c_uint64

@@ -44,6 +44,19 @@
 
 #include <errno.h>
 #include <time.h>
+#include <execinfo.h>
+#include <signal.h>
+#include <unistd.h>
+
+/* XZAMD_DEBUG_SEGV=1: print a backtrace on SIGSEGV (debug aid for the interposed-client case) */
+static void segv_handler(int sig)
+{
+	void *bt[64];
+	int n = backtrace(bt, 64);
+	backtrace_symbols_fd(bt, n, 2);
+	signal(sig, SIG_DFL);
+	raise(sig);
+}
 
 enum iseq { ISEQ_RUN, ISEQ_SYNC_FLUSH, ISEQ_FULL_FLUSH, ISEQ_FINISH, ISEQ_FULL_BARRIER, ISEQ_END, ISEQ_ERROR };
 enum sseq { SEQ_HEADER, SEQ_BLOCKS, SEQ_TAIL, SEQ_DONE };
@@ -127,8 +140,8 @@ static lzma_ret map_rc(int rc)
 
 /* Parked resources: hipMalloc of the work buffers (tens of GiB for a 1 GiB batch) and hipHostMalloc of the
  * staging areas cost seconds, so lzma_end() parks them (one set per device, a pool of pinned buffers) and
- * the next lzma_stream_encoder_mt() of the process picks them up.  xzamd_release_parked() / a library
- * destructor give them back; XZAMD_NO_PARK=1 disables parking. */
+ * the next lzma_stream_encoder_mt() of the process picks them up.  xzamd_release_parked() gives them back;
+ * XZAMD_NO_PARK=1 disables parking. */
 static struct {
 	pthread_mutex_t mu;
 	struct { int full; xzamd_ctx *ctx; void *d_in, *d_out; uint64_t d_in_cap, d_out_cap; } dev[MAX_DEVS];
@@ -359,10 +372,9 @@ static void internal_free(lzma_internal *in)
 	a_free(a, in);
 }
 
-__attribute__((destructor)) static void xzamd_stream_fini(void)
-{
-	xzamd_release_parked();
-}
+/* No library destructor frees the parked set: at process exit the HIP runtime may already be gone (its own
+ * teardown runs first), and the process's device memory goes away with it anyway.  A long-running client
+ * that is done compressing calls xzamd_release_parked(). */
 
 /* get_options(): stream_encoder_mt.c:956-1000 */
 static lzma_ret parse_options(const lzma_mt *o, xzamd_lzma_options *opt, uint64_t *block_size, int *check)
@@ -457,6 +469,10 @@ lzma_ret lzma_stream_encoder_mt(lzma_stream *strm, const lzma_mt *options)
 		if (strm->internal->magic == XZAMD_MAGIC)
 			internal_free(strm->internal);
 		strm->internal = NULL;
+	}
+	{
+		const char *dbg = getenv("XZAMD_DEBUG_SEGV");
+		if (dbg && *dbg == '1') signal(SIGSEGV, segv_handler);
 	}
 	int ndev_all = 0, cur = 0;
 	if (xzk_device_count(&ndev_all) || ndev_all <= 0 || xzk_get_device(&cur))
