@@ -81,6 +81,9 @@ def lib():
         l.xzamd_frame_index_footer.restype = C.c_uint64
         l.xzamd_frame_index_footer.argtypes = [C.c_void_p, C.c_uint64, C.c_int,
                                                C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_uint64]
+        l.xzamd_stream_decode_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64,
+                                                 C.POINTER(C.c_uint64), C.c_void_p, C.POINTER(C.c_uint64),
+                                                 C.POINTER(C.c_uint64), C.c_void_p]
         l.xzamd_debug_fetch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint64]
         l.xzamd_trace_enable.argtypes = [C.c_void_p, C.c_uint32]
         l.xzamd_trace_read.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
@@ -192,6 +195,22 @@ class Encoder:
             raise XzAmdError(f"xzamd_stream_encode_device failed ({rc}): "
                              f"{lib().xzamd_last_error(self._ctx).decode()}")
         return out[: out_size.value], list(binfo)[: nb.value]
+
+    def decode(self, xz, out_cap, expected=None):
+        """Decode an .xz Stream held in a CUDA uint8 tensor on the device.  With `expected` (CUDA uint8 tensor of
+        the original data) it is a span-parallel verification decode.  Returns (decoded tensor view, nblocks)."""
+        import torch
+        assert xz.is_cuda and xz.dtype == torch.uint8 and xz.is_contiguous()
+        out = torch.empty(max(out_cap, 1), dtype=torch.uint8, device=xz.device)
+        osz, mm, nb = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+        torch.cuda.current_stream(xz.device).synchronize()
+        rc = lib().xzamd_stream_decode_device(
+            self._ctx, C.c_void_p(xz.data_ptr()), xz.numel(), C.c_void_p(out.data_ptr()), out_cap, C.byref(osz),
+            C.c_void_p(expected.data_ptr()) if expected is not None else None, C.byref(mm), C.byref(nb), None)
+        if rc != 0:
+            raise XzAmdError(f"xzamd_stream_decode_device failed ({rc}): {lib().xzamd_last_error(self._ctx).decode()}"
+                             + (f" [{mm.value} mismatching words]" if mm.value else ""))
+        return out[: osz.value], nb.value
 
     # debug hooks used by the parity tests
     def debug_fetch(self, what, count, dtype="uint32"):

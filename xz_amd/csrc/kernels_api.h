@@ -71,6 +71,32 @@ int xzk_crc_blocks(const uint8_t *d_in, uint32_t n, uint32_t block_size, uint32_
 int xzk_assemble(const xzamd_copy_seg *d_segs, uint32_t nsegs, const uint8_t *d_scratch,
 		const uint8_t *d_lits, const uint8_t *d_in, uint8_t *d_out, void *stream);
 
+/* ---- LZMA2 Block decoder (lzma_decode.hip) ---- */
+typedef struct {
+	uint64_t cpos;       /* offset of the Block's LZMA2 data (behind the Block Header) in the stream */
+	uint64_t csize;      /* its size (Compressed Size incl. the 0x00 end marker) */
+	uint64_t upos;       /* where the Block's bytes go in the output */
+	uint64_t usize;      /* Uncompressed Size */
+	uint32_t dict_size;
+	uint32_t nunits;     /* out (k_dec_scan) */
+	uint32_t error;      /* out: 0 = fine */
+	uint32_t pad_;
+} xzamd_dec_block;
+
+typedef struct {
+	uint64_t cpos;       /* stream offset of the unit's first chunk header */
+	uint64_t upos;       /* offset of its first byte inside the Block */
+	uint32_t block;
+	uint32_t pad_;
+} xzamd_dec_unit;
+
+int xzk_dec_scan(const uint8_t *d_xz, xzamd_dec_block *d_blocks, uint32_t nblocks, xzamd_dec_unit *d_units,
+		uint32_t units_cap, int split, void *stream);
+int xzk_dec_units(const uint8_t *d_xz, const xzamd_dec_block *d_blocks, uint32_t nblocks, const xzamd_dec_unit *d_units,
+		uint32_t units_cap, const uint32_t *d_unit_first, uint32_t total_units, uint8_t *d_out, const uint8_t *d_expected,
+		uint16_t *d_lit_pool, uint32_t waves, uint32_t *d_counter, uint32_t *d_block_err, void *stream);
+int xzk_dec_compare(const uint8_t *a, const uint8_t *b, uint64_t n, unsigned long long *d_mismatches, void *stream);
+
 int xzk_malloc(void **p, uint64_t bytes);
 int xzk_free(void *p);
 int xzk_host_alloc(void **p, uint64_t bytes);

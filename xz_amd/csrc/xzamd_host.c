@@ -15,6 +15,7 @@
 #include "kernels_api.h"
 
 #include <stdio.h>
+#include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -27,24 +28,28 @@
 /* container primitives (doc/xz-file-format.txt)                        */
 /* ------------------------------------------------------------------ */
 static uint32_t crc32_tab[256];
-static int crc32_ready;
+static pthread_once_t crc32_once = PTHREAD_ONCE_INIT;
+
+static void crc32_init(void)
+{
+	for (uint32_t i = 0; i < 256; ++i) {
+		uint32_t r = i;
+		for (int k = 0; k < 8; ++k)
+			r = (r >> 1) ^ (0xEDB88320u & (0u - (r & 1)));
+		crc32_tab[i] = r;
+	}
+}
 
 static uint32_t crc32_buf(const uint8_t *p, size_t n)
 {
-	if (!crc32_ready) {
-		for (uint32_t i = 0; i < 256; ++i) {
-			uint32_t r = i;
-			for (int k = 0; k < 8; ++k)
-				r = (r >> 1) ^ (0xEDB88320u & (0u - (r & 1)));
-			crc32_tab[i] = r;
-		}
-		crc32_ready = 1;
-	}
+	pthread_once(&crc32_once, crc32_init);       /* streams may be framed from several threads */
 	uint32_t c = 0xFFFFFFFFu;
 	while (n--)
 		c = crc32_tab[(c ^ *p++) & 0xFF] ^ (c >> 8);
 	return ~c;
 }
+
+uint32_t xzamd_crc32_host_(const uint8_t *p, size_t n) { return crc32_buf(p, n); }
 
 static void le32(uint8_t *p, uint32_t v)
 {
@@ -370,6 +375,10 @@ int xzamd_ctx_set_batch_bytes(xzamd_ctx *c, uint64_t bytes)
 }
 
 const char *xzamd_last_error(const xzamd_ctx *c) { return c ? c->err : "no context"; }
+/* internal accessors for the other host translation units (xzamd_internal.h) */
+void *xzamd_ctx_stream_(xzamd_ctx *c) { return c->own_stream; }
+uint32_t xzamd_ctx_wave_slots_(const xzamd_ctx *c) { return c->wave_slots; }
+int xzamd_ctx_fail_(xzamd_ctx *c, int code, const char *what) { return fail(c, code, what, 0); }
 int xzamd_ctx_device(const xzamd_ctx *c) { return c ? c->device : -1; }
 void xzamd_get_stats(const xzamd_ctx *c, xzamd_stats *out) { *out = c->stats; }
 const char *xzamd_version(void) { return "xz_amd 0.1 (gfx950)"; }

@@ -1,0 +1,13 @@
+/* xzamd_internal.h -- shared by the plain-C host translation units only (not part of any ABI). */
+#ifndef XZAMD_INTERNAL_H
+#define XZAMD_INTERNAL_H
+#include <stddef.h>
+#include <stdint.h>
+#include "../../include/xz_amd.h"
+
+uint32_t xzamd_crc32_host_(const uint8_t *p, size_t n);
+void *xzamd_ctx_stream_(xzamd_ctx *c);
+uint32_t xzamd_ctx_wave_slots_(const xzamd_ctx *c);
+int xzamd_ctx_fail_(xzamd_ctx *c, int code, const char *what);
+
+#endif
