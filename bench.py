@@ -386,6 +386,18 @@ def main():
                     v_out, _ = enc.encode(data[:vn], opts=opts, block_size=block_size)
                     rr, dec = o.ref_decode(v_out.cpu().numpy().tobytes(), vn + 16)
                     res["roundtrip_reference_decoder"] = bool(rr == 1 and dec == host[:vn].tobytes())
+                # the WHOLE job back through the device decoder (Block checks verified, bytes compared with the input)
+                if not args.bcj:
+                    full, _ = enc.encode(data, opts=opts, block_size=block_size, out=out_buf)
+                    torch.cuda.synchronize()
+                    td = time.perf_counter()
+                    dec_t, dnb = enc.decode(full, n, expected=data)
+                    torch.cuda.synchronize()
+                    td = time.perf_counter() - td
+                    res["roundtrip_device_decoder"] = {"ok": bool(dec_t.numel() == n), "blocks": int(dnb),
+                                                       "MB/s": round(n / td / 1e6, 1),
+                                                       "what": "span-parallel verification decode of the whole Stream on the GPU + compare"}
+                    del dec_t
             except Exception as e:  # noqa: BLE001
                 res["roundtrip_reference_decoder"] = f"failed: {e}"
             if not args.no_host_to_host and not args.bcj:

@@ -49,6 +49,7 @@ typedef struct xzamd_ctx xzamd_ctx;
 #define XZAMD_CHECK_NONE   0
 #define XZAMD_CHECK_CRC32  1
 #define XZAMD_CHECK_CRC64  4
+#define XZAMD_CHECK_SHA256 10
 
 #define XZAMD_MF_HC3 0x03   /* lzma_match_finder values, api/lzma/lzma12.h:58-112 */
 #define XZAMD_MF_HC4 0x04
@@ -89,9 +90,11 @@ typedef struct {
 	uint32_t gpu_parser; /* 0 = lzma_lzma_optimum_fast semantics, 1 = windowed optimal parser (232-node DP over
 	                        per-position match lists incl. the reference's compound edges; needs pb <= 2,
 	                        else XZAMD_OPTIONS_ERROR) */
-	uint32_t bcj;        /* 0 = chain {LZMA2}; XZAMD_BCJ_X86 = chain {x86 BCJ, LZMA2} (simple/x86.c, start offset 0) */
+	uint32_t bcj;        /* 0 = chain {LZMA2}; XZAMD_BCJ_X86 / XZAMD_BCJ_ARM64 / XZAMD_FILTER_DELTA(d) = that filter in front of LZMA2 */
 } xzamd_lzma_options;
 #define XZAMD_BCJ_X86 4u    /* LZMA_FILTER_X86, api/lzma/bcj.h:20 */
+#define XZAMD_BCJ_ARM64 0x0Au   /* LZMA_FILTER_ARM64, api/lzma/bcj.h (simple/arm64.c), start offset 0 */
+#define XZAMD_FILTER_DELTA(dist) (3u | (((uint32_t)(dist) - 1u) << 8))   /* LZMA_FILTER_DELTA, dist 1..256 (delta/delta_encoder.c) */
 #define XZAMD_SA_WINDOW_MAX 5u
 
 /* lzma_lzma_preset() (lzma/lzma_encoder_presets.c:17-63) + the device mapping.

@@ -20,10 +20,10 @@
  *     lzma_mt.timeout bounds the time a lzma_code call waits for the workers (0 = no limit), a call
  *     that returns because of it returns LZMA_OK like the reference (stream_encoder_mt.c:667-713);
  *     LZMA_FULL_BARRIER returns once the input has been handed over (:803-807).
- *   - filters: {LZMA2} and {x86 BCJ, LZMA2} chains; LZMA_SYNC_FLUSH is unsupported exactly like the
- *     reference MT encoder (stream_encoder_mt.c:1201-1205).
- *   - check: LZMA_CHECK_NONE, LZMA_CHECK_CRC32 and LZMA_CHECK_CRC64 (the xz default); others
- *     return LZMA_UNSUPPORTED_CHECK.
+ *   - filters: {LZMA2} and {x86 BCJ | ARM64 BCJ | delta, LZMA2} chains; LZMA_SYNC_FLUSH is unsupported
+ *     exactly like the reference MT encoder (stream_encoder_mt.c:1201-1205).
+ *   - check: LZMA_CHECK_NONE, LZMA_CHECK_CRC32, LZMA_CHECK_CRC64 (the xz default) and
+ *     LZMA_CHECK_SHA256; others return LZMA_UNSUPPORTED_CHECK.
  */
 #ifndef XZ_AMD_LZMA_H
 #define XZ_AMD_LZMA_H
@@ -64,6 +64,16 @@ typedef enum {
 
 #define LZMA_FILTER_LZMA2 UINT64_C(0x21)
 #define LZMA_FILTER_X86   UINT64_C(0x04)
+#define LZMA_FILTER_ARM64 UINT64_C(0x0A)
+#define LZMA_FILTER_DELTA UINT64_C(0x03)
+/* api/lzma/delta.h:24-90 */
+typedef enum { LZMA_DELTA_TYPE_BYTE = 0 } lzma_delta_type;
+typedef struct {
+	lzma_delta_type type;
+	uint32_t dist;
+	uint32_t reserved_int1, reserved_int2, reserved_int3, reserved_int4;
+	void *reserved_ptr1, *reserved_ptr2;
+} lzma_options_delta;
 /* api/lzma/bcj.h:81-98 */
 typedef struct {
 	uint32_t start_offset;

@@ -114,6 +114,42 @@ int ref_encode_mt_x86(const uint8_t *in, size_t in_size, uint32_t preset,
 	return (int)r;
 }
 
+/* MT encode with the chain {filter, LZMA2(preset)}: filter_id = LZMA_FILTER_X86 / _ARM64 / _DELTA (dist). */
+int ref_encode_mt_chain(const uint8_t *in, size_t in_size, uint32_t preset, uint64_t filter_id, uint32_t delta_dist,
+		uint32_t threads, uint64_t block_size, int check,
+		uint8_t *out, size_t out_cap, size_t *out_size)
+{
+	lzma_options_lzma opt;
+	if (lzma_lzma_preset(&opt, preset))
+		return (int)LZMA_OPTIONS_ERROR;
+	lzma_options_delta dl;
+	memset(&dl, 0, sizeof(dl));
+	dl.type = LZMA_DELTA_TYPE_BYTE;
+	dl.dist = delta_dist;
+	lzma_filter f[3] = { { filter_id, filter_id == LZMA_FILTER_DELTA ? (void *)&dl : NULL },
+			{ LZMA_FILTER_LZMA2, &opt }, { LZMA_VLI_UNKNOWN, NULL } };
+	lzma_stream strm = LZMA_STREAM_INIT;
+	lzma_mt mt;
+	memset(&mt, 0, sizeof(mt));
+	mt.threads = threads;
+	mt.block_size = block_size;
+	mt.filters = f;
+	mt.check = (lzma_check)check;
+	lzma_ret r = lzma_stream_encoder_mt(&strm, &mt);
+	if (r != LZMA_OK)
+		return (int)r;
+	strm.next_in = in;
+	strm.avail_in = in_size;
+	strm.next_out = out;
+	strm.avail_out = out_cap;
+	do {
+		r = lzma_code(&strm, LZMA_FINISH);
+	} while (r == LZMA_OK && strm.avail_out > 0);
+	*out_size = out_cap - strm.avail_out;
+	lzma_end(&strm);
+	return (int)r;
+}
+
 /* Steady-state throughput of the reference MT encoder: feed `in` through lzma_code(LZMA_RUN) in 4 MiB
  * slices (output discarded) until `seconds` of wall time have passed or the input is used up, then report
  * how many input bytes the workers have actually processed (lzma_get_progress) and the wall time.  With

@@ -244,6 +244,21 @@ def ref_encode_mt_x86(data, preset, threads=1, block_size=0, check=4):
     return out[: n.value].tobytes()
 
 
+def ref_encode_mt_chain(data, preset, filter_id, delta_dist=1, threads=1, block_size=0, check=4):
+    """Reference MT encoder with the chain {filter_id, LZMA2(preset)} (x86 0x04, ARM64 0x0A, delta 0x03)."""
+    data = as_u8(data)
+    cap = len(data) + len(data) // 4 + 65536
+    out = np.empty(cap, dtype=np.uint8)
+    n = C.c_size_t(0)
+    f = ref().ref_encode_mt_chain
+    f.restype = C.c_int
+    f.argtypes = [C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64, C.c_int,
+                  C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    r = f(_ptr(data), len(data), preset, filter_id, delta_dist, threads, block_size, check, _ptr(out), cap, C.byref(n))
+    assert r == 1, r
+    return out[: n.value].tobytes()
+
+
 def ref_x86_filter(data):
     """What the reference's x86 BCJ encoder makes of one Block (fresh state, start offset 0)."""
     data = as_u8(data)

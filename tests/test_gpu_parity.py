@@ -190,6 +190,60 @@ def test_x86_bcj_chain_identical_to_reference(enc, preset):
             assert o.first_diff(got, ref) == -1, (name, preset, bs)
 
 
+def _arm64_like(n, seed):
+    """Bytes with plenty of BL (0x94......) and ADRP (0x90/0xB0/0xD0/0xF0 ......) shaped words at aligned offsets."""
+    rng = np.random.default_rng(seed)
+    w = rng.integers(0, 1 << 32, n // 4 + 1, dtype=np.uint64).astype(np.uint32)
+    sel = rng.random(len(w))
+    w[sel < 0.3] = (w[sel < 0.3] & 0x03FFFFFF) | 0x94000000
+    adrp = (sel >= 0.3) & (sel < 0.5)
+    w[adrp] = (w[adrp] & 0x60FFFFFF) | 0x90000000
+    w[adrp & (rng.random(len(w)) < 0.7)] &= 0xFF03FFFF       # small immediates: inside the +/-512 MiB range
+    return w.astype("<u4").tobytes()[:n]
+
+
+@pytest.mark.parametrize("kind", ["arm64", "delta1", "delta4", "delta256", "sha256"])
+def test_arm64_delta_chains_and_sha256_identical_to_reference(enc, kind):
+    """{ARM64 BCJ, LZMA2} (simple/arm64.c), {delta, LZMA2} (delta/delta_encoder.c) and the SHA-256 Check
+    (check/sha256.c): with one span per Block the whole .xz Stream equals the reference MT encoder's; in span mode
+    it decodes bit-exactly through the real decoder.  Blocks that are not multiples of 4, tiny inputs."""
+    import xz_amd
+    if not o.have_ref():
+        pytest.skip("oracle/_ref not built")
+    cases = {"arm": _arm64_like(600000, 3), "mixed": o.corpus_mixed(300000, 9), "tiny": bytes([0x94, 1, 2]), "five": b"\x00\x00\x00\x94\x07"}
+    for preset in (1, 3):
+        opts = xz_amd.preset_options(preset, span_size=xz_amd.SPAN_WHOLE_BLOCK)
+        check = 4
+        fid, dist = 0, 1
+        if kind == "arm64":
+            opts.bcj, fid = xz_amd.BCJ_ARM64, 0x0A
+        elif kind.startswith("delta"):
+            dist = int(kind[5:])
+            opts.bcj, fid = xz_amd.filter_delta(dist), 0x03
+        else:
+            check = 10
+        for name, data in cases.items():
+            for bs in (1 << 20, 200001, 65537):
+                t = __import__("torch").frombuffer(bytearray(data), dtype=__import__("torch").uint8).cuda()
+                out, _ = enc.encode(t, opts=opts, block_size=bs, check=check)
+                got = out.cpu().numpy().tobytes()
+                if fid:
+                    ref = o.ref_encode_mt_chain(data, preset, fid, dist, threads=2, block_size=bs, check=check)
+                else:
+                    ref = o.ref_encode_mt(data, preset, threads=2, block_size=bs, check=check)
+                assert o.first_diff(got, ref) == -1, (kind, name, preset, bs)
+    opts = xz_amd.preset_options(6)
+    if kind == "arm64":
+        opts.bcj = xz_amd.BCJ_ARM64
+    elif kind.startswith("delta"):
+        opts.bcj = xz_amd.filter_delta(int(kind[5:]))
+    data = cases["arm"] + cases["mixed"]
+    t = __import__("torch").frombuffer(bytearray(data), dtype=__import__("torch").uint8).cuda()
+    out, _ = enc.encode(t, opts=opts, block_size=300000, check=10 if kind == "sha256" else 4)
+    rr, dec = o.ref_decode(out.cpu().numpy().tobytes(), len(data) + 16)
+    assert rr == 1 and dec == data, kind
+
+
 @pytest.mark.parametrize("preset", [1, 6, 9 | 0x80000000])
 def test_x86_bcj_default_spans_roundtrip(enc, preset):
     """Span-parallel mode with the BCJ pre-pass: decodes bit-exactly through the REAL reference decoder,
@@ -500,7 +554,7 @@ def test_lzma_code_semantics(tmp_path):
             setattr(m, k, v)
         assert L.lzma_stream_encoder_mt(C.byref(s), C.byref(m)) == OPTIONS, bad
     assert L.lzma_stream_encoder_mt(C.byref(s), C.byref(Mt(threads=1, preset=6, check=16))) == PROG
-    assert L.lzma_stream_encoder_mt(C.byref(s), C.byref(Mt(threads=1, preset=6, check=10))) == UNSUP
+    assert L.lzma_stream_encoder_mt(C.byref(s), C.byref(Mt(threads=1, preset=6, check=7))) == UNSUP
     L.lzma_stream_encoder_mt_memusage.restype = C.c_uint64
     assert L.lzma_stream_encoder_mt_memusage(C.byref(Mt(threads=0, preset=6))) == 2**64 - 1
     assert 0 < L.lzma_stream_encoder_mt_memusage(C.byref(Mt(threads=4, preset=6, check=4))) < 2**63

@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("XZ_AMD_LIB") or os.path.join(_HERE, "libxz_amd.so")   # env override: A/B builds
 
-CHECK_NONE, CHECK_CRC32, CHECK_CRC64 = 0, 1, 4
+CHECK_NONE, CHECK_CRC32, CHECK_CRC64, CHECK_SHA256 = 0, 1, 4, 10
 MF_HC3, MF_HC4, MF_BT4 = 0x03, 0x04, 0x14
 PRESET_EXTREME = 0x80000000
 SPAN_WHOLE_BLOCK = 0xFFFFFFFF
@@ -19,6 +19,13 @@ SPAN_DEFAULT = 0
 SPAN_AUTO = 1
 F_BLOCKS_ONLY = 1
 BCJ_X86 = 4
+BCJ_ARM64 = 0x0A
+
+
+def filter_delta(dist):
+    """xzamd_lzma_options.bcj value of a delta filter (dist 1..256) in front of LZMA2."""
+    return 3 | ((dist - 1) << 8)
+
 
 
 class LzmaOptions(C.Structure):

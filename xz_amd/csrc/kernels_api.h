@@ -65,6 +65,11 @@ int xzk_find_matches(const xzamd_span_args *a, const uint32_t *sa, const uint32_
 int xzk_span_encode(const xzamd_span_args *a, uint32_t nspans, uint32_t waves, uint32_t *counter, void *stream);
 /* x86 BCJ encoder: d_out = filtered copy of d_in, every Block filtered independently (simple/x86.c). */
 int xzk_x86_bcj(const uint8_t *d_in, uint8_t *d_out, uint32_t n, uint32_t block_size, uint32_t nblocks, void *stream);
+/* ARM64 BCJ (kind 0x0A) / delta (kind 3, dist 1..256) encoders, every Block filtered independently. */
+int xzk_prefilter(const uint8_t *d_in, uint8_t *d_out, uint32_t n, uint32_t block_size, uint32_t nblocks, uint32_t kind, uint32_t dist,
+		void *stream);
+/* SHA-256 of every Block (32 bytes each). */
+int xzk_sha256_blocks(const uint8_t *d_in, uint32_t n, uint32_t block_size, uint32_t nblocks, uint8_t *d_out32, void *stream);
 /* Block checks: CRC64 (crc32 = 0) or CRC32 (crc32 = 1, zero-extended into d_block_crc). */
 int xzk_crc_blocks(const uint8_t *d_in, uint32_t n, uint32_t block_size, uint32_t nblocks,
 		uint32_t strip, int crc32, uint64_t *d_strip_crc, uint64_t *d_block_crc, void *stream);
@@ -87,7 +92,7 @@ typedef struct {
 	uint64_t cpos;       /* stream offset of the unit's first chunk header */
 	uint64_t upos;       /* offset of its first byte inside the Block */
 	uint32_t block;
-	uint32_t pad_;
+	uint32_t dbase;      /* Block offset of the last dictionary reset at or before the unit */
 } xzamd_dec_unit;
 
 int xzk_dec_scan(const uint8_t *d_xz, xzamd_dec_block *d_blocks, uint32_t nblocks, xzamd_dec_unit *d_units,

@@ -45,6 +45,7 @@ __global__ __launch_bounds__(64) void k_dec_scan(const uint8_t* __restrict__ xz,
     const uint8_t* p = xz + B.cpos;
     uint64_t c = 0, u = 0;
     uint32_t nunits = 0, err = DEC_OK;
+    uint64_t dbase = 0;                     // Block offset of the last dictionary reset
     bool need_dict_reset = true, need_props = true, ended = false;
     xzamd_dec_unit* U = units + (uint64_t)b * units_cap;
     while (c < B.csize) {
@@ -57,7 +58,7 @@ __global__ __launch_bounds__(64) void k_dec_scan(const uint8_t* __restrict__ xz,
             us = ((((uint64_t)ctl & 0x1F) << 16) | ((uint64_t)p[c + 1] << 8) | p[c + 2]) + 1;
             cs = (((uint64_t)p[c + 3] << 8) | p[c + 4]) + 1;
             hs = 5;
-            if (ctl >= 0xE0) need_dict_reset = false;
+            if (ctl >= 0xE0) { need_dict_reset = false; dbase = u; }
             if (need_dict_reset) { err = DEC_NEED_DICT_RESET; break; }
             if (ctl >= 0xC0) {
                 if (c + 6 > B.csize) { err = DEC_TRUNCATED; break; }
@@ -69,7 +70,7 @@ __global__ __launch_bounds__(64) void k_dec_scan(const uint8_t* __restrict__ xz,
             if (ctl >= 0xC0 && split) starts_unit = true;      // carries the properties and resets the state: self-contained
         } else if (ctl == 0x01 || ctl == 0x02) {
             if (c + 3 > B.csize) { err = DEC_TRUNCATED; break; }
-            if (ctl == 0x01) { need_dict_reset = false; need_props = true; }     // lzma2_decoder.c:121-127
+            if (ctl == 0x01) { need_dict_reset = false; need_props = true; dbase = u; }     // lzma2_decoder.c:121-127
             if (need_dict_reset) { err = DEC_NEED_DICT_RESET; break; }
             us = (((uint64_t)p[c + 1] << 8) | p[c + 2]) + 1;
             cs = us;
@@ -81,7 +82,7 @@ __global__ __launch_bounds__(64) void k_dec_scan(const uint8_t* __restrict__ xz,
             U[nunits].cpos = B.cpos + c;
             U[nunits].upos = u;
             U[nunits].block = b;
-            U[nunits].pad_ = 0;
+            U[nunits].dbase = (uint32_t)dbase;
             ++nunits;
         }
         c += hs + cs;
@@ -196,11 +197,13 @@ __device__ __noinline__ void decode_units(const uint8_t* __restrict__ xz, const 
     for (uint32_t ui = u0; ui < u1 && err == DEC_OK; ++ui) {
         uint64_t c = U[ui].cpos - B.cpos;               // offset of the unit's first chunk inside the Block's data
         uint64_t u = U[ui].upos;
+        uint64_t dbase = U[ui].dbase;                   // bytes before it are outside the dictionary (lz_decoder.h:195-198)
         const uint64_t c_end = ui + 1 < B.nunits ? U[ui + 1].cpos - B.cpos : B.csize;
         const uint8_t* p = xz + B.cpos;
         while (c < c_end && err == DEC_OK) {
             const uint32_t ctl = uni(p[c]);
             if (ctl == 0x00) { ++c; break; }
+            if (ctl == 0x01 || ctl >= 0xE0) dbase = u;      // dictionary reset
             if (ctl < 0x80) {
                 // uncompressed chunk: copy
                 const uint32_t us = ((uni(p[c + 1]) << 8) | uni(p[c + 2])) + 1;
@@ -236,11 +239,11 @@ __device__ __noinline__ void decode_units(const uint8_t* __restrict__ xz, const 
             const uint64_t u_end = u + us;
             const uint32_t pbm = (1u << pb) - 1, lpm = (1u << lp) - 1;
             while (u < u_end) {
-                const uint32_t ps = (uint32_t)u & pbm;
+                const uint32_t ps = (uint32_t)(u - dbase) & pbm;      // positions count from the last dictionary reset
                 if (!rd_bit(r, probs, D_IS_MATCH + state * 16 + ps)) {
                     // literal (lzma_decoder.c:330-400)
-                    const uint32_t prev = u ? (plain ? dict_byte(bout, u - 1) : bhist[u - 1]) : 0u;
-                    uint16_t* sub = lit + 0x300u * ((((uint32_t)u & lpm) << lc) + (uni(prev) >> (8 - lc)));
+                    const uint32_t prev = u > dbase ? (plain ? dict_byte(bout, u - 1) : bhist[u - 1]) : 0u;
+                    uint16_t* sub = lit + 0x300u * ((((uint32_t)(u - dbase) & lpm) << lc) + (uni(prev) >> (8 - lc)));
                     uint32_t sym = 1;
                     if (state < 7) {
                         do { sym = (sym << 1) | rd_bit_g(r, sub, sym); } while (sym < 0x100);
@@ -302,7 +305,7 @@ __device__ __noinline__ void decode_units(const uint8_t* __restrict__ xz, const 
                 }
             copy:
                 // dict_is_distance_valid (lzma_decoder.c:530,549): inside the data so far and the dictionary
-                if ((uint64_t)rep0 >= u || rep0 >= B.dict_size) { err = DEC_BAD_DISTANCE; break; }
+                if ((uint64_t)rep0 >= u - dbase || rep0 >= B.dict_size) { err = DEC_BAD_DISTANCE; break; }
                 if (u + len > u_end) { err = DEC_CHUNK_OVERRUN; break; }
                 {
                     const uint32_t period = rep0 + 1;

@@ -2359,6 +2359,121 @@ __global__ __launch_bounds__(256) void k_x86_bcj(const uint8_t* __restrict__ in,
 }
 
 // ------------------------------------------------------------------------------------------
+// ARM64 BCJ encoder (simple/arm64.c:20-105) and delta encoder (delta/delta_encoder.c:20-45), one fresh
+// filter per Block, start offset 0.  Both are stateless given the ORIGINAL bytes (ARM64: every aligned
+// 4-byte instruction on its own, pc = offset inside the Block; delta: byte minus the byte `dist` before it
+// in the Block, zero history), so they are plain data-parallel maps -- one thread per instruction / byte.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_arm64_bcj(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, uint32_t n,
+        uint32_t block_size, uint32_t nblocks)
+{
+    const uint32_t spb = block_size / 4;                      // instruction slots per full Block
+    if (spb == 0) return;
+    const uint64_t total = (uint64_t)spb * nblocks;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+        const uint32_t b = (uint32_t)(t / spb), k = (uint32_t)(t - (uint64_t)b * spb);
+        const uint32_t bs = b * block_size;
+        if (bs >= n) continue;
+        const uint32_t len = min(n - bs, block_size) & ~3u;   // arm64.c:26: the tail (size & 3) stays as it is
+        const uint32_t pc = k * 4;
+        if (pc + 4 > len) continue;
+        const uint32_t g = bs + pc;
+        uint32_t instr;
+        __builtin_memcpy(&instr, in + g, 4);
+        if ((instr >> 26) == 0x25) {
+            instr = 0x94000000u | ((instr + (pc >> 2)) & 0x03FFFFFFu);
+            __builtin_memcpy(out + g, &instr, 4);
+        } else if ((instr & 0x9F000000u) == 0x90000000u) {
+            const uint32_t src = ((instr >> 29) & 3) | ((instr >> 3) & 0x001FFFFCu);
+            if ((src + 0x00020000u) & 0x001C0000u) continue;
+            instr &= 0x9000001Fu;
+            const uint32_t dest = src + (pc >> 12);
+            instr |= (dest & 3) << 29;
+            instr |= (dest & 0x0003FFFCu) << 3;
+            instr |= (0u - (dest & 0x00020000u)) & 0x00E00000u;
+            __builtin_memcpy(out + g, &instr, 4);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_delta(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, uint32_t n,
+        uint32_t block_size, uint32_t dist)
+{
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < n; g += stride) {
+        const uint32_t bs = (g / block_size) * block_size;
+        const uint8_t prev = g - bs >= dist ? in[g - dist] : (uint8_t)0;
+        out[g] = (uint8_t)(in[g] - prev);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// SHA-256 Block check (check/sha256.c:120-189, FIPS 180-4): a serial hash per Block, so one THREAD per
+// Block (Blocks are the parallelism; the default Check, CRC64, stays the fast path).  32 bytes per Block.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t rotr32(uint32_t x, uint32_t r) { return (x >> r) | (x << (32 - r)); }
+
+__global__ __launch_bounds__(64) void k_sha256_blocks(const uint8_t* __restrict__ in, uint32_t n, uint32_t block_size,
+        uint32_t nblocks, uint8_t* __restrict__ out)
+{
+    static const uint32_t K[64] = {
+        0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98, 0x12835b01,
+        0x243185be, 0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174, 0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc,
+        0x2de92c6f, 0x4a7484aa, 0x5cb0a9dc, 0x76f988da, 0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147,
+        0x06ca6351, 0x14292967, 0x27b70a85, 0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85,
+        0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3, 0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070, 0x19a4c116, 0x1e376c08,
+        0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f, 0x682e6ff3, 0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208,
+        0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2 };
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nblocks) return;
+    const uint32_t bs = b * block_size;
+    const uint32_t len = min(n, bs + block_size) - bs;
+    uint32_t h[8] = { 0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19 };
+    const uint32_t nchunks = (len + 9 + 63) / 64;               // message + 0x80 + 64-bit length
+    for (uint32_t c = 0; c < nchunks; ++c) {
+        uint32_t w[64];
+        for (int i = 0; i < 16; ++i) {
+            uint32_t v = 0;
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t o = c * 64 + i * 4 + k;
+                uint32_t byte = 0;
+                if (o < len) byte = in[bs + o];
+                else if (o == len) byte = 0x80;
+                else if (c + 1 == nchunks && i >= 14) {
+                    const uint64_t bits = (uint64_t)len * 8;
+                    byte = (uint32_t)(bits >> (8 * (7 - ((i - 14) * 4 + k)))) & 0xFF;
+                }
+                v = (v << 8) | byte;
+            }
+            w[i] = v;
+        }
+        for (int i = 16; i < 64; ++i) {
+            const uint32_t s0 = rotr32(w[i - 15], 7) ^ rotr32(w[i - 15], 18) ^ (w[i - 15] >> 3);
+            const uint32_t s1 = rotr32(w[i - 2], 17) ^ rotr32(w[i - 2], 19) ^ (w[i - 2] >> 10);
+            w[i] = w[i - 16] + s0 + w[i - 7] + s1;
+        }
+        uint32_t a = h[0], bb = h[1], cc = h[2], d = h[3], e = h[4], f = h[5], g = h[6], hh = h[7];
+        for (int i = 0; i < 64; ++i) {
+            const uint32_t S1 = rotr32(e, 6) ^ rotr32(e, 11) ^ rotr32(e, 25);
+            const uint32_t ch = (e & f) ^ (~e & g);
+            const uint32_t t1 = hh + S1 + ch + K[i] + w[i];
+            const uint32_t S0 = rotr32(a, 2) ^ rotr32(a, 13) ^ rotr32(a, 22);
+            const uint32_t mj = (a & bb) ^ (a & cc) ^ (bb & cc);
+            const uint32_t t2 = S0 + mj;
+            hh = g; g = f; f = e; e = d + t1; d = cc; cc = bb; bb = a; a = t1 + t2;
+        }
+        h[0] += a; h[1] += bb; h[2] += cc; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
+    }
+    for (int i = 0; i < 8; ++i) {
+        out[b * 32 + i * 4 + 0] = (uint8_t)(h[i] >> 24);
+        out[b * 32 + i * 4 + 1] = (uint8_t)(h[i] >> 16);
+        out[b * 32 + i * 4 + 2] = (uint8_t)(h[i] >> 8);
+        out[b * 32 + i * 4 + 3] = (uint8_t)h[i];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // CRC64 (check/crc64_fast.c; ECMA-182 reflected, poly 0xC96C5795D7870F42)
 // ------------------------------------------------------------------------------------------
 // Both Block checks of the device path share the code: T = uint64_t is CRC64 (ECMA-182 reflected,
@@ -2703,6 +2818,31 @@ int xzk_x86_bcj(const uint8_t* d_in, uint8_t* d_out, uint32_t n, uint32_t block_
     if (nch == 0 || nch > 0xFFFFFFFFull) return nch ? (int)hipErrorInvalidValue : 0;
     hipLaunchKernelGGL(k_x86_bcj, dim3((uint32_t)((nch + 255) / 256)), dim3(256), 0, st, d_in, d_out, n, block_size, cpb,
             (uint32_t)nch);
+    return (int)hipGetLastError();
+}
+
+// prefilter kind: 0x0A = ARM64 BCJ, 3 = delta (dist 1..256): d_out = filtered copy of d_in
+int xzk_prefilter(const uint8_t* d_in, uint8_t* d_out, uint32_t n, uint32_t block_size, uint32_t nblocks, uint32_t kind, uint32_t dist,
+        void* stream_)
+{
+    hipStream_t st = (hipStream_t)stream_;
+    if (n == 0) return 0;
+    if (kind == 0x0A) {
+        int e = (int)hipMemcpyAsync(d_out, d_in, n, hipMemcpyDeviceToDevice, st);
+        if (e) return e;
+        hipLaunchKernelGGL(k_arm64_bcj, dim3(grid_for((uint64_t)n / 4 + 1, 256, 65536)), dim3(256), 0, st, d_in, d_out, n, block_size, nblocks);
+    } else if (kind == 3) {
+        hipLaunchKernelGGL(k_delta, dim3(grid_for(n, 256, 65536)), dim3(256), 0, st, d_in, d_out, n, block_size, dist);
+    } else {
+        return (int)hipErrorInvalidValue;
+    }
+    return (int)hipGetLastError();
+}
+
+int xzk_sha256_blocks(const uint8_t* d_in, uint32_t n, uint32_t block_size, uint32_t nblocks, uint8_t* d_out32, void* stream_)
+{
+    if (nblocks == 0) return 0;
+    hipLaunchKernelGGL(k_sha256_blocks, dim3((nblocks + 63) / 64), dim3(64), 0, (hipStream_t)stream_, d_in, n, block_size, nblocks, d_out32);
     return (int)hipGetLastError();
 }
 

@@ -78,6 +78,7 @@ static uint32_t check_bytes(int check)
 	case XZAMD_CHECK_NONE: return 0;
 	case XZAMD_CHECK_CRC32: return 4;
 	case XZAMD_CHECK_CRC64: return 8;
+	case XZAMD_CHECK_SHA256: return 32;
 	default: return 0xFFFFFFFFu;
 	}
 }
@@ -146,25 +147,37 @@ uint64_t xzamd_block_buffer_bound(uint64_t u)
 	return headers + ((lz2 + 3) & ~3ull);
 }
 
-static uint32_t block_header_size(uint64_t csize, uint64_t usize, int x86)
+/* `pre` = the filter in front of LZMA2 as xzamd_lzma_options.bcj carries it: 0 none, XZAMD_BCJ_X86,
+ * XZAMD_BCJ_ARM64, XZAMD_FILTER_DELTA(dist). */
+static uint32_t prefilter_flags_size(uint32_t pre)
 {
-	/* block_header_encoder.c:17-70 for the chains {LZMA2} and {x86, LZMA2} */
-	uint32_t s = 1 + 1 + 4 + vli_len(csize) + vli_len(usize) + 3 + (x86 ? 2 : 0);
+	const uint32_t id = pre & 0xFF;
+	return id == 0 ? 0 : (id == 3 ? 3 : 2);
+}
+
+static uint32_t block_header_size(uint64_t csize, uint64_t usize, uint32_t pre)
+{
+	/* block_header_encoder.c:17-70 for the chains {LZMA2} and {x86 | ARM64 | delta, LZMA2} */
+	uint32_t s = 1 + 1 + 4 + vli_len(csize) + vli_len(usize) + 3 + prefilter_flags_size(pre);
 	return (s + 3) & ~3u;
 }
 
-static void block_header_put(uint8_t *out, uint32_t hs, uint64_t csize, uint64_t usize, uint8_t dict_byte, int x86)
+static void block_header_put(uint8_t *out, uint32_t hs, uint64_t csize, uint64_t usize, uint8_t dict_byte, uint32_t pre)
 {
 	/* block_header_encoder.c:73-131 */
 	const uint32_t body = hs - 4;
 	memset(out, 0, body);
 	out[0] = (uint8_t)(body / 4);
-	out[1] = x86 ? 0xC1 : 0xC0;   /* both sizes present, number of filters - 1 */
+	out[1] = (pre & 0xFF) ? 0xC1 : 0xC0;   /* both sizes present, number of filters - 1 */
 	uint32_t p = 2;
 	p += vli_put(out + p, csize);
 	p += vli_put(out + p, usize);
-	if (x86) {                    /* filter_flags_encoder.c:30-55: id 0x04, no properties (start offset 0) */
-		out[p++] = 0x04;
+	if ((pre & 0xFF) == 3) {      /* delta: id 0x03, one property byte = distance - 1 (delta_encoder.c:99-111) */
+		out[p++] = 0x03;
+		out[p++] = 0x01;
+		out[p++] = (uint8_t)(pre >> 8);
+	} else if (pre & 0xFF) {      /* filter_flags_encoder.c:30-55: BCJ id, no properties (start offset 0) */
+		out[p++] = (uint8_t)(pre & 0xFF);
 		out[p++] = 0x00;
 	}
 	out[p++] = 0x21;
@@ -396,8 +409,9 @@ const char *xzamd_options_check(const xzamd_lzma_options *opt)
 		return "unsupported match finder options for the device path";
 	if (opt->dict_size < 4096 || opt->dict_size > (1u << 30))
 		return "dict_size must be 4 KiB .. 1 GiB on the device path";
-	if (opt->bcj != 0 && opt->bcj != XZAMD_BCJ_X86)
-		return "only the x86 BCJ filter is supported in front of LZMA2";
+	if (opt->bcj != 0 && opt->bcj != XZAMD_BCJ_X86 && opt->bcj != XZAMD_BCJ_ARM64
+			&& ((opt->bcj & 0xFF) != 3 || (opt->bcj >> 8) > 255))
+		return "filters in front of LZMA2: x86 BCJ, ARM64 BCJ or delta";
 	if (opt->gpu_parser && opt->pb > 2)
 		return "the optimal parser's price tables cover pb <= 2";
 	return NULL;
@@ -556,7 +570,7 @@ int xzamd_stream_encode_device(xzamd_ctx *c,
 	if ((unsigned)check > 15)
 		return fail(c, XZAMD_PROG_ERROR, "check id out of range", 0);
 	if (cbytes == 0xFFFFFFFFu)
-		return fail(c, XZAMD_UNSUPPORTED_CHECK, "only CRC32/CRC64/none are supported", 0);
+		return fail(c, XZAMD_UNSUPPORTED_CHECK, "checks: none, CRC32, CRC64, SHA-256", 0);
 	{
 		const char *why = xzamd_options_check(opt);
 		if (why)
@@ -622,8 +636,8 @@ int xzamd_stream_encode_device(xzamd_ctx *c,
 	const uint32_t spb = (uint32_t)((block_size + span - 1) / span);
 	const uint64_t span_cap = ((uint64_t)span + (span >> 3) + 4096 + 15) & ~15ull;
 	const uint64_t bound = xzamd_block_buffer_bound(block_size);
-	const int x86 = opt->bcj == XZAMD_BCJ_X86;
-	const uint32_t hs_fixed = block_header_size(bound, block_size, x86);
+	const int x86 = opt->bcj != 0;          /* any filter in front of LZMA2: the encoder reads a filtered copy */
+	const uint32_t hs_fixed = block_header_size(bound, block_size, opt->bcj);
 	const uint8_t dbyte = dict_size_byte(opt->dict_size);
 
 	memset(&c->stats, 0, sizeof(c->stats));
@@ -680,7 +694,7 @@ int xzamd_stream_encode_device(xzamd_ctx *c,
 		GROW(scratch, span_cap * nspans, 0);
 		GROW(span_bytes, 4ull * nspans, 0);
 		GROW(strip_crc, 8ull * spb_crc * nb, 0);
-		GROW(block_crc, 8ull * nb, 0);
+		GROW(block_crc, 32ull * nb, 0);
 		GROW(errw, 256, 0);
 		GROW(litp, (uint64_t)nspans * (0x300ull << (opt->lc + opt->lp)) * 4ull, 0);
 		if (opt->gpu_parser) {
@@ -694,7 +708,7 @@ int xzamd_stream_encode_device(xzamd_ctx *c,
 			}
 		}
 		GROW(h_span_bytes, 4ull * nspans, 1);
-		GROW(h_block_crc, 8ull * nb, 1);
+		GROW(h_block_crc, 32ull * nb, 1);
 		/* plan capacity: per Block header + spans + trailer, or the stored form */
 		const uint64_t segs_per_block = spb + 2 + 2 * ((block_size + 65535) / 65536) + 2;
 		const uint64_t max_segs = nb * segs_per_block + 4;
@@ -709,8 +723,11 @@ int xzamd_stream_encode_device(xzamd_ctx *c,
 		xzk_event_record(c->ev[0], st);
 		if (x86) {
 			GROW(bcj, (uint64_t)n + 16, 0);
-			int e = xzk_x86_bcj(d_in + in_off, (uint8_t *)c->bcj.p, n, (uint32_t)block_size, (uint32_t)nb, st);
-			if (e) { rc = fail(c, XZAMD_DEVICE_ERROR, "x86 bcj", e); goto done; }
+			int e = opt->bcj == XZAMD_BCJ_X86
+					? xzk_x86_bcj(d_in + in_off, (uint8_t *)c->bcj.p, n, (uint32_t)block_size, (uint32_t)nb, st)
+					: xzk_prefilter(d_in + in_off, (uint8_t *)c->bcj.p, n, (uint32_t)block_size, (uint32_t)nb, opt->bcj & 0xFF,
+							(opt->bcj >> 8) + 1, st);
+			if (e) { rc = fail(c, XZAMD_DEVICE_ERROR, "filter in front of LZMA2", e); goto done; }
 			enc_in = (const uint8_t *)c->bcj.p;
 		}
 		/* 1. match-finder structure: built on the caller's stream, unless the previous iteration already
@@ -814,6 +831,11 @@ int xzamd_stream_encode_device(xzamd_ctx *c,
 			if (e) { rc = fail(c, XZAMD_DEVICE_ERROR, "crc64 launch", e); goto done; }
 			e = xzk_d2h(c->h_block_crc.p, c->block_crc.p, 8ull * nb, st);
 			if (e) { rc = fail(c, XZAMD_DEVICE_ERROR, "d2h crc", e); goto done; }
+		} else if (check == XZAMD_CHECK_SHA256) {
+			int e = xzk_sha256_blocks(d_in + in_off, n, (uint32_t)block_size, (uint32_t)nb, (uint8_t *)c->block_crc.p, st);
+			if (e) { rc = fail(c, XZAMD_DEVICE_ERROR, "sha256 launch", e); goto done; }
+			e = xzk_d2h(c->h_block_crc.p, c->block_crc.p, 32ull * nb, st);
+			if (e) { rc = fail(c, XZAMD_DEVICE_ERROR, "d2h sha256", e); goto done; }
 		}
 		xzk_event_record(c->ev[3], st);
 		{
@@ -860,7 +882,7 @@ int xzamd_stream_encode_device(xzamd_ctx *c,
 			const uint64_t pad = (4 - (payload & 3)) & 3;
 			const uint64_t bstart = opos;
 			uint64_t unp;
-			uint8_t tail[16];
+			uint8_t tail[48];
 			uint32_t tl = 0;
 			if (hs_fixed + payload + pad + cbytes > bound) {
 				/* stream_encoder_mt.c:298,316-344 -> block_buffer_encoder.c:88-162 */
@@ -883,7 +905,7 @@ int xzamd_stream_encode_device(xzamd_ctx *c,
 				++c->stats.blocks_stored;
 			} else {
 				if (opos + hs_fixed + payload + pad + cbytes > out_cap) { rc = fail(c, XZAMD_BUF_ERROR, "output buffer too small", 0); goto done; }
-				block_header_put(small, hs_fixed, payload, usize, dbyte, x86);
+				block_header_put(small, hs_fixed, payload, usize, dbyte, opt->bcj);
 				opos = plan_lit(&pl, small, hs_fixed, opos);
 				for (uint32_t s = 0; s < spb; ++s)
 					opos = plan_seg(&pl, 0, (uint64_t)(b * spb + s) * span_cap, sb[b * spb + s], opos);
@@ -899,6 +921,9 @@ int xzamd_stream_encode_device(xzamd_ctx *c,
 			} else if (check == XZAMD_CHECK_CRC32) {
 				le32(tail + tl, (uint32_t)bcrc[b]);
 				tl += 4;
+			} else if (check == XZAMD_CHECK_SHA256) {
+				memcpy(tail + tl, (const uint8_t *)c->h_block_crc.p + 32 * b, 32);
+				tl += 32;
 			}
 			opos = plan_lit(&pl, tail, tl, opos);
 			const uint64_t gi = b0 + b;
