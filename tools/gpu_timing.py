@@ -12,6 +12,7 @@ host = xz_amd.corpus_text(n, seed=1000)
 t = torch.from_numpy(host).cuda()
 enc = xz_amd.Encoder(0)
 opts = xz_amd.preset_options(preset)
+opts.span_size = xz_amd.SPAN_AUTO
 for it in range(2):
     torch.cuda.synchronize(); t0 = time.time()
     out, _ = enc.encode(t, opts=opts)

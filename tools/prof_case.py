@@ -11,6 +11,8 @@ host = xz_amd.corpus_text(mib << 20, seed=1000)
 t = torch.from_numpy(host).cuda()
 enc = xz_amd.Encoder()
 opts = xz_amd.preset_options(preset)
+if os.environ.get('XZAMD_SPAN_AUTO'):
+    opts.span_size = xz_amd.SPAN_AUTO
 for _ in range(reps):
     torch.cuda.synchronize(); t0 = time.time()
     out, _ = enc.encode(t, opts=opts)

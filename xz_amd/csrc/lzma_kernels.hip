@@ -138,19 +138,24 @@ __global__ __launch_bounds__(256) void k_link_main(const uint32_t* __restrict__ 
     }
 }
 
-// After the stable sort by key2 / key3: prev[position] = distance to the previous position of
-// the same bucket (the value the reference's hash2/hash3 head table holds when `position` is
-// reached, expressed as delta), 0 = none.
-__global__ __launch_bounds__(256) void k_link_prev(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals,
-        uint32_t n, uint32_t* __restrict__ prev)
+// After the stable sort by key2 / key3 / key4: prev[position] = distance to the previous position of the same
+// bucket (the value the reference's hash head table holds when `position` is reached, expressed as delta),
+// 0 = none.
+// The same distances, written in sorted order (d[i] belongs to position vals[i]).  A scattered 4-byte store
+// costs a whole sector and 1.4 G of them run at ~30 G/s; sorting the (position, distance) pairs back by
+// position (invert_by_sort below: four streaming radix passes) is twice as fast.
+__global__ __launch_bounds__(256) void k_link_prev_seq(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals,
+        uint32_t n, uint32_t* __restrict__ d)
 {
     const uint32_t stride = gridDim.x * blockDim.x;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const uint32_t p = vals[i];
-        uint32_t d = 0;
-        if (i > 0 && keys[i - 1] == keys[i]) d = p - vals[i - 1];
-        prev[p] = d;
-    }
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        d[i] = (i > 0 && keys[i - 1] == keys[i]) ? vals[i] - vals[i - 1] : 0u;
+}
+
+__global__ __launch_bounds__(256) void k_iota(uint32_t* __restrict__ v, uint32_t n)
+{
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) v[i] = i;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -218,43 +223,45 @@ __global__ __launch_bounds__(256) void k_sa_block_unpack(const uint32_t* __restr
     }
 }
 
-// rk[pos[i]] = (group start + 1, distance to the left neighbour inside the group or 0).  The second word is
-// a by-product of the sort round: inside a group of equal keys positions ascend, so the left neighbour of a
-// group member is the nearest earlier position with the same 8 (round 0) / 16 (round 1) bytes.  One 8-byte
-// scatter instead of two 4-byte ones: a scattered store costs a 64-byte sector whatever it carries.
-__global__ __launch_bounds__(256) void k_sa_scatter_rank(const uint32_t* __restrict__ pos, const uint32_t* __restrict__ grp,
+// Slot order: rk[i] = (group start + 1, distance to the left neighbour inside the group or 0) of position pos[i].
+// The second word is a by-product of the sort round: inside a group of equal keys positions ascend, so the left
+// neighbour of a group member is the nearest earlier position with the same 8 (round 0) / 16 (round 1) bytes.
+// The pairs are then sorted by position (invert_by_sort), which leaves rk indexed by position.
+__global__ __launch_bounds__(256) void k_sa_rank_seq(const uint32_t* __restrict__ pos, const uint32_t* __restrict__ grp,
         uint32_t n, uint2* __restrict__ rk)
 {
     const uint32_t stride = gridDim.x * blockDim.x;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const uint32_t p = pos[i], g = grp[i];
-        rk[p] = make_uint2(g + 1, g != i ? p - pos[i - 1] : 0u);
+        const uint32_t g = grp[i];
+        rk[i] = make_uint2(g + 1, g != i ? pos[i] - pos[i - 1] : 0u);
     }
 }
 
-// doubling key: (rank[p], rank[p + h]) with 0 for a second half that starts past the Block end
-__global__ __launch_bounds__(256) void k_sa_pair_keys(const uint32_t* __restrict__ pos, const uint32_t* __restrict__ grp,
-        const uint2* __restrict__ rank, uint32_t n, uint32_t block_size, uint32_t h, uint64_t* __restrict__ keys)
+// doubling key of every position, in position order: (rank[p], rank[p + h]) with 0 for a second half that
+// starts past the Block end; vals = iota.  (The radix sort is stable and the members of a group ascend by
+// position in slot order too, so feeding it in position order gives the same result as slot order -- without
+// the random gather of rank[p + h].)
+__global__ __launch_bounds__(256) void k_sa_pair_keys_pos(const uint2* __restrict__ rank, uint32_t n, uint32_t block_size,
+        uint32_t h, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals)
 {
     const uint32_t stride = gridDim.x * blockDim.x;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const uint32_t p = pos[i];
+    for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += stride) {
         const uint32_t b = p / block_size;
         const uint32_t bend = min(n, (b + 1) * block_size);
         const uint32_t second = p + h < bend ? rank[p + h].x : 0u;
-        keys[i] = ((uint64_t)(grp[i] + 1) << 32) | second;
+        keys[p] = ((uint64_t)rank[p].x << 32) | second;
+        vals[p] = p;
     }
 }
 
-// final: sa[i] = position of slot i, sa_rank[position] = slot
-__global__ __launch_bounds__(256) void k_sa_final(const uint32_t* __restrict__ pos, uint32_t n,
-        uint32_t* __restrict__ sa, uint32_t* __restrict__ sa_rank)
+// final: sa[i] = position of slot i; slot[i] = i (sorted by position afterwards: sa_rank)
+__global__ __launch_bounds__(256) void k_sa_final_seq(const uint32_t* __restrict__ pos, uint32_t n,
+        uint32_t* __restrict__ sa, uint32_t* __restrict__ slot)
 {
     const uint32_t stride = gridDim.x * blockDim.x;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const uint32_t p = pos[i];
-        sa[i] = p;
-        sa_rank[p] = i;
+        sa[i] = pos[i];
+        slot[i] = i;
     }
 }
 
@@ -837,6 +844,8 @@ struct Work {
 
 struct RoundL {
     uint32_t rp[4];     // list-driven parser: the four rep-match lengths
+    uint32_t rl[4];     // the same, 0 when < 2 (usable rep matches)
+    uint32_t pre;       // compound precheck: some rep source has two equal bytes right behind its first mismatch
     uint64_t rm[4];     // mismatch masks of the four rep sources over the 64-byte row at x (bit o: offset o differs or is past the end)
     uint32_t l2a, l2b;  // rep0 run behind the byte after the longest / second longest match (list trailer)
     uint32_t L;         // per lane; lanes 60..63 = rep lengths (in-kernel finders)
@@ -863,15 +872,14 @@ __device__ __forceinline__ void lists_load(const Env& e, uint32_t x, uint32_t& s
 {
     const uint32_t lane = threadIdx.x;
     x = x < e.n_last ? x : e.n_last;
-    const uint64_t base = (uint64_t)x * LIST_W;
-    uint32_t v = 0;
-    if (lane < LIST_W) v = e.mdist[base + lane];
+    const uint64_t base = (uint64_t)x * LIST_W + (lane & (LIST_W - 1));
+    const uint32_t v = e.mdist[base];              // every lane loads (lanes >= LIST_W repeat the record): no exec masking
     tr = v;                                        // lane LIST_K holds the trailer
     if (e.packed) {
         sl = v >> 23; sd = v & 0x7FFFFFu;
     } else {
         sd = v;
-        sl = lane < LIST_K ? e.mlen[base + lane] : 0u;
+        sl = e.mlen[base];
     }
 }
 
@@ -886,21 +894,38 @@ __device__ __forceinline__ void round_lists(const Env& e, ListPre& LP, uint32_t 
     LP.valid = true;
     const uint32_t avail = end - x;
     const uint32_t buf_avail = avail < MATCH_LEN_MAX ? avail : MATCH_LEN_MAX;
-    // rep-match lengths, lane = byte offset: one 64-byte row of the text against the four rep
-    // sources, a ballot each.  No per-lane loops; only a match of >= 64 bytes takes the slow path.
+    // Rep-match lengths: one 64-byte row of the text against the four rep sources, lane = byte offset, a
+    // ballot each (bit o: offset o differs or lies past the end).  Everything that follows from a mask --
+    // length, "usable" length, the compound precheck -- is then worked out by lane i for rep i with vector
+    // instructions (the scalar unit is what bounds this kernel), and only the results go back to scalars.
     {
         const uint32_t off = lane < buf_avail ? lane : 0u;      // lanes past the end re-read byte 0 (masked below)
         const uint32_t cx = e.in[x + off];
         const uint32_t c0 = e.in[x - r0 - 1 + off], c1 = e.in[x - r1 - 1 + off];
         const uint32_t c2 = e.in[x - r2 - 1 + off], c3 = e.in[x - r3 - 1 + off];
-        const bool live = lane < buf_avail;
-        const uint64_t m0 = __ballot(!live || c0 != cx), m1 = __ballot(!live || c1 != cx);
-        const uint64_t m2 = __ballot(!live || c2 != cx), m3 = __ballot(!live || c3 != cx);
-        R.rp[0] = m0 ? (uint32_t)__builtin_ctzll(m0) : wave_cmplen(e.in, x, x - r0 - 1, 64, buf_avail);
-        R.rp[1] = m1 ? (uint32_t)__builtin_ctzll(m1) : wave_cmplen(e.in, x, x - r1 - 1, 64, buf_avail);
-        R.rp[2] = m2 ? (uint32_t)__builtin_ctzll(m2) : wave_cmplen(e.in, x, x - r2 - 1, 64, buf_avail);
-        R.rp[3] = m3 ? (uint32_t)__builtin_ctzll(m3) : wave_cmplen(e.in, x, x - r3 - 1, 64, buf_avail);
+        const uint64_t dead = buf_avail < 64 ? ~0ull << buf_avail : 0ull;
+        const uint64_t m0 = __builtin_amdgcn_ballot_w64(c0 != cx) | dead, m1 = __builtin_amdgcn_ballot_w64(c1 != cx) | dead;
+        const uint64_t m2 = __builtin_amdgcn_ballot_w64(c2 != cx) | dead, m3 = __builtin_amdgcn_ballot_w64(c3 != cx) | dead;
         R.rm[0] = m0; R.rm[1] = m1; R.rm[2] = m2; R.rm[3] = m3;
+        const uint32_t lo = lane == 0 ? (uint32_t)m0 : lane == 1 ? (uint32_t)m1 : lane == 2 ? (uint32_t)m2 : (uint32_t)m3;
+        const uint32_t hi = lane == 0 ? (uint32_t)(m0 >> 32) : lane == 1 ? (uint32_t)(m1 >> 32)
+                : lane == 2 ? (uint32_t)(m2 >> 32) : (uint32_t)(m3 >> 32);
+        const uint32_t l = lo ? (uint32_t)__builtin_ctz(lo) : hi ? 32u + (uint32_t)__builtin_ctz(hi) : 64u;
+        const uint32_t lu = l >= 2 ? l : 0u;
+        // two equal bytes behind the first mismatch <=> bits l+1, l+2 clear (bit l is set)
+        const uint64_t mm = ((uint64_t)hi << 32) | lo;
+        const uint32_t t3 = (uint32_t)(mm >> (l & 63u)) & 7u;
+        const bool okl = (l - 2u < 60u) || (lane == 0 && l == 0);
+        R.pre = __builtin_amdgcn_ballot_w64(lane < 4 && okl && t3 == 1u) != 0ull;
+        const uint64_t full = __builtin_amdgcn_ballot_w64(lane < 4 && l >= 64u);
+        R.rp[0] = lane_of(l, 0); R.rp[1] = lane_of(l, 1); R.rp[2] = lane_of(l, 2); R.rp[3] = lane_of(l, 3);
+        R.rl[0] = lane_of(lu, 0); R.rl[1] = lane_of(lu, 1); R.rl[2] = lane_of(lu, 2); R.rl[3] = lane_of(lu, 3);
+        if (full) {                                             // a rep match of >= 64 bytes: the slow path
+            if (full & 1) R.rl[0] = R.rp[0] = wave_cmplen(e.in, x, x - r0 - 1, 64, buf_avail);
+            if (full & 2) R.rl[1] = R.rp[1] = wave_cmplen(e.in, x, x - r1 - 1, 64, buf_avail);
+            if (full & 4) R.rl[2] = R.rp[2] = wave_cmplen(e.in, x, x - r2 - 1, 64, buf_avail);
+            if (full & 8) R.rl[3] = R.rp[3] = wave_cmplen(e.in, x, x - r3 - 1, 64, buf_avail);
+        }
     }
     const uint32_t tr = lane_of(tv, LIST_K);
     const uint32_t cnt = tr & 0xFFu;
@@ -1267,8 +1292,8 @@ __device__ __forceinline__ bool optimum_window(const Env& e, const Work& w, List
         TM_END(w, 1, t_round);
         if (j > 0 && longest >= e.nice) { next_cached = true; break; }
         TM_BEGIN(t_bits);
-        const uint32_t rp0 = RL.rp[0], rp1 = RL.rp[1], rp2 = RL.rp[2], rp3 = RL.rp[3];
-        uint32_t rl0 = rp0 >= 2 ? rp0 : 0, rl1 = rp1 >= 2 ? rp1 : 0, rl2 = rp2 >= 2 ? rp2 : 0, rl3 = rp3 >= 2 ? rp3 : 0;
+        const uint32_t rp0 = RL.rp[0];
+        uint32_t rl0 = RL.rl[0], rl1 = RL.rl[1], rl2 = RL.rl[2], rl3 = RL.rl[3];
         if (j == 0) {
             uint32_t sb = LITERAL, sl = 0;
             if (rl0 >= e.nice) { sb = 0; sl = rl0; }
@@ -1293,15 +1318,7 @@ __device__ __forceinline__ bool optimum_window(const Env& e, const Work& w, List
         Compound cp;
         cp.mask = 0; cp.L1 = cp.l2 = cp.T = cp.dist = 0;
         {
-            bool any = (RL.l2a | RL.l2b) >= 2;
-            // rep i qualifies only when it runs >= 2 bytes and ends inside the row, rep0 also when its first byte
-            // differs (the "literal + rep0" case): most rep sources of a text node fail on their first byte
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const uint32_t l = RL.rp[i];
-                if ((l >= 2 && l < 62) || (i == 0 && l == 0))
-                    any = any || ((RL.rm[i] >> (l + 1)) & 3ull) == 0;
-            }
+            const bool any = (RL.l2a | RL.l2b) >= 2 || RL.pre;
             if (any) compound_setup(RL, j, room, buf_avail, r0, r1, r2, r3, cp);
         }
         uint32_t cT_max = 0;
@@ -1615,6 +1632,8 @@ __device__ __forceinline__ void span_encode_one(const xzamd_span_args& a, const 
     RL.L = 0; RL.SL = 0; RL.SD = 0; RL.cnt = 0; RL.longest = 0; RL.l2a = RL.l2b = 0;
     RL.rp[0] = RL.rp[1] = RL.rp[2] = RL.rp[3] = 0;
     RL.rm[0] = RL.rm[1] = RL.rm[2] = RL.rm[3] = 0;
+    RL.rl[0] = RL.rl[1] = RL.rl[2] = RL.rl[3] = 0;
+    RL.pre = 0;
     LenTab lt;
     uint32_t q_pos = 0, q_end = 0;  // pending path of the optimal parser (nodes in LDS)
     bool tables_valid = false;
@@ -2574,6 +2593,27 @@ __global__ __launch_bounds__(64) void k_crc_fold(const T* __restrict__ strips, u
 // Assembly: gather span outputs (and small literal pieces prepared by the host: headers,
 // end markers, padding, checks, index, footer) into the final stream buffer.
 // One workgroup per copy segment.
+// vals_inout[key[i]] = v[i] for a permutation `key` of 0..n-1, as a sort: radix_sort_pairs by key leaves the values
+// in key order.  keys_cur / vals_inout hold the pairs, the *_alt buffers are scratch; the keys come out sorted (iota).
+template <typename V>
+static hipError_t invert_by_sort(uint32_t* keys_cur, uint32_t* keys_alt, V* vals_inout, V* vals_alt, uint32_t n,
+        void* tmp, size_t tmp_bytes, hipStream_t st)
+{
+    uint32_t bits = 1;
+    while (bits < 32 && (1ull << bits) < n) ++bits;
+    rocprim::double_buffer<uint32_t> kb(keys_cur, keys_alt);
+    rocprim::double_buffer<V> vb(vals_inout, vals_alt);
+    size_t need = 0;
+    hipError_t e = rocprim::radix_sort_pairs(nullptr, need, kb, vb, (size_t)n, 0u, bits, st);
+    if (e != hipSuccess) return e;
+    if (need > tmp_bytes) return hipErrorOutOfMemory;
+    e = rocprim::radix_sort_pairs(tmp, tmp_bytes, kb, vb, (size_t)n, 0u, bits, st);
+    if (e != hipSuccess) return e;
+    if (vb.current() != vals_inout)
+        e = hipMemcpyAsync(vals_inout, vb.current(), (size_t)n * sizeof(V), hipMemcpyDeviceToDevice, st);
+    return e;
+}
+
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_assemble(const xzamd_copy_seg* __restrict__ segs, uint32_t nsegs,
         const uint8_t* __restrict__ scratch, const uint8_t* __restrict__ lits, const uint8_t* __restrict__ in,
@@ -2697,14 +2737,15 @@ int xzk_build_chains(const uint8_t* d_in, uint32_t n, uint32_t block_size, uint3
         if (need > tb) return (int)hipErrorOutOfMemory;
         e = rocprim::radix_sort_pairs(sort_tmp, tb, kb, vb, (size_t)n, 0u, kbits + bb, st);
         if (e != hipSuccess) return (int)e;
-        if (which == 2)
-            hipLaunchKernelGGL(k_link_prev, dim3(g), dim3(256), 0, st, kb.current(), vb.current(), n, prev2);
-        else if (which == 3)
-            hipLaunchKernelGGL(k_link_prev, dim3(g), dim3(256), 0, st, kb.current(), vb.current(), n, prev3);
-        else if (sa != nullptr)
-            hipLaunchKernelGGL(k_link_prev, dim3(g), dim3(256), 0, st, kb.current(), vb.current(), n, prev4);
-        else
+        uint32_t* const target = which == 2 ? prev2 : which == 3 ? prev3 : sa != nullptr ? prev4 : nullptr;
+        if (target != nullptr) {
+            // distances in sorted order, then back to position order by a sort on the position
+            hipLaunchKernelGGL(k_link_prev_seq, dim3(g), dim3(256), 0, st, kb.current(), vb.current(), n, target);
+            e = invert_by_sort<uint32_t>(vb.current(), vb.alternate(), target, kb.current(), n, sort_tmp, tb, st);
+            if (e != hipSuccess) return (int)e;
+        } else {
             hipLaunchKernelGGL(k_link_main, dim3(g), dim3(256), 0, st, kb.current(), vb.current(), n, sorted_pos, rank);
+        }
     }
     if (sa == nullptr) return (int)hipGetLastError();
 
@@ -2751,9 +2792,14 @@ int xzk_build_chains(const uint8_t* d_in, uint32_t n, uint32_t block_size, uint3
     }
     // doubling rounds
     for (uint32_t h = 8; h <= 16; h *= 2) {
-        uint2* rkx = reinterpret_cast<uint2*>(h == 8 ? rp8 : rp16);
-        hipLaunchKernelGGL(k_sa_scatter_rank, dim3(g), dim3(256), 0, st, pos, grp, n, rkx);
-        hipLaunchKernelGGL(k_sa_pair_keys, dim3(g), dim3(256), 0, st, pos, grp, rkx, n, block_size, h, key64_a);
+        uint64_t* const rk = h == 8 ? rp8 : rp16;
+        // (rank, left-neighbour distance) of every slot, sorted back to position order
+        hipLaunchKernelGGL(k_sa_rank_seq, dim3(g), dim3(256), 0, st, pos, grp, n, reinterpret_cast<uint2*>(rk));
+        e = invert_by_sort<uint64_t>(pos, pos_alt, rk, key64_b, n, sort_tmp, tb, st);
+        if (e != hipSuccess) return (int)e;
+        // keys in position order (values = iota): both `pos` buffers are free again
+        hipLaunchKernelGGL(k_sa_pair_keys_pos, dim3(g), dim3(256), 0, st, reinterpret_cast<const uint2*>(rk), n, block_size, h,
+                key64_a, pos);
         rocprim::double_buffer<uint64_t> kk(key64_a, key64_b);
         rocprim::double_buffer<uint32_t> vv(pos, pos_alt);
         e = rocprim::radix_sort_pairs(sort_tmp, tb, kk, vv, (size_t)n, 0u, 64u, st);
@@ -2766,7 +2812,10 @@ int xzk_build_chains(const uint8_t* d_in, uint32_t n, uint32_t block_size, uint3
             if (e != hipSuccess) return (int)e;
         }
     }
-    hipLaunchKernelGGL(k_sa_final, dim3(g), dim3(256), 0, st, pos, n, sa, sa_rank);
+    // sa = slot order; sa_rank = its inverse (grp = keys_a is dead: scratch of the inversion)
+    hipLaunchKernelGGL(k_sa_final_seq, dim3(g), dim3(256), 0, st, pos, n, sa, sa_rank);
+    e = invert_by_sort<uint32_t>(pos, pos_alt, sa_rank, keys_a, n, sort_tmp, tb, st);
+    if (e != hipSuccess) return (int)e;
     return (int)hipGetLastError();
 }
 

@@ -518,8 +518,8 @@ static int batch_geometry(xzamd_ctx *c, const xzamd_lzma_options *opt, uint64_t 
 	g->sort_bytes = 0;
 	uint32_t bb = 0;
 	while ((1u << bb) < g->nb + 1) ++bb;
-	const uint32_t bits[3] = { 10 + bb, 16 + bb, hbits + bb };
-	for (int i = 0; i < 3; ++i) {
+	const uint32_t bits[4] = { 10 + bb, 16 + bb, hbits + bb, 32 };   /* 32: the by-position inversions */
+	for (int i = 0; i < 4; ++i) {
 		uint64_t sbytes = 0;
 		int e = xzk_sort_temp_bytes(g->n, bits[i], &sbytes);
 		if (e)
