@@ -396,16 +396,14 @@ static void find_sn(enc *e, uint32_t p)
 	else if (len_limit < 4)
 		return;
 
-	/* candidates: nearest equal hash2 / hash3 / hash4 / 8 bytes / 16 bytes, then the recency records of both sides */
+	/* candidates: nearest equal hash2 / hash4 / 8 bytes / 16 bytes, then the recency records of both sides.
+	 * (No hash3 head: next to the others it was measured to be worth 0.0 % on text and 0.1 % on executables,
+	 * and on the GPU it costs a sort and an inversion of the whole batch.) */
 	uint32_t cd[64], cl[64], nc = 0;
-	const uint32_t d2 = e->prev2[p], d3 = e->prev3[p], d4 = e->prev4[p], d8 = e->prev8[p], d16 = e->prev16[p];
+	const uint32_t d2 = e->prev2[p], d4 = e->prev4[p], d8 = e->prev8[p], d16 = e->prev16[p];
 	if (d2 && d2 < e->cyclic_size) {
 		uint32_t L = cmplen(cur - d2, cur, 0, len_limit);
 		if (L >= 2) { cd[nc] = d2; cl[nc] = L; ++nc; }
-	}
-	if (d3 && d3 < e->cyclic_size) {
-		uint32_t L = cmplen(cur - d3, cur, 0, len_limit);
-		if (L >= 3) { cd[nc] = d3; cl[nc] = L; ++nc; }
 	}
 	if (d4 && d4 < e->cyclic_size) {
 		uint32_t L = cmplen(cur - d4, cur, 0, len_limit);

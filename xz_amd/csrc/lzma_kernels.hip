@@ -2004,7 +2004,6 @@ struct SnArgs {
     const uint32_t* __restrict__ sa;        // slot -> position (Block-major: the slots of a Block are its positions' range)
     const uint32_t* __restrict__ sa_rank;   // position -> slot
     const uint32_t* __restrict__ prev2;
-    const uint32_t* __restrict__ prev3;
     const uint32_t* __restrict__ prev4;
     const uint32_t* __restrict__ prev8;     // stride 2 (interleaved with the round's rank)
     const uint32_t* __restrict__ prev16;    // stride 2
@@ -2071,10 +2070,12 @@ __global__ __launch_bounds__(64) void k_find_sn(xzamd_span_args a, SnArgs sn, ui
     const bool left = t < 5, right = t >= 5 && t < 10;
     const uint32_t k = left ? t : t - 5;
     const bool win_lane = (left || right) && k < W;
-    const bool hash_lane = t >= 10 && t < 15;
-    const uint32_t* __restrict__ hp = t == 10 ? sn.prev2 : t == 11 ? sn.prev3 : t == 12 ? sn.prev4 : t == 13 ? sn.prev8 : sn.prev16;
+    // hash2 / hash4 heads and the 8- / 16-byte left neighbours.  (A hash3 head, lane 11, was measured to be worth
+    // nothing on text and 0.1 % on executables next to these: its sort and inversion are not built for this finder.)
+    const bool hash_lane = t == 10 || (t >= 12 && t < 15);
+    const uint32_t* __restrict__ hp = t == 10 ? sn.prev2 : t == 12 ? sn.prev4 : t == 13 ? sn.prev8 : sn.prev16;
     const uint32_t hstride = t >= 13 ? 2u : 1u;
-    const uint32_t minlen = t == 10 ? 2u : t == 11 ? 3u : 4u;
+    const uint32_t minlen = t == 10 ? 2u : 4u;
     // masks for the prefix maximum inside a side (the right side must not look into the left one)
     const bool sh1 = t != 0 && t != 5, sh2 = (left && t >= 2) || (right && t >= 7), sh4 = (left && t >= 4) || (right && t >= 9);
 
@@ -2705,7 +2706,7 @@ int xzk_sa_temp_bytes(uint32_t n, uint64_t* bytes)
 
 // Builds the match-finder structure of a batch.
 //   exact finder (sa == NULL):   rank / sorted_pos (main chain), prev2, prev3
-//   suffix-neighbourhood finder: prev2, prev3, prev4, the suffix order sa / sa_rank and its by-products
+//   suffix-neighbourhood finder: prev2, prev4, the suffix order sa / sa_rank and its by-products
 //                                rp8 / rp16: per position (rank of the round, distance to the nearest earlier
 //                                position with the same 8 / 16 bytes)
 // keys_a/keys_b/vals_a/vals_b: n u32 each; key64_a/key64_b: n u64 each (sa != NULL only).
@@ -2725,7 +2726,7 @@ int xzk_build_chains(const uint8_t* d_in, uint32_t n, uint32_t block_size, uint3
     const uint32_t which_list[3] = { 2u, 3u, 0u };
     for (int w = 0; w < 3; ++w) {
         const uint32_t which = which_list[w];
-        if (which == 3 && hash_bytes != 4) continue;
+        if (which == 3 && (hash_bytes != 4 || sa != nullptr)) continue;      // the suffix-neighbourhood finder has no hash3 head
         const uint32_t kbits = which == 2 ? 10u : (which == 3 ? 16u : hash_bits);
         hipLaunchKernelGGL(k_hash_keys, dim3(g), dim3(256), 0, st, d_in, n, block_size, nblocks, hash_bytes,
                 hash_mask, hash_bits, which, keys_a, vals_a);
@@ -2828,7 +2829,7 @@ int xzk_find_matches(const xzamd_span_args* a, const uint32_t* sa, const uint32_
     if (a->sa_window) {
         if (!sa || !sa_rank || !prev4 || !rp8 || !rp16 || a->sa_window > SN_WMAX) return (int)hipErrorInvalidValue;
         SnArgs sn;
-        sn.in = a->in; sn.sa = sa; sn.sa_rank = sa_rank; sn.prev2 = a->prev2; sn.prev3 = a->prev3; sn.prev4 = prev4;
+        sn.in = a->in; sn.sa = sa; sn.sa_rank = sa_rank; sn.prev2 = a->prev2; sn.prev4 = prev4;
         sn.prev8 = reinterpret_cast<const uint32_t*>(rp8) + 1;        // second word of each (rank, distance) pair
         sn.prev16 = reinterpret_cast<const uint32_t*>(rp16) + 1;
         hipLaunchKernelGGL(k_find_sn, dim3(runs), dim3(64), 0, st, *a, sn, mlen, mdist);
