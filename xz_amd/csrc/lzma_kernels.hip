@@ -141,6 +141,94 @@ __global__ __launch_bounds__(256) void k_link_main(const uint32_t* __restrict__ 
 // After the stable sort by key2 / key3 / key4: prev[position] = distance to the previous position of the same
 // bucket (the value the reference's hash head table holds when `position` is reached, expressed as delta),
 // 0 = none.
+// hash2 needs no sort: its table has 1024 entries per Block, so the "previous position with the same hash" is
+// found the way the reference does it -- a head table walked in text order -- with the Block cut into segments of
+// H2_SEG positions, one wavefront each:
+//   k_h2_last   last inserted position (+1) of every hash value inside the segment      (LDS table, ds_max)
+//   k_h2_scan   per Block: exclusive running maximum of those tables over its segments   (the carry-in heads)
+//   k_h2_prev   the segment again, 64 positions a step: a lane's predecessor is the highest lower lane of the
+//               step with the same hash (ten ballots give every lane its set of peers), else the table entry;
+//               the last lane of each peer set then updates the table.
+// Positions with fewer than hash_bytes left in their Block are not inserted and get 0 (they are never looked up).
+constexpr uint32_t H2_SEG = 65536;
+
+__device__ __forceinline__ uint32_t h2_of(const uint8_t* __restrict__ in, const uint32_t* T, uint32_t p)
+{
+    return (T[in[p]] ^ in[p + 1]) & 0x3FFu;
+}
+
+__global__ __launch_bounds__(64) void k_h2_last(const uint8_t* __restrict__ in, uint32_t n, uint32_t block_size,
+        uint32_t segs_per_block, uint32_t hash_bytes, uint32_t* __restrict__ seg_tab)
+{
+    __shared__ uint32_t T[256];
+    __shared__ uint32_t tab[1024];
+    const uint32_t lane = threadIdx.x;
+    for (uint32_t i = lane; i < 256; i += 64) T[i] = crc_t0(i);
+    for (uint32_t i = lane; i < 1024; i += 64) tab[i] = 0;
+    const uint32_t b = blockIdx.x / segs_per_block, sg = blockIdx.x - b * segs_per_block;
+    const uint32_t bs = b * block_size;
+    const uint32_t bend = min(n, bs + block_size);
+    const uint32_t s0 = bs + sg * H2_SEG;
+    const uint32_t s1 = min(bend, s0 + H2_SEG);
+    wave_sync();
+    for (uint32_t x = s0 + lane; x < s1; x += 64)
+        if (bend - x >= hash_bytes) atomicMax(&tab[h2_of(in, T, x)], x + 1);
+    wave_sync();
+    uint32_t* out = seg_tab + (uint64_t)blockIdx.x * 1024;
+    for (uint32_t i = lane; i < 1024; i += 64) out[i] = tab[i];
+}
+
+__global__ __launch_bounds__(256) void k_h2_scan(uint32_t* __restrict__ seg_tab, uint32_t segs_per_block)
+{
+    // thread = (Block, hash value): exclusive running maximum along the Block's segments
+    const uint32_t b = blockIdx.x >> 2, h = ((blockIdx.x & 3) << 8) | threadIdx.x;
+    uint32_t* t = seg_tab + (uint64_t)b * segs_per_block * 1024 + h;
+    uint32_t run = 0;
+    for (uint32_t s = 0; s < segs_per_block; ++s) {
+        const uint32_t v = t[(uint64_t)s * 1024];
+        t[(uint64_t)s * 1024] = run;
+        run = max(run, v);
+    }
+}
+
+__global__ __launch_bounds__(64) void k_h2_prev(const uint8_t* __restrict__ in, uint32_t n, uint32_t block_size,
+        uint32_t segs_per_block, uint32_t hash_bytes, const uint32_t* __restrict__ seg_tab, uint32_t* __restrict__ prev2)
+{
+    __shared__ uint32_t T[256];
+    __shared__ uint32_t tab[1024];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t* carry = seg_tab + (uint64_t)blockIdx.x * 1024;
+    for (uint32_t i = lane; i < 256; i += 64) T[i] = crc_t0(i);
+    for (uint32_t i = lane; i < 1024; i += 64) tab[i] = carry[i];
+    const uint32_t b = blockIdx.x / segs_per_block, sg = blockIdx.x - b * segs_per_block;
+    const uint32_t bs = b * block_size;
+    const uint32_t bend = min(n, bs + block_size);
+    const uint32_t s0 = bs + sg * H2_SEG;
+    const uint32_t s1 = min(bend, s0 + H2_SEG);
+    const uint64_t below = (1ull << lane) - 1;
+    wave_sync();
+    for (uint32_t x0 = s0; x0 < s1; x0 += 64) {
+        const uint32_t x = x0 + lane;
+        const bool ins = x < s1 && bend - x >= hash_bytes;
+        const uint32_t h = ins ? h2_of(in, T, x) : 0u;
+        uint64_t peers = __builtin_amdgcn_ballot_w64(ins);
+#pragma unroll
+        for (uint32_t k = 0; k < 10; ++k) {
+            const uint64_t m = __builtin_amdgcn_ballot_w64(((h >> k) & 1u) != 0);
+            peers &= ((h >> k) & 1u) ? m : ~m;
+        }
+        const uint32_t head = tab[h];                       // head before this step
+        const uint64_t lower = peers & below;
+        uint32_t d = 0;
+        if (lower) d = lane - (63u - (uint32_t)__builtin_clzll(lower));
+        else if (head) d = x + 1 - head;
+        if (x < s1) prev2[x] = ins ? d : 0u;
+        wave_sync();
+        if (ins && (peers >> lane) == 1ull) tab[h] = x + 1;   // last lane of its peer set
+        wave_sync();
+    }
+}
+
 // The same distances, written in sorted order (d[i] belongs to position vals[i]).  A scattered 4-byte store
 // costs a whole sector and 1.4 G of them run at ~30 G/s; sorting the (position, distance) pairs back by
 // position (invert_by_sort below: four streaming radix passes) is twice as fast.
@@ -2724,8 +2812,18 @@ int xzk_build_chains(const uint8_t* d_in, uint32_t n, uint32_t block_size, uint3
     while ((1u << bb) < nblocks + 1) ++bb;
     size_t tb = sort_tmp_bytes;
     const uint32_t which_list[3] = { 2u, 3u, 0u };
+    // hash2 heads without a sort when the segment tables fit the scratch (always, except for tiny Blocks)
+    const uint32_t h2_spb = (block_size + H2_SEG - 1) / H2_SEG;
+    const bool h2_direct = hash_bytes >= 2 && nblocks != 0 && (uint64_t)nblocks * h2_spb * 1024ull <= (uint64_t)n;
+    if (h2_direct) {
+        const uint32_t nseg = nblocks * h2_spb;
+        hipLaunchKernelGGL(k_h2_last, dim3(nseg), dim3(64), 0, st, d_in, n, block_size, h2_spb, hash_bytes, keys_a);
+        hipLaunchKernelGGL(k_h2_scan, dim3(nblocks * 4), dim3(256), 0, st, keys_a, h2_spb);
+        hipLaunchKernelGGL(k_h2_prev, dim3(nseg), dim3(64), 0, st, d_in, n, block_size, h2_spb, hash_bytes, keys_a, prev2);
+    }
     for (int w = 0; w < 3; ++w) {
         const uint32_t which = which_list[w];
+        if (which == 2 && h2_direct) continue;
         if (which == 3 && (hash_bytes != 4 || sa != nullptr)) continue;      // the suffix-neighbourhood finder has no hash3 head
         const uint32_t kbits = which == 2 ? 10u : (which == 3 ? 16u : hash_bits);
         hipLaunchKernelGGL(k_hash_keys, dim3(g), dim3(256), 0, st, d_in, n, block_size, nblocks, hash_bytes,
