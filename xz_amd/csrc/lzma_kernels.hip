@@ -326,18 +326,21 @@ __global__ __launch_bounds__(256) void k_sa_rank_seq(const uint32_t* __restrict_
 }
 
 // doubling key of every position, in position order: (rank[p], rank[p + h]) with 0 for a second half that
-// starts past the Block end; vals = iota.  (The radix sort is stable and the members of a group ascend by
+// starts past the Block end; vals = iota.  The second rank is taken relative to the Block (sbits = bits of
+// block_size + 1), so the key is 31 + sbits bits wide instead of 62: one radix pass less for Blocks up to 32 MiB.  (The radix sort is stable and the members of a group ascend by
 // position in slot order too, so feeding it in position order gives the same result as slot order -- without
 // the random gather of rank[p + h].)
 __global__ __launch_bounds__(256) void k_sa_pair_keys_pos(const uint2* __restrict__ rank, uint32_t n, uint32_t block_size,
-        uint32_t h, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals)
+        uint32_t h, uint32_t sbits, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals)
 {
     const uint32_t stride = gridDim.x * blockDim.x;
     for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += stride) {
         const uint32_t b = p / block_size;
-        const uint32_t bend = min(n, (b + 1) * block_size);
-        const uint32_t second = p + h < bend ? rank[p + h].x : 0u;
-        keys[p] = ((uint64_t)rank[p].x << 32) | second;
+        const uint32_t bs = b * block_size;
+        const uint32_t bend = min(n, bs + block_size);
+        // the second half lies in the same Block, whose slots are [bs, bend): relative rank 1..block_size
+        const uint32_t second = p + h < bend ? rank[p + h].x - bs : 0u;
+        keys[p] = ((uint64_t)rank[p].x << sbits) | second;
         vals[p] = p;
     }
 }
@@ -2890,6 +2893,9 @@ int xzk_build_chains(const uint8_t* d_in, uint32_t n, uint32_t block_size, uint3
         if (e != hipSuccess) return (int)e;
     }
     // doubling rounds
+    uint32_t sbits = 1, fbits = 1;                    // bits of a Block-relative rank (<= block_size), of a rank (<= n)
+    while (sbits < 32 && (1ull << sbits) <= (uint64_t)min(block_size, n)) ++sbits;
+    while (fbits < 32 && (1ull << fbits) <= (uint64_t)n) ++fbits;
     for (uint32_t h = 8; h <= 16; h *= 2) {
         uint64_t* const rk = h == 8 ? rp8 : rp16;
         // (rank, left-neighbour distance) of every slot, sorted back to position order
@@ -2898,10 +2904,10 @@ int xzk_build_chains(const uint8_t* d_in, uint32_t n, uint32_t block_size, uint3
         if (e != hipSuccess) return (int)e;
         // keys in position order (values = iota): both `pos` buffers are free again
         hipLaunchKernelGGL(k_sa_pair_keys_pos, dim3(g), dim3(256), 0, st, reinterpret_cast<const uint2*>(rk), n, block_size, h,
-                key64_a, pos);
+                sbits, key64_a, pos);
         rocprim::double_buffer<uint64_t> kk(key64_a, key64_b);
         rocprim::double_buffer<uint32_t> vv(pos, pos_alt);
-        e = rocprim::radix_sort_pairs(sort_tmp, tb, kk, vv, (size_t)n, 0u, 64u, st);
+        e = rocprim::radix_sort_pairs(sort_tmp, tb, kk, vv, (size_t)n, 0u, sbits + fbits, st);
         if (e != hipSuccess) return (int)e;
         pos = vv.current();
         pos_alt = vv.alternate();
