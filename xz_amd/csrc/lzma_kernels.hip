@@ -231,7 +231,7 @@ __global__ __launch_bounds__(64) void k_h2_prev(const uint8_t* __restrict__ in, 
 
 // The same distances, written in sorted order (d[i] belongs to position vals[i]).  A scattered 4-byte store
 // costs a whole sector and 1.4 G of them run at ~30 G/s; sorting the (position, distance) pairs back by
-// position (invert_by_sort below: four streaming radix passes) is twice as fast.
+// position (invert_perm below: two streaming radix passes and an LDS step) is more than twice as fast.
 __global__ __launch_bounds__(256) void k_link_prev_seq(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals,
         uint32_t n, uint32_t* __restrict__ d)
 {
@@ -244,6 +244,39 @@ __global__ __launch_bounds__(256) void k_iota(uint32_t* __restrict__ v, uint32_t
 {
     const uint32_t stride = gridDim.x * blockDim.x;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) v[i] = i;
+}
+
+// Last step of an inversion (invert_perm below).  The (position, value) pairs arrive sorted by position >> 15;
+// the positions are a permutation of 0..n-1, so bucket b is exactly the pairs of positions [b << 15, (b + 1) << 15)
+// and sits in exactly those slots.  One workgroup per bucket places the values in LDS by the low 15 bits and
+// writes the 128 KiB out linearly: the last 15 key bits cost one read and one coalesced write instead of two
+// radix passes.  In place is fine (a bucket reads and writes the same slots, reads first).
+constexpr uint32_t INV_LOW = 15;
+__global__ __launch_bounds__(1024) void k_inv_low_u32(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals,
+        uint32_t n, uint32_t* __restrict__ out)
+{
+    __shared__ uint32_t lds_inv[1u << INV_LOW];             // 128 KiB of the 160 KiB a CU has
+    const uint32_t base = blockIdx.x << INV_LOW;
+    const uint32_t cnt = min(n - base, 1u << INV_LOW);
+    for (uint32_t i = threadIdx.x; i < cnt; i += 1024) lds_inv[keys[base + i] & ((1u << INV_LOW) - 1)] = vals[base + i];
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < cnt; i += 1024) out[base + i] = lds_inv[i];
+}
+
+// 64-bit values: the two halves go to two arrays (out_lo, out_hi), one LDS round each
+__global__ __launch_bounds__(1024) void k_inv_low_u64(const uint32_t* __restrict__ keys, const uint64_t* __restrict__ vals,
+        uint32_t n, uint32_t* __restrict__ out_lo, uint32_t* __restrict__ out_hi)
+{
+    __shared__ uint32_t lds_inv[1u << INV_LOW];             // 128 KiB of the 160 KiB a CU has
+    const uint32_t base = blockIdx.x << INV_LOW;
+    const uint32_t cnt = min(n - base, 1u << INV_LOW);
+    for (uint32_t i = threadIdx.x; i < cnt; i += 1024) lds_inv[keys[base + i] & ((1u << INV_LOW) - 1)] = (uint32_t)vals[base + i];
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < cnt; i += 1024) out_lo[base + i] = lds_inv[i];
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < cnt; i += 1024) lds_inv[keys[base + i] & ((1u << INV_LOW) - 1)] = (uint32_t)(vals[base + i] >> 32);
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < cnt; i += 1024) out_hi[base + i] = lds_inv[i];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -314,7 +347,7 @@ __global__ __launch_bounds__(256) void k_sa_block_unpack(const uint32_t* __restr
 // Slot order: rk[i] = (group start + 1, distance to the left neighbour inside the group or 0) of position pos[i].
 // The second word is a by-product of the sort round: inside a group of equal keys positions ascend, so the left
 // neighbour of a group member is the nearest earlier position with the same 8 (round 0) / 16 (round 1) bytes.
-// The pairs are then sorted by position (invert_by_sort), which leaves rk indexed by position.
+// The pairs are then brought to position order (invert_perm): two arrays indexed by position.
 __global__ __launch_bounds__(256) void k_sa_rank_seq(const uint32_t* __restrict__ pos, const uint32_t* __restrict__ grp,
         uint32_t n, uint2* __restrict__ rk)
 {
@@ -330,7 +363,7 @@ __global__ __launch_bounds__(256) void k_sa_rank_seq(const uint32_t* __restrict_
 // block_size + 1), so the key is 31 + sbits bits wide instead of 62: one radix pass less for Blocks up to 32 MiB.  (The radix sort is stable and the members of a group ascend by
 // position in slot order too, so feeding it in position order gives the same result as slot order -- without
 // the random gather of rank[p + h].)
-__global__ __launch_bounds__(256) void k_sa_pair_keys_pos(const uint2* __restrict__ rank, uint32_t n, uint32_t block_size,
+__global__ __launch_bounds__(256) void k_sa_pair_keys_pos(const uint32_t* __restrict__ rank, uint32_t n, uint32_t block_size,
         uint32_t h, uint32_t sbits, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals)
 {
     const uint32_t stride = gridDim.x * blockDim.x;
@@ -339,8 +372,8 @@ __global__ __launch_bounds__(256) void k_sa_pair_keys_pos(const uint2* __restric
         const uint32_t bs = b * block_size;
         const uint32_t bend = min(n, bs + block_size);
         // the second half lies in the same Block, whose slots are [bs, bend): relative rank 1..block_size
-        const uint32_t second = p + h < bend ? rank[p + h].x - bs : 0u;
-        keys[p] = ((uint64_t)rank[p].x << sbits) | second;
+        const uint32_t second = p + h < bend ? rank[p + h] - bs : 0u;
+        keys[p] = ((uint64_t)rank[p] << sbits) | second;
         vals[p] = p;
     }
 }
@@ -2096,8 +2129,8 @@ struct SnArgs {
     const uint32_t* __restrict__ sa_rank;   // position -> slot
     const uint32_t* __restrict__ prev2;
     const uint32_t* __restrict__ prev4;
-    const uint32_t* __restrict__ prev8;     // stride 2 (interleaved with the round's rank)
-    const uint32_t* __restrict__ prev16;    // stride 2
+    const uint32_t* __restrict__ prev8;
+    const uint32_t* __restrict__ prev16;
 };
 constexpr uint32_t SN_WMAX = 5;
 
@@ -2165,7 +2198,7 @@ __global__ __launch_bounds__(64) void k_find_sn(xzamd_span_args a, SnArgs sn, ui
     // nothing on text and 0.1 % on executables next to these: its sort and inversion are not built for this finder.)
     const bool hash_lane = t == 10 || (t >= 12 && t < 15);
     const uint32_t* __restrict__ hp = t == 10 ? sn.prev2 : t == 12 ? sn.prev4 : t == 13 ? sn.prev8 : sn.prev16;
-    const uint32_t hstride = t >= 13 ? 2u : 1u;
+    const uint32_t hstride = 1u;
     const uint32_t minlen = t == 10 ? 2u : 4u;
     // masks for the prefix maximum inside a side (the right side must not look into the left one)
     const bool sh1 = t != 0 && t != 5, sh2 = (left && t >= 2) || (right && t >= 7), sh4 = (left && t >= 4) || (right && t >= 9);
@@ -2685,25 +2718,34 @@ __global__ __launch_bounds__(64) void k_crc_fold(const T* __restrict__ strips, u
 // Assembly: gather span outputs (and small literal pieces prepared by the host: headers,
 // end markers, padding, checks, index, footer) into the final stream buffer.
 // One workgroup per copy segment.
-// vals_inout[key[i]] = v[i] for a permutation `key` of 0..n-1, as a sort: radix_sort_pairs by key leaves the values
-// in key order.  keys_cur / vals_inout hold the pairs, the *_alt buffers are scratch; the keys come out sorted (iota).
+// out[key[i]] = v[i] for a permutation `key` of 0..n-1: radix passes over the key bits above INV_LOW, then the LDS
+// step.  keys_cur / vals_cur hold the pairs, the *_alt buffers are scratch; all four are clobbered.
+// u32 values: out may be one of the value buffers.  u64 values: out_lo / out_hi must not overlap them.
 template <typename V>
-static hipError_t invert_by_sort(uint32_t* keys_cur, uint32_t* keys_alt, V* vals_inout, V* vals_alt, uint32_t n,
-        void* tmp, size_t tmp_bytes, hipStream_t st)
+static hipError_t invert_perm(uint32_t* keys_cur, uint32_t* keys_alt, V* vals_cur, V* vals_alt, uint32_t n,
+        uint32_t* out_lo, uint32_t* out_hi, void* tmp, size_t tmp_bytes, hipStream_t st)
 {
+    if (n == 0) return hipSuccess;
     uint32_t bits = 1;
     while (bits < 32 && (1ull << bits) < n) ++bits;
     rocprim::double_buffer<uint32_t> kb(keys_cur, keys_alt);
-    rocprim::double_buffer<V> vb(vals_inout, vals_alt);
-    size_t need = 0;
-    hipError_t e = rocprim::radix_sort_pairs(nullptr, need, kb, vb, (size_t)n, 0u, bits, st);
-    if (e != hipSuccess) return e;
-    if (need > tmp_bytes) return hipErrorOutOfMemory;
-    e = rocprim::radix_sort_pairs(tmp, tmp_bytes, kb, vb, (size_t)n, 0u, bits, st);
-    if (e != hipSuccess) return e;
-    if (vb.current() != vals_inout)
-        e = hipMemcpyAsync(vals_inout, vb.current(), (size_t)n * sizeof(V), hipMemcpyDeviceToDevice, st);
-    return e;
+    rocprim::double_buffer<V> vb(vals_cur, vals_alt);
+    if (bits > INV_LOW) {
+        size_t need = 0;
+        hipError_t e = rocprim::radix_sort_pairs(nullptr, need, kb, vb, (size_t)n, INV_LOW, bits, st);
+        if (e != hipSuccess) return e;
+        if (need > tmp_bytes) return hipErrorOutOfMemory;
+        e = rocprim::radix_sort_pairs(tmp, tmp_bytes, kb, vb, (size_t)n, INV_LOW, bits, st);
+        if (e != hipSuccess) return e;
+    }
+    const uint32_t nb = (n + (1u << INV_LOW) - 1) >> INV_LOW;
+    if constexpr (sizeof(V) == 4)
+        hipLaunchKernelGGL(k_inv_low_u32, dim3(nb), dim3(1024), 0, st, kb.current(),
+                reinterpret_cast<const uint32_t*>(vb.current()), n, out_lo);
+    else
+        hipLaunchKernelGGL(k_inv_low_u64, dim3(nb), dim3(1024), 0, st, kb.current(),
+                reinterpret_cast<const uint64_t*>(vb.current()), n, out_lo, out_hi);
+    return hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2843,7 +2885,7 @@ int xzk_build_chains(const uint8_t* d_in, uint32_t n, uint32_t block_size, uint3
         if (target != nullptr) {
             // distances in sorted order, then back to position order by a sort on the position
             hipLaunchKernelGGL(k_link_prev_seq, dim3(g), dim3(256), 0, st, kb.current(), vb.current(), n, target);
-            e = invert_by_sort<uint32_t>(vb.current(), vb.alternate(), target, kb.current(), n, sort_tmp, tb, st);
+            e = invert_perm<uint32_t>(vb.current(), vb.alternate(), target, kb.current(), n, target, nullptr, sort_tmp, tb, st);
             if (e != hipSuccess) return (int)e;
         } else {
             hipLaunchKernelGGL(k_link_main, dim3(g), dim3(256), 0, st, kb.current(), vb.current(), n, sorted_pos, rank);
@@ -2897,14 +2939,14 @@ int xzk_build_chains(const uint8_t* d_in, uint32_t n, uint32_t block_size, uint3
     while (sbits < 32 && (1ull << sbits) <= (uint64_t)min(block_size, n)) ++sbits;
     while (fbits < 32 && (1ull << fbits) <= (uint64_t)n) ++fbits;
     for (uint32_t h = 8; h <= 16; h *= 2) {
-        uint64_t* const rk = h == 8 ? rp8 : rp16;
-        // (rank, left-neighbour distance) of every slot, sorted back to position order
-        hipLaunchKernelGGL(k_sa_rank_seq, dim3(g), dim3(256), 0, st, pos, grp, n, reinterpret_cast<uint2*>(rk));
-        e = invert_by_sort<uint64_t>(pos, pos_alt, rk, key64_b, n, sort_tmp, tb, st);
+        // by-position arrays of the round: rank at rk32[0..n), left-neighbour distance at rk32[n..2n)
+        uint32_t* const rk32 = reinterpret_cast<uint32_t*>(h == 8 ? rp8 : rp16);
+        // (rank, left-neighbour distance) of every slot, brought to position order
+        hipLaunchKernelGGL(k_sa_rank_seq, dim3(g), dim3(256), 0, st, pos, grp, n, reinterpret_cast<uint2*>(key64_a));
+        e = invert_perm<uint64_t>(pos, pos_alt, key64_a, key64_b, n, rk32, rk32 + n, sort_tmp, tb, st);
         if (e != hipSuccess) return (int)e;
         // keys in position order (values = iota): both `pos` buffers are free again
-        hipLaunchKernelGGL(k_sa_pair_keys_pos, dim3(g), dim3(256), 0, st, reinterpret_cast<const uint2*>(rk), n, block_size, h,
-                sbits, key64_a, pos);
+        hipLaunchKernelGGL(k_sa_pair_keys_pos, dim3(g), dim3(256), 0, st, rk32, n, block_size, h, sbits, key64_a, pos);
         rocprim::double_buffer<uint64_t> kk(key64_a, key64_b);
         rocprim::double_buffer<uint32_t> vv(pos, pos_alt);
         e = rocprim::radix_sort_pairs(sort_tmp, tb, kk, vv, (size_t)n, 0u, sbits + fbits, st);
@@ -2919,7 +2961,7 @@ int xzk_build_chains(const uint8_t* d_in, uint32_t n, uint32_t block_size, uint3
     }
     // sa = slot order; sa_rank = its inverse (grp = keys_a is dead: scratch of the inversion)
     hipLaunchKernelGGL(k_sa_final_seq, dim3(g), dim3(256), 0, st, pos, n, sa, sa_rank);
-    e = invert_by_sort<uint32_t>(pos, pos_alt, sa_rank, keys_a, n, sort_tmp, tb, st);
+    e = invert_perm<uint32_t>(pos, pos_alt, sa_rank, keys_a, n, sa_rank, nullptr, sort_tmp, tb, st);
     if (e != hipSuccess) return (int)e;
     return (int)hipGetLastError();
 }
@@ -2934,8 +2976,8 @@ int xzk_find_matches(const xzamd_span_args* a, const uint32_t* sa, const uint32_
         if (!sa || !sa_rank || !prev4 || !rp8 || !rp16 || a->sa_window > SN_WMAX) return (int)hipErrorInvalidValue;
         SnArgs sn;
         sn.in = a->in; sn.sa = sa; sn.sa_rank = sa_rank; sn.prev2 = a->prev2; sn.prev4 = prev4;
-        sn.prev8 = reinterpret_cast<const uint32_t*>(rp8) + 1;        // second word of each (rank, distance) pair
-        sn.prev16 = reinterpret_cast<const uint32_t*>(rp16) + 1;
+        sn.prev8 = reinterpret_cast<const uint32_t*>(rp8) + a->n;     // second array of the round's (rank, distance) pair
+        sn.prev16 = reinterpret_cast<const uint32_t*>(rp16) + a->n;
         hipLaunchKernelGGL(k_find_sn, dim3(runs), dim3(64), 0, st, *a, sn, mlen, mdist);
     } else {
         hipLaunchKernelGGL(k_find_exact, dim3(runs), dim3(64), 0, st, *a, mlen, mdist);
