@@ -1254,6 +1254,7 @@ __device__ __forceinline__ void relax_lengths(const Work& w, const LenTab& lt, u
     const uint32_t info_rep = (s < 7 ? 8u : 11u) << 9, info_match = (s < 7 ? 7u : 10u) << 9;
     const uint32_t lo_ps = PS == 0 ? lt.lo[0] : PS == 1 ? lt.lo[1] : PS == 2 ? lt.lo[2] : lt.lo[3];
     const uint32_t SLx = lane + 1 < cnt ? SL : 0xFFFFu;      // list lengths with everything from the last entry on = infinity
+    const bool any_rep = (rl0 | rl1 | rl2 | rl3) != 0;
     // not unrolled: one pass covers 64 lengths and is all that nearly every node needs; five copies of
     // the body would only cost instruction-cache space
 #pragma unroll 1
@@ -1274,16 +1275,18 @@ __device__ __forceinline__ void relax_lengths(const Work& w, const LenTab& lt, u
         const uint32_t di = 31 - (uint32_t)__builtin_clz(dnz);
         const uint32_t slot = dist_m < 4 ? dist_m : 2 * di + ((dnz >> (di - 1)) & 1);
         const uint32_t p_dist = (uint32_t)w.dsp[ds * 64 + slot] + w.xt[dist_m < 128 ? dist_m : 128 + (dist_m & 15)];
-        const uint32_t c0 = rl0 >= l ? prep0 + lpr : PRICE_INF;
-        const uint32_t c1 = rl1 >= l ? prep1 + lpr : PRICE_INF;
-        const uint32_t c2 = rl2 >= l ? prep2 + lpr : PRICE_INF;
-        const uint32_t c3 = rl3 >= l ? prep3 + lpr : PRICE_INF;
         const uint32_t c4 = l <= longest ? pmatch + lpm + p_dist : PRICE_INF;
         uint32_t best = cur, bb = 0, n0 = r0;
-        { const bool t = c0 < best; best = t ? c0 : best; bb = t ? 0u : bb; }
-        { const bool t = c1 < best; best = t ? c1 : best; bb = t ? 1u : bb; n0 = t ? r1 : n0; }
-        { const bool t = c2 < best; best = t ? c2 : best; bb = t ? 2u : bb; n0 = t ? r2 : n0; }
-        { const bool t = c3 < best; best = t ? c3 : best; bb = t ? 3u : bb; n0 = t ? r3 : n0; }
+        if (any_rep) {                              // uniform: most nodes of a text have no usable rep match
+            const uint32_t c0 = rl0 >= l ? prep0 + lpr : PRICE_INF;
+            const uint32_t c1 = rl1 >= l ? prep1 + lpr : PRICE_INF;
+            const uint32_t c2 = rl2 >= l ? prep2 + lpr : PRICE_INF;
+            const uint32_t c3 = rl3 >= l ? prep3 + lpr : PRICE_INF;
+            { const bool t = c0 < best; best = t ? c0 : best; bb = t ? 0u : bb; }
+            { const bool t = c1 < best; best = t ? c1 : best; bb = t ? 1u : bb; n0 = t ? r1 : n0; }
+            { const bool t = c2 < best; best = t ? c2 : best; bb = t ? 2u : bb; n0 = t ? r2 : n0; }
+            { const bool t = c3 < best; best = t ? c3 : best; bb = t ? 3u : bb; n0 = t ? r3 : n0; }
+        }
         { const bool t = c4 < best; best = t ? c4 : best; bb = t ? dist_m + 4 : bb; n0 = t ? dist_m : n0; }
         const uint32_t n1 = bb == 0 ? r1 : r0;
         const uint32_t n2 = bb <= 1 ? r2 : r1;
@@ -1455,15 +1458,14 @@ __device__ __forceinline__ bool optimum_window(const Env& e, const Work& w, List
             c_bytes = (uint32_t)pl[0] | ((uint32_t)*(pl - cp.dist - 1) << 8) | ((uint32_t)*(pl - 1) << 16);
         }
 
-        if (room < MATCH_LEN_MAX) {                 // only the last nodes of a window can reach past its end
-            if (longest > room) longest = room;
-            if (rl0 > room) rl0 = room;
-            if (rl1 > room) rl1 = room;
-            if (rl2 > room) rl2 = room;
-            if (rl3 > room) rl3 = room;
+        uint32_t rmax = max(max(rl0, rl1), max(rl2, rl3));
+        uint32_t reach = max(longest, rmax);
+        if (reach > room) {                         // only the last nodes of a window can reach past its end
+            longest = min(longest, room);
+            rl0 = min(rl0, room); rl1 = min(rl1, room); rl2 = min(rl2, room); rl3 = min(rl3, room);
+            rmax = min(rmax, room);
+            reach = room;
         }
-        const uint32_t rmax = max(max(rl0, rl1), max(rl2, rl3));
-        const uint32_t reach = max(longest, rmax);
         const uint32_t new_end = max(max(max(n_end, j + reach), j + 1), cT_max);
         for (uint32_t tb = n_end + 1; tb <= new_end; tb += 64)
             if (tb + lane <= new_end) w.n_price[tb + lane] = PRICE_INF;
