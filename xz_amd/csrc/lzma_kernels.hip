@@ -1388,54 +1388,47 @@ __device__ __forceinline__ bool optimum_window(const Env& e, const Work& w, List
             c6 = m1 + e0;                                        // match
         }
     }
+    for (uint32_t t = 1 + lane; t <= WMAX; t += 64) w.n_price[t] = PRICE_INF;     // once per window, not per node
     if (lane == 0) {
         w.n_price[0] = 0;
         w.n_info[0] = z.state << 9;
     }
+    wave_sync();
     uint32_t n_end = 0, j = 0;
     bool next_cached = false, forced = false;
     LitChunk lc;                          // lane = node - (j & ~63): the node's literal prices
     lc.v[0] = lc.v[1] = lc.v[2] = lc.v[3] = lc.v[4] = 0;
     const uint32_t lmask = (0x100u << z.lp) - (0x100u >> z.lc);
+    // node 0: the coder's state; its round may be cached from the previous window
+    uint32_t s = z.state, r0 = z.rep0, r1 = z.rep1, r2 = z.rep2, r3 = z.rep3, Pj = 0;
+    uint32_t b_mb = in[pos - r0 - 1];               // rep0's byte at the node: issued early, used only for a matched literal
+    lit_chunk(in, w.ptab, z, pos, block_start, span_end, lc);
+    if (!cached) round_lists(e, P, pos, span_end, r0, r1, r2, r3, RL);
+    uint32_t longest = RL.longest;
+    {
+        // a window that opens with a >= nice_len rep or match is that symbol (optimum_normal.c:281-306)
+        uint32_t sb = LITERAL, sl = 0;
+        if (RL.rl[0] >= e.nice) { sb = 0; sl = RL.rl[0]; }
+        else if (RL.rl[1] >= e.nice) { sb = 1; sl = RL.rl[1]; }
+        else if (RL.rl[2] >= e.nice) { sb = 2; sl = RL.rl[2]; }
+        else if (RL.rl[3] >= e.nice) { sb = 3; sl = RL.rl[3]; }
+        else if (longest >= e.nice) { sb = lane_of(RL.SD, RL.cnt - 1) + 4; sl = longest; }
+        if (sl) {
+            wave_sync();
+            if (lane == 0) { w.n_price[0] = sb; w.n_info[0] = (z.state << 9) | (sl << 13); }
+            wave_sync();
+            q_end = sl;
+            return false;
+        }
+    }
+    // The loop is rotated: its body prices the edges out of node j, whose state and round are already there;
+    // the state and the round of node j + 1 are fetched at the bottom.
     for (;;) {
         const uint32_t x = pos + j;
-        uint32_t s, r0, r1, r2, r3, Pj;
-        TM_BEGIN(t_derive);
         TM_COUNT(w, 9);
-        if (j > 0) {
-            const uint4 rr = w.n_reps4[j];
-            s = (uni(w.n_info[j]) >> 9) & 15;
-            Pj = uni(w.n_price[j]);
-            r0 = uni(rr.x); r1 = uni(rr.y); r2 = uni(rr.z); r3 = uni(rr.w);
-        } else {
-            s = z.state; r0 = z.rep0; r1 = z.rep1; r2 = z.rep2; r3 = z.rep3; Pj = 0;
-        }
-        TM_END(w, 0, t_derive);
-        TM_BEGIN(t_round);
-        const uint32_t b_mb = in[x - r0 - 1];           // issued now, used only for a matched literal
-        if ((j & 63) == 0) lit_chunk(in, w.ptab, z, x, block_start, span_end, lc);
-        if (!(j == 0 && cached)) round_lists(e, P, x, span_end, r0, r1, r2, r3, RL);
-        uint32_t longest = RL.longest;
-        TM_END(w, 1, t_round);
-        if (j > 0 && longest >= e.nice) { next_cached = true; break; }
         TM_BEGIN(t_bits);
         const uint32_t rp0 = RL.rp[0];
         uint32_t rl0 = RL.rl[0], rl1 = RL.rl[1], rl2 = RL.rl[2], rl3 = RL.rl[3];
-        if (j == 0) {
-            uint32_t sb = LITERAL, sl = 0;
-            if (rl0 >= e.nice) { sb = 0; sl = rl0; }
-            else if (rl1 >= e.nice) { sb = 1; sl = rl1; }
-            else if (rl2 >= e.nice) { sb = 2; sl = rl2; }
-            else if (rl3 >= e.nice) { sb = 3; sl = rl3; }
-            else if (longest >= e.nice) { sb = lane_of(RL.SD, RL.cnt - 1) + 4; sl = longest; }
-            if (sl) {
-                wave_sync();
-                if (lane == 0) { w.n_price[0] = sb; w.n_info[0] = (z.state << 9) | (sl << 13); }
-                wave_sync();
-                q_end = sl;
-                return false;
-            }
-        }
         const uint32_t room = WMAX - j;
         const uint32_t avail = span_end - x;
         const uint32_t buf_avail = avail < MATCH_LEN_MAX ? avail : MATCH_LEN_MAX;
@@ -1466,11 +1459,7 @@ __device__ __forceinline__ bool optimum_window(const Env& e, const Work& w, List
             rmax = min(rmax, room);
             reach = room;
         }
-        const uint32_t new_end = max(max(max(n_end, j + reach), j + 1), cT_max);
-        for (uint32_t tb = n_end + 1; tb <= new_end; tb += 64)
-            if (tb + lane <= new_end) w.n_price[tb + lane] = PRICE_INF;
-        n_end = new_end;
-        wave_sync();
+        n_end = max(max(max(n_end, j + reach), j + 1), cT_max);     // (every node price was set to infinity at the window start)
 
         const uint32_t upos = x - block_start;
         const uint32_t ps = upos & pbm;
@@ -1607,6 +1596,23 @@ __device__ __forceinline__ bool optimum_window(const Env& e, const Work& w, List
         TM_END(w, 14, t_cp);
         ++j;
         if (j == n_end) { forced = j >= WMAX; break; }
+        // state and round of the next node
+        {
+            TM_BEGIN(t_derive);
+            const uint4 rr = w.n_reps4[j];
+            s = (uni(w.n_info[j]) >> 9) & 15;
+            Pj = uni(w.n_price[j]);
+            r0 = uni(rr.x); r1 = uni(rr.y); r2 = uni(rr.z); r3 = uni(rr.w);
+            TM_END(w, 0, t_derive);
+            TM_BEGIN(t_round);
+            const uint32_t xn = pos + j;
+            b_mb = in[xn - r0 - 1];
+            if ((j & 63) == 0) lit_chunk(in, w.ptab, z, xn, block_start, span_end, lc);
+            round_lists(e, P, xn, span_end, r0, r1, r2, r3, RL);
+            longest = RL.longest;
+            TM_END(w, 1, t_round);
+            if (longest >= e.nice) { next_cached = true; break; }
+        }
     }
     TM_BEGIN(t_back);
     // backtrack from node j: turn in-edges into out-edges.  A compound in-edge becomes three (two when
