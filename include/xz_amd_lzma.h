@@ -64,6 +64,11 @@ typedef enum {
 
 #define LZMA_FILTER_LZMA2 UINT64_C(0x21)
 #define LZMA_FILTER_X86   UINT64_C(0x04)
+#define LZMA_FILTER_POWERPC UINT64_C(0x05)
+#define LZMA_FILTER_IA64 UINT64_C(0x06)
+#define LZMA_FILTER_ARM UINT64_C(0x07)
+#define LZMA_FILTER_ARMTHUMB UINT64_C(0x08)
+#define LZMA_FILTER_SPARC UINT64_C(0x09)
 #define LZMA_FILTER_ARM64 UINT64_C(0x0A)
 #define LZMA_FILTER_DELTA UINT64_C(0x03)
 /* api/lzma/delta.h:24-90 */

@@ -143,6 +143,26 @@ def test_suffix_order_and_match_lists_identical_to_oracle(enc):
                 assert len(bad) == 0, ("match lists", name, bs, b0, int(bad[0]), got[bad[0]].tolist(), want[bad[0]].tolist())
 
 
+@pytest.mark.parametrize("n", [1, 5, 1000, 32767, 32768, 32769, 70001])
+def test_structure_build_edge_sizes(enc, n):
+    """Sizes around the 32 Ki-position buckets of the by-position inversion (and below one bucket, where no radix
+    pass runs at all), Blocks smaller and larger than the input: suffix order, rank and whole Stream vs the oracle."""
+    import xz_amd
+    data = xz_amd.corpus_text(max(n, 4096), seed=17).tobytes()[:n]
+    for bs in (4096, 1 << 20):
+        opts = xz_amd.preset_options(6)
+        prm = o.params_for_gpu_options(opts)
+        got, _ = gpu_encode(enc, data, opts, bs)
+        assert o.first_diff(got, o.orc_xz_stream(data, prm, bs)) == -1, (n, bs)
+        sa = enc.debug_fetch(1, n)
+        rk = enc.debug_fetch(2, n)
+        for b0 in range(0, n, bs):
+            blk = data[b0:b0 + bs]
+            osa, ork = o.orc_sa_dump(blk)
+            assert (sa[b0:b0 + len(blk)] == osa + b0).all(), ("suffix order", n, bs, b0)
+            assert (rk[b0:b0 + len(blk)] == ork + b0).all(), ("rank", n, bs, b0)
+
+
 SIZE_TOLERANCE = 0.03
 
 
@@ -200,6 +220,74 @@ def _arm64_like(n, seed):
     w[adrp] = (w[adrp] & 0x60FFFFFF) | 0x90000000
     w[adrp & (rng.random(len(w)) < 0.7)] &= 0xFF03FFFF       # small immediates: inside the +/-512 MiB range
     return w.astype("<u4").tobytes()[:n]
+
+
+_SIMPLE_BCJ = {"powerpc": 5, "ia64": 6, "arm": 7, "armthumb": 8, "sparc": 9}
+
+
+def _bcj_like(kind, n, seed):
+    """Random bytes with many branch-shaped words of the given architecture planted at aligned offsets."""
+    rng = np.random.default_rng(seed)
+    b = rng.integers(0, 256, n + 16, dtype=np.uint8)
+    if kind == "arm":
+        idx = np.arange(0, n - 4, 4)[rng.random((n - 4 + 3) // 4) < 0.3]
+        b[idx + 3] = 0xEB
+    elif kind == "powerpc":
+        idx = np.arange(0, n - 4, 4)[rng.random((n - 4 + 3) // 4) < 0.3]
+        b[idx] = 0x48 | (b[idx] & 3)
+        b[idx + 3] = (b[idx + 3] & 0xFC) | 1
+    elif kind == "sparc":
+        idx = np.arange(0, n - 4, 4)[rng.random((n - 4 + 3) // 4) < 0.3]
+        pos = rng.random(len(idx)) < 0.5
+        b[idx[pos]] = 0x40
+        b[idx[pos] + 1] &= 0x3F
+        b[idx[~pos]] = 0x7F
+        b[idx[~pos] + 1] |= 0xC0
+    elif kind == "armthumb":
+        idx = np.arange(0, n - 4, 2)[rng.random((n - 4 + 1) // 2) < 0.2]
+        b[idx + 1] = 0xF0 | (b[idx + 1] & 7)
+        b[idx + 3] = 0xF8 | (b[idx + 3] & 7)
+    elif kind == "ia64":
+        for i in range(0, n - 16, 16):
+            if rng.random() < 0.5:
+                v = int.from_bytes(b[i:i + 16].tobytes(), "little")
+                v = (v & ~0x1F) | int(rng.choice([16, 17, 18, 19, 22, 23, 24, 25, 28, 29]))
+                for slot in range(3):
+                    if rng.random() < 0.7:
+                        bp = 5 + 41 * slot
+                        v &= ~(0xF << (bp + 37)); v |= 5 << (bp + 37)
+                        v &= ~(7 << (bp + 9))
+                b[i:i + 16] = np.frombuffer((v & ((1 << 128) - 1)).to_bytes(16, "little"), dtype=np.uint8)
+    return b[:n].tobytes()
+
+
+@pytest.mark.parametrize("kind", sorted(_SIMPLE_BCJ))
+def test_simple_bcj_chains_identical_to_reference(enc, kind):
+    """{PowerPC | IA-64 | ARM | ARM-Thumb | SPARC BCJ, LZMA2} (simple/powerpc.c, ia64.c, arm.c, armthumb.c, sparc.c):
+    with one span per Block the whole .xz Stream equals the reference MT encoder's, Blocks that are not multiples of
+    the instruction size, tiny inputs; in span mode it decodes bit-exactly through the real decoder."""
+    import torch, xz_amd
+    if not o.have_ref():
+        pytest.skip("oracle/_ref not built")
+    fid = _SIMPLE_BCJ[kind]
+    cases = {"code": _bcj_like(kind, 500000, 5), "mixed": o.corpus_mixed(200000, 4), "tiny": _bcj_like(kind, 3, 1),
+             "odd": _bcj_like(kind, 4099, 2), "17": _bcj_like(kind, 17, 3)}
+    for preset in (1, 3):
+        opts = xz_amd.preset_options(preset, span_size=xz_amd.SPAN_WHOLE_BLOCK)
+        opts.bcj = fid
+        for name, data in cases.items():
+            for bs in (1 << 20, 200001, 65537):
+                t = torch.frombuffer(bytearray(data), dtype=torch.uint8).cuda()
+                out, _ = enc.encode(t, opts=opts, block_size=bs, check=4)
+                ref = o.ref_encode_mt_chain(data, preset, fid, 1, threads=2, block_size=bs, check=4)
+                assert o.first_diff(out.cpu().numpy().tobytes(), ref) == -1, (kind, name, preset, bs)
+    opts = xz_amd.preset_options(6)
+    opts.bcj = fid
+    data = cases["code"] + cases["mixed"]
+    t = torch.frombuffer(bytearray(data), dtype=torch.uint8).cuda()
+    out, _ = enc.encode(t, opts=opts, block_size=300000, check=4)
+    rr, dec = o.ref_decode(out.cpu().numpy().tobytes(), len(data) + 16)
+    assert rr == 1 and dec == data, kind
 
 
 @pytest.mark.parametrize("kind", ["arm64", "delta1", "delta4", "delta256", "sha256"])

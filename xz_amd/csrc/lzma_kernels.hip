@@ -2549,6 +2549,100 @@ __global__ __launch_bounds__(256) void k_arm64_bcj(const uint8_t* __restrict__ i
     }
 }
 
+// ARM / PowerPC / SPARC (simple/arm.c, powerpc.c, sparc.c: one 4-byte instruction per slot), ARM-Thumb
+// (simple/armthumb.c: 2-byte slots, a BL pair is 4 bytes) and IA-64 (simple/ia64.c: 16-byte bundles of three
+// 41-bit slots).  pc = offset inside the Block (start offset 0); the tail the reference leaves unfiltered
+// (size & 3, size & 15, the last < 4 bytes) stays as it is.  Every slot converts on its own: in ARM-Thumb the
+// reference skips the halfword behind a converted pair, but that halfword can never start a pair itself (its
+// second byte would have to be 0xF0..0xF7 and 0xF8..0xFF at once), so the slots are independent there too.
+__global__ __launch_bounds__(256) void k_bcj_simple(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, uint32_t n,
+        uint32_t block_size, uint32_t nblocks, uint32_t kind)
+{
+    const uint32_t unit = kind == 8 ? 2u : kind == 6 ? 16u : 4u;
+    const uint32_t spb = block_size / unit;                   // slots per full Block
+    if (spb == 0) return;
+    const uint64_t total = (uint64_t)spb * nblocks;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+        const uint32_t b = (uint32_t)(t / spb), k = (uint32_t)(t - (uint64_t)b * spb);
+        const uint32_t bs = b * block_size;
+        if (bs >= n) continue;
+        const uint32_t blen = min(n - bs, block_size);
+        const uint32_t pc = k * unit;
+        const uint8_t* p = in + bs + pc;
+        uint8_t* q = out + bs + pc;
+        if (kind == 8) {                                      // ARM-Thumb BL pair
+            if (blen < 4 || pc > blen - 4) continue;
+            if ((p[1] & 0xF8u) != 0xF0u || (p[3] & 0xF8u) != 0xF8u) continue;
+            uint32_t src = ((uint32_t)(p[1] & 7u) << 19) | ((uint32_t)p[0] << 11) | ((uint32_t)(p[3] & 7u) << 8) | p[2];
+            src <<= 1;
+            const uint32_t dest = (pc + 4 + src) >> 1;
+            q[1] = (uint8_t)(0xF0u | ((dest >> 19) & 7u));
+            q[0] = (uint8_t)(dest >> 11);
+            q[3] = (uint8_t)(0xF8u | ((dest >> 8) & 7u));
+            q[2] = (uint8_t)dest;
+        } else if (kind == 6) {                               // IA-64 bundle
+            if (pc + 16 > (blen & ~15u)) continue;
+            uint8_t bun[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) bun[i] = p[i];
+            const uint32_t tmpl = bun[0] & 0x1Fu;
+            // branch slots by template (ia64.c BRANCH_TABLE): 16,17: 4  18,19: 6  22,23: 7  24,25,28,29: 4
+            const uint32_t mask = (tmpl == 16 || tmpl == 17 || tmpl == 24 || tmpl == 25 || tmpl == 28 || tmpl == 29) ? 4u
+                    : (tmpl == 18 || tmpl == 19) ? 6u : (tmpl == 22 || tmpl == 23) ? 7u : 0u;
+            bool changed = false;
+            uint32_t bit_pos = 5;
+            for (uint32_t slot = 0; slot < 3; ++slot, bit_pos += 41) {
+                if (((mask >> slot) & 1u) == 0) continue;
+                const uint32_t byte_pos = bit_pos >> 3, bit_res = bit_pos & 7u;
+                uint64_t instruction = 0;
+                for (uint32_t j = 0; j < 6; ++j) instruction += (uint64_t)bun[j + byte_pos] << (8 * j);
+                uint64_t norm = instruction >> bit_res;
+                if (((norm >> 37) & 0xFu) != 0x5u || ((norm >> 9) & 0x7u) != 0) continue;
+                uint32_t src = (uint32_t)((norm >> 13) & 0xFFFFFu);
+                src |= (uint32_t)((norm >> 36) & 1u) << 20;
+                src <<= 4;
+                const uint32_t dest = (pc + src) >> 4;
+                norm &= ~((uint64_t)0x8FFFFF << 13);
+                norm |= (uint64_t)(dest & 0xFFFFFu) << 13;
+                norm |= (uint64_t)(dest & 0x100000u) << (36 - 20);
+                instruction &= (1u << bit_res) - 1;
+                instruction |= norm << bit_res;
+                for (uint32_t j = 0; j < 6; ++j) bun[j + byte_pos] = (uint8_t)(instruction >> (8 * j));
+                changed = true;
+            }
+            if (changed) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) q[i] = bun[i];
+            }
+        } else {
+            if (pc + 4 > (blen & ~3u)) continue;
+            if (kind == 7) {                                  // ARM BL (little endian, condition "always")
+                if (p[3] != 0xEBu) continue;
+                uint32_t src = ((uint32_t)p[2] << 16) | ((uint32_t)p[1] << 8) | p[0];
+                src <<= 2;
+                const uint32_t dest = (pc + 8 + src) >> 2;
+                q[2] = (uint8_t)(dest >> 16); q[1] = (uint8_t)(dest >> 8); q[0] = (uint8_t)dest;
+            } else if (kind == 5) {                           // PowerPC b/bl with AA = 0, LK = 1 (big endian)
+                if ((p[0] >> 2) != 0x12u || (p[3] & 3u) != 1u) continue;
+                const uint32_t src = ((uint32_t)(p[0] & 3u) << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | (p[3] & ~3u);
+                const uint32_t dest = pc + src;
+                q[0] = (uint8_t)(0x48u | ((dest >> 24) & 3u));
+                q[1] = (uint8_t)(dest >> 16);
+                q[2] = (uint8_t)(dest >> 8);
+                q[3] = (uint8_t)((p[3] & 3u) | (dest & 0xFFu));
+            } else {                                          // SPARC call (big endian)
+                if (!((p[0] == 0x40u && (p[1] & 0xC0u) == 0x00u) || (p[0] == 0x7Fu && (p[1] & 0xC0u) == 0xC0u))) continue;
+                uint32_t src = ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3];
+                src <<= 2;
+                uint32_t dest = (pc + src) >> 2;
+                dest = (((0u - ((dest >> 22) & 1u)) << 22) & 0x3FFFFFFFu) | (dest & 0x3FFFFFu) | 0x40000000u;
+                q[0] = (uint8_t)(dest >> 24); q[1] = (uint8_t)(dest >> 16); q[2] = (uint8_t)(dest >> 8); q[3] = (uint8_t)dest;
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void k_delta(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, uint32_t n,
         uint32_t block_size, uint32_t dist)
 {
@@ -3025,7 +3119,8 @@ int xzk_x86_bcj(const uint8_t* d_in, uint8_t* d_out, uint32_t n, uint32_t block_
     return (int)hipGetLastError();
 }
 
-// prefilter kind: 0x0A = ARM64 BCJ, 3 = delta (dist 1..256): d_out = filtered copy of d_in
+// prefilter kind: 0x0A = ARM64 BCJ, 5 / 6 / 7 / 8 / 9 = PowerPC / IA-64 / ARM / ARM-Thumb / SPARC BCJ, 3 = delta (dist 1..256):
+// d_out = filtered copy of d_in
 int xzk_prefilter(const uint8_t* d_in, uint8_t* d_out, uint32_t n, uint32_t block_size, uint32_t nblocks, uint32_t kind, uint32_t dist,
         void* stream_)
 {
@@ -3035,6 +3130,11 @@ int xzk_prefilter(const uint8_t* d_in, uint8_t* d_out, uint32_t n, uint32_t bloc
         int e = (int)hipMemcpyAsync(d_out, d_in, n, hipMemcpyDeviceToDevice, st);
         if (e) return e;
         hipLaunchKernelGGL(k_arm64_bcj, dim3(grid_for((uint64_t)n / 4 + 1, 256, 65536)), dim3(256), 0, st, d_in, d_out, n, block_size, nblocks);
+    } else if (kind >= 5 && kind <= 9) {
+        int e = (int)hipMemcpyAsync(d_out, d_in, n, hipMemcpyDeviceToDevice, st);
+        if (e) return e;
+        hipLaunchKernelGGL(k_bcj_simple, dim3(grid_for((uint64_t)n / 2 + 1, 256, 65536)), dim3(256), 0, st, d_in, d_out, n, block_size,
+                nblocks, kind);
     } else if (kind == 3) {
         hipLaunchKernelGGL(k_delta, dim3(grid_for(n, 256, 65536)), dim3(256), 0, st, d_in, d_out, n, block_size, dist);
     } else {

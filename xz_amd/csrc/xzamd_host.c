@@ -157,7 +157,7 @@ static uint32_t prefilter_flags_size(uint32_t pre)
 
 static uint32_t block_header_size(uint64_t csize, uint64_t usize, uint32_t pre)
 {
-	/* block_header_encoder.c:17-70 for the chains {LZMA2} and {x86 | ARM64 | delta, LZMA2} */
+	/* block_header_encoder.c:17-70 for the chains {LZMA2} and {BCJ | delta, LZMA2} */
 	uint32_t s = 1 + 1 + 4 + vli_len(csize) + vli_len(usize) + 3 + prefilter_flags_size(pre);
 	return (s + 3) & ~3u;
 }
@@ -409,9 +409,9 @@ const char *xzamd_options_check(const xzamd_lzma_options *opt)
 		return "unsupported match finder options for the device path";
 	if (opt->dict_size < 4096 || opt->dict_size > (1u << 30))
 		return "dict_size must be 4 KiB .. 1 GiB on the device path";
-	if (opt->bcj != 0 && opt->bcj != XZAMD_BCJ_X86 && opt->bcj != XZAMD_BCJ_ARM64
+	if (opt->bcj != 0 && !(opt->bcj >= XZAMD_BCJ_X86 && opt->bcj <= XZAMD_BCJ_ARM64)
 			&& ((opt->bcj & 0xFF) != 3 || (opt->bcj >> 8) > 255))
-		return "filters in front of LZMA2: x86 BCJ, ARM64 BCJ or delta";
+		return "filters in front of LZMA2: x86 / PowerPC / IA-64 / ARM / ARM-Thumb / SPARC / ARM64 BCJ or delta";
 	if (opt->gpu_parser && opt->pb > 2)
 		return "the optimal parser's price tables cover pb <= 2";
 	return NULL;
