@@ -341,7 +341,7 @@ def main():
                             f"{'per GPU' if args.scaling == 'weak' else 'in total, whole Blocks dealt to the ranks in order'}, input resident in HBM, "
                             f"output = complete .xz Stream in HBM",
                 "world_size": world,
-                "device_match_finder": ((f"suffix-neighbourhood finder (32-byte-prefix suffix order, {opts.gpu_sa_window} slots per side + hash2/3/4 + equal 8/16 bytes)"
+                "device_match_finder": ((f"suffix-neighbourhood finder (32-byte-prefix suffix order, {opts.gpu_sa_window} slots per side + hash2/hash4 heads + equal 8/16 bytes)"
                                          if opts.gpu_sa_window else f"HC{opts.gpu_mf & 15} depth {opts.gpu_depth} (sort-built chains)")
                                         + f", nice {opts.gpu_nice_len}"),
                 "device_parser": ("windowed optimal parser (232-node DP, exact prices, compound edges) over per-position match lists" if opts.gpu_parser
