@@ -90,10 +90,11 @@ typedef struct {
 	uint32_t gpu_parser; /* 0 = lzma_lzma_optimum_fast semantics, 1 = windowed optimal parser (232-node DP over
 	                        per-position match lists incl. the reference's compound edges; needs pb <= 2,
 	                        else XZAMD_OPTIONS_ERROR) */
-	uint32_t bcj;        /* 0 = chain {LZMA2}; XZAMD_BCJ_* / XZAMD_FILTER_DELTA(d) = that filter in front of LZMA2 (no RISC-V BCJ) */
+	uint32_t bcj;        /* 0 = chain {LZMA2}; XZAMD_BCJ_* / XZAMD_FILTER_DELTA(d) = that filter in front of LZMA2 */
 } xzamd_lzma_options;
 #define XZAMD_BCJ_X86 4u    /* LZMA_FILTER_X86, api/lzma/bcj.h:20 */
 #define XZAMD_BCJ_ARM64 0x0Au   /* LZMA_FILTER_ARM64, api/lzma/bcj.h (simple/arm64.c), start offset 0 */
+#define XZAMD_BCJ_RISCV 0x0Bu   /* LZMA_FILTER_RISCV (simple/riscv.c) */
 #define XZAMD_BCJ_POWERPC 5u    /* LZMA_FILTER_POWERPC (simple/powerpc.c) */
 #define XZAMD_BCJ_IA64 6u       /* LZMA_FILTER_IA64 (simple/ia64.c) */
 #define XZAMD_BCJ_ARM 7u        /* LZMA_FILTER_ARM (simple/arm.c) */

@@ -70,6 +70,7 @@ typedef enum {
 #define LZMA_FILTER_ARMTHUMB UINT64_C(0x08)
 #define LZMA_FILTER_SPARC UINT64_C(0x09)
 #define LZMA_FILTER_ARM64 UINT64_C(0x0A)
+#define LZMA_FILTER_RISCV UINT64_C(0x0B)
 #define LZMA_FILTER_DELTA UINT64_C(0x03)
 /* api/lzma/delta.h:24-90 */
 typedef enum { LZMA_DELTA_TYPE_BYTE = 0 } lzma_delta_type;

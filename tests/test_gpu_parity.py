@@ -222,7 +222,7 @@ def _arm64_like(n, seed):
     return w.astype("<u4").tobytes()[:n]
 
 
-_SIMPLE_BCJ = {"powerpc": 5, "ia64": 6, "arm": 7, "armthumb": 8, "sparc": 9}
+_SIMPLE_BCJ = {"powerpc": 5, "ia64": 6, "arm": 7, "armthumb": 8, "sparc": 9, "riscv": 0x0B}
 
 
 def _bcj_like(kind, n, seed):
@@ -258,19 +258,42 @@ def _bcj_like(kind, n, seed):
                         v &= ~(0xF << (bp + 37)); v |= 5 << (bp + 37)
                         v &= ~(7 << (bp + 9))
                 b[i:i + 16] = np.frombuffer((v & ((1 << 128) - 1)).to_bytes(16, "little"), dtype=np.uint8)
+    elif kind == "riscv":
+        # JAL (rd x1/x5 and others), AUIPC pairs with matching and non-matching second instructions, AUIPC with
+        # rd x0/x2 in and out of the encoder's special form: every jump length of the reference's walk (2/4/6/8)
+        for i in range(0, n - 8, 2):
+            r = rng.random()
+            if r < 0.08:
+                b[i] = 0xEF
+                if rng.random() < 0.7:
+                    b[i + 1] &= 0xF2
+            elif r < 0.2:
+                inst = (int(rng.integers(0, 1 << 32)) & ~0x7F) | 0x17
+                if rng.random() < 0.5:
+                    rd = int(rng.choice([1, 3, 5, 6, 10, 31]))
+                    inst = (inst & ~(0x1F << 7)) | (rd << 7)
+                    if rng.random() < 0.7:
+                        i2 = (int(rng.integers(0, 1 << 32)) & ~(0x1F << 15)) | (rd << 15) | 3
+                        b[i + 4:i + 8] = np.frombuffer(i2.to_bytes(4, "little"), dtype=np.uint8)
+                else:
+                    inst = (inst & ~0x3FFF) | 0x3117 if rng.random() < 0.7 else (inst & ~(0x1F << 7)) | (int(rng.choice([0, 2])) << 7)
+                    if rng.random() < 0.3:
+                        inst &= 0x07FFFFFF
+                b[i:i + 4] = np.frombuffer((inst & 0xFFFFFFFF).to_bytes(4, "little"), dtype=np.uint8)
     return b[:n].tobytes()
 
 
 @pytest.mark.parametrize("kind", sorted(_SIMPLE_BCJ))
 def test_simple_bcj_chains_identical_to_reference(enc, kind):
-    """{PowerPC | IA-64 | ARM | ARM-Thumb | SPARC BCJ, LZMA2} (simple/powerpc.c, ia64.c, arm.c, armthumb.c, sparc.c):
+    """{PowerPC | IA-64 | ARM | ARM-Thumb | SPARC | RISC-V BCJ, LZMA2} (simple/powerpc.c, ia64.c, arm.c, armthumb.c, sparc.c,
+    riscv.c):
     with one span per Block the whole .xz Stream equals the reference MT encoder's, Blocks that are not multiples of
     the instruction size, tiny inputs; in span mode it decodes bit-exactly through the real decoder."""
     import torch, xz_amd
     if not o.have_ref():
         pytest.skip("oracle/_ref not built")
     fid = _SIMPLE_BCJ[kind]
-    cases = {"code": _bcj_like(kind, 500000, 5), "mixed": o.corpus_mixed(200000, 4), "tiny": _bcj_like(kind, 3, 1),
+    cases = {"code": _bcj_like(kind, 120000 if kind == "riscv" else 500000, 5), "mixed": o.corpus_mixed(200000, 4), "tiny": _bcj_like(kind, 3, 1),
              "odd": _bcj_like(kind, 4099, 2), "17": _bcj_like(kind, 17, 3)}
     for preset in (1, 3):
         opts = xz_amd.preset_options(preset, span_size=xz_amd.SPAN_WHOLE_BLOCK)

@@ -20,6 +20,7 @@ SPAN_AUTO = 1
 F_BLOCKS_ONLY = 1
 BCJ_X86 = 4
 BCJ_ARM64 = 0x0A
+BCJ_RISCV = 0x0B
 BCJ_POWERPC, BCJ_IA64, BCJ_ARM, BCJ_ARMTHUMB, BCJ_SPARC = 5, 6, 7, 8, 9
 
 

@@ -2643,6 +2643,106 @@ __global__ __launch_bounds__(256) void k_bcj_simple(const uint8_t* __restrict__ 
     }
 }
 
+// RISC-V (simple/riscv.c:352-609, encoder).  The reference walks the Block in 2-byte steps; what it finds at an
+// examined position decides how far it jumps: 2 (nothing), 4 (a converted JAL, or an AUIPC with rd x0/x2 that is
+// not the special form), 6 (an AUIPC that has no partner), 8 (a converted AUIPC pair in either direction).  All
+// of that is read from bytes no earlier conversion has touched, so step(i) is a function of the input, and a
+// position is examined unless an examined position 2, 4 or 6 bytes before it jumps over it.  Hence the
+// synchronisation rule used to cut the walk into chunks (the x86 kernel above does the same with its own
+// rule): a position whose three predecessors cannot reach over it whatever their state -- step(i-2) <= 2,
+// step(i-4) <= 4, step(i-6) <= 6 -- is examined by every walk.  Each chunk's owner starts at the first such
+// position inside its chunk and stops at the first one behind its chunk.
+__device__ __forceinline__ uint32_t rv_rd32(const uint8_t* p)
+{
+    return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
+}
+// not a pair: rd of the AUIPC != rs1 of the second instruction, or its two lowest opcode bits are not 11
+__device__ __forceinline__ bool rv_not_pair(uint32_t auipc, uint32_t inst2) { return (((auipc << 8) ^ inst2) & 0xF8003u) != 3u; }
+// the special form the encoder itself produces: rd = x2, bits 13:12 = 11, and a "rs1" that is neither x0 nor x2
+__device__ __forceinline__ bool rv_special(uint32_t auipc) { return (auipc & 0x3FFFu) == 0x3117u && ((auipc >> 27) & 0x1Du) != 0; }
+__device__ __forceinline__ uint32_t rv_step(const uint8_t* b, uint32_t i, uint32_t limit)
+{
+    if (i > limit) return 2;
+    const uint32_t b0 = b[i];
+    if (b0 == 0xEFu) return (b[i + 1] & 0x0Du) ? 2u : 4u;
+    if ((b0 & 0x7Fu) != 0x17u) return 2;
+    const uint32_t inst = rv_rd32(b + i);
+    if (inst & 0xE80u) return rv_not_pair(inst, rv_rd32(b + i + 4)) ? 6u : 8u;
+    return rv_special(inst) ? 8u : 4u;
+}
+__device__ __forceinline__ bool rv_sync(const uint8_t* b, uint32_t i, uint32_t limit)
+{
+    return (i < 2 || rv_step(b, i - 2, limit) <= 2) && (i < 4 || rv_step(b, i - 4, limit) <= 4) && (i < 6 || rv_step(b, i - 6, limit) <= 6);
+}
+
+__global__ __launch_bounds__(256) void k_riscv_bcj(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, uint32_t n,
+        uint32_t block_size, uint32_t chunks_per_block, uint32_t nchunks)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nchunks) return;
+    const uint32_t blk = t / chunks_per_block, k = t - blk * chunks_per_block;
+    const uint32_t bs = blk * block_size;
+    if (bs >= n) return;
+    const uint32_t size = min(n - bs, block_size);
+    if (size < 8) return;
+    const uint32_t limit = size - 8;                 // last position the filter examines (riscv.c:364-372)
+    const uint32_t s = k * BCJ_CHUNK;                // BCJ_CHUNK is even
+    if (s > limit) return;
+    const uint32_t e = s + BCJ_CHUNK;
+    const uint8_t* __restrict__ b = in + bs;
+    uint8_t* __restrict__ o = out + bs;
+    uint32_t pos = 0;
+    if (k != 0) {
+        bool found = false;
+        for (uint32_t q = s; q <= limit && q < e; q += 2)
+            if (rv_sync(b, q, limit)) { pos = q; found = true; break; }
+        if (!found) return;                          // the previous owner walks through this chunk
+    }
+    while (pos <= limit) {
+        if (pos >= e && rv_sync(b, pos, limit)) break;      // the next owner's start
+        const uint32_t b0 = b[pos];
+        if (b0 == 0xEFu) {
+            // JAL with rd = x1 / x5: pc-relative 20-bit immediate -> absolute, stored big endian (riscv.c:379-438)
+            const uint32_t b1 = b[pos + 1];
+            if (b1 & 0x0Du) { pos += 2; continue; }
+            const uint32_t b2 = b[pos + 2], b3 = b[pos + 3];
+            uint32_t addr = ((b1 & 0xF0u) << 8) | ((b2 & 0x0Fu) << 16) | ((b2 & 0x10u) << 7) | ((b2 & 0xE0u) >> 4)
+                    | ((b3 & 0x7Fu) << 4) | ((b3 & 0x80u) << 13);
+            addr += pos;
+            o[pos + 1] = (uint8_t)((b1 & 0x0Fu) | ((addr >> 13) & 0xF0u));
+            o[pos + 2] = (uint8_t)(addr >> 9);
+            o[pos + 3] = (uint8_t)(addr >> 1);
+            pos += 4;
+        } else if ((b0 & 0x7Fu) == 0x17u) {
+            uint32_t inst = rv_rd32(b + pos);
+            if (inst & 0xE80u) {
+                // AUIPC with rd other than x0 / x2 (riscv.c:440-551)
+                const uint32_t inst2 = rv_rd32(b + pos + 4);
+                if (rv_not_pair(inst, inst2)) { pos += 6; continue; }
+                uint32_t addr = inst & 0xFFFFF000u;
+                addr += (inst2 >> 20) - ((inst2 >> 19) & 0x1000u);
+                addr += pos;
+                inst = 0x17u | (2u << 7) | (inst2 << 12);
+                o[pos] = (uint8_t)inst; o[pos + 1] = (uint8_t)(inst >> 8); o[pos + 2] = (uint8_t)(inst >> 16); o[pos + 3] = (uint8_t)(inst >> 24);
+                o[pos + 4] = (uint8_t)(addr >> 24); o[pos + 5] = (uint8_t)(addr >> 16); o[pos + 6] = (uint8_t)(addr >> 8); o[pos + 7] = (uint8_t)addr;
+            } else {
+                // AUIPC with rd x0 / x2: only the special form is (un)converted (riscv.c:552-602)
+                if (!rv_special(inst)) { pos += 4; continue; }
+                const uint32_t fake_rs1 = inst >> 27;
+                const uint32_t fake_addr = rv_rd32(b + pos + 4);
+                const uint32_t fake_inst2 = (inst >> 12) | (fake_addr << 20);
+                inst = 0x17u | (fake_rs1 << 7) | (fake_addr & 0xFFFFF000u);
+                o[pos] = (uint8_t)inst; o[pos + 1] = (uint8_t)(inst >> 8); o[pos + 2] = (uint8_t)(inst >> 16); o[pos + 3] = (uint8_t)(inst >> 24);
+                o[pos + 4] = (uint8_t)fake_inst2; o[pos + 5] = (uint8_t)(fake_inst2 >> 8); o[pos + 6] = (uint8_t)(fake_inst2 >> 16);
+                o[pos + 7] = (uint8_t)(fake_inst2 >> 24);
+            }
+            pos += 8;
+        } else {
+            pos += 2;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void k_delta(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, uint32_t n,
         uint32_t block_size, uint32_t dist)
 {
@@ -3119,7 +3219,7 @@ int xzk_x86_bcj(const uint8_t* d_in, uint8_t* d_out, uint32_t n, uint32_t block_
     return (int)hipGetLastError();
 }
 
-// prefilter kind: 0x0A = ARM64 BCJ, 5 / 6 / 7 / 8 / 9 = PowerPC / IA-64 / ARM / ARM-Thumb / SPARC BCJ, 3 = delta (dist 1..256):
+// prefilter kind: 0x0A = ARM64 BCJ, 0x0B = RISC-V BCJ, 5 / 6 / 7 / 8 / 9 = PowerPC / IA-64 / ARM / ARM-Thumb / SPARC BCJ, 3 = delta (dist 1..256):
 // d_out = filtered copy of d_in
 int xzk_prefilter(const uint8_t* d_in, uint8_t* d_out, uint32_t n, uint32_t block_size, uint32_t nblocks, uint32_t kind, uint32_t dist,
         void* stream_)
@@ -3130,6 +3230,14 @@ int xzk_prefilter(const uint8_t* d_in, uint8_t* d_out, uint32_t n, uint32_t bloc
         int e = (int)hipMemcpyAsync(d_out, d_in, n, hipMemcpyDeviceToDevice, st);
         if (e) return e;
         hipLaunchKernelGGL(k_arm64_bcj, dim3(grid_for((uint64_t)n / 4 + 1, 256, 65536)), dim3(256), 0, st, d_in, d_out, n, block_size, nblocks);
+    } else if (kind == 0x0B) {
+        int e = (int)hipMemcpyAsync(d_out, d_in, n, hipMemcpyDeviceToDevice, st);
+        if (e) return e;
+        const uint32_t cpb = (block_size + BCJ_CHUNK - 1) / BCJ_CHUNK;
+        const uint64_t nch = (uint64_t)cpb * nblocks;
+        if (nch > 0xFFFFFFFFull) return (int)hipErrorInvalidValue;
+        hipLaunchKernelGGL(k_riscv_bcj, dim3((uint32_t)((nch + 255) / 256)), dim3(256), 0, st, d_in, d_out, n, block_size, cpb,
+                (uint32_t)nch);
     } else if (kind >= 5 && kind <= 9) {
         int e = (int)hipMemcpyAsync(d_out, d_in, n, hipMemcpyDeviceToDevice, st);
         if (e) return e;

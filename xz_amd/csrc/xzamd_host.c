@@ -409,9 +409,9 @@ const char *xzamd_options_check(const xzamd_lzma_options *opt)
 		return "unsupported match finder options for the device path";
 	if (opt->dict_size < 4096 || opt->dict_size > (1u << 30))
 		return "dict_size must be 4 KiB .. 1 GiB on the device path";
-	if (opt->bcj != 0 && !(opt->bcj >= XZAMD_BCJ_X86 && opt->bcj <= XZAMD_BCJ_ARM64)
+	if (opt->bcj != 0 && !(opt->bcj >= XZAMD_BCJ_X86 && opt->bcj <= XZAMD_BCJ_RISCV)
 			&& ((opt->bcj & 0xFF) != 3 || (opt->bcj >> 8) > 255))
-		return "filters in front of LZMA2: x86 / PowerPC / IA-64 / ARM / ARM-Thumb / SPARC / ARM64 BCJ or delta";
+		return "filters in front of LZMA2: x86 / PowerPC / IA-64 / ARM / ARM-Thumb / SPARC / ARM64 / RISC-V BCJ or delta";
 	if (opt->gpu_parser && opt->pb > 2)
 		return "the optimal parser's price tables cover pb <= 2";
 	return NULL;

@@ -386,8 +386,8 @@ static lzma_ret parse_options(const lzma_mt *o, xzamd_lzma_options *opt, uint64_
 	if (o->filters != NULL) {
 		const lzma_filter *f = o->filters;
 		uint32_t bcj = 0;
-		if (f[0].id >= LZMA_FILTER_X86 && f[0].id <= LZMA_FILTER_ARM64) {
-			/* {BCJ, LZMA2} for x86, PowerPC, IA-64, ARM, ARM-Thumb, SPARC, ARM64 (the filter ids are the values
+		if (f[0].id >= LZMA_FILTER_X86 && f[0].id <= LZMA_FILTER_RISCV) {
+			/* {BCJ, LZMA2} for x86, PowerPC, IA-64, ARM, ARM-Thumb, SPARC, ARM64, RISC-V (the filter ids are the values
 			 * of xzamd_lzma_options.bcj): start offset must be 0 (bcj.h:81-98, NULL options = defaults) */
 			const lzma_options_bcj *b = (const lzma_options_bcj *)f[0].options;
 			if (b != NULL && b->start_offset != 0)
@@ -403,7 +403,7 @@ static lzma_ret parse_options(const lzma_mt *o, xzamd_lzma_options *opt, uint64_
 			++f;
 		}
 		if (f[0].id != LZMA_FILTER_LZMA2 || f[0].options == NULL || f[1].id != LZMA_VLI_UNKNOWN)
-			return LZMA_OPTIONS_ERROR;      /* device path: {LZMA2} and {BCJ (not RISC-V) | delta, LZMA2} */
+			return LZMA_OPTIONS_ERROR;      /* device path: {LZMA2} and {BCJ | delta, LZMA2} */
 		const lzma_options_lzma *l = (const lzma_options_lzma *)f[0].options;
 		if (l->preset_dict != NULL && l->preset_dict_size != 0)
 			return LZMA_OPTIONS_ERROR;
@@ -593,7 +593,7 @@ uint64_t lzma_mt_block_size(const lzma_filter *filters)
 			uint64_t b = (uint64_t)l->dict_size * 3;
 			if (b < (1u << 20)) b = 1u << 20;
 			if (b > max) max = b;
-		} else if (!(filters[i].id >= LZMA_FILTER_X86 && filters[i].id <= LZMA_FILTER_ARM64)
+		} else if (!(filters[i].id >= LZMA_FILTER_X86 && filters[i].id <= LZMA_FILTER_RISCV)
 				&& filters[i].id != LZMA_FILTER_DELTA) {
 			return 0;
 		}
