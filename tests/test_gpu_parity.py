@@ -508,10 +508,12 @@ def test_out_of_memory_falls_back_to_smaller_batches(monkeypatch):
     got, _ = e2.encode(t, opts=opts, block_size=1 << 20)
     assert e2.stats().batches > 1
     assert got.cpu().numpy().tobytes() == want
-    monkeypatch.setenv("XZAMD_TEST_ALLOC_LIMIT_MIB", "1")       # not even one Block fits: a clean error
-    with pytest.raises(xz_amd.XzAmdError):
-        e2.encode(t, opts=opts, block_size=1 << 20)
     e2.close()
+    monkeypatch.setenv("XZAMD_TEST_ALLOC_LIMIT_MIB", "1")       # not even one Block fits: a clean error
+    e3 = xz_amd.Encoder(0)                                      # (the hook is read when a context is created)
+    with pytest.raises(xz_amd.XzAmdError):
+        e3.encode(t, opts=opts, block_size=1 << 20)
+    e3.close()
 
 
 def test_missing_gpu_fails_loudly():

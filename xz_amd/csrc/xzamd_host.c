@@ -274,6 +274,8 @@ struct xzamd_ctx {
 	uint64_t batch_bytes;
 	uint32_t wave_slots;         /* span wavefronts resident at once (CUs x 16) */
 	uint32_t span_waves;         /* != 0: persistent span kernel with this many wavefronts */
+	int overlap_off;             /* an event of the low-priority pipeline could not be created: no prefetch */
+	uint64_t alloc_limit;        /* test hook (XZAMD_TEST_ALLOC_LIMIT_MIB, read once at creation): larger allocations fail; 0 = none */
 	char err[256];
 	char err_msg_buf[200];
 	/* device buffers */
@@ -306,12 +308,8 @@ static int dgrow(xzamd_ctx *c, dbuf *b, uint64_t bytes, int host)
 		b->cap = 0;
 	}
 	bytes = (bytes + 255) & ~255ull;
-	{
-		/* test hook: pretend allocations above this size fail (exercises the smaller-batch retry) */
-		const char *lim = getenv("XZAMD_TEST_ALLOC_LIMIT_MIB");
-		if (lim && *lim && bytes > ((uint64_t)atoll(lim) << 20))
-			return fail(c, XZAMD_MEM_ERROR, "allocation above XZAMD_TEST_ALLOC_LIMIT_MIB", 0);
-	}
+	if (c->alloc_limit && bytes > c->alloc_limit)   /* test hook: exercises the smaller-batch retry */
+		return fail(c, XZAMD_MEM_ERROR, "allocation above XZAMD_TEST_ALLOC_LIMIT_MIB", 0);
 	int e = host ? xzk_host_alloc(&b->p, bytes) : xzk_malloc(&b->p, bytes);
 	if (e)
 		return fail(c, XZAMD_MEM_ERROR, host ? "hipHostMalloc" : "hipMalloc", e);
@@ -333,12 +331,17 @@ int xzamd_ctx_create(xzamd_ctx **out, int device)
 	}
 	if (device >= ndev || xzk_set_device(device)) { free(c); return XZAMD_DEVICE_ERROR; }
 	c->device = device;
-	if (xzk_stream_create(&c->own_stream)) { free(c); return XZAMD_DEVICE_ERROR; }
+	/* from here on every failure goes through xzamd_ctx_destroy (streams and events already made are released) */
+	if (xzk_stream_create(&c->own_stream)) { c->own_stream = NULL; xzamd_ctx_destroy(c); return XZAMD_DEVICE_ERROR; }
 	if (xzk_stream_create_low(&c->lo_stream)) c->lo_stream = NULL;      /* no overlap then */
 	for (int i = 0; i < 8; ++i)
-		if (xzk_event_create(&c->ev_lo[i >> 2][i & 3])) { c->ev_lo[i >> 2][i & 3] = NULL; c->lo_stream = NULL; }
+		if (xzk_event_create(&c->ev_lo[i >> 2][i & 3])) { c->ev_lo[i >> 2][i & 3] = NULL; c->overlap_off = 1; }
 	for (int i = 0; i < 10; ++i)
-		if (xzk_event_create(&c->ev[i])) { free(c); return XZAMD_DEVICE_ERROR; }
+		if (xzk_event_create(&c->ev[i])) { c->ev[i] = NULL; xzamd_ctx_destroy(c); return XZAMD_DEVICE_ERROR; }
+	{
+		const char *lim = getenv("XZAMD_TEST_ALLOC_LIMIT_MIB");
+		c->alloc_limit = (lim && *lim && atoll(lim) > 0) ? (uint64_t)atoll(lim) << 20 : 0;
+	}
 	c->batch_bytes = DEFAULT_BATCH;
 	{
 		int cus = 0;
@@ -661,7 +664,7 @@ int xzamd_stream_encode_device(xzamd_ctx *c,
 
 	int rc = XZAMD_OK;
 	/* chain-build overlap: more than one batch, no BCJ copy to double-buffer, not disabled */
-	const int overlap = c->lo_stream != NULL && !x86 && total_blocks > max_blocks && getenv("XZAMD_NO_OVERLAP") == NULL;
+	const int overlap = c->lo_stream != NULL && !c->overlap_off && !x86 && total_blocks > max_blocks && getenv("XZAMD_NO_OVERLAP") == NULL;
 	int prefetched = 0, chains_on_lo = 0, lists_cur = 0, find_on_lo = 0;
 	uint64_t prefetched_b0 = 0;
 	xzk_event_record(c->ev[8], st);
@@ -675,8 +678,8 @@ int xzamd_stream_encode_device(xzamd_ctx *c,
 		const uint32_t nspans = (uint32_t)(nb * spb);
 		const uint32_t spb_crc = (uint32_t)((block_size + CRC_STRIP - 1) / CRC_STRIP);
 
-		/* Out of device memory: retry this batch with half the Blocks (dgrow has released the buffer
-		 * it failed on; the others are reused or shrink-to-fit is not needed: capacities only grow). */
+		/* Out of device memory: retry this batch with half the Blocks (retry_smaller releases every per-batch
+		 * buffer first). */
 #define GROW(buf, bytes, host) do { int r_ = dgrow(c, &c->buf, (bytes), host); \
 		if (r_ == XZAMD_MEM_ERROR && nb > 1) { max_blocks = (nb + 1) / 2; goto retry_smaller; } \
 		if (r_) { rc = r_; goto done; } } while (0)
@@ -965,6 +968,17 @@ int xzamd_stream_encode_device(xzamd_ctx *c,
 retry_smaller:
 		c->err[0] = 0;
 		if (prefetched) { xzk_sync(c->lo_stream); prefetched = 0; }
+		/* The buffers grown so far have full-batch capacity: a retry that kept them would fight for what is left.
+		 * Nothing of this batch has been launched; earlier batches may still be assembling, so wait, then release
+		 * every per-batch device buffer and let the smaller geometry allocate afresh. */
+		xzk_sync(st);
+		{
+			dbuf *d[] = { &c->keys_a, &c->keys_b, &c->vals_a, &c->vals_b, &c->rank, &c->sorted_pos,
+				&c->prev2, &c->prev3, &c->prev4, &c->prev8, &c->prev16, &c->key64_a, &c->key64_b, &c->sa, &c->sa_rank,
+				&c->sort_tmp, &c->scratch, &c->litp, &c->mlen, &c->mdist, &c->mlen2, &c->mdist2, &c->bcj };
+			for (size_t i = 0; i < sizeof(d) / sizeof(d[0]); ++i)
+				if (d[i]->p) { xzk_free(d[i]->p); d[i]->p = NULL; d[i]->cap = 0; }
+		}
 	}
 done:
 	if (rc == XZAMD_OK && whole) {
