@@ -85,7 +85,7 @@ typedef struct {
 	uint32_t gpu_sa_window; /* 0 = exact HC3/HC4 semantics of the reference; else the suffix-neighbourhood
 	                        finder (the BT4 successor): recency records among this many slots (<= 5) on
 	                        either side of a position in 32-byte-prefix suffix order, plus the nearest
-	                        equal hash2/hash3/hash4 and equal 8 / 16 bytes; needs gpu_mf = HC4 and
+	                        equal hash2 / hash4 and equal 8 / 16 bytes; needs gpu_mf = HC4 and
 	                        gpu_parser = 1 */
 	uint32_t gpu_parser; /* 0 = lzma_lzma_optimum_fast semantics, 1 = windowed optimal parser (232-node DP over
 	                        per-position match lists incl. the reference's compound edges; needs pb <= 2,

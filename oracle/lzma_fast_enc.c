@@ -43,7 +43,7 @@
  *                    rank-doubling rounds, ties by position) and take, for each
  *                    position, the records among the sa_window (<= 5) slots to the
  *                    left and to the right of its own slot, plus the nearest
- *                    previous position with equal hash2 / hash3 / hash4 and with
+ *                    previous position with equal hash2 / hash4 and with
  *                    the same 8 / 16 bytes (by-products of the sort rounds).  All candidates
  *                    are merged by the Pareto rule "longer than everything
  *                    closer"; the LIST_K longest survive.

@@ -17,12 +17,14 @@
  *     encoder for presets 0-3 on every test corpus;
  *   - x86 BCJ encoder: byte-identical to the reference filter's output.
  * PARITY UNPINNED (by the reference) for the two algorithms that are OURS and
- * have no counterpart to compare bytes with: find_pareto (HC4+H8 finder, the
- * BT4 successor) and optimum_window (windowed optimal parser) -- what presets
- * 4-9 run.  Their pins are indirect: every stream they produce must decode
- * bit-exactly through the REAL reference decoder, the symbol coder / range
- * coder / chunker underneath them are the pinned ones, and their compressed
- * size is tracked against `xz -6` (+4.4 % on the bench corpus).
+ * have no counterpart to compare bytes with: build_sa / find_sn (suffix-
+ * neighbourhood finder, the BT4 successor) and optimum_window (windowed optimal
+ * parser with the reference's compound edges) -- what presets 4-9 run.  Their
+ * pins are indirect: every stream they produce must decode bit-exactly through
+ * the REAL reference decoder, the symbol coder / range coder / chunker
+ * underneath them are the pinned ones, and their compressed size is held to a
+ * stated tolerance: <= 1.03 x liblzma's at the same preset and Block size
+ * (tests/test_oracle_encoder.py, tests/test_gpu_parity.py).
  * Reference citations are file:line relative to /root/reference.
  */
 #ifndef XZ_AMD_ORACLE_H
@@ -120,7 +122,7 @@ typedef struct {
 	                       else independent state-reset spans (GPU mode) */
 	uint32_t sa_window; /* 0 = exact HC3/HC4; else the suffix-neighbourhood finder: recency records among
 	                       `sa_window` (<= 5) slots on either side in 32-byte-prefix suffix order, plus the
-	                       nearest equal hash2/hash3/hash4 and equal 8 / 16 bytes (`depth` unused) */
+	                       nearest equal hash2 / hash4 and equal 8 / 16 bytes (`depth` unused) */
 	uint32_t parser;    /* 0 = optimum_fast (reference); 1 = windowed optimal parser (ours) */
 } orc_enc_params;
 
