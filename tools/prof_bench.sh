@@ -6,11 +6,13 @@ TAG=$1; shift
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
-rocprofv3 --kernel-trace --stats -d $OUT/trace -o b --output-format csv -- python bench.py "$@" --no-cpu-baseline --no-host-to-host > $OUT/bench_under_trace.json 2> $OUT/trace.log
+rocprofv3 --kernel-trace --stats -d $OUT/trace -o b --output-format csv -- python bench.py "$@" --steps 2 --warmup 1 --no-cpu-baseline --no-host-to-host > $OUT/bench_under_trace.json 2> $OUT/trace.log
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $C -d $OUT/pmc/$C -o p --output-format csv -- python bench.py "$@" --no-cpu-baseline --no-host-to-host > $OUT/bench_under_$C.json 2> $OUT/$C.log
+  rocprofv3 --kernel-trace --pmc $C -d $OUT/pmc/$C -o p --output-format csv -- python bench.py "$@" --steps 1 --warmup 0 --no-cpu-baseline --no-host-to-host > $OUT/bench_under_$C.json 2> $OUT/$C.log
 done
-rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_WAIT_ANY -d $OUT/pmc/SQ -o p --output-format csv -- python bench.py "$@" --no-cpu-baseline --no-host-to-host > $OUT/bench_under_SQ.json 2> $OUT/SQ.log
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_WAIT_ANY -d $OUT/pmc/SQ -o p --output-format csv -- python bench.py "$@" --steps 1 --warmup 0 --no-cpu-baseline --no-host-to-host > $OUT/bench_under_SQ.json 2> $OUT/SQ.log
 python tools/pmc_summary.py $OUT/pmc $OUT/pmc_summary.json > $OUT/pmc_summary.txt
 find $OUT/trace -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats.csv \;
+find $OUT -name "*kernel_trace.csv" -size +8M -delete
+find $OUT -name "*counter_collection.csv" -size +8M -delete
 ls $OUT
