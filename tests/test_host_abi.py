@@ -185,3 +185,32 @@ int main(void)
         subprocess.run(["gcc", "-O1", *flags, str(src), "-o", exe], check=True)
         outs.append(subprocess.run([exe], capture_output=True, text=True, check=True).stdout)
     assert outs[0] == outs[1], "\n".join(l for l in outs[0].splitlines() if l not in outs[1].splitlines())
+
+
+def test_mt_block_size_of_filter_chains(product_lib):
+    """lzma_mt_block_size (common/filter_encoder.c:270-292) for {LZMA2} and every {BCJ | delta, LZMA2} chain the
+    device path takes: the same value as the real liblzma's."""
+    import glob
+    if not o.have_ref():
+        pytest.skip("oracle/_ref not built")
+    reflib = C.CDLL(glob.glob(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "*.so"))[0])
+
+    class Filter(C.Structure):
+        _fields_ = [("id", C.c_uint64), ("options", C.c_void_p)]
+    for lib in (product_lib, reflib):
+        lib.lzma_mt_block_size.restype = C.c_uint64
+        lib.lzma_mt_block_size.argtypes = [C.POINTER(Filter)]
+    delta = (C.c_uint32 * 8)(0, 4)               # lzma_options_delta: type BYTE, dist 4
+    for preset in (0, 3, 6, 9):
+        lz = (C.c_uint8 * 128)()
+        assert reflib.lzma_lzma_preset(lz, preset) == 0
+        for fid in (None, 3, 4, 5, 6, 7, 8, 9, 0x0A, 0x0B):
+            chain = (Filter * 3)()
+            k = 0
+            if fid is not None:
+                chain[0].id, chain[0].options = fid, (C.cast(delta, C.c_void_p) if fid == 3 else None)
+                k = 1
+            chain[k].id, chain[k].options = 0x21, C.cast(lz, C.c_void_p)
+            chain[k + 1].id, chain[k + 1].options = 0xFFFFFFFFFFFFFFFF, None
+            want = reflib.lzma_mt_block_size(chain)
+            assert want != 0 and product_lib.lzma_mt_block_size(chain) == want, (preset, fid)
