@@ -143,10 +143,11 @@ def test_suffix_order_and_match_lists_identical_to_oracle(enc):
                 assert len(bad) == 0, ("match lists", name, bs, b0, int(bad[0]), got[bad[0]].tolist(), want[bad[0]].tolist())
 
 
-@pytest.mark.parametrize("n", [1, 5, 1000, 32767, 32768, 32769, 70001])
+@pytest.mark.parametrize("n", [1, 5, 1000, 32767, 32768, 32769, 70001, 1200000])
 def test_structure_build_edge_sizes(enc, n):
     """Sizes around the 32 Ki-position buckets of the by-position inversion (and below one bucket, where no radix
-    pass runs at all), Blocks smaller and larger than the input: suffix order, rank and whole Stream vs the oracle."""
+    pass runs at all), Blocks smaller and larger than the input, more than 256 Blocks (one sort of everything plus a
+    sort by Block number instead of one sort per Block): suffix order, rank and whole Stream vs the oracle."""
     import xz_amd
     data = xz_amd.corpus_text(max(n, 4096), seed=17).tobytes()[:n]
     for bs in (4096, 1 << 20):

@@ -311,12 +311,16 @@ __global__ __launch_bounds__(256) void k_sa_chunk_keys(const uint8_t* __restrict
     }
 }
 
-// grp[i] = i where the 64-bit key differs from its left neighbour, else 0 (input of the max-scan)
-__global__ __launch_bounds__(256) void k_sa_flags64(const uint64_t* __restrict__ keys, uint32_t n, uint32_t* __restrict__ grp)
+// grp[i] = i where the 64-bit key differs from its left neighbour (or, with block_size != 0, where a Block
+// starts: the slots of a Block are its positions' range), else 0 (input of the max-scan)
+__global__ __launch_bounds__(256) void k_sa_flags64(const uint64_t* __restrict__ keys, uint32_t n, uint32_t block_size,
+        uint32_t* __restrict__ grp)
 {
     const uint32_t stride = gridDim.x * blockDim.x;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
-        grp[i] = (i != 0 && keys[i] != keys[i - 1]) ? i : 0u;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const bool first = i != 0 && (keys[i] != keys[i - 1] || (block_size != 0 && i % block_size == 0));
+        grp[i] = first ? i : 0u;
+    }
 }
 
 // round 0, second step: pack (position, chunk group) as the value, Block number as the key
@@ -3101,40 +3105,79 @@ int xzk_build_chains(const uint8_t* d_in, uint32_t n, uint32_t block_size, uint3
     size_t need = 0;
     // round 0: chunk sort
     hipLaunchKernelGGL(k_sa_chunk_keys, dim3(g), dim3(256), 0, st, d_in, n, block_size, key64_a, vals_a);
-    rocprim::double_buffer<uint64_t> k64(key64_a, key64_b);
-    rocprim::double_buffer<uint32_t> pv(vals_a, vals_b);
-    e = rocprim::radix_sort_pairs(nullptr, need, k64, pv, (size_t)n, 0u, 64u, st);
-    if (e != hipSuccess) return (int)e;
-    if (need > tb) return (int)hipErrorOutOfMemory;
-    e = rocprim::radix_sort_pairs(sort_tmp, tb, k64, pv, (size_t)n, 0u, 64u, st);
-    if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(k_sa_flags64, dim3(g), dim3(256), 0, st, k64.current(), n, grp);
-    e = rocprim::inclusive_scan(nullptr, need, grp, grp, (size_t)n, rocprim::maximum<uint32_t>(), st);
-    if (e != hipSuccess) return (int)e;
-    if (need > tb) return (int)hipErrorOutOfMemory;
-    e = rocprim::inclusive_scan(sort_tmp, tb, grp, grp, (size_t)n, rocprim::maximum<uint32_t>(), st);
-    if (e != hipSuccess) return (int)e;
-    uint32_t* pos = pv.current();
-    uint32_t* pos_alt = pv.alternate();
-    if (nblocks > 1) {
-        // stable sort by Block number; values = (position, chunk group), the chunk keys are dead now
-        uint32_t* bk_a = keys_b;
-        uint32_t* bk_b = pos_alt;
-        uint64_t* bv_a = k64.alternate();
-        uint64_t* bv_b = k64.current();
-        hipLaunchKernelGGL(k_sa_block_keys, dim3(g), dim3(256), 0, st, pos, grp, n, block_size, bk_a, bv_a);
-        rocprim::double_buffer<uint32_t> bk(bk_a, bk_b);
-        rocprim::double_buffer<uint64_t> bv(bv_a, bv_b);
-        e = rocprim::radix_sort_pairs(nullptr, need, bk, bv, (size_t)n, 0u, bb, st);
+    uint32_t* pos;
+    uint32_t* pos_alt;
+    if (nblocks > 1 && nblocks <= 256) {
+        // Few, large Blocks (the normal case): one sort per Block.  The positions start out in Block order, so a
+        // sort that never mixes Blocks needs no sort by Block number afterwards, and no rocprim call exceeds the
+        // 2^30 elements above which it splits every pass into two launches.
+        int in_alt = -1;
+        for (uint32_t b = 0; b < nblocks; ++b) {
+            const size_t off = (size_t)b * block_size;
+            if (off >= n) break;
+            const size_t cnt = (size_t)n - off < block_size ? (size_t)n - off : block_size;
+            rocprim::double_buffer<uint64_t> k(key64_a + off, key64_b + off);
+            rocprim::double_buffer<uint32_t> v(vals_a + off, vals_b + off);
+            e = rocprim::radix_sort_pairs(nullptr, need, k, v, cnt, 0u, 64u, st);
+            if (e != hipSuccess) return (int)e;
+            if (need > tb) return (int)hipErrorOutOfMemory;
+            e = rocprim::radix_sort_pairs(sort_tmp, tb, k, v, cnt, 0u, 64u, st);
+            if (e != hipSuccess) return (int)e;
+            const int alt = k.current() == key64_b + off;
+            if (in_alt < 0) in_alt = alt;
+            else if (alt != in_alt) {
+                // a Block of another size class took another route through rocprim: bring it to the common side
+                e = hipMemcpyAsync((in_alt ? key64_b : key64_a) + off, k.current(), cnt * 8, hipMemcpyDeviceToDevice, st);
+                if (e == hipSuccess)
+                    e = hipMemcpyAsync((in_alt ? vals_b : vals_a) + off, v.current(), cnt * 4, hipMemcpyDeviceToDevice, st);
+                if (e != hipSuccess) return (int)e;
+            }
+        }
+        pos = in_alt ? vals_b : vals_a;
+        pos_alt = in_alt ? vals_a : vals_b;
+        hipLaunchKernelGGL(k_sa_flags64, dim3(g), dim3(256), 0, st, in_alt ? key64_b : key64_a, n, block_size, grp);
+        e = rocprim::inclusive_scan(nullptr, need, grp, grp, (size_t)n, rocprim::maximum<uint32_t>(), st);
         if (e != hipSuccess) return (int)e;
         if (need > tb) return (int)hipErrorOutOfMemory;
-        e = rocprim::radix_sort_pairs(sort_tmp, tb, bk, bv, (size_t)n, 0u, bb, st);
-        if (e != hipSuccess) return (int)e;
-        // positions go back to `pos` (vals buffer that held them before; its content is dead)
-        hipLaunchKernelGGL(k_sa_block_unpack, dim3(g), dim3(256), 0, st, bk.current(), bv.current(), n, pos, grp);
-        // pos_alt may have been used as a key buffer: both vals buffers are free for reuse below except `pos`
         e = rocprim::inclusive_scan(sort_tmp, tb, grp, grp, (size_t)n, rocprim::maximum<uint32_t>(), st);
         if (e != hipSuccess) return (int)e;
+    } else {
+        rocprim::double_buffer<uint64_t> k64(key64_a, key64_b);
+        rocprim::double_buffer<uint32_t> pv(vals_a, vals_b);
+        e = rocprim::radix_sort_pairs(nullptr, need, k64, pv, (size_t)n, 0u, 64u, st);
+        if (e != hipSuccess) return (int)e;
+        if (need > tb) return (int)hipErrorOutOfMemory;
+        e = rocprim::radix_sort_pairs(sort_tmp, tb, k64, pv, (size_t)n, 0u, 64u, st);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(k_sa_flags64, dim3(g), dim3(256), 0, st, k64.current(), n, 0u, grp);
+        e = rocprim::inclusive_scan(nullptr, need, grp, grp, (size_t)n, rocprim::maximum<uint32_t>(), st);
+        if (e != hipSuccess) return (int)e;
+        if (need > tb) return (int)hipErrorOutOfMemory;
+        e = rocprim::inclusive_scan(sort_tmp, tb, grp, grp, (size_t)n, rocprim::maximum<uint32_t>(), st);
+        if (e != hipSuccess) return (int)e;
+        pos = pv.current();
+        pos_alt = pv.alternate();
+        if (nblocks > 1) {
+            // many small Blocks: one sort of everything, then a stable sort by Block number; values = (position,
+            // chunk group), the chunk keys are dead now
+            uint32_t* bk_a = keys_b;
+            uint32_t* bk_b = pos_alt;
+            uint64_t* bv_a = k64.alternate();
+            uint64_t* bv_b = k64.current();
+            hipLaunchKernelGGL(k_sa_block_keys, dim3(g), dim3(256), 0, st, pos, grp, n, block_size, bk_a, bv_a);
+            rocprim::double_buffer<uint32_t> bk(bk_a, bk_b);
+            rocprim::double_buffer<uint64_t> bv(bv_a, bv_b);
+            e = rocprim::radix_sort_pairs(nullptr, need, bk, bv, (size_t)n, 0u, bb, st);
+            if (e != hipSuccess) return (int)e;
+            if (need > tb) return (int)hipErrorOutOfMemory;
+            e = rocprim::radix_sort_pairs(sort_tmp, tb, bk, bv, (size_t)n, 0u, bb, st);
+            if (e != hipSuccess) return (int)e;
+            // positions go back to `pos` (vals buffer that held them before; its content is dead)
+            hipLaunchKernelGGL(k_sa_block_unpack, dim3(g), dim3(256), 0, st, bk.current(), bv.current(), n, pos, grp);
+            // pos_alt may have been used as a key buffer: both vals buffers are free for reuse below except `pos`
+            e = rocprim::inclusive_scan(sort_tmp, tb, grp, grp, (size_t)n, rocprim::maximum<uint32_t>(), st);
+            if (e != hipSuccess) return (int)e;
+        }
     }
     // doubling rounds
     uint32_t sbits = 1, fbits = 1;                    // bits of a Block-relative rank (<= block_size), of a rank (<= n)
@@ -3156,7 +3199,7 @@ int xzk_build_chains(const uint8_t* d_in, uint32_t n, uint32_t block_size, uint3
         pos = vv.current();
         pos_alt = vv.alternate();
         if (h == 8) {
-            hipLaunchKernelGGL(k_sa_flags64, dim3(g), dim3(256), 0, st, kk.current(), n, grp);
+            hipLaunchKernelGGL(k_sa_flags64, dim3(g), dim3(256), 0, st, kk.current(), n, 0u, grp);
             e = rocprim::inclusive_scan(sort_tmp, tb, grp, grp, (size_t)n, rocprim::maximum<uint32_t>(), st);
             if (e != hipSuccess) return (int)e;
         }
