@@ -3,28 +3,34 @@
 // Replaces, for a whole batch of .xz Blocks resident in HBM, what one worker
 // thread of the reference runs per Block (stream_encoder_mt.c:219-298):
 //
-//   lz/lz_encoder_mf.c      HC3/HC4 match finder      -> k_hash_keys + radix sort + k_link_*
+//   lz/lz_encoder_mf.c      HC3/HC4 match finder      -> k_h2_* / k_hash_keys + radix sort + k_link_*
 //                                                       (Block-global "sorted bucket" chains)
-//                                                       + wave-parallel candidate evaluation
-//   lzma/lzma_encoder_optimum_fast.c  parser           -> optimum_fast() below (wave-uniform)
+//                                                       + wave-parallel candidate evaluation (do_round)
+//   lz/lz_encoder_mf.c      BT4 (presets 4-9)         -> suffix-neighbourhood finder: k_sa_* (suffix order of every
+//                                                       Block by radix sorts + rank doubling), k_find_sn
+//   lzma/lzma_encoder_optimum_fast.c    parser        -> fast parser block of span_encode_one (wave-uniform)
+//   lzma/lzma_encoder_optimum_normal.c  parser        -> optimum_window() (windowed DP, lane = length / candidate)
 //   lzma/lzma_encoder.c     symbol coder               -> encode_symbol()
 //   rangecoder/range_encoder.h  range coder            -> struct RC
-//   lzma/lzma2_encoder.c    chunk framing              -> k_span_encode epilogue
-//   check/crc64_fast.c      CRC64 of the Block         -> k_crc64_strips / k_crc64_fold
+//   lzma/lzma2_encoder.c    chunk framing              -> span_encode_one epilogue
+//   simple/*.c, delta/      filters in front of LZMA2  -> k_x86_bcj, k_riscv_bcj, k_arm64_bcj, k_bcj_simple, k_delta
+//   check/crc64_fast.c, crc32, sha256.c                -> k_crc_strips / k_crc_fold, k_sha256_blocks
 //   block_encoder.c / stream_encoder_mt.c assembly     -> k_assemble (gather of span outputs)
 //
-// Design: the sequential insert-then-search hash chain of the
-// reference is replaced by a parse-independent structure built in parallel:
-// every position's masked hash is radix-sorted (key = block<<hash_bits | hash,
-// stable, so positions ascend inside a bucket).  rank4[pos] gives the slot of
-// a position in that order; the `depth` slots before it ARE the hash chain the
-// reference would walk (same candidates, same order, collisions included), so
-// one coalesced read fetches the whole chain and 64 lanes evaluate all
-// candidates at once.  hash2/hash3 "head" tables become prev2/prev3 link
-// arrays built the same way.  The LZMA state machine + range coder is serial
-// by construction; parallelism there comes from cutting each Block into spans
-// that are entropy-coded independently (LZMA2 state-reset chunks), one
-// wavefront per span, probability model in LDS.
+// Design: the sequential insert-then-search structures of the
+// reference are replaced by parse-independent ones built in parallel.  Hash
+// chains: every position's masked hash is radix-sorted (key = block<<hash_bits
+// | hash, stable, so positions ascend inside a bucket); the `depth` slots before
+// a position's slot ARE the hash chain the reference would walk (same candidates,
+// same order, collisions included), so one coalesced read fetches the whole
+// chain and 64 lanes evaluate all candidates at once.  BT4's tree is the
+// Cartesian tree of (suffix order, insertion time): its search path is the set
+// of recency records around a position in suffix order, which a sort provides.
+// Nothing is scattered: whatever a sort produces is brought back to position
+// order by two radix passes and one LDS step (invert_perm).  The LZMA state
+// machine + range coder is serial by construction; parallelism there comes from
+// cutting each Block into spans that are entropy-coded independently (LZMA2
+// state-reset chunks), one wavefront per span, probability model in LDS.
 //
 // No MFMA: there is no dense contraction anywhere on this path.
 
