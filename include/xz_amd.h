@@ -204,6 +204,11 @@ int xzamd_debug_fetch(xzamd_ctx *ctx, int what, void *host_out, uint64_t bytes);
 /* Seeded synthetic corpora used by bench.py and the tests (host memory). */
 void xzamd_corpus_lorem(uint8_t *out, uint64_t n);                 /* tests/create_compress_files.c:110-152 continued */
 void xzamd_corpus_text(uint8_t *out, uint64_t n, uint64_t seed, int threads);   /* Zipf/Markov "enwik-style" */
+/* ustar stream of the source trees under `roots` (':'-separated directories of the box,
+ * walked in strcmp order), cycled to n bytes with a per-cycle byte-level perturbation.  Returns the number of
+ * files in one cycle (0: nothing readable, out is zero-filled). */
+uint64_t xzamd_corpus_tar(uint8_t *out, uint64_t n, const char *roots, uint64_t seed);
+#define XZAMD_TAR_ROOTS "/opt/rocm/include:/usr/include:/usr/lib/python3:/usr/lib/python3.10"
 
 const char *xzamd_version(void);
 

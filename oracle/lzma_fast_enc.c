@@ -64,7 +64,10 @@
 #define MATCH_LEN_MAX 273u
 #define LIT 0xFFFFFFFFu
 #define NO_DELTA 0xFFFFFFFFu
-#define WMAX 232u                 /* optimal-parser window (nodes 0..WMAX); sized so the GPU's node arrays +
+#ifndef WMAX
+#define WMAX 232u
+#endif
+#define WMAX_                     /* optimal-parser window (nodes 0..WMAX); sized so the GPU's node arrays +
                                    * model + price tables fit 10 KiB of LDS per wavefront */
 #ifndef WTAIL
 #define WTAIL 16u
@@ -74,7 +77,10 @@
 #define LIST_K 7u
 #endif
 #define LIST_K_                 /* matches kept per position (the LIST_K longest) */
-#define SA_WMAX 5u                /* widest suffix-order window per side: the GPU gives every position 16 lanes
+#ifndef SA_WMAX
+#define SA_WMAX 5u
+#endif
+#define SA_WMAX_                  /* widest suffix-order window per side: the GPU gives every position 16 lanes
                                    * (5 + 5 neighbours, hash2/3/4, prev8, prev16) and four positions to a wavefront */
 #define LEN2_MAX 127u             /* cap of the rep0 run of a compound edge */
 #define PRICE_INF (1u << 30)
@@ -270,7 +276,7 @@ static int build_sa(enc *e)
 			if (prevx)
 				prevx[sa[i]] = g != i ? sa[i] - sa[i - 1] : 0;
 		}
-		if (h == 32)
+		if (h >= (e->prm.sa_depth ? e->prm.sa_depth : 32u))
 			break;
 		for (uint32_t i = 0; i < n; ++i) {
 			const uint32_t p = sa[i];
@@ -385,7 +391,7 @@ static void find_sn(enc *e, uint32_t p)
 {
 	const uint8_t *cur = e->in + p;
 	const uint32_t nice = e->prm.nice_len;
-	const uint32_t avail = e->span_end - p;
+	const uint32_t avail = e->n - p;          /* the lists are span independent: the parser clamps them (do_round) */
 	const uint32_t W = e->prm.sa_window;
 	e->m_count = 0;
 	e->m_longest = 0;
@@ -485,6 +491,22 @@ static void do_round(enc *e, uint32_t x, const uint32_t r[4])
 {
 	if (e->prm.sa_window) {
 		find_sn(e, x);
+		/* The record of a position is made for the whole Block (k_find_sn runs before the spans are cut); a
+		 * span may not reference bytes behind its end, so the parser clamps what it reads: lengths to the
+		 * bytes left in the span, the rep0 run of the compound edge to what follows match + literal. */
+		const uint32_t left = e->span_end - x;
+		if (left < MATCH_LEN_MAX + 1 + LEN2_MAX) {
+			for (uint32_t t = 0; t < 2 && t < e->m_count; ++t) {
+				const uint32_t L = t == 0 ? e->m_longest : e->m_len[e->m_count - 2];
+				uint32_t l2 = e->m_len2[t];
+				if (L + 1 >= left) l2 = 0;
+				else if (l2 > left - L - 1) l2 = left - L - 1;
+				e->m_len2[t] = l2;
+			}
+			for (uint32_t k = 0; k < e->m_count; ++k)
+				if (e->m_len[k] > left) e->m_len[k] = left;
+			if (e->m_longest > left) e->m_longest = left;
+		}
 	} else {
 		find_exact(e, x);
 		e->m_len2[0] = e->m_len2[1] = 0;
@@ -1021,6 +1043,15 @@ static uint32_t row_run_after(const uint8_t *cur, uint32_t dist, uint32_t first,
  * with the coder's current state/reps/probabilities, stores the chosen symbols
  * in the queue.  `cached` as in optimum_fast.  Returns 1 if the round for the
  * position right after the window has been done (nice-length cut). */
+#ifdef ORC_STATS
+#include <stdio.h>
+static uint64_t st_nodes, st_syms;
+#define ST_NODE() (++st_nodes)
+#define ST_SYM() (++st_syms)
+#else
+#define ST_NODE() ((void)0)
+#define ST_SYM() ((void)0)
+#endif
 static int optimum_window(enc *e, uint32_t pos, int cached)
 {
 	const uint32_t nice = e->prm.nice_len;
@@ -1035,6 +1066,7 @@ static int optimum_window(enc *e, uint32_t pos, int cached)
 	uint32_t j = 0;
 	for (;;) {
 		const uint32_t x = pos + j;
+		ST_NODE();
 		if (j > 0) {
 			/* the path into node j is final: derive its coder state */
 			const uint32_t tot = nd[j].len + (nd[j].len2 ? 1 + nd[j].len2 : 0);
@@ -1206,6 +1238,91 @@ static int optimum_window(enc *e, uint32_t pos, int cached)
 	return next_cached;
 }
 
+/* ---- cost-balanced spans (OUR definition; the device: k_span_est / k_span_cut) -------------------
+ * A span costs the wavefront that codes it one step per position the optimal parser has to visit, and a
+ * state reset costs a few hundred bytes of model learning whatever the data.  Positions covered by a
+ * match of nice_len bytes or more are not visited (optimum_window takes such a match at once), so highly
+ * compressible data is both cheap to parse and small when coded: spans are cut by estimated parser work,
+ * not by input bytes, which equalises the running time of the spans AND bounds what the resets cost (the
+ * coded bytes per visited position vary little between kinds of data).  The estimate of a chunk of
+ * ORC_EST_CHUNK positions is a walk over the (span independent) match lists: a position whose longest
+ * match reaches nice_len costs ORC_EST_LONG units and the walk jumps over the match (it may run past the
+ * chunk end), any other position costs one unit. */
+#define ORC_EST_LONG 4u
+/* The same walk also makes a rough estimate of the coded size in bits (a greedy parse: at a symbol
+ * boundary take the longest match when it is >= 3 bytes long, or 2 bytes at a distance < 128, for 14 bits +
+ * the bit length of the distance; else a literal, 6 bits): spans of highly compressible data must not end
+ * before they have produced span_bits of it, or the resets would dominate their size. */
+static void est_chunk(enc *e, uint32_t c0, uint32_t c1, uint32_t *work, uint32_t *bits)
+{
+	uint32_t w = 0, b = 0, x = c0, gnext = c0;
+	while (x < c1) {
+		uint32_t len = 0, dist = 0;
+		if (x > 0) {
+			find_sn(e, x);
+			len = e->m_longest;
+			if (e->m_count) dist = e->m_dist[e->m_count - 1];
+		}
+		if (x >= gnext) {
+			if (len >= 3 || (len == 2 && dist < 128)) {
+				uint32_t bl = 0;
+				while (dist >> bl) ++bl;
+				b += 14 + bl;
+				gnext = x + len;
+			} else {
+				b += 6;
+				gnext = x + 1;
+			}
+		}
+		if (len >= e->prm.nice_len) {
+			w += ORC_EST_LONG;
+			x += len;
+		} else {
+			w += 1;
+			x += 1;
+		}
+	}
+	*work = w;
+	*bits = b;
+}
+
+static uint32_t plan_spans(enc *e, uint32_t *chunk_cost, uint32_t *span_start, uint32_t span_cap)
+{
+	const uint32_t n = e->n;
+	const uint32_t m = (n + ORC_EST_CHUNK - 1) / ORC_EST_CHUNK;
+	const uint32_t T = e->prm.span_cost;
+	const uint32_t min_len = e->prm.span_size ? e->prm.span_size : 65536u;
+	uint32_t *cc = chunk_cost ? chunk_cost : (uint32_t *)malloc((size_t)(m + 1) * 8);
+	uint32_t *cb = cc + m;      /* chunk_cost: m work estimates, then m bit estimates */
+	uint64_t total = 0;
+	for (uint32_t c = 0; c < m; ++c) {
+		const uint32_t c0 = c * ORC_EST_CHUNK, c1 = n - c0 < ORC_EST_CHUNK ? n : c0 + ORC_EST_CHUNK;
+		est_chunk(e, c0, c1, &cc[c], &cb[c]);
+		total += cc[c];
+	}
+	/* k spans of equal estimated work: k = floor(total / T), at least one; threshold = ceil(total / k) */
+	const uint64_t k = total / T ? total / T : 1;
+	const uint64_t Tb = (total + k - 1) / k;
+	uint32_t ns = 0, start = 0;
+	uint64_t acc = 0, accb = 0;
+	if (n && span_start && ns < span_cap) span_start[0] = 0;
+	if (n) ns = 1;
+	for (uint32_t c = 0; c + 1 < m; ++c) {
+		acc += cc[c];
+		accb += cb[c];
+		const uint64_t len = (uint64_t)(c + 1 - start) * ORC_EST_CHUNK;
+		if (len >= ORC_SPAN_MAX || (acc >= Tb && accb >= e->prm.span_bits && len >= min_len)) {
+			acc = 0;
+			accb = 0;
+			start = c + 1;
+			if (span_start && ns < span_cap) span_start[ns] = start * ORC_EST_CHUNK;
+			++ns;
+		}
+	}
+	if (!chunk_cost) free(cc);
+	return ns;
+}
+
 /* ---- per-span chunk loop: lzma_encoder.c:313-436 + lzma2_encoder.c:135-259 - */
 static int put(uint8_t *out, uint64_t cap, uint64_t *pos, const uint8_t *src, uint64_t n)
 {
@@ -1216,7 +1333,23 @@ static int put(uint8_t *out, uint64_t cap, uint64_t *pos, const uint8_t *src, ui
 	return 0;
 }
 
+static int encode_span_(enc *e, uint32_t start, uint32_t end, int first_in_block,
+		uint8_t *out, uint64_t cap, uint64_t *opos);
 static int encode_span(enc *e, uint32_t start, uint32_t end, int first_in_block,
+		uint8_t *out, uint64_t cap, uint64_t *opos)
+{
+#ifdef ORC_STATS
+	const uint64_t n0 = st_nodes, s0 = st_syms, o0 = *opos;
+	const int r = encode_span_(e, start, end, first_in_block, out, cap, opos);
+	fprintf(stderr, "SPAN %u %u nodes %llu syms %llu out %llu\n", start, end - start, (unsigned long long)(st_nodes - n0),
+			(unsigned long long)(st_syms - s0), (unsigned long long)(*opos - o0));
+	return r;
+#else
+	return encode_span_(e, start, end, first_in_block, out, cap, opos);
+#endif
+}
+
+static int encode_span_(enc *e, uint32_t start, uint32_t end, int first_in_block,
 		uint8_t *out, uint64_t cap, uint64_t *opos)
 {
 	int need_props = 1, need_dict_reset = first_in_block, need_state_reset = 0;
@@ -1265,6 +1398,7 @@ static int encode_span(enc *e, uint32_t start, uint32_t end, int first_in_block,
 				++e->q_head;
 			}
 			enc_symbol(e, cur, back, len);
+			ST_SYM();
 			cur += len;
 		}
 		rc_flush(e);
@@ -1381,10 +1515,19 @@ int orc_lzma2_encode_block(const uint8_t *in, uint32_t n, const orc_enc_params *
 	e->trace = trace;
 	uint64_t opos = 0;
 	int r = 0;
-	const uint32_t span = p->span_size ? p->span_size : (n ? n : 1);
-	for (uint32_t s = 0; s < n && !r; s += span) {
-		const uint32_t end = n - s < span ? n : s + span;
-		r = encode_span(e, s, end, s == 0, out, cap, &opos);
+	if (p->span_cost && p->sa_window) {
+		const uint32_t scap = n / 4096 + 2;
+		uint32_t *ss = (uint32_t *)malloc((size_t)scap * 4);
+		const uint32_t ns = plan_spans(e, NULL, ss, scap);
+		for (uint32_t k = 0; k < ns && !r; ++k)
+			r = encode_span(e, ss[k], k + 1 < ns ? ss[k + 1] : n, k == 0, out, cap, &opos);
+		free(ss);
+	} else {
+		const uint32_t span = p->span_size ? p->span_size : (n ? n : 1);
+		for (uint32_t s = 0; s < n && !r; s += span) {
+			const uint32_t end = n - s < span ? n : s + span;
+			r = encode_span(e, s, end, s == 0, out, cap, &opos);
+		}
 	}
 	if (!r) {
 		/* end marker: lzma2_encoder.c:146-149 */
@@ -1416,6 +1559,18 @@ int orc_mf_dump(const uint8_t *in, uint32_t n, const orc_enc_params *p,
 	}
 	enc_free(e);
 	return 0;
+}
+
+uint32_t orc_span_plan(const uint8_t *in, uint32_t n, const orc_enc_params *p, uint32_t *chunk_cost,
+		uint32_t *span_start, uint32_t span_cap)
+{
+	if (!p->sa_window || !p->span_cost)
+		return 0;
+	enc *e = enc_new(in, n, p);
+	if (!e) return 0;
+	const uint32_t ns = plan_spans(e, chunk_cost, span_start, span_cap);
+	enc_free(e);
+	return ns;
 }
 
 /* Debug/test hooks for the device parity tests: the suffix order and the per-position match-list

@@ -124,7 +124,24 @@ typedef struct {
 	                       `sa_window` (<= 5) slots on either side in 32-byte-prefix suffix order, plus the
 	                       nearest equal hash2 / hash4 and equal 8 / 16 bytes (`depth` unused) */
 	uint32_t parser;    /* 0 = optimum_fast (reference); 1 = windowed optimal parser (ours) */
+	uint32_t sa_depth;  /* suffix-neighbourhood finder: bytes of prefix the suffix order compares: 32 (0 = 32), 64,
+	                       128 or 256 (one more rank-doubling round each) */
+	uint32_t span_cost; /* != 0 (needs sa_window): cost-balanced spans instead of spans of span_size bytes.  Every
+	                       ORC_EST_CHUNK bytes get an estimate of the parser's work from a walk over the match lists
+	                       (one unit per position the parser visits); a Block of estimated work `total` is cut into
+	                       k = max(1, total / span_cost) spans: a span ends at the first chunk boundary where its
+	                       estimate reaches ceil(total / k) and it is >= span_size bytes long (span_size 0: 64 KiB) */
+	uint32_t span_bits; /* with span_cost: a span also has to reach this estimated coded size (bits, greedy parse
+	                       over the match lists) before it may end */
 } orc_enc_params;
+#define ORC_EST_CHUNK 4096u
+#define ORC_SPAN_MAX (16u << 20)
+
+/* The span plan of one Block under p->span_cost: chunk_cost (optional, 2 * ceil(n / ORC_EST_CHUNK) entries: work
+ * estimates, then bit estimates) receives the per-chunk estimates, span_start (optional, capacity span_cap) the first byte of every span; returns the
+ * number of spans (0 on error). */
+uint32_t orc_span_plan(const uint8_t *in, uint32_t n, const orc_enc_params *p, uint32_t *chunk_cost,
+		uint32_t *span_start, uint32_t span_cap);
 
 int orc_preset(uint32_t preset, orc_enc_params *p, uint32_t *mode_normal);
 

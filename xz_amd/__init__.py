@@ -98,6 +98,8 @@ def lib():
         l.xzamd_trace_read.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
         l.xzamd_corpus_lorem.argtypes = [C.c_void_p, C.c_uint64]
         l.xzamd_corpus_text.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_int]
+        l.xzamd_corpus_tar.restype = C.c_uint64
+        l.xzamd_corpus_tar.argtypes = [C.c_void_p, C.c_uint64, C.c_char_p, C.c_uint64]
         l.xzamd_version.restype = C.c_char_p
         _lib = l
     return _lib
@@ -128,6 +130,18 @@ def corpus_text(n, seed=1, threads=0):
         threads = min(64, os.cpu_count() or 1)
     a = np.empty(n, dtype=np.uint8)
     lib().xzamd_corpus_text(a.ctypes.data, n, seed, threads)
+    return a
+
+
+TAR_ROOTS = "/opt/rocm/include:/usr/include:/usr/lib/python3:/usr/lib/python3.10"
+
+
+def corpus_tar(n, roots=TAR_ROOTS, seed=1):
+    """ustar stream of the box's source trees, cycled to n bytes."""
+    import numpy as np
+    a = np.empty(n, dtype=np.uint8)
+    if lib().xzamd_corpus_tar(a.ctypes.data, n, roots.encode(), seed) == 0:
+        raise RuntimeError(f"no readable files under {roots}")
     return a
 
 

@@ -207,3 +207,152 @@ void xzamd_corpus_text(uint8_t *out, uint64_t n, uint64_t seed, int threads)
 	for (int t = 0; t < threads; ++t)
 		pthread_join(th[t], NULL);
 }
+
+/* ---- "concatenated tarballs" (SURVEY.md 8d, config C4): a ustar stream of the source trees present on
+ * the box, cycled until n bytes are there.  roots = ':'-separated directories, walked depth first in
+ * strcmp order of the entry names (deterministic for a given image); regular files only, symlinks are
+ * not followed.  Cycle c >= 1 perturbs the file contents at the byte level (one alphanumeric byte per
+ * 4 KiB replaced by another, seeded by (seed, c)) so that the cycles are not identical.
+ * Returns the number of files of the first cycle, 0 if the roots hold no readable regular file. */
+#include <dirent.h>
+#include <stdio.h>
+#include <sys/stat.h>
+
+typedef struct { char **v; size_t n, cap; } strlist;
+
+static int cmp_str(const void *a, const void *b) { return strcmp(*(char *const *)a, *(char *const *)b); }
+
+static void walk(const char *dir, strlist *files)
+{
+	DIR *d = opendir(dir);
+	if (!d) return;
+	strlist names = { NULL, 0, 0 };
+	struct dirent *de;
+	while ((de = readdir(d)) != NULL) {
+		if (!strcmp(de->d_name, ".") || !strcmp(de->d_name, "..")) continue;
+		if (names.n == names.cap) {
+			names.cap = names.cap ? names.cap * 2 : 64;
+			names.v = (char **)realloc(names.v, names.cap * sizeof(char *));
+		}
+		names.v[names.n++] = strdup(de->d_name);
+	}
+	closedir(d);
+	qsort(names.v, names.n, sizeof(char *), cmp_str);
+	for (size_t i = 0; i < names.n; ++i) {
+		const size_t len = strlen(dir) + strlen(names.v[i]) + 2;
+		char *path = (char *)malloc(len);
+		snprintf(path, len, "%s/%s", dir, names.v[i]);
+		struct stat st;
+		if (lstat(path, &st) == 0 && S_ISDIR(st.st_mode)) {
+			walk(path, files);
+			free(path);
+		} else if (lstat(path, &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0) {
+			if (files->n == files->cap) {
+				files->cap = files->cap ? files->cap * 2 : 1024;
+				files->v = (char **)realloc(files->v, files->cap * sizeof(char *));
+			}
+			files->v[files->n++] = path;
+		} else {
+			free(path);
+		}
+		free(names.v[i]);
+	}
+	free(names.v);
+}
+
+static void tar_octal(uint8_t *dst, int width, uint64_t v)
+{
+	for (int i = width - 2; i >= 0; --i) { dst[i] = (uint8_t)('0' + (v & 7)); v >>= 3; }
+	dst[width - 1] = 0;
+}
+
+static void tar_header(uint8_t h[512], const char *path, uint64_t size)
+{
+	memset(h, 0, 512);
+	while (*path == '/') ++path;
+	const size_t len = strlen(path);
+	if (len <= 100) {
+		memcpy(h, path, len);
+	} else {
+		/* ustar: split at a '/' into prefix (<= 155) and name (<= 100); else keep the tail */
+		const char *cut = NULL;
+		for (const char *s = path + (len > 255 ? len - 255 : 0); *s; ++s)
+			if (*s == '/' && (size_t)(s - path) <= 155 && len - (size_t)(s - path) - 1 <= 100) { cut = s; break; }
+		if (cut) {
+			memcpy(h + 345, path, (size_t)(cut - path));
+			memcpy(h, cut + 1, len - (size_t)(cut - path) - 1);
+		} else {
+			memcpy(h, path + len - 100, 100);
+		}
+	}
+	tar_octal(h + 100, 8, 0644);
+	tar_octal(h + 108, 8, 0);
+	tar_octal(h + 116, 8, 0);
+	tar_octal(h + 124, 12, size);
+	tar_octal(h + 136, 12, 0);
+	memset(h + 148, ' ', 8);
+	h[156] = '0';
+	memcpy(h + 257, "ustar", 6);
+	h[263] = '0'; h[264] = '0';
+	uint32_t sum = 0;
+	for (int i = 0; i < 512; ++i) sum += h[i];
+	tar_octal(h + 148, 7, sum);
+	h[155] = ' ';
+}
+
+uint64_t xzamd_corpus_tar(uint8_t *out, uint64_t n, const char *roots, uint64_t seed)
+{
+	strlist files = { NULL, 0, 0 };
+	char *r = strdup(roots ? roots : "");
+	for (char *tok = r, *next; tok && *tok; tok = next) {
+		next = strchr(tok, ':');
+		if (next) *next++ = 0;
+		size_t l = strlen(tok);
+		while (l > 1 && tok[l - 1] == '/') tok[--l] = 0;
+		walk(tok, &files);
+	}
+	free(r);
+	const uint64_t nfiles = files.n;
+	uint64_t pos = 0, made = 0;
+	for (uint64_t cycle = 0; pos < n && nfiles; ++cycle) {
+		const uint64_t before = pos;
+		for (size_t f = 0; f < files.n && pos < n; ++f) {
+			FILE *fp = fopen(files.v[f], "rb");
+			if (!fp) continue;
+			struct stat st;
+			if (fstat(fileno(fp), &st) != 0 || !S_ISREG(st.st_mode) || st.st_size <= 0) { fclose(fp); continue; }
+			const uint64_t size = (uint64_t)st.st_size;
+			uint8_t h[512];
+			tar_header(h, files.v[f], size);
+			const uint64_t hn = n - pos < 512 ? n - pos : 512;
+			memcpy(out + pos, h, hn);
+			pos += hn;
+			const uint64_t body = n - pos < size ? n - pos : size;
+			const uint64_t got = body ? fread(out + pos, 1, body, fp) : 0;
+			fclose(fp);
+			if (got < body) memset(out + pos + got, 0, body - got);
+			if (cycle) {
+				uint64_t s = seed * 0x9E3779B97F4A7C15ull + cycle * 0xD1B54A32D192ED03ull + f;
+				for (uint64_t o = 0; o + 4096 <= body; o += 4096) {
+					const uint64_t rr = rng_next(&s);
+					uint8_t *b = out + pos + o + (rr & 4095);
+					if ((*b >= 'a' && *b <= 'z') || (*b >= 'A' && *b <= 'Z'))
+						*b = (uint8_t)((*b & 0xE0) | (1 + ((rr >> 16) % 26)));
+					else if (*b >= '0' && *b <= '9')
+						*b = (uint8_t)('0' + (rr >> 16) % 10);
+				}
+			}
+			pos += body;
+			const uint64_t padn = (512 - (size & 511)) & 511;
+			const uint64_t pn = n - pos < padn ? n - pos : padn;
+			memset(out + pos, 0, pn);
+			pos += pn;
+			++made;
+		}
+		if (pos == before) break;       /* nothing readable: avoid spinning */
+	}
+	if (pos < n) memset(out + pos, 0, n - pos);
+	for (size_t i = 0; i < files.n; ++i) free(files.v[i]);
+	free(files.v);
+	return made ? nfiles : 0;
+}
