@@ -232,9 +232,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-to-host", action="store_true")
     ap.add_argument("--bcj", action="store_true", help="chain {x86 BCJ, LZMA2} (SURVEY.md 8d config C5)")
-    ap.add_argument("--corpus", choices=["text", "elf"], default="text",
+    ap.add_argument("--corpus", choices=["text", "elf", "tar"], default="text",
                     help="text: seeded synthetic enwik-style text (the headline workload); elf: the x86-64 shared "
-                         "objects present on the box, concatenated and cycled (config C5's input)")
+                         "objects present on the box, concatenated and cycled (config C5's input); tar: ustar stream "
+                         "of the box's source trees, cycled with a per-cycle perturbation (config C4's input)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -271,7 +272,12 @@ def main():
 
     if args.bcj:
         opts.bcj = xz_amd.BCJ_X86
-    host = corpus_elf(max(n, 1), rank) if args.corpus == "elf" else xz_amd.corpus_text(max(n, 1), seed=1000 + rank)
+    if args.corpus == "elf":
+        host = corpus_elf(max(n, 1), rank)
+    elif args.corpus == "tar":
+        host = xz_amd.corpus_tar(max(n, 1), seed=1000 + rank)
+    else:
+        host = xz_amd.corpus_text(max(n, 1), seed=1000 + rank)
     host = host[:n]
     data = torch.from_numpy(host).to(dev)
     enc = xz_amd.Encoder(local_rank)
@@ -298,7 +304,7 @@ def main():
     for _ in range(args.steps):
         out, binfo = step()
         st = enc.stats()
-        enc_ms += st.ms_encode - st.ms_find      # the span kernel alone (the finder is timed separately)
+        enc_ms += st.ms_encode - st.ms_find - st.ms_plan      # the span kernel alone (finder and span plan are timed separately)
         launches += st.encode_launches
     torch.cuda.synchronize()
     if world > 1:
@@ -333,20 +339,21 @@ def main():
             "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "u8",
-            "data": "synthetic" if args.corpus == "text" else "x86-64 ELF shared objects of the box, concatenated/cycled",
+            "data": {"text": "synthetic", "elf": "x86-64 ELF shared objects of the box, concatenated/cycled",
+                     "tar": "ustar stream of the box's source trees (" + xz_amd.TAR_ROOTS + "), cycled with a per-cycle perturbation"}[args.corpus],
             "config": {
                 "workload": f"preset -{args.preset & 31}{'e' if args.preset >> 31 else ''} options (dict {opts.dict_size >> 20} MiB, {block_size >> 20} MiB Blocks, "
                             f"CRC64{', x86 BCJ + LZMA2' if args.bcj else ''}), {args.size_mib} MiB "
-                            f"{'synthetic enwik-style text' if args.corpus == 'text' else 'ELF shared objects'} "
+                            f"{ {'text': 'synthetic enwik-style text', 'elf': 'ELF shared objects', 'tar': 'tar stream of source trees'}[args.corpus]} "
                             f"{'per GPU' if args.scaling == 'weak' else 'in total, whole Blocks dealt to the ranks in order'}, input resident in HBM, "
                             f"output = complete .xz Stream in HBM",
                 "world_size": world,
-                "device_match_finder": ((f"suffix-neighbourhood finder (32-byte-prefix suffix order, {opts.gpu_sa_window} slots per side + hash2/hash4 heads + equal 8/16 bytes)"
+                "device_match_finder": ((f"suffix-neighbourhood finder ({opts.gpu_sa_depth or 32}-byte-prefix suffix order, {opts.gpu_sa_window} slots per side + hash2/hash4 heads + equal 8/16 bytes)"
                                          if opts.gpu_sa_window else f"HC{opts.gpu_mf & 15} depth {opts.gpu_depth} (sort-built chains)")
                                         + f", nice {opts.gpu_nice_len}"),
                 "device_parser": ("windowed optimal parser (232-node DP, exact prices, compound edges) over per-position match lists" if opts.gpu_parser
                                   else "lzma_lzma_optimum_fast semantics (greedy + 1-byte lazy)"),
-                "span_bytes": int(st.span_size),
+                "span_bytes": int(st.span_size) if st.span_size else f"cost-balanced (work target {int(st.span_cost_used)} per span, >= 64 KiB)",
                 "parallelism": f"{world} x (one wavefront per span, {int(st.spans)} spans on rank 0)",
             },
             "ratio": {"ours": round(local_out_bytes / max(n, 1), 5)},
@@ -365,7 +372,8 @@ def main():
             },
             "stage_ms_last_step": {"chains": round(st.ms_chains, 2), "find": round(st.ms_find, 2),
                                    "find_under_previous_span": round(st.ms_find_overlapped, 2),
-                                   "span_encode": round(st.ms_encode - st.ms_find, 2),
+                                   "span_plan": round(st.ms_plan, 2),
+                                   "span_encode": round(st.ms_encode - st.ms_find - st.ms_plan, 2),
                                    "crc": round(st.ms_crc, 2), "assemble": round(st.ms_assemble, 2),
                                    "total": round(st.ms_total, 2)},
         }
@@ -376,7 +384,9 @@ def main():
                 if o.have_ref():
                     sample_n = min(n, 4 * block_size)
                     ref_size = reference_ratio(host[:sample_n], args.preset, args.bcj, block_size)
-                    opts.span_size = int(st.span_size)        # the span size the timed run used
+                    opts.span_size = int(st.span_size)        # the span plan the timed run used
+                    if not st.span_size:
+                        opts.span_cost = int(st.span_cost_used)
                     s_out, _ = enc.encode(data[:sample_n], opts=opts, block_size=block_size)
                     res["ratio"]["sample_mib"] = sample_n >> 20
                     res["ratio"]["ours_on_sample"] = round(s_out.numel() / sample_n, 5)

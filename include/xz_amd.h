@@ -64,8 +64,8 @@ typedef struct xzamd_ctx xzamd_ctx;
  * for fast-mode HC3/HC4 chains (presets 0-3). */
 #define XZAMD_SPAN_WHOLE_BLOCK 0xFFFFFFFFu
 #define XZAMD_SPAN_DEFAULT 0u
-/* Span size derived from the batch geometry and the GPU's wave slots (full rounds of wavefronts per
- * launch; between half the default and the default).  The size used is reported in xzamd_stats. */
+/* Same as XZAMD_SPAN_DEFAULT (kept for callers of the round-2 interface: the span plan is derived from the
+ * batch and the GPU's wave slots either way). */
 #define XZAMD_SPAN_AUTO 1u
 
 /* LZMA2 options: the encoder-relevant subset of lzma_options_lzma
@@ -91,7 +91,20 @@ typedef struct {
 	                        per-position match lists incl. the reference's compound edges; needs pb <= 2,
 	                        else XZAMD_OPTIONS_ERROR) */
 	uint32_t bcj;        /* 0 = chain {LZMA2}; XZAMD_BCJ_* / XZAMD_FILTER_DELTA(d) = that filter in front of LZMA2 */
+	uint32_t gpu_sa_depth; /* suffix-neighbourhood finder: prefix bytes the suffix order compares, 32 / 64 / 128 / 256
+	                        (0 = 32); one rank-doubling round more per step.  Presets: 32 for nice_len <= 32, 64 up to
+	                        nice_len 64, 256 above (what lz_encoder_mf.c:450-512 orders by is the whole suffix) */
+	uint32_t span_cost;  /* != 0 with span_size XZAMD_SPAN_DEFAULT / _AUTO and the optimal parser: cost-balanced spans.
+	                        The match lists give every 4 KiB an estimate of the parser's work (one unit per position it
+	                        has to visit: positions under a match of nice_len bytes or more are skipped); a Block is cut
+	                        into spans of equal estimated work >= span_cost units (more when the batch would give more
+	                        spans than the GPU holds wavefronts), each at least 64 KiB long.  0: spans of span_size bytes */
+	uint32_t span_bits;  /* with span_cost: a span also has to reach this estimated coded size (bits, greedy parse over
+	                        the match lists) before it ends, so that resets cannot dominate highly compressible data */
 } xzamd_lzma_options;
+#define XZAMD_SPAN_COST_DEFAULT 131072u   /* text: 128 KiB spans */
+#define XZAMD_SPAN_BITS_DEFAULT 400000u
+#define XZAMD_SPAN_MIN_LEN 65536u         /* shortest cost-balanced span */
 #define XZAMD_BCJ_X86 4u    /* LZMA_FILTER_X86, api/lzma/bcj.h:20 */
 #define XZAMD_BCJ_ARM64 0x0Au   /* LZMA_FILTER_ARM64, api/lzma/bcj.h (simple/arm64.c), start offset 0 */
 #define XZAMD_BCJ_RISCV 0x0Bu   /* LZMA_FILTER_RISCV (simple/riscv.c) */
@@ -106,6 +119,9 @@ typedef struct {
 /* lzma_lzma_preset() (lzma/lzma_encoder_presets.c:17-63) + the device mapping.
  * Returns nonzero for an invalid preset. */
 int xzamd_lzma_preset(xzamd_lzma_options *opt, uint32_t preset);
+/* For hand-made option sets: fill in what a BT2/BT3/BT4 + normal-mode request runs on the device (suffix-
+ * neighbourhood finder, suffix depth from gpu_nice_len, windowed optimal parser, cost-balanced spans). */
+void xzamd_sn_defaults(xzamd_lzma_options *opt);
 /* NULL when the device path runs this option set, else the reason it does not (static string). */
 const char *xzamd_options_check(const xzamd_lzma_options *opt);
 /* Give back the device / pinned buffers lzma_end() keeps parked for the next stream of the process. */
@@ -138,8 +154,11 @@ typedef struct {
 	float ms_total;              /* first launch -> last kernel done */
 	uint32_t encode_launches;
 	float ms_find;               /* the k_find part of ms_encode */
-	uint32_t span_size;          /* bytes per span the last encode used */
+	uint32_t span_size;          /* bytes per span the last encode used (0: cost-balanced spans) */
 	float ms_find_overlapped;    /* k_find of batches whose structure + lists were made underneath the previous span kernel */
+	uint32_t span_cost_used;     /* cost-balanced spans: work target of the LAST batch (>= span_cost) */
+	float ms_plan;               /* span plan (k_span_est + k_span_cut) */
+	uint32_t wave_slots;         /* span wavefronts the GPU holds at once (CUs x occupancy of the span kernel) */
 } xzamd_stats;
 void xzamd_get_stats(const xzamd_ctx *ctx, xzamd_stats *out);
 
@@ -199,6 +218,10 @@ int xzamd_trace_read(xzamd_ctx *ctx, uint32_t *out, uint32_t cap, uint32_t *coun
 #define XZAMD_DEBUG_SA_RANK 2
 #define XZAMD_DEBUG_LISTS 3
 #define XZAMD_DEBUG_LIST_LENS 4
+#define XZAMD_DEBUG_SPAN_TAB 5      /* span plan: (first byte, end) per span slot, slots = Block * (block_size / 64 KiB + 2) + k */
+#define XZAMD_DEBUG_SPAN_CNT 6      /* spans per Block */
+#define XZAMD_DEBUG_LITP 8          /* literal-coder slices of the span slots (timing builds leave a per-span record there) */
+#define XZAMD_DEBUG_SPAN_EST 7      /* per 4 KiB chunk: work estimates of every Block, then the bit estimates */
 int xzamd_debug_fetch(xzamd_ctx *ctx, int what, void *host_out, uint64_t bytes);
 
 /* Seeded synthetic corpora used by bench.py and the tests (host memory). */

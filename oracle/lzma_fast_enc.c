@@ -1577,11 +1577,12 @@ uint32_t orc_span_plan(const uint8_t *in, uint32_t n, const orc_enc_params *p, u
  * records exactly as the GPU's k_find_sn / k_find_exact store them (packed format: 7 entries
  * length << 23 | distance-1 sorted by length, then count | len2a << 8 | len2b << 16; entries past
  * the count are reported as 0). */
-int orc_sa_dump(const uint8_t *in, uint32_t n, uint32_t *sa_out, uint32_t *rank_out)
+int orc_sa_dump(const uint8_t *in, uint32_t n, uint32_t depth, uint32_t *sa_out, uint32_t *rank_out)
 {
 	orc_enc_params p;
 	memset(&p, 0, sizeof(p));
 	p.dict_size = 1u << 23; p.lc = 3; p.pb = 2; p.nice_len = 64; p.mf = 4; p.depth = 1; p.sa_window = 1; p.parser = 1;
+	p.sa_depth = depth;
 	enc *e = enc_new(in, n, &p);
 	if (!e) return -3;
 	memcpy(sa_out, e->sa, (size_t)n * 4);
@@ -1599,6 +1600,8 @@ int orc_list_dump(const uint8_t *in, uint32_t n, const orc_enc_params *p, uint32
 	for (uint32_t x = 0; x < n; ++x) {
 		const uint32_t se = (x / span + 1) * span;
 		e->span_end = se < n && se > x ? se : n;
+		if (p->sa_window)
+			e->span_end = n;        /* the suffix-neighbourhood finder's records are span independent */
 		uint32_t *w = words + (size_t)x * 8;
 		memset(w, 0, 32);
 		if (x == 0 && 0) continue;

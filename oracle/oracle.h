@@ -162,7 +162,7 @@ int orc_mf_dump(const uint8_t *in, uint32_t n, const orc_enc_params *p,
 
 /* Device-parity debug hooks (OUR structures): suffix order of one Block (slot -> position and
  * position -> slot) and the 8-word match-list record of every position, as the GPU stores them. */
-int orc_sa_dump(const uint8_t *in, uint32_t n, uint32_t *sa_out, uint32_t *rank_out);
+int orc_sa_dump(const uint8_t *in, uint32_t n, uint32_t depth, uint32_t *sa_out, uint32_t *rank_out);
 int orc_list_dump(const uint8_t *in, uint32_t n, const orc_enc_params *p, uint32_t *words);
 
 /* ------------------------------------------------------------------ */

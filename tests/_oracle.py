@@ -281,16 +281,16 @@ def orc_x86_encode(data):
     return buf.tobytes()
 
 
-def orc_sa_dump(data):
-    """(slot -> position, position -> slot) of one Block in the oracle's 32-byte-prefix suffix order."""
+def orc_sa_dump(data, depth=32):
+    """(slot -> position, position -> slot) of one Block in the oracle's `depth`-byte-prefix suffix order."""
     data = as_u8(data)
     n = len(data)
     sa = np.zeros(max(n, 1), dtype=np.uint32)
     rk = np.zeros(max(n, 1), dtype=np.uint32)
     f = orc().orc_sa_dump
     f.restype = C.c_int
-    f.argtypes = [u8p, C.c_uint32, u32p, u32p]
-    assert f(_ptr(data), n, _ptr(sa, u32p), _ptr(rk, u32p)) == 0
+    f.argtypes = [u8p, C.c_uint32, C.c_uint32, u32p, u32p]
+    assert f(_ptr(data), n, depth, _ptr(sa, u32p), _ptr(rk, u32p)) == 0
     return sa[:n], rk[:n]
 
 
@@ -432,21 +432,44 @@ def orc_xz_stream(data, prm, block_size, check=4):
     return out[:n].tobytes()
 
 
-def params_for_gpu_options(opts, span_size=None):
-    """Oracle parameters equal to what the device path runs for an xz_amd.LzmaOptions."""
+def params_for_gpu_options(opts, span_size=None, span_cost_used=None):
+    """Oracle parameters equal to what the device path runs for an xz_amd.LzmaOptions.  Cost-balanced spans
+    (the default of the optimal-parser presets): span_cost_used = the target the device reports
+    (Encoder.stats().span_cost_used; equals opts.span_cost unless the batch filled the GPU)."""
     p = OrcParams()
     p.dict_size = opts.dict_size
     p.lc, p.lp, p.pb = opts.lc, opts.lp, opts.pb
     p.nice_len = opts.gpu_nice_len
     p.mf = opts.gpu_mf & 0x0F
     p.depth = opts.gpu_depth
-    sp = opts.span_size if span_size is None else span_size
-    if sp == 0:
-        sp = 131072 if opts.gpu_parser else 65536    # xzamd_host.c DEFAULT_SPAN_OPT / DEFAULT_SPAN
-    p.span_size = 0 if sp == 0xFFFFFFFF else sp
     p.sa_window = opts.gpu_sa_window
     p.parser = opts.gpu_parser
+    p.sa_depth = opts.gpu_sa_depth
+    sp = opts.span_size if span_size is None else span_size
+    if sp in (0, 1) and opts.gpu_parser and opts.gpu_sa_window and opts.span_cost:
+        p.span_size = 65536                         # XZAMD_SPAN_MIN_LEN
+        p.span_cost = span_cost_used if span_cost_used else opts.span_cost
+        p.span_bits = opts.span_bits
+        return p
+    if sp in (0, 1):
+        sp = 131072 if opts.gpu_parser else 65536    # xzamd_host.c DEFAULT_SPAN_OPT / DEFAULT_SPAN
+    p.span_size = 0 if sp == 0xFFFFFFFF else sp
     return p
+
+
+def orc_span_plan(data, prm):
+    """(chunk work estimates, chunk bit estimates, span starts) of one Block under prm.span_cost."""
+    data = as_u8(data)
+    n = len(data)
+    m = (n + 4095) // 4096
+    cc = np.zeros(2 * max(m, 1), dtype=np.uint32)
+    ss = np.zeros(n // 4096 + 2, dtype=np.uint32)
+    f = orc().orc_span_plan
+    f.restype = C.c_uint32
+    f.argtypes = [u8p, C.c_uint32, C.POINTER(OrcParams), u32p, u32p, C.c_uint32]
+    ns = f(_ptr(data), n, C.byref(prm), _ptr(cc, u32p), _ptr(ss, u32p), len(ss))
+    assert ns > 0
+    return cc[:m], cc[m:2 * m], ss[:ns]
 
 
 def first_diff(a, b):

@@ -109,7 +109,7 @@ def test_successor_finder_and_optimal_parser_identical_to_oracle(enc, preset, pa
 
 
 def test_suffix_order_and_match_lists_identical_to_oracle(enc):
-    """The two device structures behind presets 4-9, stage by stage: the 32-byte-prefix suffix order of every
+    """The two device structures behind presets 4-9, stage by stage: the 32 / 64 / 128 / 256-byte-prefix suffix order of every
     Block (rocprim radix sorts + rank doubling vs the oracle's build_sa) and the per-position match-list
     records of k_find_sn (vs the oracle's find_sn), several Blocks per batch, ragged last Block."""
     import xz_amd
@@ -117,10 +117,13 @@ def test_suffix_order_and_match_lists_identical_to_oracle(enc):
              "runs": (b"a" * 70000 + b"ab" * 30000 + bytes(range(256)) * 300)[:200000],
              "text": xz_amd.corpus_text(250000, seed=3).tobytes()}
     for name, data in cases.items():
-        for bs, span, window in ((1 << 20, 0, None), (65536, 8192, None), (100000, 0xFFFFFFFF, 3)):
+        for bs, span, window, depth in ((1 << 20, 0, None, None), (65536, 8192, None, 32), (100000, 0xFFFFFFFF, 3, 256),
+                                        (1 << 20, 16384, None, 128)):
             opts = xz_amd.preset_options(6, span_size=span)
             if window is not None:
                 opts.gpu_sa_window = window
+            if depth is not None:
+                opts.gpu_sa_depth = depth
             prm = o.params_for_gpu_options(opts)
             gpu_encode(enc, data, opts, bs)
             n = len(data)
@@ -129,7 +132,7 @@ def test_suffix_order_and_match_lists_identical_to_oracle(enc):
             lists = enc.debug_fetch(3, 8 * n).reshape(n, 8)
             for b0 in range(0, n, bs):
                 blk = data[b0:b0 + bs]
-                osa, ork = o.orc_sa_dump(blk)
+                osa, ork = o.orc_sa_dump(blk, opts.gpu_sa_depth)
                 assert (sa[b0:b0 + len(blk)] == osa + b0).all(), ("suffix order", name, bs, b0,
                                                                   int(np.nonzero(sa[b0:b0 + len(blk)] != osa + b0)[0][0]))
                 assert (rk[b0:b0 + len(blk)] == ork + b0).all(), ("rank", name, bs, b0)
@@ -159,9 +162,51 @@ def test_structure_build_edge_sizes(enc, n):
         rk = enc.debug_fetch(2, n)
         for b0 in range(0, n, bs):
             blk = data[b0:b0 + bs]
-            osa, ork = o.orc_sa_dump(blk)
+            osa, ork = o.orc_sa_dump(blk, opts.gpu_sa_depth)
             assert (sa[b0:b0 + len(blk)] == osa + b0).all(), ("suffix order", n, bs, b0)
             assert (rk[b0:b0 + len(blk)] == ork + b0).all(), ("rank", n, bs, b0)
+
+
+def test_span_plan_identical_to_oracle(enc):
+    """Cost-balanced spans, stage by stage: the per-chunk work / bit estimates of k_span_est and the cuts of k_span_cut
+    vs the oracle's est_chunk / plan_spans (several Blocks per batch, a ragged last Block, text next to long runs
+    and incompressible bytes so that the spans differ in length a lot), then the whole Stream."""
+    import xz_amd
+    rng = np.random.default_rng(5)
+    lorem = o.corpus_lorem(600000)
+    mix = (lorem[:300000] + b"\0" * 400000 + bytes(rng.integers(0, 256, size=200000, dtype=np.uint8))
+           + (lorem[:4000] * 200) + xz_amd.corpus_text(500000, seed=9).tobytes())
+    for bs, cost, bits in ((1 << 20, 0, None), (700000, 40000, 50000), (1 << 21, 20000, 0)):
+        opts = xz_amd.preset_options(6)
+        if cost:
+            opts.span_cost = cost
+        if bits is not None:
+            opts.span_bits = bits
+        got, _ = gpu_encode(enc, mix, opts, bs)
+        st = enc.stats()
+        assert st.span_size == 0 and st.span_cost_used == opts.span_cost
+        prm = o.params_for_gpu_options(opts, span_cost_used=st.span_cost_used)
+        nb = (len(mix) + bs - 1) // bs
+        spb, cpb = bs // 65536 + 2, (bs + 4095) // 4096
+        tab = enc.debug_fetch(5, 2 * nb * spb).reshape(nb, spb, 2)
+        cnt = enc.debug_fetch(6, nb)
+        est = enc.debug_fetch(7, 2 * nb * cpb).reshape(2, nb, cpb)
+        total_spans = 0
+        for b in range(nb):
+            blk = mix[b * bs:(b + 1) * bs]
+            work, bitsv, starts = o.orc_span_plan(blk, prm)
+            m = len(work)
+            assert (est[0, b, :m] == work).all(), ("work estimates", bs, b, int(np.nonzero(est[0, b, :m] != work)[0][0]))
+            assert (est[1, b, :m] == bitsv).all(), ("bit estimates", bs, b)
+            assert cnt[b] == len(starts), ("span count", bs, b, int(cnt[b]), len(starts))
+            assert (tab[b, :cnt[b], 0] == starts + b * bs).all(), ("span starts", bs, b)
+            ends = np.append(starts[1:], len(blk)) + b * bs
+            assert (tab[b, :cnt[b], 1] == ends).all(), ("span ends", bs, b)
+            total_spans += len(starts)
+        assert st.spans == total_spans
+        assert o.first_diff(got, o.orc_xz_stream(mix, prm, bs)) == -1, ("stream", bs, cost)
+        rr, rdec = o.ref_decode(got, len(mix) + 16)
+        assert rr == 1 and rdec == mix
 
 
 SIZE_TOLERANCE = 0.03

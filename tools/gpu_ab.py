@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""A/B timing of whole encodes under different environment knobs in one process (one corpus, one torch import).
+usage: tools/gpu_ab.py MiB PRESET [corpus=text|tar] name:ENV=V,ENV=V ...   (XZ_AMD_LIB selects the library build)"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch, xz_amd
+mib = int(sys.argv[1]); preset = int(sys.argv[2], 0)
+args = sys.argv[3:]
+corpus = "text"
+if args and args[0].startswith("corpus="):
+    corpus = args.pop(0).split("=", 1)[1]
+n = mib << 20
+host = xz_amd.corpus_tar(n, seed=1000) if corpus == "tar" else xz_amd.corpus_text(n, seed=1000)
+t = torch.from_numpy(host).cuda()
+KNOBS = ("XZAMD_SPAN_ROUNDS", "XZAMD_PREFETCH_AFTER", "XZAMD_NO_OVERLAP", "XZAMD_SPAN_WAVES_PER_CU", "XZAMD_BATCH_MIB",
+         "XZAMD_SPAN_COST", "XZAMD_SA_DEPTH")
+for cfg in args or ["default:"]:
+    name, _, envs = cfg.partition(":")
+    for k in KNOBS:
+        os.environ.pop(k, None)
+    for kv in filter(None, envs.split(",")):
+        k, v = kv.split("=")
+        os.environ[k] = v
+    enc = xz_amd.Encoder(0)
+    opts = xz_amd.preset_options(preset)
+    if os.environ.get("XZAMD_SPAN_COST"):
+        opts.span_cost = int(os.environ["XZAMD_SPAN_COST"])
+    if os.environ.get("XZAMD_SA_DEPTH"):
+        opts.gpu_sa_depth = int(os.environ["XZAMD_SA_DEPTH"])
+    for it in range(2):
+        torch.cuda.synchronize(); t0 = time.time()
+        out, _ = enc.encode(t, opts=opts)
+        torch.cuda.synchronize(); dt = time.time() - t0
+        st = enc.stats()
+    print(f"{name:24s} {n/dt/1e6:8.1f} MB/s ratio {out.numel()/n:.5f} | chains {st.ms_chains:7.1f} find {st.ms_find:6.1f} (+{st.ms_find_overlapped:6.1f} lo) "
+          f"plan {st.ms_plan:5.1f} span {st.ms_encode-st.ms_find-st.ms_plan:7.1f} crc {st.ms_crc:5.1f} total {st.ms_total:7.1f} ms | spans {st.spans} cost {st.span_cost_used} slots {st.wave_slots}", flush=True)
+    enc.close()
+    del enc
+    torch.cuda.empty_cache()

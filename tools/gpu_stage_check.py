@@ -40,7 +40,7 @@ def check(enc, name, data, preset, bs, span, window=None):
     for b0 in range(0, n, bs):
         blk = data[b0:b0 + bs]
         m = len(blk)
-        osa, ork = o.orc_sa_dump(blk)
+        osa, ork = o.orc_sa_dump(blk, opts.gpu_sa_depth)
         d = np.nonzero(sa[b0:b0 + m] != osa + b0)[0]
         if len(d):
             ok = False

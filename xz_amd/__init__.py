@@ -33,7 +33,8 @@ def filter_delta(dist):
 class LzmaOptions(C.Structure):
     _fields_ = [(n, C.c_uint32) for n in (
         "dict_size", "lc", "lp", "pb", "mode", "nice_len", "mf", "depth",
-        "gpu_mf", "gpu_nice_len", "gpu_depth", "span_size", "gpu_sa_window", "gpu_parser", "bcj")]
+        "gpu_mf", "gpu_nice_len", "gpu_depth", "span_size", "gpu_sa_window", "gpu_parser", "bcj",
+        "gpu_sa_depth", "span_cost", "span_bits")]
 
 
 class Stats(C.Structure):
@@ -41,7 +42,8 @@ class Stats(C.Structure):
                 ("spans", C.c_uint64), ("batches", C.c_uint64), ("blocks_stored", C.c_uint64),
                 ("ms_chains", C.c_float), ("ms_encode", C.c_float), ("ms_crc", C.c_float),
                 ("ms_assemble", C.c_float), ("ms_total", C.c_float), ("encode_launches", C.c_uint32),
-                ("ms_find", C.c_float), ("span_size", C.c_uint32), ("ms_find_overlapped", C.c_float)]
+                ("ms_find", C.c_float), ("span_size", C.c_uint32), ("ms_find_overlapped", C.c_float),
+                ("span_cost_used", C.c_uint32), ("ms_plan", C.c_float), ("wave_slots", C.c_uint32)]
 
 
 class BlockInfo(C.Structure):

@@ -18,28 +18,39 @@ typedef struct {
 	const uint32_t *sorted_pos;  /* slot -> pos | first_of_bucket << 31 */
 	const uint32_t *prev2;       /* distance to previous position with equal hash2, 0 = none */
 	const uint32_t *prev3;       /* same for hash3 (HC4 only) */
-	uint8_t *scratch;            /* span s writes at scratch + s * span_cap */
-	uint64_t span_cap;
-	uint32_t *span_bytes;        /* out: bytes produced per span */
+	uint8_t *scratch;            /* span slot s = block * max_spb + k covering [start, end) writes at
+	                                scratch + align16(start + start / 8) + s * XZAMD_SPAN_SLACK, at most end - start +
+	                                (end - start) / 8 + 4096 bytes */
+	/* span plan: Block b has span_cnt[b] spans, its k-th one is span_tab[2 * (b * max_spb + k)] (first byte) ..
+	 * span_tab[2 * (b * max_spb + k) + 1] (end, exclusive), offsets into the batch.  Written by the host (spans of
+	 * span_size bytes) or by xzk_span_plan (cost-balanced spans). */
+	const uint32_t *span_tab;
+	const uint32_t *span_cnt;
+	uint32_t max_spb;            /* span slots per Block */
+	uint32_t *span_bytes;        /* out: bytes produced per span slot */
 	uint32_t *lit;               /* literal-coder probabilities: 6144 x u32 per span */
 	/* per-position match lists (parser != 0), written by xzk_find_matches: 8 x u32 per position =
 	 * 7 entries sorted by length + trailer (count | len2 of the longest << 8 | len2 of the second << 16) */
 	const uint16_t *mlen;        /* 8 x u16 per position, lengths of the entries (list_packed == 0 only) */
 	const uint32_t *mdist;
 	uint32_t list_packed;        /* 1: entries are length << 23 | distance-1 and mlen is unused (dict_size <= 8 MiB) */
+	uint16_t *mtop;              /* per position, written by k_find_sn for the span plan: length of the longest entry
+	                                (incl. the > nice_len extension) | bit length of its zero-based distance << 9; 0 = no match */
 	uint32_t *trace;             /* optional debug: 4 x u32 per symbol (span,pos,back,len) */
 	uint32_t *trace_count;
 	uint32_t trace_cap;
 	uint32_t *err;               /* 8 x u32: [0] != 0 -> a span hit an internal consistency check */
 	uint32_t n;
 	uint32_t block_size;
-	uint32_t span_size;
-	uint32_t spans_per_block;
+	uint32_t span_size;          /* k_find_exact only (its lists end at the span end): spans of span_size bytes */
 	uint32_t dict_size, nice_len, depth, hash_bytes;
 	uint32_t lc, lp, pb;
 	uint32_t sa_window;          /* suffix-neighbourhood finder: slots examined on either side (0 = exact HC3/HC4 finder) */
 	uint32_t parser;             /* 0 = optimum_fast, 1 = windowed optimal parser */
 } xzamd_span_args;
+#define XZAMD_SPAN_SLACK 4112u      /* 4096 + 16 bytes of scratch per span slot on top of 9/8 of the input */
+#define XZAMD_EST_CHUNK 4096u       /* positions per work estimate of the span plan */
+#define XZAMD_SPAN_MAX (16u << 20)  /* longest cost-balanced span */
 
 /* One gather segment of the final assembly. kind 0: src is an offset into the span scratch,
  * 1: into the literal-bytes buffer prepared by the host, 2: into the batch input (raw). */
@@ -53,7 +64,7 @@ typedef struct {
 
 int xzk_sort_temp_bytes(uint32_t n, uint32_t end_bit, uint64_t *bytes);
 int xzk_build_chains(const uint8_t *d_in, uint32_t n, uint32_t block_size, uint32_t nblocks,
-		uint32_t hash_bytes, uint32_t hash_mask, uint32_t hash_bits,
+		uint32_t hash_bytes, uint32_t hash_mask, uint32_t hash_bits, uint32_t sa_depth,
 		uint32_t *keys_a, uint32_t *keys_b, uint32_t *vals_a, uint32_t *vals_b,
 		void *sort_tmp, uint64_t sort_tmp_bytes,
 		uint32_t *rank, uint32_t *sorted_pos, uint32_t *prev2, uint32_t *prev3,
@@ -62,7 +73,15 @@ int xzk_build_chains(const uint8_t *d_in, uint32_t n, uint32_t block_size, uint3
 int xzk_sa_temp_bytes(uint32_t n, uint64_t *bytes);
 int xzk_find_matches(const xzamd_span_args *a, const uint32_t *sa, const uint32_t *sa_rank, const uint32_t *prev4,
 		const uint64_t *rp8, const uint64_t *rp16, uint16_t *mlen, uint32_t *mdist, void *stream);
-int xzk_span_encode(const xzamd_span_args *a, uint32_t nspans, uint32_t waves, uint32_t *counter, void *stream);
+/* Cost-balanced span plan of a batch from its match lists (oracle: plan_spans): est[0 .. 2 * nblocks * cpb) receives
+ * the per-chunk work and bit estimates (cpb = chunks per Block), totals[0 .. nblocks] the per-Block work and, last,
+ * the batch total (u64 each); then span_tab / span_cnt as described in xzamd_span_args.  target = max(cost_min,
+ * ceil(batch total / slots)); totals[nblocks + 1] receives the target used. */
+int xzk_span_plan(const xzamd_span_args *a, uint32_t nblocks, uint32_t *est, unsigned long long *totals,
+		uint32_t *span_tab, uint32_t *span_cnt, uint32_t cost_min, uint32_t bits_min, uint32_t min_len, uint32_t slots,
+		void *stream);
+int xzk_span_encode(const xzamd_span_args *a, uint32_t nslots, uint32_t waves, uint32_t *counter, void *stream);
+int xzk_span_occupancy(int parser, int *waves_per_cu);
 /* x86 BCJ encoder: d_out = filtered copy of d_in, every Block filtered independently (simple/x86.c). */
 int xzk_x86_bcj(const uint8_t *d_in, uint8_t *d_out, uint32_t n, uint32_t block_size, uint32_t nblocks, void *stream);
 /* ARM64 BCJ (kind 0x0A) / delta (kind 3, dist 1..256) encoders, every Block filtered independently. */

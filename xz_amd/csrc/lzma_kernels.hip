@@ -368,6 +368,13 @@ __global__ __launch_bounds__(256) void k_sa_rank_seq(const uint32_t* __restrict_
     }
 }
 
+// the same for the rounds that only want the rank (sa_depth > 32)
+__global__ __launch_bounds__(256) void k_sa_rank_only_seq(const uint32_t* __restrict__ grp, uint32_t n, uint32_t* __restrict__ rk)
+{
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) rk[i] = grp[i] + 1;
+}
+
 // doubling key of every position, in position order: (rank[p], rank[p + h]) with 0 for a second half that
 // starts past the Block end; vals = iota.  The second rank is taken relative to the Block (sbits = bits of
 // block_size + 1), so the key is 31 + sbits bits wide instead of 62: one radix pass less for Blocks up to 32 MiB.  (The radix sort is stable and the members of a group ascend by
@@ -567,6 +574,7 @@ struct Env {
 };
 constexpr uint32_t LIST_K = 7;                // entries kept per position (the LIST_K longest)
 constexpr uint32_t LIST_W = 8;                // words per position: LIST_K entries + trailer (count | len2 of the two longest)
+constexpr uint32_t LEN2_MAX = 127;            // cap of the rep0 run recorded with the two longest entries
 
 // ------------------------------------------------------------------------------------------
 // Software prefetch of the parse-independent per-position data.  Rounds mostly visit consecutive
@@ -1063,12 +1071,24 @@ __device__ __forceinline__ void round_lists(const Env& e, ListPre& LP, uint32_t 
     }
     const uint32_t tr = lane_of(tv, LIST_K);
     const uint32_t cnt = tr & 0xFFu;
-    R.SL = sl;
+    uint32_t slc = sl, l2a = (tr >> 8) & 0xFFu, l2b = (tr >> 16) & 0xFFu;
+    uint32_t longest = cnt ? lane_of(sl, cnt - 1) : 0;
+    if (avail < MATCH_LEN_MAX + 1 + LEN2_MAX) {
+        // The records are made for the whole Block; a span may not reference bytes behind its end, so near the end
+        // the parser clamps what it reads (oracle: do_round): lengths to the bytes left, the rep0 run of the
+        // "match + literal + rep0" edge to what follows match + literal.
+        const uint32_t second = cnt >= 2 ? lane_of(sl, cnt - 2) : 0;
+        l2a = longest + 1 >= avail ? 0u : min(l2a, avail - longest - 1);
+        l2b = second + 1 >= avail ? 0u : min(l2b, avail - second - 1);
+        slc = min(sl, avail);
+        longest = min(longest, avail);
+    }
+    R.SL = slc;
     R.SD = sd;
     R.cnt = cnt;
-    R.l2a = (tr >> 8) & 0xFFu;
-    R.l2b = (tr >> 16) & 0xFFu;
-    R.longest = cnt ? lane_of(sl, cnt - 1) : 0;
+    R.l2a = l2a;
+    R.l2b = l2b;
+    R.longest = longest;
 }
 
 // ---- prices (rangecoder/price.h:28-92) ------------------------------------------------------
@@ -1701,17 +1721,15 @@ __device__ __forceinline__ void span_encode_one(const xzamd_span_args& a, const 
 #endif
     uint16_t* const probs = reinterpret_cast<uint16_t*>(pool);
     const uint32_t lane = threadIdx.x;
-    const uint32_t blk = span / a.spans_per_block;
-    const uint32_t k = span - blk * a.spans_per_block;
+    const uint32_t blk = span / a.max_spb;
+    const uint32_t k = span - blk * a.max_spb;
+    if (k >= a.span_cnt[blk]) return;                  // an unused slot of the span plan
     const uint32_t block_start = blk * a.block_size;
     const uint32_t block_end = min(a.n, block_start + a.block_size);
-    const uint32_t span_start = block_start + k * a.span_size;
-    if (span_start >= block_end) {
-        if (lane == 0) a.span_bytes[span] = 0;
-        return;
-    }
-    const uint32_t span_end = min(block_end, span_start + a.span_size);
-    uint8_t* const outp = a.scratch + (uint64_t)span * a.span_cap;
+    const uint32_t span_start = uni(a.span_tab[2 * span]), span_end = uni(a.span_tab[2 * span + 1]);
+    // scratch of the slot: 9/8 of the input bytes in front of it plus XZAMD_SPAN_SLACK per slot (kernels_api.h)
+    uint8_t* const outp = a.scratch + ((((uint64_t)span_start + (span_start >> 3)) + 15) & ~15ull) + (uint64_t)span * XZAMD_SPAN_SLACK;
+    const uint32_t span_cap = (span_end - span_start) + ((span_end - span_start) >> 3) + 4096;
     const uint8_t* __restrict__ in = a.in;
 
     Env e;
@@ -1762,8 +1780,8 @@ __device__ __forceinline__ void span_encode_one(const xzamd_span_args& a, const 
     RC rc;
     rc.cpos = 0; rc.out = outp; rc.reset();
 
-    bool need_props = true, need_dict_reset = (k == 0), need_state_reset = true;
-    bool initialized = (k != 0);
+    bool need_props = true, need_dict_reset = (span_start == block_start), need_state_reset = true;
+    bool initialized = (span_start != block_start);
     uint32_t cur = span_start;
     uint32_t read_ahead = 0;        // exact/fast path bookkeeping (as in the reference)
     bool cached = false;            // list paths: the round for `cur` has been done
@@ -1972,7 +1990,7 @@ __device__ __forceinline__ void span_encode_one(const xzamd_span_args& a, const 
             }
             if (len == 0 || len > MATCH_LEN_MAX || cur + len > span_end
                     || (back != LITERAL && back >= 4 && back - 4 >= cur - block_start)
-                    || out_off + hl + rc.cpos + 64 > a.span_cap) {
+                    || out_off + hl + rc.cpos + 64 > span_cap) {
                 // internal consistency failure: report instead of corrupting memory
                 if (lane == 0 && a.err) {
                     if (atomicCAS(a.err, 0u, 1u) == 0u) {
@@ -2053,6 +2071,15 @@ __device__ __forceinline__ void span_encode_one(const xzamd_span_args& a, const 
     if constexpr (OPT) {
         if (lane == 0 && a.err) {
             tm_lds[8] = __builtin_amdgcn_s_memtime() - tm_start;
+            {   // per-span record for tools/gpu_span_times.py, in the (now dead) literal-coder slice of the span
+                uint32_t hw_id;
+                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
+                uint32_t xcc_id;
+                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_id));
+                z.lit[0] = 0x54494D45u; z.lit[1] = (uint32_t)tm_lds[8]; z.lit[2] = (uint32_t)(tm_lds[8] >> 32);
+                z.lit[3] = hw_id; z.lit[4] = xcc_id; z.lit[5] = (uint32_t)tm_lds[9]; z.lit[6] = (uint32_t)(tm_start >> 10);
+                z.lit[7] = span_end - span_start;
+            }
             unsigned long long* g = reinterpret_cast<unsigned long long*>(a.err + 16);
             for (int i = 0; i < 12; ++i) atomicAdd(g + i, tm_lds[i]);
             atomicMax(g + 12, tm_lds[8]);
@@ -2103,7 +2130,6 @@ void k_span_encode_t(xzamd_span_args a, uint32_t nspans, uint32_t* __restrict__ 
 // rep0" edge of the parser, lzma_encoder_optimum_normal.c:728-790).
 // ------------------------------------------------------------------------------------------
 constexpr uint32_t FIND_RUN = 256;
-constexpr uint32_t LEN2_MAX = 127;
 
 // bytes matched inside one 16-byte trip (16 = all)
 __device__ __forceinline__ uint32_t match16(const uint4& a, const uint4& b)
@@ -2221,25 +2247,20 @@ __global__ __launch_bounds__(64) void k_find_sn(xzamd_span_args a, SnArgs sn, ui
     // masks for the prefix maximum inside a side (the right side must not look into the left one)
     const bool sh1 = t != 0 && t != 5, sh2 = (left && t >= 2) || (right && t >= 7), sh4 = (left && t >= 4) || (right && t >= 9);
 
-    // geometry of the row's current position (per lane, equal inside a row): Block start / end, span end
-    uint32_t g_bs, g_be, g_se;
+    // geometry of the row's current position (per lane, equal inside a row): Block start / end.  The records are
+    // span independent (a match may run to the Block end): the spans are cut from these lists afterwards
+    // (k_span_est / k_span_cut) and the parser clamps what it reads to its span (round_lists).
+    uint32_t g_bs, g_be;
     {
         const uint32_t p = xr0 < n ? xr0 : 0u;
         const uint32_t blk = p / a.block_size;
         g_bs = blk * a.block_size;
         g_be = min(n, g_bs + a.block_size);
-        const uint64_t kk = (p - g_bs) / a.span_size;
-        const uint64_t se = (uint64_t)g_bs + (kk + 1) * a.span_size;
-        g_se = se < g_be ? (uint32_t)se : g_be;
     }
-    auto geo_next = [&](uint32_t& bs, uint32_t& be, uint32_t& se, uint32_t p) {      // (bs, be, se) of p - 1 -> of p
-        const bool nb = p >= be, ns = p >= se;
-        const uint32_t bs2 = nb ? be : bs;
-        const uint32_t be2 = nb ? min(n, be + a.block_size) : be;
-        const uint32_t base = nb ? bs2 : se;
-        const uint64_t se2 = (uint64_t)base + a.span_size;
-        se = ns ? (se2 < be2 ? (uint32_t)se2 : be2) : se;
-        bs = bs2; be = be2;
+    auto geo_next = [&](uint32_t& bs, uint32_t& be, uint32_t p) {      // (bs, be) of p - 1 -> of p
+        const bool nb = p >= be;
+        bs = nb ? be : bs;
+        be = nb ? min(n, be + a.block_size) : be;
     };
     auto clampp = [&](uint32_t p) -> uint32_t { return p < n ? p : n - 1; };
     // neighbour of this lane for position p with rank r inside Block [bs, be)
@@ -2272,10 +2293,10 @@ __global__ __launch_bounds__(64) void k_find_sn(xzamd_span_args a, SnArgs sn, ui
 
     // ---- prologue: positions i = 0, 1, 2 of the row
     const uint32_t xend = min(n, xr0 + ROW_RUN);                          // this row's positions: [xr0, xend)
-    uint32_t g1_bs = g_bs, g1_be = g_be, g1_se = g_se;                    // geometry of x + 1
-    geo_next(g1_bs, g1_be, g1_se, xr0 + 1);
-    uint32_t g2_bs = g1_bs, g2_be = g1_be, g2_se = g1_se;                 // geometry of x + 2
-    geo_next(g2_bs, g2_be, g2_se, xr0 + 2);
+    uint32_t g1_bs = g_bs, g1_be = g_be;                                  // geometry of x + 1
+    geo_next(g1_bs, g1_be, xr0 + 1);
+    uint32_t g2_bs = g1_bs, g2_be = g1_be;                                // geometry of x + 2
+    geo_next(g2_bs, g2_be, xr0 + 2);
     uint32_t rk1 = sn.sa_rank[clampp(xr0 + 1)];
     uint32_t rk2 = sn.sa_rank[clampp(xr0 + 2)];
     uint32_t hw1 = hash_lane ? hp[hstride * clampp(xr0 + 1)] : 0u;
@@ -2309,7 +2330,7 @@ __global__ __launch_bounds__(64) void k_find_sn(xzamd_span_args a, SnArgs sn, ui
         if (x < xend) {
             const uint32_t q = q0;
             const bool valid = v0;
-            const uint32_t avail = g_se - x;
+            const uint32_t avail = g_be - x;
             const uint32_t buf_avail = avail < MATCH_LEN_MAX ? avail : MATCH_LEN_MAX;
             const uint32_t len_limit = nice <= avail ? nice : avail;
             const bool mf_ok = nice <= avail || avail >= 4;    // "pending": nothing is reported (lz_encoder_mf.c:190-201)
@@ -2367,12 +2388,14 @@ __global__ __launch_bounds__(64) void k_find_sn(xzamd_span_args a, SnArgs sn, ui
             // trailer: count | len2(longest) << 8 | len2(second) << 16, written bytewise by the lanes that know
             uint8_t* tr = reinterpret_cast<uint8_t*>(mdist + rec_base + LIST_K);
             if (cnt == 0) {
-                if (t == 0) mdist[rec_base + LIST_K] = 0;
+                if (t == 0) { mdist[rec_base + LIST_K] = 0; a.mtop[x] = 0; }
             } else {
                 if (top) {
                     *reinterpret_cast<uint16_t*>(tr) = (uint16_t)((cnt - drop) | (l2 << 8));
                     tr[3] = 0;
                     if (cnt == 1) tr[2] = 0;
+                    // what the span plan's walk needs of this position (k_span_est), 2 bytes instead of the 32-byte record
+                    a.mtop[x] = (uint16_t)(len_out | ((dist > 1 ? 32u - (uint32_t)__builtin_clz(dist - 1) : 0u) << 9));
                 }
                 if (second) tr[2] = (uint8_t)l2;
             }
@@ -2381,9 +2404,123 @@ __global__ __launch_bounds__(64) void k_find_sn(xzamd_span_args a, SnArgs sn, ui
         q0 = q1; v0 = v1; pf0 = pf1; A0 = A1; B0 = B1;
         w1 = w2; hw1 = hw2;
         rk2 = rk3;
-        g_bs = g1_bs; g_be = g1_be; g_se = g1_se;
-        g1_bs = g2_bs; g1_be = g2_be; g1_se = g2_se;
-        geo_next(g2_bs, g2_be, g2_se, x + 3);
+        g_bs = g1_bs; g_be = g1_be;
+        g1_bs = g2_bs; g1_be = g2_be;
+        geo_next(g2_bs, g2_be, x + 3);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Cost-balanced spans (oracle: est_chunk / plan_spans).  A wavefront needs one step per position the optimal
+// parser visits, and positions covered by a match of nice_len bytes or more are not visited; a state reset costs a
+// few hundred bytes of model learning whatever the data.  So spans are cut by estimated parser work instead of
+// input bytes: the spans of a launch take about equally long whatever they hold, and highly compressible data
+// gets the long spans its small output needs.
+//   k_span_est   one thread per chunk of XZAMD_EST_CHUNK positions: a walk over the match lists.  A position whose
+//                longest match reaches nice_len costs EST_LONG units and the walk jumps over the match, any other
+//                position one unit; alongside, a greedy-parse estimate of the coded size in bits.
+//   k_span_cut   one wavefront per Block: k = max(1, work of the Block / target) spans of equal estimated work.
+// ------------------------------------------------------------------------------------------
+constexpr uint32_t EST_LONG = 4;
+
+__global__ __launch_bounds__(256) void k_span_est(xzamd_span_args a, uint32_t nblocks, uint32_t cpb,
+        uint32_t* __restrict__ est, unsigned long long* __restrict__ totals)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t nch = nblocks * cpb;
+    if (t >= nch) return;
+    const uint32_t b = t / cpb, c = t - b * cpb;
+    const uint32_t bs = b * a.block_size;
+    const uint32_t be = min(a.n, bs + a.block_size);
+    const uint64_t c0_ = (uint64_t)bs + (uint64_t)c * XZAMD_EST_CHUNK;
+    uint32_t w = 0, bits = 0;
+    if (c0_ < be) {
+        const uint32_t c0 = (uint32_t)c0_;
+        const uint32_t c1 = be - c0 < XZAMD_EST_CHUNK ? be : c0 + XZAMD_EST_CHUNK;
+        uint32_t x = c0, gnext = c0;
+        while (x < c1) {
+            const uint32_t v = a.mtop[x];
+            const uint32_t len = v & 0x1FFu, bl = v >> 9;          // bl <= 7 <=> zero-based distance < 128
+            if (x >= gnext) {
+                if (len >= 3 || (len == 2 && bl <= 7)) {
+                    bits += 14 + bl;
+                    gnext = x + len;
+                } else {
+                    bits += 6;
+                    gnext = x + 1;
+                }
+            }
+            if (len >= a.nice_len) { w += EST_LONG; x += len; }
+            else { w += 1; x += 1; }
+        }
+        atomicAdd(&totals[b], (unsigned long long)w);
+        atomicAdd(&totals[nblocks], (unsigned long long)w);
+    }
+    est[t] = w;
+    est[nch + t] = bits;
+}
+
+__device__ __forceinline__ uint32_t wave_incl_sum(uint32_t v)
+{
+    const uint32_t lane = threadIdx.x;
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1) {
+        const uint32_t o = __shfl_up(v, s);
+        if (lane >= (uint32_t)s) v += o;
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(64) void k_span_cut(xzamd_span_args a, uint32_t nblocks, uint32_t cpb,
+        const uint32_t* __restrict__ est, unsigned long long* __restrict__ totals, uint32_t* __restrict__ span_tab,
+        uint32_t* __restrict__ span_cnt, uint32_t cost_min, uint32_t bits_min, uint32_t min_len, uint32_t slots)
+{
+    const uint32_t lane = threadIdx.x;
+    const uint32_t b = blockIdx.x;
+    const uint32_t nch = nblocks * cpb;
+    const uint32_t bs = b * a.block_size;
+    const uint32_t be = min(a.n, bs + a.block_size);
+    const uint32_t m = (be - bs + XZAMD_EST_CHUNK - 1) / XZAMD_EST_CHUNK;      // chunks of this Block
+    const unsigned long long batch_total = totals[nblocks], total = totals[b];
+    unsigned long long T = (batch_total + slots - 1) / slots;
+    if (T < cost_min) T = cost_min;
+    if (b == 0 && lane == 0) totals[nblocks + 1] = T;
+    const unsigned long long k = total / T ? total / T : 1ull;
+    const unsigned long long Tb = (total + k - 1) / k;
+    const uint32_t* wk = est + (uint64_t)b * cpb;
+    const uint32_t* bt = est + nch + (uint64_t)b * cpb;
+    uint32_t* tab = span_tab + 2ull * b * a.max_spb;
+    uint32_t ns = 1, start = 0;                       // spans so far, first chunk of the open span
+    unsigned long long carry_w = 0, carry_b = 0;      // estimates of the open span in front of the window
+    if (lane == 0) tab[0] = bs;
+    for (uint32_t c0 = 0; c0 < m; c0 += 64) {
+        const uint32_t c = c0 + lane;
+        const uint32_t pw = wave_incl_sum(c < m ? wk[c] : 0u), pb = wave_incl_sum(c < m ? bt[c] : 0u);
+        uint32_t subw = 0, subb = 0;                  // window sums up to the last cut inside the window
+        for (;;) {
+            const unsigned long long accw = carry_w + (pw - subw), accb = carry_b + (pb - subb);
+            const unsigned long long len = (unsigned long long)(c + 1 - start) * XZAMD_EST_CHUNK;
+            const bool cut = c + 1 < m && c >= start && ns < a.max_spb
+                    && (len >= XZAMD_SPAN_MAX || (accw >= Tb && accb >= bits_min && len >= min_len));
+            const uint64_t mask = __builtin_amdgcn_ballot_w64(cut);
+            if (!mask) break;
+            const uint32_t L = (uint32_t)__builtin_ctzll(mask);
+            start = c0 + L + 1;
+            subw = lane_of(pw, L); subb = lane_of(pb, L);
+            carry_w = 0; carry_b = 0;
+            if (lane == 0) {
+                const uint32_t p = bs + start * XZAMD_EST_CHUNK;
+                tab[2 * ns - 1] = p;                  // end of the span just closed
+                tab[2 * ns] = p;
+            }
+            ++ns;
+        }
+        carry_w += lane_of(pw, 63) - subw;
+        carry_b += lane_of(pb, 63) - subb;
+    }
+    if (lane == 0) {
+        tab[2 * ns - 1] = be;
+        span_cnt[b] = ns;
     }
 }
 
@@ -3056,7 +3193,7 @@ int xzk_sa_temp_bytes(uint32_t n, uint64_t* bytes)
 //                                position with the same 8 / 16 bytes)
 // keys_a/keys_b/vals_a/vals_b: n u32 each; key64_a/key64_b: n u64 each (sa != NULL only).
 int xzk_build_chains(const uint8_t* d_in, uint32_t n, uint32_t block_size, uint32_t nblocks,
-        uint32_t hash_bytes, uint32_t hash_mask, uint32_t hash_bits,
+        uint32_t hash_bytes, uint32_t hash_mask, uint32_t hash_bits, uint32_t sa_depth,
         uint32_t* keys_a, uint32_t* keys_b, uint32_t* vals_a, uint32_t* vals_b,
         void* sort_tmp, uint64_t sort_tmp_bytes,
         uint32_t* rank, uint32_t* sorted_pos, uint32_t* prev2, uint32_t* prev3,
@@ -3189,22 +3326,35 @@ int xzk_build_chains(const uint8_t* d_in, uint32_t n, uint32_t block_size, uint3
     uint32_t sbits = 1, fbits = 1;                    // bits of a Block-relative rank (<= block_size), of a rank (<= n)
     while (sbits < 32 && (1ull << sbits) <= (uint64_t)min(block_size, n)) ++sbits;
     while (fbits < 32 && (1ull << fbits) <= (uint64_t)n) ++fbits;
-    for (uint32_t h = 8; h <= 16; h *= 2) {
-        // by-position arrays of the round: rank at rk32[0..n), left-neighbour distance at rk32[n..2n)
-        uint32_t* const rk32 = reinterpret_cast<uint32_t*>(h == 8 ? rp8 : rp16);
-        // (rank, left-neighbour distance) of every slot, brought to position order
-        hipLaunchKernelGGL(k_sa_rank_seq, dim3(g), dim3(256), 0, st, pos, grp, n, reinterpret_cast<uint2*>(key64_a));
-        e = invert_perm<uint64_t>(pos, pos_alt, key64_a, key64_b, n, rk32, rk32 + n, sort_tmp, tb, st);
-        if (e != hipSuccess) return (int)e;
-        // keys in position order (values = iota): both `pos` buffers are free again
-        hipLaunchKernelGGL(k_sa_pair_keys_pos, dim3(g), dim3(256), 0, st, rk32, n, block_size, h, sbits, key64_a, pos);
+    if (sa_depth < 32) sa_depth = 32;
+    for (uint32_t h = 8; 2 * h <= sa_depth; h *= 2) {
+        if (h <= 16) {
+            // by-position arrays of the round: rank at rk32[0..n), left-neighbour distance at rk32[n..2n)
+            uint32_t* const rk32 = reinterpret_cast<uint32_t*>(h == 8 ? rp8 : rp16);
+            // (rank, left-neighbour distance) of every slot, brought to position order
+            hipLaunchKernelGGL(k_sa_rank_seq, dim3(g), dim3(256), 0, st, pos, grp, n, reinterpret_cast<uint2*>(key64_a));
+            e = invert_perm<uint64_t>(pos, pos_alt, key64_a, key64_b, n, rk32, rk32 + n, sort_tmp, tb, st);
+            if (e != hipSuccess) return (int)e;
+            // keys in position order (values = iota): both `pos` buffers are free again
+            hipLaunchKernelGGL(k_sa_pair_keys_pos, dim3(g), dim3(256), 0, st, rk32, n, block_size, h, sbits, key64_a, pos);
+        } else {
+            // deeper rounds (sa_depth 64 / 128 / 256): only the rank is wanted by position; it goes where the rank of
+            // round h = 8 was (dead since that round's keys were made; the distances behind it stay)
+            uint32_t* const rk32 = reinterpret_cast<uint32_t*>(rp8);
+            uint32_t* const ra = reinterpret_cast<uint32_t*>(key64_a);
+            uint32_t* const rb = reinterpret_cast<uint32_t*>(key64_b);
+            hipLaunchKernelGGL(k_sa_rank_only_seq, dim3(g), dim3(256), 0, st, grp, n, ra);
+            e = invert_perm<uint32_t>(pos, pos_alt, ra, rb, n, rk32, nullptr, sort_tmp, tb, st);
+            if (e != hipSuccess) return (int)e;
+            hipLaunchKernelGGL(k_sa_pair_keys_pos, dim3(g), dim3(256), 0, st, rk32, n, block_size, h, sbits, key64_a, pos);
+        }
         rocprim::double_buffer<uint64_t> kk(key64_a, key64_b);
         rocprim::double_buffer<uint32_t> vv(pos, pos_alt);
         e = rocprim::radix_sort_pairs(sort_tmp, tb, kk, vv, (size_t)n, 0u, sbits + fbits, st);
         if (e != hipSuccess) return (int)e;
         pos = vv.current();
         pos_alt = vv.alternate();
-        if (h == 8) {
+        if (4 * h <= sa_depth) {            // another round follows: its ranks need the groups of this order
             hipLaunchKernelGGL(k_sa_flags64, dim3(g), dim3(256), 0, st, kk.current(), n, 0u, grp);
             e = rocprim::inclusive_scan(sort_tmp, tb, grp, grp, (size_t)n, rocprim::maximum<uint32_t>(), st);
             if (e != hipSuccess) return (int)e;
@@ -3224,7 +3374,7 @@ int xzk_find_matches(const xzamd_span_args* a, const uint32_t* sa, const uint32_
     const uint32_t runs = (a->n + FIND_RUN - 1) / FIND_RUN;
     if (runs == 0) return 0;
     if (a->sa_window) {
-        if (!sa || !sa_rank || !prev4 || !rp8 || !rp16 || a->sa_window > SN_WMAX) return (int)hipErrorInvalidValue;
+        if (!sa || !sa_rank || !prev4 || !rp8 || !rp16 || !a->mtop || a->sa_window > SN_WMAX) return (int)hipErrorInvalidValue;
         SnArgs sn;
         sn.in = a->in; sn.sa = sa; sn.sa_rank = sa_rank; sn.prev2 = a->prev2; sn.prev4 = prev4;
         sn.prev8 = reinterpret_cast<const uint32_t*>(rp8) + a->n;     // second array of the round's (rank, distance) pair
@@ -3236,12 +3386,30 @@ int xzk_find_matches(const xzamd_span_args* a, const uint32_t* sa, const uint32_
     return (int)hipGetLastError();
 }
 
+int xzk_span_plan(const xzamd_span_args* a, uint32_t nblocks, uint32_t* est, unsigned long long* totals,
+        uint32_t* span_tab, uint32_t* span_cnt, uint32_t cost_min, uint32_t bits_min, uint32_t min_len, uint32_t slots,
+        void* stream_)
+{
+    hipStream_t st = (hipStream_t)stream_;
+    if (nblocks == 0 || a->n == 0) return 0;
+    if (!a->mtop || a->max_spb == 0 || slots == 0 || cost_min == 0) return (int)hipErrorInvalidValue;
+    const uint32_t cpb = (a->block_size + XZAMD_EST_CHUNK - 1) / XZAMD_EST_CHUNK;
+    hipError_t e = hipMemsetAsync(totals, 0, (size_t)(nblocks + 2) * sizeof(unsigned long long), st);
+    if (e != hipSuccess) return (int)e;
+    const uint64_t nch = (uint64_t)nblocks * cpb;
+    hipLaunchKernelGGL(k_span_est, dim3((uint32_t)((nch + 255) / 256)), dim3(256), 0, st, *a, nblocks, cpb, est, totals);
+    hipLaunchKernelGGL(k_span_cut, dim3(nblocks), dim3(64), 0, st, *a, nblocks, cpb, est, totals, span_tab, span_cnt,
+            cost_min, bits_min, min_len, slots);
+    return (int)hipGetLastError();
+}
+
 // waves = 0: one wavefront per span; else a persistent launch of min(waves, nspans) wavefronts that pull
 // span numbers from *counter (must be zero at launch).
 int xzk_span_encode(const xzamd_span_args* a, uint32_t nspans, uint32_t waves, uint32_t* counter, void* stream_)
 {
     hipStream_t st = (hipStream_t)stream_;
     if (nspans == 0) return 0;
+    if (!a->span_tab || !a->span_cnt || a->max_spb == 0) return (int)hipErrorInvalidValue;
     const bool persist = waves != 0 && counter != nullptr && waves < nspans;
     const uint32_t grid = persist ? waves : nspans;
     uint32_t* cnt = persist ? counter : nullptr;
@@ -3253,6 +3421,17 @@ int xzk_span_encode(const xzamd_span_args* a, uint32_t nspans, uint32_t waves, u
         hipLaunchKernelGGL((k_span_encode_t<0, false>), dim3(grid), dim3(64), 0, st, *a, nspans, cnt);
     }
     return (int)hipGetLastError();
+}
+
+// wavefronts of the span kernel one CU holds at once (what the launch geometry of the span plan is sized for)
+int xzk_span_occupancy(int parser, int* waves_per_cu)
+{
+    int nb = 0;
+    hipError_t e = parser
+            ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_span_encode_t<2, true>, 64, 0)
+            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_span_encode_t<0, false>, 64, 0);
+    *waves_per_cu = nb;
+    return (int)e;
 }
 
 int xzk_x86_bcj(const uint8_t* d_in, uint8_t* d_out, uint32_t n, uint32_t block_size, uint32_t nblocks, void* stream_)

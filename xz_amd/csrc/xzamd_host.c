@@ -201,6 +201,17 @@ uint64_t xzamd_stream_buffer_bound(uint64_t in_size, uint64_t block_size)
 /* ------------------------------------------------------------------ */
 /* presets                                                              */
 /* ------------------------------------------------------------------ */
+/* What a BT2/BT3/BT4 request runs on the device: the suffix-neighbourhood finder over a suffix order deep enough
+ * for the request's nice_len, the windowed optimal parser, cost-balanced spans. */
+void xzamd_sn_defaults(xzamd_lzma_options *o)
+{
+	o->gpu_sa_window = XZAMD_SA_WINDOW_MAX;
+	o->gpu_parser = 1;
+	o->gpu_sa_depth = o->gpu_nice_len <= 32 ? 32 : o->gpu_nice_len <= 64 ? 64 : 256;
+	o->span_cost = XZAMD_SPAN_COST_DEFAULT;
+	o->span_bits = XZAMD_SPAN_BITS_DEFAULT;
+}
+
 int xzamd_lzma_preset(xzamd_lzma_options *o, uint32_t preset)
 {
 	/* lzma/lzma_encoder_presets.c:17-63 */
@@ -245,8 +256,7 @@ int xzamd_lzma_preset(xzamd_lzma_options *o, uint32_t preset)
 		o->gpu_mf = XZAMD_MF_HC4;
 		o->gpu_nice_len = o->nice_len;
 		o->gpu_depth = 1;
-		o->gpu_sa_window = XZAMD_SA_WINDOW_MAX;
-		o->gpu_parser = 1;
+		xzamd_sn_defaults(o);
 	}
 	o->span_size = XZAMD_SPAN_DEFAULT;
 	return 0;
@@ -274,6 +284,9 @@ struct xzamd_ctx {
 	uint64_t batch_bytes;
 	uint32_t wave_slots;         /* span wavefronts resident at once (CUs x 16) */
 	uint32_t span_waves;         /* != 0: persistent span kernel with this many wavefronts */
+	uint32_t span_rounds;        /* cost-balanced spans: a batch is cut into at most wave_slots * span_rounds spans (XZAMD_SPAN_ROUNDS, default 3: the running
+	                              * time of equal-work spans still varies by +-25 %, so a launch needs a few rounds to even out) */
+	int prefetch_after;          /* XZAMD_PREFETCH_AFTER=1: enqueue the next batch's build behind the span kernel launch instead of in front of it */
 	int overlap_off;             /* an event of the low-priority pipeline could not be created: no prefetch */
 	uint64_t alloc_limit;        /* test hook (XZAMD_TEST_ALLOC_LIMIT_MIB, read once at creation): larger allocations fail; 0 = none */
 	char err[256];
@@ -281,8 +294,9 @@ struct xzamd_ctx {
 	/* device buffers */
 	dbuf keys_a, keys_b, vals_a, vals_b, rank, sorted_pos, prev2, prev3, prev4, prev8, prev16, key64_a, key64_b, sa, sa_rank, sort_tmp;
 	dbuf scratch, span_bytes, strip_crc, block_crc, segs, lits, trace, errw, litp, mlen, mdist, mlen2, mdist2, bcj;
+	dbuf est, totals, span_tab, span_cnt, mtop, mtop2;      /* span plan (kernels_api.h) */
 	/* pinned host buffers */
-	dbuf h_span_bytes, h_block_crc, h_segs, h_lits;
+	dbuf h_span_bytes, h_block_crc, h_segs, h_lits, h_span_tab, h_span_cnt;
 	void *ev[10];
 	uint32_t trace_cap;
 	int trace_on;
@@ -346,11 +360,17 @@ int xzamd_ctx_create(xzamd_ctx **out, int device)
 	{
 		int cus = 0;
 		if (xzk_cu_count(device, &cus) || cus <= 0) cus = 256;
-		c->wave_slots = (uint32_t)cus * 16u;       /* the span kernels run 4 waves per SIMD = 16 per CU */
+		int occ = 0;
+		if (xzk_span_occupancy(1, &occ) || occ <= 0 || occ > 32) occ = 16;     /* the span kernels are built for 4 waves per SIMD */
+		c->wave_slots = (uint32_t)cus * (uint32_t)occ;
 		/* XZAMD_SPAN_WAVES_PER_CU = k: persistent span kernel with k wavefronts per CU (k < 16 leaves
 		 * register space for the low-priority stream's kernels); 0 / unset: one wavefront per span */
 		const char *pw = getenv("XZAMD_SPAN_WAVES_PER_CU");
 		c->span_waves = (pw && atoi(pw) > 0) ? (uint32_t)cus * (uint32_t)atoi(pw) : 0;
+		const char *pa = getenv("XZAMD_PREFETCH_AFTER");
+		c->prefetch_after = pa && *pa == '1';
+		const char *pr = getenv("XZAMD_SPAN_ROUNDS");
+		c->span_rounds = (pr && atoi(pr) > 0 && atoi(pr) <= 16) ? (uint32_t)atoi(pr) : 3;
 	}
 	const char *env = getenv("XZAMD_BATCH_MIB");
 	if (env && atoll(env) > 0)
@@ -367,10 +387,11 @@ void xzamd_ctx_destroy(xzamd_ctx *c)
 	dbuf *d[] = { &c->keys_a, &c->keys_b, &c->vals_a, &c->vals_b, &c->rank, &c->sorted_pos,
 		&c->prev2, &c->prev3, &c->prev4, &c->prev8, &c->prev16, &c->key64_a, &c->key64_b, &c->sa, &c->sa_rank, &c->sort_tmp,
 		&c->scratch, &c->span_bytes, &c->strip_crc,
-		&c->block_crc, &c->segs, &c->lits, &c->trace, &c->errw, &c->litp, &c->mlen, &c->mdist, &c->mlen2, &c->mdist2, &c->bcj };
+		&c->block_crc, &c->segs, &c->lits, &c->trace, &c->errw, &c->litp, &c->mlen, &c->mdist, &c->mlen2, &c->mdist2, &c->bcj,
+		&c->est, &c->totals, &c->span_tab, &c->span_cnt, &c->mtop, &c->mtop2 };
 	for (size_t i = 0; i < sizeof(d) / sizeof(d[0]); ++i)
 		if (d[i]->p) xzk_free(d[i]->p);
-	dbuf *h[] = { &c->h_span_bytes, &c->h_block_crc, &c->h_segs, &c->h_lits };
+	dbuf *h[] = { &c->h_span_bytes, &c->h_block_crc, &c->h_segs, &c->h_lits, &c->h_span_tab, &c->h_span_cnt };
 	for (size_t i = 0; i < sizeof(h) / sizeof(h[0]); ++i)
 		if (h[i]->p) xzk_host_free(h[i]->p);
 	for (int i = 0; i < 10; ++i)
@@ -417,6 +438,9 @@ const char *xzamd_options_check(const xzamd_lzma_options *opt)
 		return "filters in front of LZMA2: x86 / PowerPC / IA-64 / ARM / ARM-Thumb / SPARC / ARM64 / RISC-V BCJ or delta";
 	if (opt->gpu_parser && opt->pb > 2)
 		return "the optimal parser's price tables cover pb <= 2";
+	if (opt->gpu_sa_depth != 0 && opt->gpu_sa_depth != 32 && opt->gpu_sa_depth != 64 && opt->gpu_sa_depth != 128
+			&& opt->gpu_sa_depth != 256)
+		return "gpu_sa_depth: 32, 64, 128 or 256";
 	return NULL;
 }
 
@@ -437,7 +461,9 @@ int xzamd_debug_fetch(xzamd_ctx *c, int what, void *out, uint64_t bytes)
 	if (!c || !out)
 		return XZAMD_PROG_ERROR;
 	const dbuf *b = what == XZAMD_DEBUG_SA ? &c->sa : what == XZAMD_DEBUG_SA_RANK ? &c->sa_rank
-			: what == XZAMD_DEBUG_LISTS ? &c->mdist : what == XZAMD_DEBUG_LIST_LENS ? &c->mlen : NULL;
+			: what == XZAMD_DEBUG_LISTS ? &c->mdist : what == XZAMD_DEBUG_LIST_LENS ? &c->mlen
+			: what == XZAMD_DEBUG_SPAN_TAB ? &c->span_tab : what == XZAMD_DEBUG_SPAN_CNT ? &c->span_cnt
+			: what == XZAMD_DEBUG_SPAN_EST ? &c->est : what == XZAMD_DEBUG_LITP ? &c->litp : NULL;
 	if (!b || !b->p || b->cap < bytes)
 		return XZAMD_PROG_ERROR;
 	xzk_set_device(c->device);
@@ -542,7 +568,7 @@ static int batch_geometry(xzamd_ctx *c, const xzamd_lzma_options *opt, uint64_t 
 static int launch_chains(xzamd_ctx *c, const xzamd_lzma_options *opt, const uint8_t *enc_in, const batch_geo *g,
 		uint64_t block_size, uint32_t hb, uint32_t hmask, uint32_t hbits, void *st)
 {
-	int e = xzk_build_chains(enc_in, g->n, (uint32_t)block_size, (uint32_t)g->nb, hb, hmask, hbits,
+	int e = xzk_build_chains(enc_in, g->n, (uint32_t)block_size, (uint32_t)g->nb, hb, hmask, hbits, opt->gpu_sa_depth,
 			(uint32_t *)c->keys_a.p, (uint32_t *)c->keys_b.p, (uint32_t *)c->vals_a.p,
 			(uint32_t *)c->vals_b.p, c->sort_tmp.p, g->sort_bytes,
 			(uint32_t *)c->rank.p, (uint32_t *)c->sorted_pos.p, (uint32_t *)c->prev2.p,
@@ -620,31 +646,20 @@ int xzamd_stream_encode_device(xzamd_ctx *c,
 		max_blocks = (total_blocks + nbatch - 1) / nbatch;
 	}
 	if (nblocks_out) *nblocks_out = total_blocks;
-	if (opt->span_size == XZAMD_SPAN_AUTO && total_blocks) {
-		/* One wavefront per span and spans of about equal cost: a launch runs in rounds of `wave_slots`
-		 * spans.  Size the spans so that the rounds of a batch are full: between half the default and
-		 * the default span. */
-		const uint64_t nbb = total_blocks < max_blocks ? total_blocks : max_blocks;
-		const uint64_t spb0 = (block_size + span - 1) / span;
-		const uint64_t rounds = (nbb * spb0 + c->wave_slots - 1) / c->wave_slots;
-		uint64_t spb_new = rounds * c->wave_slots / nbb;
-		if (spb_new > spb0) {
-			uint64_t sp = (block_size + spb_new - 1) / spb_new;
-			sp = (sp + 15) & ~15ull;
-			if (sp < span / 2) sp = span / 2;
-			if (sp < 4096) sp = 4096;
-			if (sp < span) span = (uint32_t)sp;
-		}
-	}
-	const uint32_t spb = (uint32_t)((block_size + span - 1) / span);
-	const uint64_t span_cap = ((uint64_t)span + (span >> 3) + 4096 + 15) & ~15ull;
+	/* Span plan.  Optimal parser over the suffix-neighbourhood finder with no explicit span size: cost-balanced
+	 * spans cut on the device from the match lists (xzk_span_plan).  Else spans of `span` bytes, table written here. */
+	const int adaptive = opt->gpu_parser && opt->gpu_sa_window && opt->span_cost != 0
+			&& (opt->span_size == XZAMD_SPAN_DEFAULT || opt->span_size == XZAMD_SPAN_AUTO);
+	const uint32_t spb = adaptive ? (uint32_t)(block_size / XZAMD_SPAN_MIN_LEN + 2) : (uint32_t)((block_size + span - 1) / span);   /* span slots per Block */
+	const uint32_t cpb = (uint32_t)((block_size + XZAMD_EST_CHUNK - 1) / XZAMD_EST_CHUNK);
 	const uint64_t bound = xzamd_block_buffer_bound(block_size);
 	const int x86 = opt->bcj != 0;          /* any filter in front of LZMA2: the encoder reads a filtered copy */
 	const uint32_t hs_fixed = block_header_size(bound, block_size, opt->bcj);
 	const uint8_t dbyte = dict_size_byte(opt->dict_size);
 
 	memset(&c->stats, 0, sizeof(c->stats));
-	c->stats.span_size = span;
+	c->stats.span_size = adaptive ? 0 : span;
+	c->stats.wave_slots = c->wave_slots;
 	uint64_t opos = 0;
 	uint8_t small[64];
 	uint64_t *rec_unp = NULL, *rec_unc = NULL;
@@ -694,8 +709,16 @@ int xzamd_stream_encode_device(xzamd_ctx *c,
 			GROW(rank, 4ull * n, 0); GROW(sorted_pos, 4ull * n, 0);
 		}
 		GROW(sort_tmp, sort_bytes + 256, 0);
-		GROW(scratch, span_cap * nspans, 0);
+		GROW(scratch, (uint64_t)n + (n >> 3) + 32 + (uint64_t)XZAMD_SPAN_SLACK * nspans, 0);
 		GROW(span_bytes, 4ull * nspans, 0);
+		GROW(span_tab, 8ull * nspans, 0);
+		GROW(span_cnt, 4ull * nb, 0);
+		GROW(h_span_tab, 8ull * nspans, 1);
+		GROW(h_span_cnt, 4ull * nb + 16, 1);
+		if (adaptive) {
+			GROW(est, 8ull * nb * cpb, 0);
+			GROW(totals, 8ull * (nb + 2), 0);
+		}
 		GROW(strip_crc, 8ull * spb_crc * nb, 0);
 		GROW(block_crc, 32ull * nb, 0);
 		GROW(errw, 256, 0);
@@ -704,6 +727,8 @@ int xzamd_stream_encode_device(xzamd_ctx *c,
 			/* per-position match lists: 8 x u32 (7 entries + trailer), + 8 x u16 lengths when not packed */
 			if (!list_packed) GROW(mlen, 16ull * n, 0);
 			GROW(mdist, 32ull * n, 0);
+			if (opt->gpu_sa_window) GROW(mtop, 2ull * n, 0);
+			if (overlap && opt->gpu_sa_window) GROW(mtop2, 2ull * n, 0);
 			if (overlap) {
 				/* second list buffer: the next batch's finder runs underneath this batch's span kernel */
 				if (!list_packed) GROW(mlen2, 16ull * n, 0);
@@ -762,7 +787,9 @@ int xzamd_stream_encode_device(xzamd_ctx *c,
 			a.sa_window = opt->gpu_sa_window;
 			a.parser = opt->gpu_parser;
 			a.scratch = (uint8_t *)c->scratch.p;
-			a.span_cap = span_cap;
+			a.span_tab = (const uint32_t *)c->span_tab.p;
+			a.span_cnt = (const uint32_t *)c->span_cnt.p;
+			a.max_spb = spb;
 			a.span_bytes = (uint32_t *)c->span_bytes.p;
 			a.err = (uint32_t *)c->errw.p;
 			a.lit = (uint32_t *)c->litp.p;
@@ -775,7 +802,6 @@ int xzamd_stream_encode_device(xzamd_ctx *c,
 			a.n = n;
 			a.block_size = (uint32_t)block_size;
 			a.span_size = span;
-			a.spans_per_block = spb;
 			a.dict_size = opt->dict_size;
 			a.nice_len = opt->gpu_nice_len;
 			a.depth = opt->gpu_depth;
@@ -789,6 +815,7 @@ int xzamd_stream_encode_device(xzamd_ctx *c,
 				a.mlen = ml_cur;
 				a.list_packed = (uint32_t)list_packed;
 				a.mdist = md_cur;
+				a.mtop = (uint16_t *)(lists_cur ? c->mtop2.p : c->mtop.p);
 				if (!find_on_lo) {
 					e = xzk_find_matches(&a, (const uint32_t *)c->sa.p, (const uint32_t *)c->sa_rank.p, (const uint32_t *)c->prev4.p,
 							(const uint64_t *)c->prev8.p, (const uint64_t *)c->prev16.p, ml_cur, md_cur, st);
@@ -796,35 +823,70 @@ int xzamd_stream_encode_device(xzamd_ctx *c,
 				}
 				xzk_event_record(c->ev[5], st);
 			}
+			/* 2b. span plan */
+			uint32_t *const htab = (uint32_t *)c->h_span_tab.p, *const hcnt = (uint32_t *)c->h_span_cnt.p;
+			xzk_event_record(c->ev[7], st);
+			if (adaptive) {
+				e = xzk_span_plan(&a, (uint32_t)nb, (uint32_t *)c->est.p, (unsigned long long *)c->totals.p,
+						(uint32_t *)c->span_tab.p, (uint32_t *)c->span_cnt.p, opt->span_cost, opt->span_bits,
+						XZAMD_SPAN_MIN_LEN, c->wave_slots * c->span_rounds, st);
+				if (e) { rc = fail(c, XZAMD_DEVICE_ERROR, "span plan launch", e); goto done; }
+				/* the host lays the Blocks out from the plan: fetched with the span sizes below */
+				e = xzk_d2h(htab, c->span_tab.p, 8ull * nspans, st);
+				if (!e) e = xzk_d2h(hcnt, c->span_cnt.p, 4ull * nb, st);
+				if (!e) e = xzk_d2h(hcnt + 2 * ((nb + 1) / 2), (uint8_t *)c->totals.p + 8ull * (nb + 1), 8, st);   /* target used, behind the counts */
+				if (e) { rc = fail(c, XZAMD_DEVICE_ERROR, "d2h span plan", e); goto done; }
+			} else {
+				for (uint64_t b = 0; b < nb; ++b) {
+					const uint64_t bs = b * block_size, be = n64 - bs < block_size ? n64 : bs + block_size;
+					uint32_t k = 0;
+					for (uint64_t p = bs; p < be; p += span, ++k) {
+						htab[2 * (b * spb + k)] = (uint32_t)p;
+						htab[2 * (b * spb + k) + 1] = (uint32_t)(be - p < span ? be : p + span);
+					}
+					hcnt[b] = k;
+				}
+				e = xzk_h2d(c->span_tab.p, htab, 8ull * nspans, st);
+				if (!e) e = xzk_h2d(c->span_cnt.p, hcnt, 4ull * nb, st);
+				if (e) { rc = fail(c, XZAMD_DEVICE_ERROR, "h2d span plan", e); goto done; }
+			}
+			xzk_event_record(c->ev[6], st);
 			/* The chain arrays are free once the finder is done (the fast kernels read them, so they keep
 			 * them): build the NEXT batch's chains and match lists now, on the lowest-priority stream, into
 			 * the other list buffer.  The span kernel takes every slot it can use; the sorts and the finder
 			 * fill what its rounds leave idle. */
-			if (overlap && opt->gpu_parser && b0 + nb < total_blocks) {
-				batch_geo g2;
-				if (batch_geometry(c, opt, b0 + nb, total_blocks, max_blocks, block_size, in_size, hbits, &g2) == XZAMD_OK
-						&& g2.n <= n && g2.sort_bytes + 256 <= c->sort_tmp.cap) {
-					xzamd_span_args a2 = a;
-					a2.in = d_in + g2.in_off;
-					a2.n = g2.n;
-					uint16_t *const ml_nx = list_packed ? NULL : (uint16_t *)(lists_cur ? c->mlen.p : c->mlen2.p);
-					uint32_t *const md_nx = (uint32_t *)(lists_cur ? c->mdist.p : c->mdist2.p);
-					void **evn = c->ev_lo[lists_cur ^ 1];
-					int e2 = xzk_event_record(evn[0], st);
-					if (!e2) e2 = xzk_stream_wait_event(c->lo_stream, evn[0]);
-					if (!e2) e2 = xzk_event_record(evn[1], c->lo_stream);
-					if (!e2 && launch_chains(c, opt, d_in + g2.in_off, &g2, block_size, hb, hmask, hbits, c->lo_stream) != XZAMD_OK) e2 = 1;
-					if (!e2) e2 = xzk_event_record(evn[2], c->lo_stream);
-					if (!e2) e2 = xzk_find_matches(&a2, (const uint32_t *)c->sa.p, (const uint32_t *)c->sa_rank.p, (const uint32_t *)c->prev4.p,
-							(const uint64_t *)c->prev8.p, (const uint64_t *)c->prev16.p, ml_nx, md_nx, c->lo_stream);
-					if (!e2) e2 = xzk_event_record(evn[3], c->lo_stream);
-					if (e2) { rc = fail(c, XZAMD_DEVICE_ERROR, "chain prefetch", e2); goto done; }
-					prefetched = 1;
-					prefetched_b0 = b0 + nb;
+			const int pf_after = c->prefetch_after;
+			for (int phase = 0; phase < 2; ++phase) {
+				if (phase == (pf_after ? 0 : 1)) {
+					e = xzk_span_encode(&a, nspans, c->span_waves, (uint32_t *)c->errw.p + 60, st);
+					if (e) { rc = fail(c, XZAMD_DEVICE_ERROR, "span_encode launch", e); goto done; }
+					continue;
+				}
+				if (overlap && opt->gpu_parser && b0 + nb < total_blocks) {
+					batch_geo g2;
+					if (batch_geometry(c, opt, b0 + nb, total_blocks, max_blocks, block_size, in_size, hbits, &g2) == XZAMD_OK
+							&& g2.n <= n && g2.sort_bytes + 256 <= c->sort_tmp.cap) {
+						xzamd_span_args a2 = a;
+						a2.in = d_in + g2.in_off;
+						a2.n = g2.n;
+						a2.mtop = (uint16_t *)(lists_cur ? c->mtop.p : c->mtop2.p);
+						uint16_t *const ml_nx = list_packed ? NULL : (uint16_t *)(lists_cur ? c->mlen.p : c->mlen2.p);
+						uint32_t *const md_nx = (uint32_t *)(lists_cur ? c->mdist.p : c->mdist2.p);
+						void **evn = c->ev_lo[lists_cur ^ 1];
+						/* the chain arrays are free once the finder and the span plan of this batch are done: ev[6] */
+						int e2 = xzk_stream_wait_event(c->lo_stream, c->ev[6]);
+						if (!e2) e2 = xzk_event_record(evn[1], c->lo_stream);
+						if (!e2 && launch_chains(c, opt, d_in + g2.in_off, &g2, block_size, hb, hmask, hbits, c->lo_stream) != XZAMD_OK) e2 = 1;
+						if (!e2) e2 = xzk_event_record(evn[2], c->lo_stream);
+						if (!e2) e2 = xzk_find_matches(&a2, (const uint32_t *)c->sa.p, (const uint32_t *)c->sa_rank.p, (const uint32_t *)c->prev4.p,
+								(const uint64_t *)c->prev8.p, (const uint64_t *)c->prev16.p, ml_nx, md_nx, c->lo_stream);
+						if (!e2) e2 = xzk_event_record(evn[3], c->lo_stream);
+						if (e2) { rc = fail(c, XZAMD_DEVICE_ERROR, "chain prefetch", e2); goto done; }
+						prefetched = 1;
+						prefetched_b0 = b0 + nb;
+					}
 				}
 			}
-			e = xzk_span_encode(&a, nspans, c->span_waves, (uint32_t *)c->errw.p + 60, st);
-			if (e) { rc = fail(c, XZAMD_DEVICE_ERROR, "span_encode launch", e); goto done; }
 		}
 		xzk_event_record(c->ev[2], st);
 		/* 3. Block checks */
@@ -875,12 +937,15 @@ int xzamd_stream_encode_device(xzamd_ctx *c,
 		pl.lits = (uint8_t *)c->h_lits.p; pl.lits_len = 0; pl.lits_cap = max_lits;
 		pl.segs = (xzamd_copy_seg *)c->h_segs.p; pl.nsegs = 0; pl.segs_cap = max_segs;
 		const uint32_t *sb = (const uint32_t *)c->h_span_bytes.p;
+		const uint32_t *htab = (const uint32_t *)c->h_span_tab.p, *hcnt = (const uint32_t *)c->h_span_cnt.p;
 		const uint64_t *bcrc = (const uint64_t *)c->h_block_crc.p;
 		for (uint64_t b = 0; b < nb; ++b) {
 			const uint64_t boff = b * block_size;                 /* in batch */
 			const uint64_t usize = n64 - boff < block_size ? n64 - boff : block_size;
 			uint64_t payload = 1;                                 /* end marker */
-			for (uint32_t s = 0; s < spb; ++s)
+			const uint32_t nsp = hcnt[b];                         /* spans of this Block (slots b * spb ...) */
+			if (nsp == 0 || nsp > spb) { rc = fail(c, XZAMD_PROG_ERROR, "span plan out of range", 0); goto done; }
+			for (uint32_t s = 0; s < nsp; ++s)
 				payload += sb[b * spb + s];
 			const uint64_t pad = (4 - (payload & 3)) & 3;
 			const uint64_t bstart = opos;
@@ -910,8 +975,10 @@ int xzamd_stream_encode_device(xzamd_ctx *c,
 				if (opos + hs_fixed + payload + pad + cbytes > out_cap) { rc = fail(c, XZAMD_BUF_ERROR, "output buffer too small", 0); goto done; }
 				block_header_put(small, hs_fixed, payload, usize, dbyte, opt->bcj);
 				opos = plan_lit(&pl, small, hs_fixed, opos);
-				for (uint32_t s = 0; s < spb; ++s)
-					opos = plan_seg(&pl, 0, (uint64_t)(b * spb + s) * span_cap, sb[b * spb + s], opos);
+				for (uint32_t s = 0; s < nsp; ++s) {
+					const uint64_t slot = b * spb + s, start = htab[2 * slot];
+					opos = plan_seg(&pl, 0, ((start + (start >> 3) + 15) & ~15ull) + slot * XZAMD_SPAN_SLACK, sb[slot], opos);
+				}
 				tail[tl++] = 0x00;
 				for (uint64_t i = 0; i < pad; ++i) tail[tl++] = 0;
 				unp = hs_fixed + payload + cbytes;
@@ -959,8 +1026,14 @@ int xzamd_stream_encode_device(xzamd_ctx *c,
 		if (opt->gpu_parser && !find_on_lo && !xzk_event_elapsed_ms(c->ev[1], c->ev[5], &ms)) c->stats.ms_find += ms;
 		if (!xzk_event_elapsed_ms(c->ev[2], c->ev[3], &ms)) c->stats.ms_crc += ms;
 		if (!xzk_event_elapsed_ms(c->ev[3], c->ev[4], &ms)) c->stats.ms_assemble += ms;
+		if (!xzk_event_elapsed_ms(c->ev[7], c->ev[6], &ms)) c->stats.ms_plan += ms;
 		c->stats.blocks += nb;
-		c->stats.spans += nspans;
+		for (uint64_t b = 0; b < nb; ++b) c->stats.spans += hcnt[b];
+		if (adaptive) {
+			uint64_t tgt;
+			memcpy(&tgt, hcnt + 2 * ((nb + 1) / 2), 8);
+			c->stats.span_cost_used = tgt > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)tgt;
+		}
 		c->stats.batches += 1;
 		c->stats.encode_launches += 1;
 		b0 += nb;
@@ -975,7 +1048,7 @@ retry_smaller:
 		{
 			dbuf *d[] = { &c->keys_a, &c->keys_b, &c->vals_a, &c->vals_b, &c->rank, &c->sorted_pos,
 				&c->prev2, &c->prev3, &c->prev4, &c->prev8, &c->prev16, &c->key64_a, &c->key64_b, &c->sa, &c->sa_rank,
-				&c->sort_tmp, &c->scratch, &c->litp, &c->mlen, &c->mdist, &c->mlen2, &c->mdist2, &c->bcj };
+				&c->sort_tmp, &c->scratch, &c->litp, &c->mlen, &c->mdist, &c->mlen2, &c->mdist2, &c->bcj, &c->est, &c->mtop, &c->mtop2 };
 			for (size_t i = 0; i < sizeof(d) / sizeof(d[0]); ++i)
 				if (d[i]->p) { xzk_free(d[i]->p); d[i]->p = NULL; d[i]->cap = 0; }
 		}

@@ -431,8 +431,7 @@ static lzma_ret parse_options(const lzma_mt *o, xzamd_lzma_options *opt, uint64_
 			opt->gpu_mf = XZAMD_MF_HC4;
 			opt->gpu_nice_len = l->nice_len < 4 ? 4 : l->nice_len;
 			opt->gpu_depth = 1;
-			opt->gpu_sa_window = XZAMD_SA_WINDOW_MAX;
-			opt->gpu_parser = 1;
+			xzamd_sn_defaults(opt);
 		} else {
 			return LZMA_OPTIONS_ERROR;
 		}
