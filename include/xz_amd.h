@@ -192,13 +192,14 @@ int xzamd_stream_encode_device(xzamd_ctx *ctx,
 
 /* Device .xz decoder (the reference's stream_decoder_mt.c / lzma2_decoder.c / lzma_decoder.c path, SURVEY.md
  * 8f.3): decode a single-Stream .xz file resident in device memory (filter chain {LZMA2}; checks none / CRC32 /
- * CRC64 are verified) into d_out.  Blocks decode in parallel, one wavefront each.  With d_expected (the original
- * data, device memory, *out_size bytes) it is a VERIFICATION decode: every chunk chain that starts with a state
+ * CRC64 / SHA-256 are verified, any other Check id is XZAMD_UNSUPPORTED_CHECK) into d_out.  Blocks decode in parallel, one wavefront each.  With d_expected (the original
+ * data, device memory, expected_size bytes: a Stream of another uncompressed size is XZAMD_DATA_ERROR) it is a VERIFICATION decode: every chunk chain that starts with a state
  * reset + properties (our spans) is its own unit, history is read from d_expected, and the decoded bytes are
  * compared with it afterwards (*mismatches).  Returns XZAMD_OK, 7 (LZMA_FORMAT_ERROR: not an .xz Stream),
  * XZAMD_OPTIONS_ERROR (unsupported chain), XZAMD_DATA_ERROR (corrupt / mismatch), XZAMD_BUF_ERROR (out_cap). */
 int xzamd_stream_decode_device(xzamd_ctx *ctx, const void *d_xz, uint64_t xz_size, void *d_out, uint64_t out_cap,
-		uint64_t *out_size, const void *d_expected, uint64_t *mismatches, uint64_t *nblocks, void *stream);
+		uint64_t *out_size, const void *d_expected, uint64_t expected_size, uint64_t *mismatches, uint64_t *nblocks,
+		void *stream);
 
 /* Host-side framing helpers for the multi-GPU path: Stream Header (12 bytes),
  * Index + Stream Footer from gathered Block records. Return bytes written. */

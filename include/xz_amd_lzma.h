@@ -62,6 +62,7 @@ typedef enum {
 	LZMA_MF_HC3 = 0x03, LZMA_MF_HC4 = 0x04, LZMA_MF_BT2 = 0x12, LZMA_MF_BT3 = 0x13, LZMA_MF_BT4 = 0x14
 } lzma_match_finder;
 
+#define LZMA_FILTER_LZMA1 UINT64_C(0x4000000000000001)   /* api/lzma/lzma12.h:40 */
 #define LZMA_FILTER_LZMA2 UINT64_C(0x21)
 #define LZMA_FILTER_X86   UINT64_C(0x04)
 #define LZMA_FILTER_POWERPC UINT64_C(0x05)

@@ -329,6 +329,15 @@ def corpus_x86(n, seed=1, density=24, runs=True):
     return a.tobytes()
 
 
+def ref_raw_decode(payload, dict_size, out_cap):
+    """Raw LZMA2 payload through the REAL reference decoder."""
+    payload = as_u8(payload)
+    out = np.empty(max(out_cap, 1), dtype=np.uint8)
+    n = C.c_size_t(0)
+    r = ref().ref_raw_lzma2_decode(_ptr(payload), len(payload), dict_size, _ptr(out), out_cap, C.byref(n))
+    return r, out[: n.value].tobytes()
+
+
 def ref_decode(stream, out_cap):
     stream = as_u8(stream)
     out = np.empty(max(out_cap, 1), dtype=np.uint8)

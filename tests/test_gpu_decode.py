@@ -93,3 +93,43 @@ def test_decodes_reference_encoder_output(enc):
         assert got.cpu().numpy().tobytes() == data
         got2, _ = enc.decode(_cuda(raw), len(data) + 16, expected=_cuda(data))
         assert got2.cpu().numpy().tobytes() == data
+
+
+def test_block_checks_are_verified_or_refused(enc):
+    """Every Check the decoder accepts is verified (none, CRC32, CRC64, SHA-256: check/check.c, sha256.c); a Stream whose
+    Check id it cannot verify is refused with XZAMD_UNSUPPORTED_CHECK (3) instead of being passed unverified; a
+    verification decode against an original of another size is refused (no out-of-bounds reads of `expected`)."""
+    import xz_amd
+    data = o.corpus_mixed(700000, 3) + o.corpus_lorem(200000)
+    t = _cuda(data)
+    for check in (xz_amd.CHECK_NONE, xz_amd.CHECK_CRC32, xz_amd.CHECK_CRC64, xz_amd.CHECK_SHA256):
+        for bs in (1 << 18, 250001):
+            xz, _ = enc.encode(t, preset=1, block_size=bs, check=check)
+            xz = xz.clone()
+            got, nb = enc.decode(xz, len(data) + 16)
+            assert got.cpu().numpy().tobytes() == data, (check, bs)
+            if check != xz_amd.CHECK_NONE:
+                # flip a bit of the last Block's stored Check (it sits right in front of the Index)
+                raw = bytearray(xz.cpu().numpy().tobytes())
+                isz = (int.from_bytes(raw[-8:-4], "little") + 1) * 4
+                raw[len(raw) - 12 - isz - 1] ^= 0x10
+                with pytest.raises(xz_amd.XzAmdError):
+                    enc.decode(_cuda(bytes(raw)), len(data) + 16)
+    if o.have_ref():
+        raw = o.ref_encode_mt(data, 1, threads=2, block_size=1 << 18, check=10)       # SHA-256 from the real encoder
+        got, _ = enc.decode(_cuda(raw), len(data) + 16)
+        assert got.cpu().numpy().tobytes() == data
+    # a Check id without a verifier: patch the Stream Flags of a CRC32 Stream to id 2 (same size) and fix their CRC32s
+    xz, _ = enc.encode(t, preset=1, block_size=1 << 18, check=xz_amd.CHECK_CRC32)
+    raw = bytearray(xz.cpu().numpy().tobytes())
+    for off in (7, len(raw) - 3):
+        raw[off] = 2
+    import zlib
+    raw[8:12] = zlib.crc32(bytes(raw[6:8])).to_bytes(4, "little")
+    raw[-12:-8] = zlib.crc32(bytes(raw[-8:-2])).to_bytes(4, "little")
+    with pytest.raises(xz_amd.XzAmdError) as ei:
+        enc.decode(_cuda(bytes(raw)), len(data) + 16)
+    assert "(3)" in str(ei.value), str(ei.value)          # XZAMD_UNSUPPORTED_CHECK
+    xz, _ = enc.encode(t, preset=1, block_size=1 << 18)
+    with pytest.raises(xz_amd.XzAmdError):
+        enc.decode(xz.clone(), len(data) + 16, expected=t[: len(data) - 5].clone())

@@ -214,3 +214,48 @@ def test_mt_block_size_of_filter_chains(product_lib):
             chain[k + 1].id, chain[k + 1].options = 0xFFFFFFFFFFFFFFFF, None
             want = reflib.lzma_mt_block_size(chain)
             assert want != 0 and product_lib.lzma_mt_block_size(chain) == want, (preset, fid)
+
+
+def test_mt_block_size_error_cases_match_the_reference(product_lib):
+    """filter_encoder.c:270-293 reports every failure as UINT64_MAX (clients test that value, src/xz/coder.c:482):
+    NULL array, a filter id without an encoder, an invalid LZMA2 dictionary size, a chain in which no filter has a
+    block size (BCJ / delta / LZMA1 only, or empty).  Same answers as the real liblzma."""
+    import glob
+    if not o.have_ref():
+        pytest.skip("oracle/_ref not built")
+    reflib = C.CDLL(glob.glob(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "*.so"))[0])
+
+    class Filter(C.Structure):
+        _fields_ = [("id", C.c_uint64), ("options", C.c_void_p)]
+    for lib in (product_lib, reflib):
+        lib.lzma_mt_block_size.restype = C.c_uint64
+        lib.lzma_mt_block_size.argtypes = [C.POINTER(Filter)]
+    END = 0xFFFFFFFFFFFFFFFF
+    lz = (C.c_uint8 * 128)()
+    assert reflib.lzma_lzma_preset(lz, 6) == 0
+    bad = (C.c_uint8 * 128)()
+    assert reflib.lzma_lzma_preset(bad, 6) == 0
+    C.cast(bad, C.POINTER(C.c_uint32))[0] = 100          # dict_size below LZMA_DICT_SIZE_MIN
+    delta = (C.c_uint32 * 8)(0, 4)
+    lzp, badp, dp = C.cast(lz, C.c_void_p), C.cast(bad, C.c_void_p), C.cast(delta, C.c_void_p)
+    cases = {
+        "empty": [(END, None)],
+        "unknown id": [(0x77, None), (0x21, lzp), (END, None)],
+        "unknown id behind LZMA2": [(0x21, lzp), (0x77, None), (END, None)],
+        "bad dict": [(0x21, badp), (END, None)],
+        "bcj only": [(4, None), (END, None)],
+        "delta only": [(3, dp), (END, None)],
+        "lzma1 only": [(0x4000000000000001, lzp), (END, None)],
+        "five filters": [(4, None), (5, None), (3, dp), (7, None), (0x21, lzp), (END, None)],
+    }
+    for lib in (product_lib, reflib):
+        assert lib.lzma_mt_block_size(None) == END
+    for name, fl in cases.items():
+        chain = (Filter * len(fl))()
+        for i, (fid, opt) in enumerate(fl):
+            chain[i].id, chain[i].options = fid, opt
+        want = reflib.lzma_mt_block_size(chain)
+        got = product_lib.lzma_mt_block_size(chain)
+        assert got == want, (name, hex(got), hex(want))
+        if name != "five filters":
+            assert want == END, name

@@ -154,11 +154,12 @@ def _elf_mix(n):
     return bytes(out[:n])
 
 
-@pytest.mark.parametrize("corpus,n", [("lorem", 4 << 20), ("text", 4 << 20), ("elf", 4 << 20)])
+@pytest.mark.parametrize("corpus,n", [("lorem", 4 << 20), ("text", 4 << 20), ("elf", 4 << 20), ("tar", 6 << 20),
+                                      ("rocm_headers", 6 << 20)])
 def test_size_within_tolerance_of_reference_preset6(corpus, n):
-    """Oracle restatement of what the device runs for preset 6 (128 KiB spans) against the REAL liblzma at
-    preset 6 on the same Block: compressed size within the stated tolerance.  (The GPU test repeats this at
-    16 MiB through the product path.)"""
+    """Oracle restatement of what the device runs for preset 6 (64-byte suffix order, cost-balanced spans) against
+    the REAL liblzma at preset 6 on the same Block: compressed size within the stated tolerance.  (The GPU test
+    repeats this on full 24 MiB Blocks through the product path.)"""
     if not o.have_ref():
         pytest.skip("oracle/_ref not built")
     import xz_amd
@@ -166,10 +167,42 @@ def test_size_within_tolerance_of_reference_preset6(corpus, n):
         data = o.corpus_lorem(n)
     elif corpus == "text":
         data = xz_amd.corpus_text(n, seed=1000).tobytes()
+    elif corpus == "tar":
+        data = xz_amd.corpus_tar(n).tobytes()
+    elif corpus == "rocm_headers":
+        data = xz_amd.corpus_tar(n, "/opt/rocm/include").tobytes()
     else:
         data = _elf_mix(n)
         if len(data) < n:
             pytest.skip("not enough ELF files on this box")
-    ours = len(o.orc_encode_block(data, o.OrcParams(1 << 23, 3, 0, 2, 64, 4, 1, 131072, 5, 1)))
+    prm = o.params_for_gpu_options(xz_amd.preset_options(6))
+    assert prm.span_cost and prm.sa_depth == 64
+    ours_raw = o.orc_encode_block(data, prm)
+    r, dec = o.ref_raw_decode(ours_raw, prm.dict_size, len(data) + 16)
+    assert r == 1 and dec == data
     ref = len(o.ref_raw_encode(data, o.OrcParams(1 << 23, 3, 0, 2, 64, 0x14, 0, 0, 0, 0), mode=2))
-    assert ours <= ref * (1 + SIZE_TOLERANCE), (corpus, ours, ref, ours / ref - 1)
+    assert len(ours_raw) <= ref * (1 + SIZE_TOLERANCE), (corpus, len(ours_raw), ref, len(ours_raw) / ref - 1)
+
+
+def test_span_plan_properties():
+    """Cost-balanced spans (oracle plan_spans): the spans tile the Block, start on 4 KiB boundaries, respect the
+    minimum length (all but the last), adapt to the data (long spans over highly compressible stretches), and a
+    larger work target gives fewer spans; the plan of an incompressible Block falls back to the minimum length."""
+    import xz_amd
+    rng = np.random.default_rng(3)
+    lorem = o.corpus_lorem(1 << 20)
+    data = lorem + b"\0" * (3 << 20) + bytes(rng.integers(0, 256, size=1 << 20, dtype=np.uint8)) + lorem[:500000]
+    prm = o.params_for_gpu_options(xz_amd.preset_options(6))
+    work, bits, starts = o.orc_span_plan(data, prm)
+    assert starts[0] == 0 and (starts % 4096 == 0).all() and (np.diff(starts) > 0).all()
+    lens = np.diff(np.append(starts, len(data)))
+    assert (lens[:-1] >= prm.span_size).all()
+    zero_spans = [l for s, l in zip(starts, lens) if (1 << 20) <= s and s + l <= (4 << 20)]
+    assert max(lens) >= 1 << 20 and len(zero_spans) <= 2           # the run of zeros costs next to nothing
+    rnd = [l for s, l in zip(starts, lens) if s >= (4 << 20) + 65536 and s + l <= (5 << 20)]
+    assert rnd and max(rnd) <= 262144                               # incompressible bytes: one unit of work each
+    prm2 = o.params_for_gpu_options(xz_amd.preset_options(6))
+    prm2.span_cost = 4 * prm.span_cost
+    _, _, starts2 = o.orc_span_plan(data, prm2)
+    assert len(starts2) < len(starts)
+    assert int(work.sum()) >= (len(data) - (3 << 20)) // 2

@@ -93,7 +93,7 @@ def lib():
         l.xzamd_frame_index_footer.argtypes = [C.c_void_p, C.c_uint64, C.c_int,
                                                C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_uint64]
         l.xzamd_stream_decode_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64,
-                                                 C.POINTER(C.c_uint64), C.c_void_p, C.POINTER(C.c_uint64),
+                                                 C.POINTER(C.c_uint64), C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64),
                                                  C.POINTER(C.c_uint64), C.c_void_p]
         l.xzamd_debug_fetch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint64]
         l.xzamd_trace_enable.argtypes = [C.c_void_p, C.c_uint32]
@@ -226,12 +226,16 @@ class Encoder:
         the original data) it is a span-parallel verification decode.  Returns (decoded tensor view, nblocks)."""
         import torch
         assert xz.is_cuda and xz.dtype == torch.uint8 and xz.is_contiguous()
+        if expected is not None:
+            assert (expected.is_cuda and expected.dtype == torch.uint8 and expected.is_contiguous()
+                    and expected.device == xz.device), "expected: contiguous CUDA uint8 tensor on the Stream's device"
         out = torch.empty(max(out_cap, 1), dtype=torch.uint8, device=xz.device)
         osz, mm, nb = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
         torch.cuda.current_stream(xz.device).synchronize()
         rc = lib().xzamd_stream_decode_device(
             self._ctx, C.c_void_p(xz.data_ptr()), xz.numel(), C.c_void_p(out.data_ptr()), out_cap, C.byref(osz),
-            C.c_void_p(expected.data_ptr()) if expected is not None else None, C.byref(mm), C.byref(nb), None)
+            C.c_void_p(expected.data_ptr()) if expected is not None else None,
+            expected.numel() if expected is not None else 0, C.byref(mm), C.byref(nb), None)
         if rc != 0:
             raise XzAmdError(f"xzamd_stream_decode_device failed ({rc}): {lib().xzamd_last_error(self._ctx).decode()}"
                              + (f" [{mm.value} mismatching words]" if mm.value else ""))

@@ -45,7 +45,8 @@ static uint32_t rd32(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1]
 #define HIPD(call, msg) do { if (call) FAILD(XZAMD_DEVICE_ERROR, msg); } while (0)
 
 int xzamd_stream_decode_device(xzamd_ctx *c, const void *d_xz_, uint64_t xz_size, void *d_out_, uint64_t out_cap,
-		uint64_t *out_size, const void *d_expected_, uint64_t *mismatches, uint64_t *nblocks_out, void *stream)
+		uint64_t *out_size, const void *d_expected_, uint64_t expected_size, uint64_t *mismatches, uint64_t *nblocks_out,
+		void *stream)
 {
 	if (!c || !d_xz_ || !out_size || (!d_out_ && out_cap))
 		return XZAMD_PROG_ERROR;
@@ -57,6 +58,8 @@ int xzamd_stream_decode_device(xzamd_ctx *c, const void *d_xz_, uint64_t xz_size
 	uint8_t *index = NULL;
 	xzamd_dec_block *hb = NULL;
 	uint64_t *stored = NULL, *h_crc = NULL;
+	uint8_t *stored32 = NULL;          /* SHA-256: the 32 stored bytes of every Block */
+	void *d_sha = NULL;
 	uint32_t *unit_first = NULL, *h_err = NULL;
 	void *d_blocks = NULL, *d_units = NULL, *d_first = NULL, *d_lit = NULL, *d_misc = NULL, *d_strip = NULL, *d_crc = NULL;
 	*out_size = 0;
@@ -78,6 +81,9 @@ int xzamd_stream_decode_device(xzamd_ctx *c, const void *d_xz_, uint64_t xz_size
 	if (hf[6] != 0 || (hf[7] & 0xF0) || hf[6] != hf[20] || hf[7] != hf[21])
 		FAILD(XZAMD_OPTIONS_ERROR, "unsupported or inconsistent Stream Flags");
 	const int check = hf[7] & 0x0F;
+	/* a Check that cannot be verified is reported, not skipped (the reference: LZMA_UNSUPPORTED_CHECK) */
+	if (check != XZAMD_CHECK_NONE && check != XZAMD_CHECK_CRC32 && check != XZAMD_CHECK_CRC64 && check != XZAMD_CHECK_SHA256)
+		FAILD(XZAMD_UNSUPPORTED_CHECK, "Check id the device decoder cannot verify");
 	static const uint8_t check_sizes[16] = { 0, 4, 4, 4, 8, 8, 8, 16, 16, 16, 32, 32, 32, 64, 64, 64 };
 	const uint32_t csz = check_sizes[check];
 	const uint64_t index_size = ((uint64_t)rd32(hf + 16) + 1) * 4;
@@ -98,6 +104,8 @@ int xzamd_stream_decode_device(xzamd_ctx *c, const void *d_xz_, uint64_t xz_size
 	stored = (uint64_t *)calloc(nb ? nb : 1, 8);
 	h_crc = (uint64_t *)calloc(nb ? nb : 1, 8);
 	h_err = (uint32_t *)calloc(nb ? nb : 1, 4);
+	stored32 = (uint8_t *)calloc(nb ? nb : 1, 32);
+	if (!stored32) FAILD(XZAMD_MEM_ERROR, "malloc");
 	unit_first = (uint32_t *)calloc(nb + 1, 4);
 	if (!hb || !stored || !h_crc || !h_err || !unit_first) FAILD(XZAMD_MEM_ERROR, "malloc");
 	uint64_t pos = 12, utotal = 0, max_usize = 0;
@@ -160,6 +168,7 @@ int xzamd_stream_decode_device(xzamd_ctx *c, const void *d_xz_, uint64_t xz_size
 		uint64_t sv = 0;
 		for (uint32_t i = 0; i < csz && i < 8; ++i) sv |= (uint64_t)tail[padn + i] << (8 * i);
 		stored[b] = sv;
+		if (csz == 32) memcpy(stored32 + 32 * b, tail + padn, 32);
 		pos += padded;
 		utotal += usize;
 		if (usize > max_usize) max_usize = usize;
@@ -174,6 +183,8 @@ int xzamd_stream_decode_device(xzamd_ctx *c, const void *d_xz_, uint64_t xz_size
 	*out_size = utotal;
 	if (utotal > out_cap)
 		FAILD(XZAMD_BUF_ERROR, "output buffer too small");
+	if (d_expected && expected_size != utotal)
+		FAILD(XZAMD_DATA_ERROR, "the Stream's uncompressed size differs from the size of the original given for verification");
 	if (nb == 0 || utotal == 0) {
 		if (nb != 0) {
 			/* Blocks of zero bytes still carry a chunk chain: decode it below */
@@ -250,6 +261,28 @@ int xzamd_stream_decode_device(xzamd_ctx *c, const void *d_xz_, uint64_t xz_size
 			for (uint64_t b = 0; b < nb; ++b)
 				if (h_crc[b] != stored[b]) FAILD(XZAMD_DATA_ERROR, "Block Check mismatch");
 		}
+		if (check == XZAMD_CHECK_SHA256) {
+			/* check/sha256.c over the decoded bytes: one hash per Block (serial by nature); equally long Blocks in one
+			 * launch, else one launch each */
+			int uniform = 1;
+			for (uint64_t b = 0; b + 1 < nb; ++b)
+				if (hb[b].usize != hb[0].usize) uniform = 0;
+			if (nb > 1 && hb[nb - 1].usize > hb[0].usize) uniform = 0;
+			HIPD(xzk_malloc(&d_sha, 32 * nb + 64), "hipMalloc");
+			if (uniform && utotal < (1ull << 31) && hb[0].usize) {
+				HIPD(xzk_sha256_blocks(d_out, (uint32_t)utotal, (uint32_t)hb[0].usize, nbk, (uint8_t *)d_sha, st), "sha256 launch");
+			} else {
+				for (uint64_t b = 0; b < nb; ++b)
+					HIPD(xzk_sha256_blocks(d_out + hb[b].upos, (uint32_t)hb[b].usize, hb[b].usize ? (uint32_t)hb[b].usize : 1u, 1,
+							(uint8_t *)d_sha + 32 * b, st), "sha256 launch");
+			}
+			uint8_t *h_sha = (uint8_t *)malloc(32 * nb);
+			if (!h_sha) FAILD(XZAMD_MEM_ERROR, "malloc");
+			int bad = xzk_d2h(h_sha, d_sha, 32 * nb, st) || xzk_sync(st) ? -1 : memcmp(h_sha, stored32, 32 * nb) != 0;
+			free(h_sha);
+			if (bad < 0) FAILD(XZAMD_DEVICE_ERROR, "d2h sha256");
+			if (bad) FAILD(XZAMD_DATA_ERROR, "Block Check mismatch (SHA-256)");
+		}
 		if (d_expected) {
 			unsigned long long mm = 0;
 			HIPD(xzk_dec_compare(d_out, d_expected, utotal, d_mism, st), "compare launch");
@@ -267,6 +300,8 @@ done:
 	if (d_misc) xzk_free(d_misc);
 	if (d_strip) xzk_free(d_strip);
 	if (d_crc) xzk_free(d_crc);
+	if (d_sha) xzk_free(d_sha);
+	free(stored32);
 	free(index); free(hb); free(stored); free(h_crc); free(h_err); free(unit_first);
 	return rc;
 }

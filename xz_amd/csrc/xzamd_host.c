@@ -287,6 +287,7 @@ struct xzamd_ctx {
 	uint32_t span_rounds;        /* cost-balanced spans: a batch is cut into at most wave_slots * span_rounds spans (XZAMD_SPAN_ROUNDS, default 3: the running
 	                              * time of equal-work spans still varies by +-25 %, so a launch needs a few rounds to even out) */
 	int prefetch_after;          /* XZAMD_PREFETCH_AFTER=1: enqueue the next batch's build behind the span kernel launch instead of in front of it */
+	int sha_early;               /* this batch's SHA-256 was launched on the second stream */
 	int overlap_off;             /* an event of the low-priority pipeline could not be created: no prefetch */
 	uint64_t alloc_limit;        /* test hook (XZAMD_TEST_ALLOC_LIMIT_MIB, read once at creation): larger allocations fail; 0 = none */
 	char err[256];
@@ -855,6 +856,17 @@ int xzamd_stream_encode_device(xzamd_ctx *c,
 			 * them): build the NEXT batch's chains and match lists now, on the lowest-priority stream, into
 			 * the other list buffer.  The span kernel takes every slot it can use; the sorts and the finder
 			 * fill what its rounds leave idle. */
+			/* SHA-256 is one serial hash per Block (a single wavefront for the whole batch, hundreds of ms): it runs on
+			 * the second stream underneath the span kernel instead of behind it */
+			int sha_early = 0;
+			if (check == XZAMD_CHECK_SHA256 && c->lo_stream != NULL && c->ev_lo[0][0] != NULL) {
+				int e3 = xzk_stream_wait_event(c->lo_stream, c->ev[0]);
+				if (!e3) e3 = xzk_sha256_blocks(d_in + in_off, n, (uint32_t)block_size, (uint32_t)nb, (uint8_t *)c->block_crc.p, c->lo_stream);
+				if (!e3) e3 = xzk_event_record(c->ev_lo[0][0], c->lo_stream);
+				if (e3) { rc = fail(c, XZAMD_DEVICE_ERROR, "sha256 launch", e3); goto done; }
+				sha_early = 1;
+			}
+			c->sha_early = sha_early;
 			const int pf_after = c->prefetch_after;
 			for (int phase = 0; phase < 2; ++phase) {
 				if (phase == (pf_after ? 0 : 1)) {
@@ -897,7 +909,8 @@ int xzamd_stream_encode_device(xzamd_ctx *c,
 			e = xzk_d2h(c->h_block_crc.p, c->block_crc.p, 8ull * nb, st);
 			if (e) { rc = fail(c, XZAMD_DEVICE_ERROR, "d2h crc", e); goto done; }
 		} else if (check == XZAMD_CHECK_SHA256) {
-			int e = xzk_sha256_blocks(d_in + in_off, n, (uint32_t)block_size, (uint32_t)nb, (uint8_t *)c->block_crc.p, st);
+			int e = c->sha_early ? xzk_stream_wait_event(st, c->ev_lo[0][0])
+					: xzk_sha256_blocks(d_in + in_off, n, (uint32_t)block_size, (uint32_t)nb, (uint8_t *)c->block_crc.p, st);
 			if (e) { rc = fail(c, XZAMD_DEVICE_ERROR, "sha256 launch", e); goto done; }
 			e = xzk_d2h(c->h_block_crc.p, c->block_crc.p, 32ull * nb, st);
 			if (e) { rc = fail(c, XZAMD_DEVICE_ERROR, "d2h sha256", e); goto done; }

@@ -470,14 +470,16 @@ lzma_ret lzma_stream_encoder_mt(lzma_stream *strm, const lzma_mt *options)
 	uint64_t block_size = 0;
 	int check = 0;
 	lzma_ret r = parse_options(options, &opt, &block_size, &check);
-	if (r != LZMA_OK)
-		return r;
-	/* lzma_next_strm_init (common.h:401-410): re-initialising a stream replaces its coder */
-	if (strm->internal != NULL) {
-		if (strm->internal->magic == XZAMD_MAGIC)
-			internal_free(strm->internal);
+	/* lzma_next_strm_init (common.h:401-410): re-initialising a stream replaces its coder, and an init that
+	 * fails ends the stream (lzma_end): a coder of ours must not survive in strm->internal -- an interposer
+	 * would hand it to the real liblzma next (preload.c), which would read it as its own lzma_internal */
+	if (strm->internal != NULL && strm->internal->magic == XZAMD_MAGIC) {
+		internal_free(strm->internal);
 		strm->internal = NULL;
 	}
+	if (r != LZMA_OK)
+		return r;
+	strm->internal = NULL;
 	{
 		const char *dbg = getenv("XZAMD_DEBUG_SEGV");
 		if (dbg && *dbg == '1') signal(SIGSEGV, segv_handler);
@@ -507,6 +509,12 @@ lzma_ret lzma_stream_encoder_mt(lzma_stream *strm, const lzma_mt *options)
 		const char *e = getenv("XZAMD_DEVICES");
 		if (e && atoi(e) > 0 && atoi(e) < ndev) ndev = atoi(e);
 	}
+	/* XZAMD_TEST_WORKERS=n (test knob): n workers, dealt round-robin to the visible GPUs -- two contexts on one
+	 * GPU exercise the ordered draining of concurrently finished jobs on a single-GPU box */
+	{
+		const char *e = getenv("XZAMD_TEST_WORKERS");
+		if (e && atoi(e) > 0 && atoi(e) <= MAX_DEVS) ndev = atoi(e);
+	}
 	for (int i = 0; i < ndev; ++i) {
 		devslot *d = &in->dev[i];
 		d->device = (cur + i) % ndev_all;
@@ -525,7 +533,10 @@ lzma_ret lzma_stream_encoder_mt(lzma_stream *strm, const lzma_mt *options)
 	xzk_set_device(cur);
 	in->njobs = in->ndev + 1;        /* one job is filled while every GPU works on one */
 	/* batch = whole Blocks; several GPUs or a known-small input do not need the full GiB */
-	uint64_t batch = 1ull << 30;
+	/* One job = one device batch.  A lone GPU wants it large (full launches); with several workers the jobs must
+	 * be small enough that a typical input deals at least two to every worker (stream_encoder_mt.c:599-665 deals
+	 * Block by Block): 256 MiB, i.e. a 4 GiB input is 16 jobs. */
+	uint64_t batch = in->ndev > 1 ? 256ull << 20 : 1ull << 30;
 	const char *env = getenv("XZAMD_BATCH_MIB");
 	if (env && atoll(env) > 0)
 		batch = (uint64_t)atoll(env) << 20;
@@ -544,7 +555,14 @@ lzma_ret lzma_stream_encoder_mt(lzma_stream *strm, const lzma_mt *options)
 	}
 	in->mu_ok = 1;
 	for (int i = 0; i < in->ndev; ++i) {
-		if (pthread_create(&in->dev[i].thr, NULL, worker_main, &in->dev[i])) {
+		/* mythread_create (src/common/mythread.h:181-192): workers run with every signal blocked, so the
+		 * client's handlers (xz: SIGALRM progress, SIGINT cleanup) only ever run on its own threads */
+		sigset_t all, old;
+		sigfillset(&all);
+		pthread_sigmask(SIG_SETMASK, &all, &old);
+		const int pe = pthread_create(&in->dev[i].thr, NULL, worker_main, &in->dev[i]);
+		pthread_sigmask(SIG_SETMASK, &old, NULL);
+		if (pe) {
 			internal_free(in);
 			return LZMA_MEM_ERROR;
 		}
@@ -577,27 +595,27 @@ uint64_t lzma_stream_encoder_mt_memusage(const lzma_mt *options)
 
 uint64_t lzma_mt_block_size(const lzma_filter *filters)
 {
-	/* filter_encoder.c:270-292: the largest block size any filter of the chain asks for; only LZMA2 does
-	 * (lzma2_encoder.c:403-413: max(3 x dict_size, 1 MiB)).  0 = unsupported chain. */
+	/* filter_encoder.c:270-293: the largest block size any filter of the chain asks for; only LZMA2 does
+	 * (lzma2_encoder.c:403-413: max(3 x dict_size, 1 MiB), UINT64_MAX for an invalid dictionary size).
+	 * UINT64_MAX = error: NULL array, a filter id without an encoder, no filter with a block size
+	 * (clients test exactly that value, src/xz/coder.c:482). */
 	if (filters == NULL)
-		return 0;
+		return UINT64_MAX;
 	uint64_t max = 0;
 	for (size_t i = 0; filters[i].id != LZMA_VLI_UNKNOWN; ++i) {
-		if (i >= 4)
-			return 0;
 		if (filters[i].id == LZMA_FILTER_LZMA2) {
 			const lzma_options_lzma *l = (const lzma_options_lzma *)filters[i].options;
 			if (l == NULL || l->dict_size < 4096 || l->dict_size > (1u << 30) + (1u << 29))
-				return 0;
+				return UINT64_MAX;
 			uint64_t b = (uint64_t)l->dict_size * 3;
 			if (b < (1u << 20)) b = 1u << 20;
 			if (b > max) max = b;
 		} else if (!(filters[i].id >= LZMA_FILTER_X86 && filters[i].id <= LZMA_FILTER_RISCV)
-				&& filters[i].id != LZMA_FILTER_DELTA) {
-			return 0;
+				&& filters[i].id != LZMA_FILTER_DELTA && filters[i].id != LZMA_FILTER_LZMA1) {
+			return UINT64_MAX;      /* encoder_find() == NULL */
 		}
 	}
-	return max;
+	return max == 0 ? UINT64_MAX : max;
 }
 
 uint32_t lzma_cputhreads(void)
