@@ -164,20 +164,36 @@ def reference_ratio(sample, preset, bcj, block_size):
     return len(enc)
 
 
-def host_to_host(host, preset, block_size, reps=2):
+def host_to_host(host, preset, block_size, reps=2, bcj=False):
     """The SURVEY 8(d) end-to-end number: lzma_stream_encoder_mt + lzma_code(LZMA_FINISH) of libxz_amd.so on
-    HOST buffers -- staging copy, H2D, device encode, D2H of the Stream all inside the timed region."""
+    HOST buffers -- staging copy, H2D, device encode, D2H of the Stream all inside the timed region -- over the
+    WHOLE input, and the WHOLE output back through the reference's own (multi-threaded) decoder, compared by sha256."""
     import ctypes as C
+    import hashlib
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     from bench_lzma_code import Mt, Stream
     L = xz_amd.lib()
     n = host.size
-    out = np.empty(n // 2 + (1 << 20), dtype=np.uint8)
+    out = np.empty(n // 2 + (n >> 3) + (1 << 20), dtype=np.uint8)
     best = None
-    os.environ["XZAMD_SPAN_AUTO"] = "1"          # same span policy as the device-resident number
+
+    class Filter(C.Structure):
+        _fields_ = [("id", C.c_uint64), ("options", C.c_void_p)]
+    class OptLzma(C.Structure):           # lzma_options_lzma (api/lzma/lzma12.h:216-525)
+        _fields_ = [("dict_size", C.c_uint32), ("preset_dict", C.c_void_p), ("preset_dict_size", C.c_uint32),
+                    ("lc", C.c_uint32), ("lp", C.c_uint32), ("pb", C.c_uint32), ("mode", C.c_int),
+                    ("nice_len", C.c_uint32), ("mf", C.c_int), ("depth", C.c_uint32), ("pad", C.c_uint8 * 64)]
+    fl = None
+    if bcj:
+        po = xz_amd.preset_options(preset)
+        lz = OptLzma(dict_size=po.dict_size, lc=po.lc, lp=po.lp, pb=po.pb, mode=po.mode, nice_len=po.nice_len,
+                     mf=po.mf, depth=po.depth)
+        fl = (Filter * 3)(Filter(4, None), Filter(0x21, C.cast(C.pointer(lz), C.c_void_p)), Filter(2 ** 64 - 1, None))
     for _ in range(reps):
         s = Stream()
         m = Mt(threads=1, preset=preset, check=4, block_size=block_size)
+        if fl is not None:
+            m.filters = C.cast(fl, C.c_void_p)
         if L.lzma_stream_encoder_mt(C.byref(s), C.byref(m)) != 0:
             return None
         s.next_in = host.ctypes.data
@@ -195,10 +211,25 @@ def host_to_host(host, preset, block_size, reps=2):
             return {"value": None, "error": int(rc)}
         if best is None or dt < best[0]:
             best = (dt, total_out)
-    return {"value": round(n / best[0] / 1e6, 2), "unit": "MB/s", "bytes": int(n), "ms": round(best[0] * 1e3, 1),
-            "ratio": round(best[1] / n, 5),
-            "what": "lzma_stream_encoder_mt + lzma_code(LZMA_FINISH) of libxz_amd.so, input and output in host RAM "
-                    "(staging, H2D, device encode, D2H inside the timed region), best of %d" % reps}
+    res = {"value": round(n / best[0] / 1e6, 2), "unit": "MB/s", "bytes": int(n), "ms": round(best[0] * 1e3, 1),
+           "ratio": round(best[1] / n, 5),
+           "what": "lzma_stream_encoder_mt + lzma_code(LZMA_FINISH) of libxz_amd.so, the WHOLE input and output in host RAM "
+                   "(staging, H2D, device encode, D2H inside the timed region), best of %d" % reps}
+    try:
+        import _oracle as o
+        if o.have_ref():
+            L.xzamd_release_parked()
+            dec = np.empty(n + 16, dtype=np.uint8)
+            t0 = time.perf_counter()
+            r, dn = o.ref_decode_mt(out[:best[1]], dec)
+            td = time.perf_counter() - t0
+            ok = r == 1 and dn == n and hashlib.sha256(dec[:n]).digest() == hashlib.sha256(host).digest()
+            res["roundtrip_reference_decoder_whole_output"] = {
+                "ok": bool(ok), "bytes": int(n), "seconds": round(td, 1),
+                "what": "the whole Stream through liblzma 5.8.3's lzma_stream_decoder_mt (oracle/_ref), sha256 of the result == sha256 of the input"}
+    except Exception as e:  # noqa: BLE001
+        res["roundtrip_reference_decoder_whole_output"] = {"ok": False, "error": str(e)}
+    return res
 
 
 def relaunch_under_torchrun(args_list, n):
@@ -345,8 +376,8 @@ def main():
                 "workload": f"preset -{args.preset & 31}{'e' if args.preset >> 31 else ''} options (dict {opts.dict_size >> 20} MiB, {block_size >> 20} MiB Blocks, "
                             f"CRC64{', x86 BCJ + LZMA2' if args.bcj else ''}), {args.size_mib} MiB "
                             f"{ {'text': 'synthetic enwik-style text', 'elf': 'ELF shared objects', 'tar': 'tar stream of source trees'}[args.corpus]} "
-                            f"{'per GPU' if args.scaling == 'weak' else 'in total, whole Blocks dealt to the ranks in order'}, input resident in HBM, "
-                            f"output = complete .xz Stream in HBM",
+                            f"{'per GPU' if args.scaling == 'weak' else 'in total, whole Blocks dealt to the ranks in order'}; `value` = input resident in HBM, "
+                            f"output = complete .xz Stream in HBM; the same job through lzma_code with host buffers (SURVEY 8d end-to-end) is `host_to_host`",
                 "world_size": world,
                 "device_match_finder": ((f"suffix-neighbourhood finder ({opts.gpu_sa_depth or 32}-byte-prefix suffix order, {opts.gpu_sa_window} slots per side + hash2/hash4 heads + equal 8/16 bytes)"
                                          if opts.gpu_sa_window else f"HC{opts.gpu_mf & 15} depth {opts.gpu_depth} (sort-built chains)")
@@ -410,13 +441,13 @@ def main():
                     del dec_t
             except Exception as e:  # noqa: BLE001
                 res["roundtrip_reference_decoder"] = f"failed: {e}"
-            if not args.no_host_to_host and not args.bcj:
+            if not args.no_host_to_host:
                 try:
                     # the front end owns its own device context: give the device-resident one's work buffers back first
                     del data, out_buf, out
                     enc.close()
                     torch.cuda.empty_cache()
-                    res["host_to_host"] = host_to_host(host[:min(n, 2 << 30)], args.preset, block_size)
+                    res["host_to_host"] = host_to_host(host, args.preset, block_size, bcj=args.bcj)
                 except Exception as e:  # noqa: BLE001
                     res["host_to_host"] = {"value": None, "error": str(e)}
             if not args.no_cpu_baseline:

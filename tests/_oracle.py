@@ -338,6 +338,18 @@ def ref_raw_decode(payload, dict_size, out_cap):
     return r, out[: n.value].tobytes()
 
 
+def ref_decode_mt(stream, out, threads=0):
+    """Whole .xz Stream through the reference's MULTI-THREADED decoder into the numpy array `out`; returns
+    (lzma_ret, bytes produced)."""
+    stream = as_u8(stream) if not isinstance(stream, np.ndarray) else stream
+    f = ref().ref_decode_mt
+    f.restype = C.c_int
+    f.argtypes = [C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    n = C.c_size_t(0)
+    r = f(stream.ctypes.data, stream.size, threads, out.ctypes.data, out.size, C.byref(n))
+    return r, n.value
+
+
 def ref_decode(stream, out_cap):
     stream = as_u8(stream)
     out = np.empty(max(out_cap, 1), dtype=np.uint8)

@@ -1,0 +1,160 @@
+/* driver.c -- TEST INFRASTRUCTURE ONLY: drives the product's plain-C host layer (xzamd_stream.c + xzamd_host.c over
+ * the CPU stand-in stub_xzk.c) through the liblzma entry points the way a client does, under sanitizers.
+ * usage: driver OUTDIR   -> writes OUTDIR/caseN.in / caseN.xz; exit code 0 when every call behaved. */
+#include "../../include/xz_amd.h"
+#include "../../include/xz_amd_lzma.h"
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define CHECK(c) do { if (!(c)) { fprintf(stderr, "driver: %s:%d: %s\n", __FILE__, __LINE__, #c); exit(1); } } while (0)
+
+static void save(const char *dir, const char *name, const uint8_t *p, size_t n)
+{
+	char path[512];
+	snprintf(path, sizeof(path), "%s/%s", dir, name);
+	FILE *f = fopen(path, "wb");
+	CHECK(f != NULL);
+	CHECK(fwrite(p, 1, n, f) == n);
+	fclose(f);
+}
+
+/* feed `in` in pieces of in_step, drain into pieces of out_step; flush_at: LZMA_FULL_FLUSH once that many bytes are in */
+static size_t stream_encode(const lzma_mt *mt, const uint8_t *in, size_t n, size_t in_step, size_t out_step,
+		size_t flush_at, lzma_action flush_action, uint8_t *out, size_t out_cap)
+{
+	lzma_stream s = LZMA_STREAM_INIT;
+	CHECK(lzma_stream_encoder_mt(&s, mt) == LZMA_OK);
+	size_t ipos = 0, opos = 0;
+	int flushed = flush_at == 0;
+	for (;;) {
+		lzma_action act = LZMA_RUN;
+		size_t limit = n;
+		if (!flushed && flush_at <= n) limit = flush_at;
+		if (s.avail_in == 0 && ipos < limit) {
+			size_t k = limit - ipos < in_step ? limit - ipos : in_step;
+			s.next_in = in + ipos;
+			s.avail_in = k;
+			ipos += k;
+		}
+		if (ipos == limit && !flushed) act = flush_action;
+		else if (ipos == n) act = LZMA_FINISH;
+		if (s.avail_out == 0) {
+			CHECK(opos < out_cap);
+			size_t k = out_cap - opos < out_step ? out_cap - opos : out_step;
+			s.next_out = out + opos;
+			s.avail_out = k;
+			opos += k;
+		}
+		lzma_ret r = lzma_code(&s, act);
+		uint64_t pin = 0, pout = 0;
+		lzma_get_progress(&s, &pin, &pout);
+		CHECK(pin <= n);
+		if (r == LZMA_STREAM_END) {
+			if (act == LZMA_FINISH) break;
+			CHECK(act == flush_action && s.avail_in == 0);
+			flushed = 1;
+			continue;
+		}
+		CHECK(r == LZMA_OK);
+	}
+	opos -= s.avail_out;
+	CHECK(s.total_in == n && s.total_out == opos);
+	/* after STREAM_END every further call says STREAM_END (common.c:283-284) */
+	CHECK(lzma_code(&s, LZMA_FINISH) == LZMA_STREAM_END);
+	lzma_end(&s);
+	return opos;
+}
+
+int main(int argc, char **argv)
+{
+	CHECK(argc == 2);
+	const char *dir = argv[1];
+	const size_t n1 = (5u << 20) + 12345, n2 = (3u << 20) + 7;
+	uint8_t *in = (uint8_t *)malloc(n1);
+	uint8_t *out = (uint8_t *)malloc(n1 + (n1 >> 2) + (1u << 20));
+	CHECK(in && out);
+	xzamd_corpus_lorem(in, n1);
+
+	/* 1. fast-parser preset, many small jobs, three workers, tiny client buffers, timeout */
+	setenv("XZAMD_BATCH_MIB", "1", 1);
+	setenv("XZAMD_TEST_WORKERS", "3", 1);
+	lzma_mt mt;
+	memset(&mt, 0, sizeof(mt));
+	mt.threads = 4; mt.preset = 1; mt.check = LZMA_CHECK_CRC64; mt.block_size = 256u << 10; mt.timeout = 1;
+	size_t w = stream_encode(&mt, in, n1, 8192, 4096, 0, LZMA_RUN, out, n1 + (n1 >> 2) + (1u << 20));
+	save(dir, "case1.in", in, n1);
+	save(dir, "case1.xz", out, w);
+
+	/* 2. optimal-parser preset (device-side span plan path), FULL_FLUSH in the middle, CRC32, one worker */
+	unsetenv("XZAMD_TEST_WORKERS");
+	memset(&mt, 0, sizeof(mt));
+	mt.threads = 1; mt.preset = 6; mt.check = LZMA_CHECK_CRC32; mt.block_size = 1u << 20;
+	w = stream_encode(&mt, in, n2, 100000, 65536, (1u << 20) + 500, LZMA_FULL_FLUSH, out, n1 + (n1 >> 2) + (1u << 20));
+	save(dir, "case2.in", in, n2);
+	save(dir, "case2.xz", out, w);
+
+	/* 3. FULL_BARRIER, two workers, no Check */
+	setenv("XZAMD_TEST_WORKERS", "2", 1);
+	memset(&mt, 0, sizeof(mt));
+	mt.threads = 2; mt.preset = 0; mt.check = LZMA_CHECK_NONE; mt.block_size = 300000;
+	w = stream_encode(&mt, in, n2, 1u << 20, 1u << 20, 700000, LZMA_FULL_BARRIER, out, n1 + (n1 >> 2) + (1u << 20));
+	save(dir, "case3.in", in, n2);
+	save(dir, "case3.xz", out, w);
+	unsetenv("XZAMD_TEST_WORKERS");
+
+	/* 4. option validation and stream life cycle (stream_encoder_mt.c:956-1000, common.c:203-389) */
+	{
+		lzma_stream s = LZMA_STREAM_INIT;
+		CHECK(lzma_stream_encoder_mt(&s, NULL) == LZMA_PROG_ERROR);
+		memset(&mt, 0, sizeof(mt));
+		mt.threads = 1; mt.preset = 6; mt.check = LZMA_CHECK_CRC64;
+		mt.flags = 1;
+		CHECK(lzma_stream_encoder_mt(&s, &mt) == LZMA_OPTIONS_ERROR);
+		mt.flags = 0; mt.threads = 0;
+		CHECK(lzma_stream_encoder_mt(&s, &mt) == LZMA_OPTIONS_ERROR);
+		mt.threads = 1; mt.preset = 77;
+		CHECK(lzma_stream_encoder_mt(&s, &mt) == LZMA_OPTIONS_ERROR);
+		mt.preset = 6; mt.check = (lzma_check)99;
+		CHECK(lzma_stream_encoder_mt(&s, &mt) == LZMA_PROG_ERROR);
+		mt.check = LZMA_CHECK_CRC64;
+		CHECK(lzma_stream_encoder_mt(&s, &mt) == LZMA_OK);
+		/* re-init replaces the coder; an init that fails ends the stream (lzma_next_strm_init) */
+		CHECK(lzma_stream_encoder_mt(&s, &mt) == LZMA_OK);
+		mt.preset = 77;
+		CHECK(lzma_stream_encoder_mt(&s, &mt) == LZMA_OPTIONS_ERROR);
+		CHECK(s.internal == NULL);
+		mt.preset = 6;
+		CHECK(lzma_stream_encoder_mt(&s, &mt) == LZMA_OK);
+		/* SYNC_FLUSH is not supported by the MT encoder (:1201-1205) */
+		s.next_in = in; s.avail_in = 10; s.next_out = out; s.avail_out = 100;
+		CHECK(lzma_code(&s, LZMA_SYNC_FLUSH) == LZMA_PROG_ERROR);
+		lzma_end(&s);
+		lzma_end(&s);           /* idempotent */
+		lzma_end(NULL);
+		lzma_stream z = LZMA_STREAM_INIT;
+		lzma_end(&z);           /* never initialised */
+		CHECK(lzma_stream_encoder_mt_memusage(&mt) != UINT64_MAX);
+		mt.preset = 77;
+		CHECK(lzma_stream_encoder_mt_memusage(&mt) == UINT64_MAX);
+	}
+
+	/* 5. one-shot buffer API, empty input */
+	{
+		size_t pos = 0;
+		CHECK(lzma_easy_buffer_encode(1, LZMA_CHECK_CRC64, NULL, in, 600000, out, &pos, n1) == LZMA_OK);
+		save(dir, "case5.in", in, 600000);
+		save(dir, "case5.xz", out, pos);
+		pos = 0;
+		CHECK(lzma_easy_buffer_encode(6, LZMA_CHECK_CRC64, NULL, in, 0, out, &pos, n1) == LZMA_OK);
+		save(dir, "case6.in", in, 0);
+		save(dir, "case6.xz", out, pos);
+		pos = 5;
+		CHECK(lzma_easy_buffer_encode(6, LZMA_CHECK_CRC64, NULL, in, 600000, out, &pos, 100) == LZMA_BUF_ERROR && pos == 5);
+	}
+	xzamd_release_parked();
+	free(in);
+	free(out);
+	puts("driver: ok");
+	return 0;
+}

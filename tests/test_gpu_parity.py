@@ -673,6 +673,52 @@ def test_ld_preload_interposer_with_stock_xz(tmp_path, level):
     assert p2.returncode == 0 and b"-> GPU" not in p2.stderr
 
 
+def test_ld_preload_block_size_and_block_list(tmp_path):
+    """`xz --block-size` (lzma_mt.block_size) and `xz --block-list` (LZMA_FULL_FLUSH at the listed sizes,
+    src/xz/coder.c:1163-1218) through the interposer: Block boundaries where the options put them, same bytes as the
+    device API with that Block size, bit-exact through the plain binary."""
+    import shutil
+    import subprocess
+    import torch
+    import xz_amd
+    xz = shutil.which("xz")
+    pre = os.path.join(os.path.dirname(xz_amd.LIB_PATH), "libxz_amd_preload.so")
+    if not xz:
+        pytest.skip("no xz binary")
+    data = xz_amd.corpus_text(8 << 20, seed=6).tobytes()[: (7 << 20) + 4321]
+    src = tmp_path / "input.bin"
+    src.write_bytes(data)
+    env = dict(os.environ, LD_PRELOAD=pre, XZ_AMD_VERBOSE="1")
+
+    def blocks_of(stream):
+        r, dec, nb = o.orc_xz_decode(stream, len(data) + 16)
+        assert r == 0 and dec == data
+        return nb
+
+    p = subprocess.run([xz, "-T4", "-1", "--block-size=2MiB", "-c", str(src)], capture_output=True, env=env, timeout=600)
+    assert p.returncode == 0 and b"-> GPU" in p.stderr, p.stderr.decode()[-2000:]
+    assert blocks_of(p.stdout) == 4
+    enc = xz_amd.Encoder(0)
+    t = torch.frombuffer(bytearray(data), dtype=torch.uint8).cuda()
+    want, _ = enc.encode(t, preset=1, block_size=2 << 20)
+    enc.close()
+    assert o.first_diff(p.stdout, want.cpu().numpy().tobytes()) == -1
+    # --block-list: 1 MiB, 3 MiB, then the rest in Blocks of the default size (3 MiB at -1): 1 + 3 + 3 + 0.004 MiB
+    p = subprocess.run([xz, "-T4", "-1", "--block-list=1MiB,3MiB,0", "-c", str(src)], capture_output=True, env=env, timeout=600)
+    assert p.returncode == 0 and b"-> GPU" in p.stderr, p.stderr.decode()[-2000:]
+    got = p.stdout
+    assert blocks_of(got) == 4
+    lst = subprocess.run([xz, "--robot", "--list", "-vv"], input=b"", capture_output=True)     # availability probe only
+    f = tmp_path / "bl.xz"
+    f.write_bytes(got)
+    lst = subprocess.run([xz, "--robot", "--list", "-vv", str(f)], capture_output=True, text=True)
+    if lst.returncode == 0:
+        usizes = [int(l.split("\t")[7]) for l in lst.stdout.splitlines() if l.startswith("block\t")]
+        assert usizes[:2] == [1 << 20, 3 << 20] and sum(usizes) == len(data), usizes
+    d = subprocess.run([xz, "-dc", str(f)], capture_output=True, timeout=600)
+    assert d.returncode == 0 and d.stdout == data
+
+
 def test_one_shot_buffer_api():
     """lzma_easy_buffer_encode / lzma_stream_buffer_encode / lzma_stream_buffer_bound
     (common/easy_buffer_encoder.c, stream_buffer_encoder.c): same bytes as the streaming API, BUF_ERROR
