@@ -60,18 +60,20 @@
 #include "oracle.h"
 #include <stdlib.h>
 #include <string.h>
+#ifdef ORC_SA_STATS
+#include <stdio.h>
+#endif
 
 #define MATCH_LEN_MAX 273u
 #define LIT 0xFFFFFFFFu
 #define NO_DELTA 0xFFFFFFFFu
-#ifndef WMAX
-#define WMAX 232u
-#endif
-#define WMAX_                     /* optimal-parser window (nodes 0..WMAX); sized so the GPU's node arrays +
+#define WMAX_STD 232u             /* optimal-parser window (nodes 0..WMAX); sized so the GPU's node arrays +
                                    * model + price tables fit 10 KiB of LDS per wavefront */
 #ifndef WTAIL
 #define WTAIL 16u
 #endif
+#define WMAX_LONG 464u            /* nice_len > 128 (the extreme presets): 15.8 KiB per wavefront */
+#define WMAX_CAP WMAX_LONG
 #define WTAIL_                 /* symbols ending less than WTAIL nodes before a forced window cut are re-parsed */
 #ifndef LIST_K
 #define LIST_K 7u
@@ -146,7 +148,8 @@ typedef struct {
 	uint32_t cpos;
 	/* optimal parser */
 	node *nodes;
-	uint32_t q_back[WMAX + 2], q_len[WMAX + 2], q_head, q_count;
+	uint32_t q_back[WMAX_CAP + 2], q_len[WMAX_CAP + 2], q_head, q_count;
+	uint32_t wmax;              /* window of this option set: WMAX_STD, or WMAX_LONG when nice_len > 128 */
 	uint8_t price_tab[128];
 	/* cached price tables (role of length_update_prices / fill_dist_prices /
 	 * fill_align_prices), refreshed at window starts by symbol counters */
@@ -276,6 +279,14 @@ static int build_sa(enc *e)
 			if (prevx)
 				prevx[sa[i]] = g != i ? sa[i] - sa[i - 1] : 0;
 		}
+#ifdef ORC_SA_STATS
+		{
+			uint32_t unres = 0;
+			for (uint32_t i = 0; i < n; ++i)
+				if ((i && key[i] == key[i - 1]) || (i + 1 < n && key[i] == key[i + 1])) ++unres;
+			fprintf(stderr, "SA after %u bytes: %.2f%% of positions in groups of >= 2\n", h, 100.0 * unres / (n ? n : 1));
+		}
+#endif
 		if (h >= (e->prm.sa_depth ? e->prm.sa_depth : 32u))
 			break;
 		for (uint32_t i = 0; i < n; ++i) {
@@ -1111,7 +1122,7 @@ static int optimum_window(enc *e, uint32_t pos, int cached)
 				return 0;
 			}
 		}
-		const uint32_t room = WMAX - j;              /* targets must stay inside the window */
+		const uint32_t room = e->wmax - j;              /* targets must stay inside the window */
 		if (longest > room) longest = room;
 		for (uint32_t i = 0; i < 4; ++i)
 			if (rl[i] > room) rl[i] = room;
@@ -1161,7 +1172,7 @@ static int optimum_window(enc *e, uint32_t pos, int cached)
 		/* (a) literal + rep0: the rep0 byte differs here and a run of >= 2 follows inside the row */
 		if (e->rep_len[0] == 0) {
 			const uint32_t l2 = row_run_after(cur, nd[j].reps[0], 0, buf_avail);
-			if (l2 >= 2 && j + 1 + l2 <= WMAX) {
+			if (l2 >= 2 && j + 1 + l2 <= e->wmax) {
 				const uint32_t s2 = state_after(s, LIT, 1), ps2 = (x + 1) & pbm;
 				while (n_end < j + 1 + l2) nd[++n_end].price = PRICE_INF;
 				relax(&nd[j + 1 + l2], plit + REP0_AFTER_LIT(s2, ps2, l2), LIT, 0, l2);
@@ -1173,7 +1184,7 @@ static int optimum_window(enc *e, uint32_t pos, int cached)
 			if (L1 < 2 || L1 > room || L1 >= buf_avail)
 				continue;
 			const uint32_t l2 = row_run_after(cur, nd[j].reps[i], L1, buf_avail);
-			if (l2 < 2 || j + L1 + 1 + l2 > WMAX)
+			if (l2 < 2 || j + L1 + 1 + l2 > e->wmax)
 				continue;
 			const uint32_t sr = state_after(s, i, L1), psl = (x + L1) & pbm;
 			uint32_t pr = prep + pure[i] + e->lp[1][ps & 3][L1 - 2] + pr_bit(e, P_IS_MATCH + sr * 16 + psl, 0)
@@ -1189,7 +1200,7 @@ static int optimum_window(enc *e, uint32_t pos, int cached)
 			const uint32_t k = e->m_count - 1 - t;
 			const uint32_t L1 = t == 0 ? e->m_longest : e->m_len[k];
 			const uint32_t dist = e->m_dist[k], l2 = e->m_len2[t];
-			if (L1 < 2 || L1 > room || l2 < 2 || L1 > 61 || j + L1 + 1 + l2 > WMAX)
+			if (L1 < 2 || L1 > room || l2 < 2 || L1 > 61 || j + L1 + 1 + l2 > e->wmax)
 				continue;
 			const uint32_t sm = state_after(s, dist + 4, L1), psl = (x + L1) & pbm;
 			uint32_t pr = pmatch + e->lp[0][ps & 3][L1 - 2] + tab_dist(e, dist, L1 < 6 ? L1 - 2 : 3)
@@ -1202,7 +1213,7 @@ static int optimum_window(enc *e, uint32_t pos, int cached)
 #undef REP0_AFTER_LIT
 		++j;
 		if (j == n_end) {
-			forced = j >= WMAX;     /* cut by the node limit, not by convergence */
+			forced = j >= e->wmax;     /* cut by the node limit, not by convergence */
 			break;
 		}
 	}
@@ -1492,7 +1503,8 @@ static enc *enc_new(const uint8_t *in, uint32_t n, const orc_enc_params *p)
 		e->sa_rank = (uint32_t *)calloc((size_t)n + 1, 4);
 	}
 	e->cbuf = (uint8_t *)malloc(1 << 17);
-	e->nodes = (node *)calloc(WMAX + MATCH_LEN_MAX + 2, sizeof(node));
+	e->nodes = (node *)calloc(WMAX_CAP + MATCH_LEN_MAX + 2, sizeof(node));
+	e->wmax = e->prm.nice_len > 128 ? WMAX_LONG : WMAX_STD;
 	if (!e->prev2 || !e->prev3 || !e->son || !e->cbuf || !e->nodes
 			|| (p->sa_window && (!e->prev4 || !e->prev8 || !e->prev16 || !e->sa || !e->sa_rank))
 			|| build_links(e) || (p->sa_window && build_sa(e))) {

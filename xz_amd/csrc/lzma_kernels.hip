@@ -35,6 +35,7 @@
 // No MFMA: there is no dense contraction anywhere on this path.
 
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
@@ -373,6 +374,70 @@ __global__ __launch_bounds__(256) void k_sa_rank_only_seq(const uint32_t* __rest
 {
     const uint32_t stride = gridDim.x * blockDim.x;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) rk[i] = grp[i] + 1;
+}
+
+// ---- rank doubling on the unresolved slots only -------------------------------------------------------------
+// After the 16-byte round most positions of ordinary data are alone in their group (text: 88 %, after 32 bytes
+// 99.95 %): their slot is final.  A round then only has to order the slots that still share a group with another one:
+//   k_sa_unres     u[i] = 1 when slot i lies in a group of >= 2 slots            (exclusive scan -> compact index)
+//   k_sa_compact   (key, position, slot) of the unresolved slots, in slot order; key = (rank, rank of p + h) as
+//                  k_sa_pair_keys_pos makes it
+//   radix sort of those m elements (stable: equal keys keep ascending positions, as in the full round)
+//   k_sa_newgrp    group starts of the sorted elements (max-scan over "slot where the key changes")
+//   k_sa_writeback the j-th sorted element goes to the j-th unresolved slot (the groups are contiguous slot ranges in
+//                  ascending order, so the sorted sequence enumerates them in place); position, group start and the
+//                  by-position rank of the moved elements are updated
+__global__ __launch_bounds__(256) void k_sa_unres(const uint32_t* __restrict__ grp, uint32_t n, uint32_t* __restrict__ u)
+{
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        u[i] = (grp[i] != i || (i + 1 < n && grp[i + 1] == i)) ? 1u : 0u;
+}
+
+__global__ void k_sa_count(const uint32_t* __restrict__ idx, const uint32_t* __restrict__ grp, uint32_t n, uint32_t* __restrict__ count)
+{
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        *count = idx[n - 1] + ((grp[n - 1] != n - 1) ? 1u : 0u);      // the last slot has no right neighbour
+}
+
+__global__ __launch_bounds__(256) void k_sa_compact(const uint32_t* __restrict__ pos, const uint32_t* __restrict__ grp,
+        const uint32_t* __restrict__ idx, const uint32_t* __restrict__ rank, uint32_t n, uint32_t block_size, uint32_t h,
+        uint32_t sbits, uint64_t* __restrict__ ckey, uint32_t* __restrict__ cval, uint32_t* __restrict__ cslot)
+{
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint32_t g = grp[i];
+        if (!(g != i || (i + 1 < n && grp[i + 1] == i))) continue;
+        const uint32_t j = idx[i];
+        const uint32_t p = pos[i];
+        const uint32_t bs = (p / block_size) * block_size;
+        const uint32_t bend = min(n, bs + block_size);
+        const uint32_t second = p + h < bend ? rank[p + h] - bs : 0u;
+        ckey[j] = ((uint64_t)(g + 1) << sbits) | second;
+        cval[j] = p;
+        cslot[j] = i;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_sa_newgrp(const uint64_t* __restrict__ ckey, const uint32_t* __restrict__ cslot,
+        uint32_t m, uint32_t* __restrict__ gs)
+{
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < m; j += stride)
+        gs[j] = (j == 0 || ckey[j] != ckey[j - 1]) ? cslot[j] : 0u;
+}
+
+__global__ __launch_bounds__(256) void k_sa_writeback(const uint32_t* __restrict__ cval, const uint32_t* __restrict__ cslot,
+        const uint32_t* __restrict__ gs, uint32_t m, uint32_t* __restrict__ pos, uint32_t* __restrict__ grp,
+        uint32_t* __restrict__ rank)
+{
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < m; j += stride) {
+        const uint32_t sl = cslot[j], p = cval[j], g = gs[j];
+        pos[sl] = p;
+        grp[sl] = g;
+        rank[p] = g + 1;
+    }
 }
 
 // doubling key of every position, in position order: (rank[p], rank[p + h]) with 0 for a second half that
@@ -950,10 +1015,11 @@ __device__ __forceinline__ bool change_pair(uint32_t small_dist, uint32_t big_di
 // Semantics are defined by oracle/lzma_fast_enc.c (build_sa / find_sn / optimum_window); the code
 // below is their wave-parallel form and must stay bit-exact with them.
 // ------------------------------------------------------------------------------------------
-#ifndef XZAMD_WMAX
-#define XZAMD_WMAX 232        /* LDS per wave <= 10 KiB -> 16 waves per CU */
-#endif
-constexpr uint32_t WMAX = XZAMD_WMAX;            // optimal-parser window: nodes 0..WMAX
+// Optimal-parser window: nodes 0..WM, a template parameter of the parser.  WMAX_STD: LDS per wave <= 10 KiB -> 16 waves
+// per CU, what every option set with nice_len <= 128 runs.  WMAX_LONG (nice_len > 128: the extreme presets): matches
+// of 233..273 bytes fit a window and the tail re-parse weighs half as much -- 15.8 KiB per wave, 10 waves per CU.
+constexpr uint32_t WMAX_STD = 232;
+constexpr uint32_t WMAX_LONG = 464;
 constexpr uint32_t PRICE_INF = 1u << 30;
 
 #ifdef XZAMD_TIMING
@@ -969,10 +1035,10 @@ constexpr uint32_t PRICE_INF = 1u << 30;
 // Per-wave LDS carve for the list-based paths.
 struct Work {
     // optimal parser only
-    uint32_t* n_price;  // [WMAX+1] node price; after backtracking: out-edge `back`
-    uint32_t* n_info;   // [WMAX+1] in-len (9) | state (4) << 9 | out-len (9) << 13 | in-edge kind (3) << 22
+    uint32_t* n_price;  // [WM+1] node price; after backtracking: out-edge `back`
+    uint32_t* n_info;   // [WM+1] in-len (9) | state (4) << 9 | out-len (9) << 13 | in-edge kind (3) << 22
                         //          kind: 0..3 = rep index, 4 = match (its distance is the node's rep0), 5 = literal
-    uint4* n_reps4;     // [WMAX+1] rep distances of the node (complete when the parser reaches it)
+    uint4* n_reps4;     // [WM+1] rep distances of the node (complete when the parser reaches it)
     uint16_t* dsp;      // [4*64]  dist-slot price (+ direct bits for slot >= 14)
     uint16_t* xt;       // [128]   price of the footer bits of distances < 128 (slots 4..13, 0 below)
     uint16_t* ap;       // [16]    align price; == xt + 128, so one table: index dist < 128 ? dist : 128 + (dist & 15)
@@ -1349,7 +1415,7 @@ __device__ __forceinline__ uint32_t mask_run_after(uint64_t m, uint32_t first)
 }
 
 __device__ __forceinline__ void compound_setup(const RoundL& RL, uint32_t j, uint32_t room, uint32_t buf_avail,
-        uint32_t r0, uint32_t r1, uint32_t r2, uint32_t r3, Compound& c)
+        uint32_t r0, uint32_t r1, uint32_t r2, uint32_t r3, Compound& c, const uint32_t WMAX)
 {
     const uint32_t lane = threadIdx.x;
     // uniform per-candidate geometry
@@ -1392,6 +1458,7 @@ __device__ __forceinline__ void compound_setup(const RoundL& RL, uint32_t j, uin
 // stored as out-edges: node t -> (n_price[t] = back, out-len in n_info[t]); q_end = last node to code
 // (a window cut by the node limit only commits the symbols that end WTAIL nodes before the cut).
 constexpr uint32_t WTAIL = 16;
+template <uint32_t WMAX>
 __device__ __forceinline__ bool optimum_window(const Env& e, const Work& w, ListPre& P, uint16_t* probs, const Lz& z, LenTab& lt,
         const uint8_t* __restrict__ in, uint32_t pos, uint32_t block_start, uint32_t span_end, bool cached,
         RoundL& RL, uint32_t& q_end)
@@ -1469,7 +1536,7 @@ __device__ __forceinline__ bool optimum_window(const Env& e, const Work& w, List
         cp.mask = 0; cp.L1 = cp.l2 = cp.T = cp.dist = 0;
         {
             const bool any = (RL.l2a | RL.l2b) >= 2 || RL.pre;
-            if (any) compound_setup(RL, j, room, buf_avail, r0, r1, r2, r3, cp);
+            if (any) compound_setup(RL, j, room, buf_avail, r0, r1, r2, r3, cp, WMAX);
         }
         uint32_t cT_max = 0;
         for (uint64_t mm = cp.mask; mm; mm &= mm - 1) cT_max = max(cT_max, lane_of(cp.T, (uint32_t)__builtin_ctzll(mm)));
@@ -1695,7 +1762,7 @@ __device__ __forceinline__ bool optimum_window(const Env& e, const Work& w, List
 // the kernel (fast parser), 2 = per-position match lists written by k_find_sn / k_find_exact;
 // OPT selects the parser (false = optimum_fast of the reference).
 // ------------------------------------------------------------------------------------------
-template <int FINDER, bool OPT>      // FINDER: 0 = exact HC3/HC4 in-kernel, 2 = lists from the batch finders
+template <int FINDER, bool OPT, uint32_t WMAX>      // FINDER: 0 = exact HC3/HC4 in-kernel, 2 = lists from the batch finders
 #ifndef XZAMD_WAVES_FAST
 #define XZAMD_WAVES_FAST 4
 #endif
@@ -1875,7 +1942,7 @@ __device__ __forceinline__ void span_encode_one(const xzamd_span_args& a, const 
                         cached = false;
                         q_pos = q_end = 0;
                     } else {
-                        cached = optimum_window(e, w, LP, probs, z, lt, in, cur, block_start, span_end, cached, RL, q_end);
+                        cached = optimum_window<WMAX>(e, w, LP, probs, z, lt, in, cur, block_start, span_end, cached, RL, q_end);
                         q_pos = 0;
                         if (q_end == 0) {            // consistency failure reported by the parser
                             if (lane == 0) a.span_bytes[span] = 0;
@@ -2099,9 +2166,9 @@ __device__ __forceinline__ void span_encode_one(const xzamd_span_args& a, const 
 // Persistent form: a launch has at most as many wavefronts as the GPU holds at once (the host passes the
 // count); each pulls span numbers from a counter until none is left, so a launch is not a sequence of rounds
 // of equally long spans and fewer resident wavefronts can be asked for (leaving room for other streams).
-template <int FINDER, bool OPT>
+template <int FINDER, bool OPT, uint32_t WMAX = WMAX_STD>
 __global__ __launch_bounds__(64)
-__attribute__((amdgpu_waves_per_eu(OPT ? XZAMD_WAVES_OPT : XZAMD_WAVES_FAST, OPT ? XZAMD_WAVES_OPT : XZAMD_WAVES_FAST)))
+__attribute__((amdgpu_waves_per_eu(OPT ? (WMAX > WMAX_STD ? 2 : XZAMD_WAVES_OPT) : XZAMD_WAVES_FAST, OPT ? XZAMD_WAVES_OPT : XZAMD_WAVES_FAST)))
 void k_span_encode_t(xzamd_span_args a, uint32_t nspans, uint32_t* __restrict__ counter)
 {
     for (;;) {
@@ -2111,7 +2178,7 @@ void k_span_encode_t(xzamd_span_args a, uint32_t nspans, uint32_t* __restrict__ 
             s = uni(s);
         }
         if (s >= nspans) break;
-        span_encode_one<FINDER, OPT>(a, s);
+        span_encode_one<FINDER, OPT, WMAX>(a, s);
         if (counter == nullptr) break;
         __builtin_amdgcn_s_waitcnt(0);      // this span's stores are out before the LDS pool is reused
         wave_sync();
@@ -2312,7 +2379,9 @@ __global__ __launch_bounds__(64) void k_find_sn(xzamd_span_args a, SnArgs sn, ui
     uint4 A0 = make_uint4(0, 0, 0, 0), B0 = A0;
     if (pf0) { A0 = load16(q0); B0 = load16(xr0); }
 
-    for (uint32_t i = 0; i < ROW_RUN; ++i) {
+    uint32_t macc = 0;
+    uint32_t i = 0;
+    for (; i < ROW_RUN; ++i) {
         const uint32_t x = xr0 + i;
         if (__builtin_amdgcn_readfirstlane((int)(blockIdx.x * FIND_RUN + i)) >= (int)n) break;   // every row is past the end
         // stage 0: window of x + 2 (its rank arrived last iteration), rank of x + 3, hash word of x + 2
@@ -2327,6 +2396,7 @@ __global__ __launch_bounds__(64) void k_find_sn(xzamd_span_args a, SnArgs sn, ui
         uint4 A1 = A0, B1 = B0;
         if (pf1) { A1 = load16(q1); B1 = load16(x + 1); }
         // stage 2: position x
+        uint32_t mval = 0;                                  // this position's 16-bit summary for the span plan (top lane)
         if (x < xend) {
             const uint32_t q = q0;
             const bool valid = v0;
@@ -2388,16 +2458,27 @@ __global__ __launch_bounds__(64) void k_find_sn(xzamd_span_args a, SnArgs sn, ui
             // trailer: count | len2(longest) << 8 | len2(second) << 16, written bytewise by the lanes that know
             uint8_t* tr = reinterpret_cast<uint8_t*>(mdist + rec_base + LIST_K);
             if (cnt == 0) {
-                if (t == 0) { mdist[rec_base + LIST_K] = 0; a.mtop[x] = 0; }
+                if (t == 0) mdist[rec_base + LIST_K] = 0;
             } else {
                 if (top) {
                     *reinterpret_cast<uint16_t*>(tr) = (uint16_t)((cnt - drop) | (l2 << 8));
                     tr[3] = 0;
                     if (cnt == 1) tr[2] = 0;
                     // what the span plan's walk needs of this position (k_span_est), 2 bytes instead of the 32-byte record
-                    a.mtop[x] = (uint16_t)(len_out | ((dist > 1 ? 32u - (uint32_t)__builtin_clz(dist - 1) : 0u) << 9));
+                    mval = len_out | ((dist > 1 ? 32u - (uint32_t)__builtin_clz(dist - 1) : 0u) << 9);
                 }
                 if (second) tr[2] = (uint8_t)l2;
+            }
+        }
+        // the summaries of 16 consecutive positions of a row are collected in its 16 lanes and stored together
+        // (a 2-byte store per position from one lane per row costs as much as the whole 32-byte record)
+        {
+            uint32_t rv = mval;
+            rv |= row_ror<1>(rv); rv |= row_ror<2>(rv); rv |= row_ror<4>(rv); rv |= row_ror<8>(rv);
+            macc = t == (i & 15u) ? rv : macc;
+            if ((i & 15u) == 15u) {
+                const uint32_t px = xr0 + (i & ~15u) + t;
+                if (px < xend) a.mtop[px] = (uint16_t)macc;
             }
         }
         // shift the pipeline
@@ -2407,6 +2488,10 @@ __global__ __launch_bounds__(64) void k_find_sn(xzamd_span_args a, SnArgs sn, ui
         g_bs = g1_bs; g_be = g1_be;
         g1_bs = g2_bs; g1_be = g2_be;
         geo_next(g2_bs, g2_be, x + 3);
+    }
+    if (i & 15u) {                                          // the loop ended inside a group of 16 (end of the batch)
+        const uint32_t px = xr0 + (i & ~15u) + t;
+        if (t < (i & 15u) && px < xend) a.mtop[px] = (uint16_t)macc;
     }
 }
 
@@ -2438,8 +2523,14 @@ __global__ __launch_bounds__(256) void k_span_est(xzamd_span_args a, uint32_t nb
         const uint32_t c0 = (uint32_t)c0_;
         const uint32_t c1 = be - c0 < XZAMD_EST_CHUNK ? be : c0 + XZAMD_EST_CHUNK;
         uint32_t x = c0, gnext = c0;
+        uint32_t cb = 0xFFFFFFFFu;                       // eight summaries at a time (16 bytes) through registers
+        uint4 buf = make_uint4(0, 0, 0, 0);
         while (x < c1) {
-            const uint32_t v = a.mtop[x];
+            const uint32_t base = x & ~7u;
+            if (base != cb) { buf = *reinterpret_cast<const uint4*>(a.mtop + base); cb = base; }
+            const uint32_t k = x & 7u;
+            const uint32_t wv = k < 2 ? buf.x : k < 4 ? buf.y : k < 6 ? buf.z : buf.w;
+            const uint32_t v = (k & 1u) ? wv >> 16 : wv & 0xFFFFu;
             const uint32_t len = v & 0x1FFu, bl = v >> 9;          // bl <= 7 <=> zero-based distance < 128
             if (x >= gnext) {
                 if (len >= 3 || (len == 2 && bl <= 7)) {
@@ -3327,37 +3418,95 @@ int xzk_build_chains(const uint8_t* d_in, uint32_t n, uint32_t block_size, uint3
     while (sbits < 32 && (1ull << sbits) <= (uint64_t)min(block_size, n)) ++sbits;
     while (fbits < 32 && (1ull << fbits) <= (uint64_t)n) ++fbits;
     if (sa_depth < 32) sa_depth = 32;
-    for (uint32_t h = 8; 2 * h <= sa_depth; h *= 2) {
-        if (h <= 16) {
-            // by-position arrays of the round: rank at rk32[0..n), left-neighbour distance at rk32[n..2n)
-            uint32_t* const rk32 = reinterpret_cast<uint32_t*>(h == 8 ? rp8 : rp16);
-            // (rank, left-neighbour distance) of every slot, brought to position order
-            hipLaunchKernelGGL(k_sa_rank_seq, dim3(g), dim3(256), 0, st, pos, grp, n, reinterpret_cast<uint2*>(key64_a));
-            e = invert_perm<uint64_t>(pos, pos_alt, key64_a, key64_b, n, rk32, rk32 + n, sort_tmp, tb, st);
-            if (e != hipSuccess) return (int)e;
-            // keys in position order (values = iota): both `pos` buffers are free again
-            hipLaunchKernelGGL(k_sa_pair_keys_pos, dim3(g), dim3(256), 0, st, rk32, n, block_size, h, sbits, key64_a, pos);
-        } else {
-            // deeper rounds (sa_depth 64 / 128 / 256): only the rank is wanted by position; it goes where the rank of
-            // round h = 8 was (dead since that round's keys were made; the distances behind it stay)
-            uint32_t* const rk32 = reinterpret_cast<uint32_t*>(rp8);
-            uint32_t* const ra = reinterpret_cast<uint32_t*>(key64_a);
-            uint32_t* const rb = reinterpret_cast<uint32_t*>(key64_b);
-            hipLaunchKernelGGL(k_sa_rank_only_seq, dim3(g), dim3(256), 0, st, grp, n, ra);
-            e = invert_perm<uint32_t>(pos, pos_alt, ra, rb, n, rk32, nullptr, sort_tmp, tb, st);
-            if (e != hipSuccess) return (int)e;
-            hipLaunchKernelGGL(k_sa_pair_keys_pos, dim3(g), dim3(256), 0, st, rk32, n, block_size, h, sbits, key64_a, pos);
-        }
+    // round h = 8: every slot takes part (text: 71 % of the positions still share their 8 bytes with another one)
+    {
+        uint32_t* const rk32 = reinterpret_cast<uint32_t*>(rp8);     // rank at rk32[0..n), left-neighbour distance at rk32[n..2n)
+        hipLaunchKernelGGL(k_sa_rank_seq, dim3(g), dim3(256), 0, st, pos, grp, n, reinterpret_cast<uint2*>(key64_a));
+        e = invert_perm<uint64_t>(pos, pos_alt, key64_a, key64_b, n, rk32, rk32 + n, sort_tmp, tb, st);
+        if (e != hipSuccess) return (int)e;
+        // keys in position order (values = iota): both `pos` buffers are free again
+        hipLaunchKernelGGL(k_sa_pair_keys_pos, dim3(g), dim3(256), 0, st, rk32, n, block_size, 8u, sbits, key64_a, pos);
         rocprim::double_buffer<uint64_t> kk(key64_a, key64_b);
         rocprim::double_buffer<uint32_t> vv(pos, pos_alt);
         e = rocprim::radix_sort_pairs(sort_tmp, tb, kk, vv, (size_t)n, 0u, sbits + fbits, st);
         if (e != hipSuccess) return (int)e;
         pos = vv.current();
         pos_alt = vv.alternate();
-        if (4 * h <= sa_depth) {            // another round follows: its ranks need the groups of this order
-            hipLaunchKernelGGL(k_sa_flags64, dim3(g), dim3(256), 0, st, kk.current(), n, 0u, grp);
-            e = rocprim::inclusive_scan(sort_tmp, tb, grp, grp, (size_t)n, rocprim::maximum<uint32_t>(), st);
+        hipLaunchKernelGGL(k_sa_flags64, dim3(g), dim3(256), 0, st, kk.current(), n, 0u, grp);
+        e = rocprim::inclusive_scan(sort_tmp, tb, grp, grp, (size_t)n, rocprim::maximum<uint32_t>(), st);
+        if (e != hipSuccess) return (int)e;
+    }
+    // rounds h = 16, 32, ...: by-position rank in rkpos (kept up to date by the compact rounds), slots in pos, groups in grp
+    uint32_t* const rkpos = reinterpret_cast<uint32_t*>(rp16);
+    uint32_t* const idx = keys_b;                     // free since round 0
+    uint32_t* const d_count = reinterpret_cast<uint32_t*>(key64_b);
+    bool rank_valid = false;
+    const char* const cenv = getenv("XZAMD_SA_COMPACT");          // 0: every round orders all slots (measurement knob)
+    const bool compact_on = !(cenv && *cenv == '0');
+    for (uint32_t h = 16; 2 * h <= sa_depth; h *= 2) {
+        const bool more = 4 * h <= sa_depth;
+        if (h == 16) {
+            // (rank, distance to the left neighbour inside the 16-byte group) of every slot, brought to position order;
+            // the slot order itself stays (the inversion works on a copy of it)
+            hipLaunchKernelGGL(k_sa_rank_seq, dim3(g), dim3(256), 0, st, pos, grp, n, reinterpret_cast<uint2*>(key64_a));
+            e = hipMemcpyAsync(idx, pos, (size_t)n * 4, hipMemcpyDeviceToDevice, st);
             if (e != hipSuccess) return (int)e;
+            e = invert_perm<uint64_t>(idx, sa, key64_a, key64_b, n, rkpos, rkpos + n, sort_tmp, tb, st);
+            if (e != hipSuccess) return (int)e;
+            rank_valid = true;
+        } else if (!rank_valid) {
+            uint32_t* const ra = reinterpret_cast<uint32_t*>(key64_a);
+            uint32_t* const rb = reinterpret_cast<uint32_t*>(key64_b);
+            hipLaunchKernelGGL(k_sa_rank_only_seq, dim3(g), dim3(256), 0, st, grp, n, ra);
+            e = hipMemcpyAsync(idx, pos, (size_t)n * 4, hipMemcpyDeviceToDevice, st);
+            if (e != hipSuccess) return (int)e;
+            e = invert_perm<uint32_t>(idx, sa, ra, rb, n, rkpos, nullptr, sort_tmp, tb, st);
+            if (e != hipSuccess) return (int)e;
+            rank_valid = true;
+        }
+        uint32_t m = n;
+        if (compact_on && n >= 2) {
+            // how many slots are still undecided?  (One word back to the host: the sort below is sized by it.)
+            hipLaunchKernelGGL(k_sa_unres, dim3(g), dim3(256), 0, st, grp, n, idx);
+            e = rocprim::exclusive_scan(nullptr, need, idx, idx, 0u, (size_t)n, rocprim::plus<uint32_t>(), st);
+            if (e != hipSuccess) return (int)e;
+            if (need > tb) return (int)hipErrorOutOfMemory;
+            e = rocprim::exclusive_scan(sort_tmp, tb, idx, idx, 0u, (size_t)n, rocprim::plus<uint32_t>(), st);
+            if (e != hipSuccess) return (int)e;
+            hipLaunchKernelGGL(k_sa_count, dim3(1), dim3(1), 0, st, idx, grp, n, d_count);
+            e = hipMemcpyAsync(&m, d_count, 4, hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess) e = hipStreamSynchronize(st);
+            if (e != hipSuccess) return (int)e;
+            if (m == 0) break;                        // every suffix is distinguished: the order is final
+        }
+        if (compact_on && n >= 2 && (uint64_t)m * 10 <= (uint64_t)n * 6) {
+            uint32_t* const cslot = pos_alt;
+            const uint32_t gm = grid_for(m, 256, 256 * 16);
+            hipLaunchKernelGGL(k_sa_compact, dim3(g), dim3(256), 0, st, pos, grp, idx, rkpos, n, block_size, h, sbits,
+                    key64_a, sa, cslot);
+            rocprim::double_buffer<uint64_t> kk(key64_a, key64_b);
+            rocprim::double_buffer<uint32_t> vv(sa, sa_rank);
+            e = rocprim::radix_sort_pairs(sort_tmp, tb, kk, vv, (size_t)m, 0u, sbits + fbits, st);
+            if (e != hipSuccess) return (int)e;
+            hipLaunchKernelGGL(k_sa_newgrp, dim3(gm), dim3(256), 0, st, kk.current(), cslot, m, idx);
+            e = rocprim::inclusive_scan(sort_tmp, tb, idx, idx, (size_t)m, rocprim::maximum<uint32_t>(), st);
+            if (e != hipSuccess) return (int)e;
+            hipLaunchKernelGGL(k_sa_writeback, dim3(gm), dim3(256), 0, st, vv.current(), cslot, idx, m, pos, grp, rkpos);
+        } else {
+            // most slots are undecided (highly repetitive data): the full round, keys made in position order
+            hipLaunchKernelGGL(k_sa_pair_keys_pos, dim3(g), dim3(256), 0, st, rkpos, n, block_size, h, sbits, key64_a, pos);
+            rocprim::double_buffer<uint64_t> kk(key64_a, key64_b);
+            rocprim::double_buffer<uint32_t> vv(pos, pos_alt);
+            e = rocprim::radix_sort_pairs(sort_tmp, tb, kk, vv, (size_t)n, 0u, sbits + fbits, st);
+            if (e != hipSuccess) return (int)e;
+            pos = vv.current();
+            pos_alt = vv.alternate();
+            if (more) {            // another round follows: its ranks need the groups of this order
+                hipLaunchKernelGGL(k_sa_flags64, dim3(g), dim3(256), 0, st, kk.current(), n, 0u, grp);
+                e = rocprim::inclusive_scan(sort_tmp, tb, grp, grp, (size_t)n, rocprim::maximum<uint32_t>(), st);
+                if (e != hipSuccess) return (int)e;
+            }
+            rank_valid = false;
         }
     }
     // sa = slot order; sa_rank = its inverse (grp = keys_a is dead: scratch of the inversion)
@@ -3415,7 +3564,10 @@ int xzk_span_encode(const xzamd_span_args* a, uint32_t nspans, uint32_t waves, u
     uint32_t* cnt = persist ? counter : nullptr;
     if (a->parser) {
         if ((!a->mlen && !a->list_packed) || !a->mdist) return (int)hipErrorInvalidValue;
-        hipLaunchKernelGGL((k_span_encode_t<2, true>), dim3(grid), dim3(64), 0, st, *a, nspans, cnt);
+        if (a->nice_len > 128)
+            hipLaunchKernelGGL((k_span_encode_t<2, true, WMAX_LONG>), dim3(grid), dim3(64), 0, st, *a, nspans, cnt);
+        else
+            hipLaunchKernelGGL((k_span_encode_t<2, true>), dim3(grid), dim3(64), 0, st, *a, nspans, cnt);
     } else {
         if (a->sa_window) return (int)hipErrorInvalidValue;      // the fast parser runs on the exact finder only
         hipLaunchKernelGGL((k_span_encode_t<0, false>), dim3(grid), dim3(64), 0, st, *a, nspans, cnt);

@@ -208,8 +208,11 @@ void xzamd_sn_defaults(xzamd_lzma_options *o)
 	o->gpu_sa_window = XZAMD_SA_WINDOW_MAX;
 	o->gpu_parser = 1;
 	o->gpu_sa_depth = o->gpu_nice_len <= 32 ? 32 : o->gpu_nice_len <= 64 ? 64 : 256;
-	o->span_cost = XZAMD_SPAN_COST_DEFAULT;
-	o->span_bits = XZAMD_SPAN_BITS_DEFAULT;
+	/* nice_len > 128 (the extreme presets) asks for ratio first: spans twice as long (half the state resets; whole
+	 * batches are cut to the GPU's size anyway) and the 464-node parser window (kernels: WMAX_LONG) */
+	const uint32_t k = o->gpu_nice_len > 128 ? 2 : 1;
+	o->span_cost = k * XZAMD_SPAN_COST_DEFAULT;
+	o->span_bits = k * XZAMD_SPAN_BITS_DEFAULT;
 }
 
 int xzamd_lzma_preset(xzamd_lzma_options *o, uint32_t preset)
