@@ -47,10 +47,13 @@ def baseline_metric():
 
 
 def span_kernel_name(opts, pmc=False):
-    """Name of the dominant kernel for these options (template args: finder source, parser)."""
+    """Name of the dominant kernel for these options (template args: finder source, parser, parser window)."""
     finder = 2 if opts.gpu_parser else 0
     sep = ", " if pmc else ","
-    return "k_span_encode_t<%d%s%s>" % (finder, sep, "true" if opts.gpu_parser else "false")
+    wm = 464 if (opts.gpu_parser and opts.gpu_nice_len > 128) else 232
+    if pmc:          # prefix as rocprofv3 prints it (the window argument follows)
+        return "k_span_encode_t<%d%s%s" % (finder, sep, "true" if opts.gpu_parser else "false")
+    return "k_span_encode_t<%d,%s,%d>" % (finder, "true" if opts.gpu_parser else "false", wm)
 
 
 def pmc_traffic(opts):

@@ -97,8 +97,9 @@ typedef struct {
 	uint32_t span_cost;  /* != 0 with span_size XZAMD_SPAN_DEFAULT / _AUTO and the optimal parser: cost-balanced spans.
 	                        The match lists give every 4 KiB an estimate of the parser's work (one unit per position it
 	                        has to visit: positions under a match of nice_len bytes or more are skipped); a Block is cut
-	                        into spans of equal estimated work >= span_cost units (more when the batch would give more
-	                        spans than the GPU holds wavefronts), each at least 64 KiB long.  0: spans of span_size bytes */
+	                        into spans of equal estimated work of about span_cost units, each at least 64 KiB long (a batch that
+	                        fills the GPU: 0.8 .. 2 x span_cost, chosen so that the rounds of the launch are full; the target
+	                        used is reported in xzamd_stats.span_cost_used).  0: spans of span_size bytes */
 	uint32_t span_bits;  /* with span_cost: a span also has to reach this estimated coded size (bits, greedy parse over
 	                        the match lists) before it ends, so that resets cannot dominate highly compressible data */
 } xzamd_lzma_options;

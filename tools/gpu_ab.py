@@ -13,7 +13,7 @@ if args and args[0].startswith("corpus="):
 n = mib << 20
 host = xz_amd.corpus_tar(n, seed=1000) if corpus == "tar" else xz_amd.corpus_text(n, seed=1000)
 t = torch.from_numpy(host).cuda()
-KNOBS = ("XZAMD_SPAN_ROUNDS", "XZAMD_PREFETCH_AFTER", "XZAMD_NO_OVERLAP", "XZAMD_SPAN_WAVES_PER_CU", "XZAMD_BATCH_MIB",
+KNOBS = ("XZAMD_PREFETCH_AFTER", "XZAMD_NO_OVERLAP", "XZAMD_SPAN_WAVES_PER_CU", "XZAMD_BATCH_MIB", "XZAMD_SA_COMPACT",
          "XZAMD_SPAN_COST", "XZAMD_SA_DEPTH")
 for cfg in args or ["default:"]:
     name, _, envs = cfg.partition(":")

@@ -1,18 +1,19 @@
 #!/usr/bin/env python3
 """Per-span running times of the span kernel (a -DXZAMD_TIMING build leaves a record in every span's literal-coder
-slice): distribution, and how it correlates with XCD / CU / start time.  usage: XZ_AMD_LIB=...timing.so tools/gpu_span_times.py [MiB] [rounds]"""
+slice): distribution, and how it correlates with XCD / CU / start time.
+usage: XZ_AMD_LIB=...timing.so tools/gpu_span_times.py [MiB] [span_cost]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 mib = int(sys.argv[1]) if len(sys.argv) > 1 else 1368
-if len(sys.argv) > 2:
-    os.environ["XZAMD_SPAN_ROUNDS"] = sys.argv[2]
 os.environ["XZAMD_NO_OVERLAP"] = "1"
 import numpy as np, torch, xz_amd
 n = mib << 20
 t = torch.from_numpy(xz_amd.corpus_text(n, seed=1000)).cuda()
 enc = xz_amd.Encoder(0)
 opts = xz_amd.preset_options(6)
+if len(sys.argv) > 2:
+    opts.span_cost = int(sys.argv[2])
 bs = xz_amd.mt_block_size(opts)
 for _ in range(2):
     enc.encode(t, opts=opts)

@@ -75,8 +75,9 @@ int xzk_find_matches(const xzamd_span_args *a, const uint32_t *sa, const uint32_
 		const uint64_t *rp8, const uint64_t *rp16, uint16_t *mlen, uint32_t *mdist, void *stream);
 /* Cost-balanced span plan of a batch from its match lists (oracle: plan_spans): est[0 .. 2 * nblocks * cpb) receives
  * the per-chunk work and bit estimates (cpb = chunks per Block), totals[0 .. nblocks] the per-Block work and, last,
- * the batch total (u64 each); then span_tab / span_cnt as described in xzamd_span_args.  target = max(cost_min,
- * ceil(batch total / slots)); totals[nblocks + 1] receives the target used. */
+ * the batch total (u64 each); then span_tab / span_cnt as described in xzamd_span_args.  The work target of a span is
+ * cost_min, or, for a batch of more than `slots` such spans, what makes the rounds of the launch full (k_span_cut);
+ * totals[nblocks + 1] receives the target used. */
 int xzk_span_plan(const xzamd_span_args *a, uint32_t nblocks, uint32_t *est, unsigned long long *totals,
 		uint32_t *span_tab, uint32_t *span_cnt, uint32_t cost_min, uint32_t bits_min, uint32_t min_len, uint32_t slots,
 		void *stream);

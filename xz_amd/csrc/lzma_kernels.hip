@@ -2573,8 +2573,21 @@ __global__ __launch_bounds__(64) void k_span_cut(xzamd_span_args a, uint32_t nbl
     const uint32_t be = min(a.n, bs + a.block_size);
     const uint32_t m = (be - bs + XZAMD_EST_CHUNK - 1) / XZAMD_EST_CHUNK;      // chunks of this Block
     const unsigned long long batch_total = totals[nblocks], total = totals[b];
-    unsigned long long T = (batch_total + slots - 1) / slots;
-    if (T < cost_min) T = cost_min;
+    // Work target of a span.  A launch runs in rounds of `slots` wavefronts, so the spans of a batch that fills the GPU
+    // are sized for FULL rounds: R = ceil(rounds at cost_min) rounds of slightly lighter spans (down to 0.8 cost_min),
+    // else one round less of heavier ones.  A batch below one round keeps cost_min.
+    unsigned long long T = cost_min;
+    {
+        const unsigned long long denom = (unsigned long long)cost_min * slots;
+        if (batch_total > denom) {
+            unsigned long long R = (batch_total + denom - 1) / denom;
+            T = (batch_total + R * slots - 1) / (R * slots);
+            if (T * 5 < (unsigned long long)cost_min * 4 && R > 1) {
+                --R;
+                T = (batch_total + R * slots - 1) / (R * slots);
+            }
+        }
+    }
     if (b == 0 && lane == 0) totals[nblocks + 1] = T;
     const unsigned long long k = total / T ? total / T : 1ull;
     const unsigned long long Tb = (total + k - 1) / k;

@@ -287,8 +287,6 @@ struct xzamd_ctx {
 	uint64_t batch_bytes;
 	uint32_t wave_slots;         /* span wavefronts resident at once (CUs x 16) */
 	uint32_t span_waves;         /* != 0: persistent span kernel with this many wavefronts */
-	uint32_t span_rounds;        /* cost-balanced spans: a batch is cut into at most wave_slots * span_rounds spans (XZAMD_SPAN_ROUNDS, default 3: the running
-	                              * time of equal-work spans still varies by +-25 %, so a launch needs a few rounds to even out) */
 	int prefetch_after;          /* XZAMD_PREFETCH_AFTER=1: enqueue the next batch's build behind the span kernel launch instead of in front of it */
 	int sha_early;               /* this batch's SHA-256 was launched on the second stream */
 	int overlap_off;             /* an event of the low-priority pipeline could not be created: no prefetch */
@@ -373,8 +371,6 @@ int xzamd_ctx_create(xzamd_ctx **out, int device)
 		c->span_waves = (pw && atoi(pw) > 0) ? (uint32_t)cus * (uint32_t)atoi(pw) : 0;
 		const char *pa = getenv("XZAMD_PREFETCH_AFTER");
 		c->prefetch_after = pa && *pa == '1';
-		const char *pr = getenv("XZAMD_SPAN_ROUNDS");
-		c->span_rounds = (pr && atoi(pr) > 0 && atoi(pr) <= 16) ? (uint32_t)atoi(pr) : 3;
 	}
 	const char *env = getenv("XZAMD_BATCH_MIB");
 	if (env && atoll(env) > 0)
@@ -833,7 +829,7 @@ int xzamd_stream_encode_device(xzamd_ctx *c,
 			if (adaptive) {
 				e = xzk_span_plan(&a, (uint32_t)nb, (uint32_t *)c->est.p, (unsigned long long *)c->totals.p,
 						(uint32_t *)c->span_tab.p, (uint32_t *)c->span_cnt.p, opt->span_cost, opt->span_bits,
-						XZAMD_SPAN_MIN_LEN, c->wave_slots * c->span_rounds, st);
+						XZAMD_SPAN_MIN_LEN, c->wave_slots, st);
 				if (e) { rc = fail(c, XZAMD_DEVICE_ERROR, "span plan launch", e); goto done; }
 				/* the host lays the Blocks out from the plan: fetched with the span sizes below */
 				e = xzk_d2h(htab, c->span_tab.p, 8ull * nspans, st);
