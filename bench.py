@@ -50,7 +50,7 @@ def span_kernel_name(opts, pmc=False):
     """Name of the dominant kernel for these options (template args: finder source, parser, parser window)."""
     finder = 2 if opts.gpu_parser else 0
     sep = ", " if pmc else ","
-    wm = 464 if (opts.gpu_parser and opts.gpu_nice_len > 128) else 232
+    wm = 360 if (opts.gpu_parser and opts.gpu_nice_len > 128) else 232
     if pmc:          # prefix as rocprofv3 prints it (the window argument follows)
         return "k_span_encode_t<%d%s%s" % (finder, sep, "true" if opts.gpu_parser else "false")
     return "k_span_encode_t<%d,%s,%d>" % (finder, "true" if opts.gpu_parser else "false", wm)
@@ -385,7 +385,7 @@ def main():
                 "device_match_finder": ((f"suffix-neighbourhood finder ({opts.gpu_sa_depth or 32}-byte-prefix suffix order, {opts.gpu_sa_window} slots per side + hash2/hash4 heads + equal 8/16 bytes)"
                                          if opts.gpu_sa_window else f"HC{opts.gpu_mf & 15} depth {opts.gpu_depth} (sort-built chains)")
                                         + f", nice {opts.gpu_nice_len}"),
-                "device_parser": ("windowed optimal parser (232-node DP, exact prices, compound edges) over per-position match lists" if opts.gpu_parser
+                "device_parser": (f"windowed optimal parser ({360 if opts.gpu_nice_len > 128 else 232}-node DP, exact prices, compound edges) over per-position match lists" if opts.gpu_parser
                                   else "lzma_lzma_optimum_fast semantics (greedy + 1-byte lazy)"),
                 "span_bytes": int(st.span_size) if st.span_size else f"cost-balanced (work target {int(st.span_cost_used)} per span, >= 64 KiB)",
                 "parallelism": f"{world} x (one wavefront per span, {int(st.spans)} spans on rank 0)",

@@ -100,8 +100,10 @@ typedef struct {
 	                        into spans of equal estimated work of about span_cost units, each at least 64 KiB long (a batch that
 	                        fills the GPU: 0.8 .. 2 x span_cost, chosen so that the rounds of the launch are full; the target
 	                        used is reported in xzamd_stats.span_cost_used).  0: spans of span_size bytes */
-	uint32_t span_bits;  /* with span_cost: a span also has to reach this estimated coded size (bits, greedy parse over
-	                        the match lists) before it ends, so that resets cannot dominate highly compressible data */
+	uint32_t span_bits;  /* with span_cost: a Block whose estimated coded size is `bits` (greedy parse over the match lists)
+	                        gets at most bits / span_bits spans: a state reset costs a few hundred bytes whatever the data,
+	                        so what bounds the number of resets is the Block's OUTPUT (highly compressible Blocks: fewer,
+	                        longer spans) */
 } xzamd_lzma_options;
 #define XZAMD_SPAN_COST_DEFAULT 131072u   /* text: 128 KiB spans */
 #define XZAMD_SPAN_BITS_DEFAULT 400000u

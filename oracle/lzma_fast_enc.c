@@ -72,7 +72,7 @@
 #ifndef WTAIL
 #define WTAIL 16u
 #endif
-#define WMAX_LONG 464u            /* nice_len > 128 (the extreme presets): 15.8 KiB per wavefront */
+#define WMAX_LONG 360u            /* nice_len > 128 (the extreme presets): 13 KiB per wavefront = 12 per CU */
 #define WMAX_CAP WMAX_LONG
 #define WTAIL_                 /* symbols ending less than WTAIL nodes before a forced window cut are re-parsed */
 #ifndef LIST_K
@@ -1260,6 +1260,7 @@ static int optimum_window(enc *e, uint32_t pos, int cached)
  * match reaches nice_len costs ORC_EST_LONG units and the walk jumps over the match (it may run past the
  * chunk end), any other position costs one unit. */
 #define ORC_EST_LONG 4u
+
 /* The same walk also makes a rough estimate of the coded size in bits (a greedy parse: at a symbol
  * boundary take the longest match when it is >= 3 bytes long, or 2 bytes at a distance < 128, for 14 bits +
  * the bit length of the distance; else a literal, 6 bits): spans of highly compressible data must not end
@@ -1311,20 +1312,24 @@ static uint32_t plan_spans(enc *e, uint32_t *chunk_cost, uint32_t *span_start, u
 		est_chunk(e, c0, c1, &cc[c], &cb[c]);
 		total += cc[c];
 	}
-	/* k spans of equal estimated work: k = floor(total / T), at least one; threshold = ceil(total / k) */
-	const uint64_t k = total / T ? total / T : 1;
+	/* k spans of equal estimated work: k = floor(total / T), but no more than the Block's estimated coded size
+	 * allows at span_bits per span (a state reset costs a few hundred bytes whatever the data, so what bounds the
+	 * number of resets is the Block's OUTPUT), at least one; threshold = ceil(total / k) */
+	uint64_t total_bits = 0;
+	for (uint32_t c = 0; c < m; ++c) total_bits += cb[c];
+	uint64_t k = total / T;
+	if (e->prm.span_bits && total_bits / e->prm.span_bits < k) k = total_bits / e->prm.span_bits;
+	if (k == 0) k = 1;
 	const uint64_t Tb = (total + k - 1) / k;
 	uint32_t ns = 0, start = 0;
-	uint64_t acc = 0, accb = 0;
+	uint64_t acc = 0;
 	if (n && span_start && ns < span_cap) span_start[0] = 0;
 	if (n) ns = 1;
 	for (uint32_t c = 0; c + 1 < m; ++c) {
 		acc += cc[c];
-		accb += cb[c];
 		const uint64_t len = (uint64_t)(c + 1 - start) * ORC_EST_CHUNK;
-		if (len >= ORC_SPAN_MAX || (acc >= Tb && accb >= e->prm.span_bits && len >= min_len)) {
+		if (len >= ORC_SPAN_MAX || (acc >= Tb && len >= min_len)) {
 			acc = 0;
-			accb = 0;
 			start = c + 1;
 			if (span_start && ns < span_cap) span_start[ns] = start * ORC_EST_CHUNK;
 			++ns;

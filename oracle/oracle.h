@@ -129,10 +129,10 @@ typedef struct {
 	uint32_t span_cost; /* != 0 (needs sa_window): cost-balanced spans instead of spans of span_size bytes.  Every
 	                       ORC_EST_CHUNK bytes get an estimate of the parser's work from a walk over the match lists
 	                       (one unit per position the parser visits); a Block of estimated work `total` is cut into
-	                       k = max(1, total / span_cost) spans: a span ends at the first chunk boundary where its
-	                       estimate reaches ceil(total / k) and it is >= span_size bytes long (span_size 0: 64 KiB) */
-	uint32_t span_bits; /* with span_cost: a span also has to reach this estimated coded size (bits, greedy parse
-	                       over the match lists) before it may end */
+	                       k = max(1, min(total / span_cost, bits / span_bits)) spans: a span ends at the first chunk
+	                       boundary where its estimate reaches ceil(total / k) and it is >= span_size bytes long (span_size 0: 64 KiB) */
+	uint32_t span_bits; /* with span_cost: a Block of estimated coded size `bits` (greedy parse over the match lists) gets
+	                       at most bits / span_bits spans: the number of state resets is bounded by the Block's OUTPUT */
 } orc_enc_params;
 #define ORC_EST_CHUNK 4096u
 #define ORC_SPAN_MAX (16u << 20)

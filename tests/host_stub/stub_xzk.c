@@ -38,7 +38,7 @@ int xzk_event_record(void *ev, void *st) { (void)ev; (void)st; return 0; }
 int xzk_event_elapsed_ms(void *a, void *b, float *ms) { (void)a; (void)b; *ms = 0.0f; return 0; }
 const char *xzk_error_string(int e) { (void)e; return "stub error"; }
 int xzk_mem_info(uint64_t *free_b, uint64_t *total_b) { *free_b = *total_b = 1ull << 34; return 0; }
-int xzk_span_occupancy(int parser, int *w) { (void)parser; *w = 16; return 0; }
+int xzk_span_occupancy(int parser, uint32_t nice_len, int *w) { (void)parser; (void)nice_len; *w = 16; return 0; }
 int xzk_sort_temp_bytes(uint32_t n, uint32_t end_bit, uint64_t *bytes) { (void)n; (void)end_bit; *bytes = 64; return 0; }
 int xzk_sa_temp_bytes(uint32_t n, uint64_t *bytes) { (void)n; *bytes = 64; return 0; }
 
@@ -66,9 +66,10 @@ int xzk_find_matches(const xzamd_span_args *a, const uint32_t *sa, const uint32_
 /* a plan with the documented shape: spans of 192 KiB (a multiple of the estimate chunk), at least min_len long */
 int xzk_span_plan(const xzamd_span_args *a, uint32_t nblocks, uint32_t *est, unsigned long long *totals,
 		uint32_t *span_tab, uint32_t *span_cnt, uint32_t cost_min, uint32_t bits_min, uint32_t min_len, uint32_t slots,
-		void *stream)
+		uint32_t *order_bufs, void *sort_tmp, uint64_t sort_tmp_bytes, uint32_t **order_out, void *stream)
 {
-	(void)est; (void)bits_min; (void)slots; (void)stream;
+	(void)est; (void)bits_min; (void)slots; (void)stream; (void)order_bufs; (void)sort_tmp; (void)sort_tmp_bytes;
+	*order_out = NULL;
 	uint32_t span = 192u << 10;
 	if (span < min_len) span = min_len;
 	for (uint32_t b = 0; b < nblocks; ++b) {
@@ -90,7 +91,8 @@ int xzk_span_plan(const xzamd_span_args *a, uint32_t nblocks, uint32_t *est, uns
 int xzk_span_encode(const xzamd_span_args *a, uint32_t nslots, uint32_t waves, uint32_t *counter, void *stream)
 {
 	(void)waves; (void)counter; (void)stream;
-	for (uint32_t s = 0; s < nslots; ++s) {
+	for (uint32_t wg = 0; wg < nslots; ++wg) {
+		const uint32_t s = a->order ? a->order[wg] : wg;
 		const uint32_t b = s / a->max_spb, k = s - b * a->max_spb;
 		if ((uint64_t)b * a->block_size >= a->n || k >= a->span_cnt[b])
 			continue;

@@ -11,10 +11,14 @@ corpus = "text"
 if args and args[0].startswith("corpus="):
     corpus = args.pop(0).split("=", 1)[1]
 n = mib << 20
-host = xz_amd.corpus_tar(n, seed=1000) if corpus == "tar" else xz_amd.corpus_text(n, seed=1000)
+if corpus == "elf":
+    import bench
+    host = bench.corpus_elf(n, 0)
+else:
+    host = xz_amd.corpus_tar(n, seed=1000) if corpus == "tar" else xz_amd.corpus_text(n, seed=1000)
 t = torch.from_numpy(host).cuda()
 KNOBS = ("XZAMD_PREFETCH_AFTER", "XZAMD_NO_OVERLAP", "XZAMD_SPAN_WAVES_PER_CU", "XZAMD_BATCH_MIB", "XZAMD_SA_COMPACT",
-         "XZAMD_SPAN_COST", "XZAMD_SA_DEPTH")
+         "XZAMD_SPAN_COST", "XZAMD_SPAN_BITS", "XZAMD_SA_DEPTH", "XZAMD_BCJ", "XZAMD_WMAX_STD", "XZAMD_NICE")
 for cfg in args or ["default:"]:
     name, _, envs = cfg.partition(":")
     for k in KNOBS:
@@ -28,7 +32,13 @@ for cfg in args or ["default:"]:
         opts.span_cost = int(os.environ["XZAMD_SPAN_COST"])
     if os.environ.get("XZAMD_SA_DEPTH"):
         opts.gpu_sa_depth = int(os.environ["XZAMD_SA_DEPTH"])
-    for it in range(2):
+    if os.environ.get("XZAMD_SPAN_BITS"):
+        opts.span_bits = int(os.environ["XZAMD_SPAN_BITS"])
+    if os.environ.get("XZAMD_BCJ"):
+        opts.bcj = xz_amd.BCJ_X86
+    if os.environ.get("XZAMD_NICE"):
+        opts.gpu_nice_len = int(os.environ["XZAMD_NICE"])
+    for it in range(int(os.environ.get("AB_REPS", "2"))):
         torch.cuda.synchronize(); t0 = time.time()
         out, _ = enc.encode(t, opts=opts)
         torch.cuda.synchronize(); dt = time.time() - t0

@@ -27,6 +27,8 @@ typedef struct {
 	const uint32_t *span_tab;
 	const uint32_t *span_cnt;
 	uint32_t max_spb;            /* span slots per Block */
+	const uint32_t *order;       /* optional: workgroup i codes span slot order[i] (longest estimated work first, so that a
+	                                launch ends with its short spans); NULL = slot i */
 	uint32_t *span_bytes;        /* out: bytes produced per span slot */
 	uint32_t *lit;               /* literal-coder probabilities: 6144 x u32 per span */
 	/* per-position match lists (parser != 0), written by xzk_find_matches: 8 x u32 per position =
@@ -80,9 +82,11 @@ int xzk_find_matches(const xzamd_span_args *a, const uint32_t *sa, const uint32_
  * totals[nblocks + 1] receives the target used. */
 int xzk_span_plan(const xzamd_span_args *a, uint32_t nblocks, uint32_t *est, unsigned long long *totals,
 		uint32_t *span_tab, uint32_t *span_cnt, uint32_t cost_min, uint32_t bits_min, uint32_t min_len, uint32_t slots,
-		void *stream);
+		uint32_t *order_bufs, void *sort_tmp, uint64_t sort_tmp_bytes, uint32_t **order_out, void *stream);
+/* order_bufs: 4 x (nblocks * max_spb) u32 of scratch; *order_out = where the launch order ends up (inside order_bufs) */
 int xzk_span_encode(const xzamd_span_args *a, uint32_t nslots, uint32_t waves, uint32_t *counter, void *stream);
-int xzk_span_occupancy(int parser, int *waves_per_cu);
+/* wavefronts of the span kernel variant for (parser, nice_len) one CU holds at once */
+int xzk_span_occupancy(int parser, uint32_t nice_len, int *waves_per_cu);
 /* x86 BCJ encoder: d_out = filtered copy of d_in, every Block filtered independently (simple/x86.c). */
 int xzk_x86_bcj(const uint8_t *d_in, uint8_t *d_out, uint32_t n, uint32_t block_size, uint32_t nblocks, void *stream);
 /* ARM64 BCJ (kind 0x0A) / delta (kind 3, dist 1..256) encoders, every Block filtered independently. */

@@ -1017,9 +1017,10 @@ __device__ __forceinline__ bool change_pair(uint32_t small_dist, uint32_t big_di
 // ------------------------------------------------------------------------------------------
 // Optimal-parser window: nodes 0..WM, a template parameter of the parser.  WMAX_STD: LDS per wave <= 10 KiB -> 16 waves
 // per CU, what every option set with nice_len <= 128 runs.  WMAX_LONG (nice_len > 128: the extreme presets): matches
-// of 233..273 bytes fit a window and the tail re-parse weighs half as much -- 15.8 KiB per wave, 10 waves per CU.
+// of 233..273 bytes fit a window and the tail re-parse weighs less -- 13 KiB per wave = 12 waves per CU, which is also
+// what 168 VGPRs per wave (3 per SIMD, a fifth of the scratch spills) allow.
 constexpr uint32_t WMAX_STD = 232;
-constexpr uint32_t WMAX_LONG = 464;
+constexpr uint32_t WMAX_LONG = 360;
 constexpr uint32_t PRICE_INF = 1u << 30;
 
 #ifdef XZAMD_TIMING
@@ -2168,7 +2169,7 @@ __device__ __forceinline__ void span_encode_one(const xzamd_span_args& a, const 
 // of equally long spans and fewer resident wavefronts can be asked for (leaving room for other streams).
 template <int FINDER, bool OPT, uint32_t WMAX = WMAX_STD>
 __global__ __launch_bounds__(64)
-__attribute__((amdgpu_waves_per_eu(OPT ? (WMAX > WMAX_STD ? 2 : XZAMD_WAVES_OPT) : XZAMD_WAVES_FAST, OPT ? XZAMD_WAVES_OPT : XZAMD_WAVES_FAST)))
+__attribute__((amdgpu_waves_per_eu(OPT ? (WMAX > WMAX_STD ? 3 : XZAMD_WAVES_OPT) : XZAMD_WAVES_FAST, OPT ? (WMAX > WMAX_STD ? 3 : XZAMD_WAVES_OPT) : XZAMD_WAVES_FAST)))
 void k_span_encode_t(xzamd_span_args a, uint32_t nspans, uint32_t* __restrict__ counter)
 {
     for (;;) {
@@ -2178,7 +2179,7 @@ void k_span_encode_t(xzamd_span_args a, uint32_t nspans, uint32_t* __restrict__ 
             s = uni(s);
         }
         if (s >= nspans) break;
-        span_encode_one<FINDER, OPT, WMAX>(a, s);
+        span_encode_one<FINDER, OPT, WMAX>(a, a.order ? a.order[s] : s);
         if (counter == nullptr) break;
         __builtin_amdgcn_s_waitcnt(0);      // this span's stores are out before the LDS pool is reused
         wave_sync();
@@ -2564,7 +2565,8 @@ __device__ __forceinline__ uint32_t wave_incl_sum(uint32_t v)
 
 __global__ __launch_bounds__(64) void k_span_cut(xzamd_span_args a, uint32_t nblocks, uint32_t cpb,
         const uint32_t* __restrict__ est, unsigned long long* __restrict__ totals, uint32_t* __restrict__ span_tab,
-        uint32_t* __restrict__ span_cnt, uint32_t cost_min, uint32_t bits_min, uint32_t min_len, uint32_t slots)
+        uint32_t* __restrict__ span_cnt, uint32_t cost_min, uint32_t bits_min, uint32_t min_len, uint32_t slots,
+        uint32_t* __restrict__ span_key)
 {
     const uint32_t lane = threadIdx.x;
     const uint32_t b = blockIdx.x;
@@ -2589,42 +2591,55 @@ __global__ __launch_bounds__(64) void k_span_cut(xzamd_span_args a, uint32_t nbl
         }
     }
     if (b == 0 && lane == 0) totals[nblocks + 1] = T;
-    const unsigned long long k = total / T ? total / T : 1ull;
-    const unsigned long long Tb = (total + k - 1) / k;
     const uint32_t* wk = est + (uint64_t)b * cpb;
     const uint32_t* bt = est + nch + (uint64_t)b * cpb;
+    // spans of this Block: total / T of equal estimated work, but no more than its estimated coded size allows at
+    // bits_min per span -- a state reset costs a few hundred bytes whatever the data, so what bounds the number of
+    // resets of a Block is its OUTPUT (highly compressible Blocks get fewer, longer spans)
+    unsigned long long total_bits = 0;
+    for (uint32_t c0 = 0; c0 < m; c0 += 64) {
+        const uint32_t c = c0 + lane;
+        total_bits += lane_of(wave_incl_sum(c < m ? bt[c] : 0u), 63);
+    }
+    unsigned long long k = total / T;
+    if (bits_min && total_bits / bits_min < k) k = total_bits / bits_min;
+    if (k == 0) k = 1;
+    const unsigned long long Tb = (total + k - 1) / k;
     uint32_t* tab = span_tab + 2ull * b * a.max_spb;
     uint32_t ns = 1, start = 0;                       // spans so far, first chunk of the open span
-    unsigned long long carry_w = 0, carry_b = 0;      // estimates of the open span in front of the window
+    unsigned long long carry_w = 0;                   // estimated work of the open span in front of the window
     if (lane == 0) tab[0] = bs;
     for (uint32_t c0 = 0; c0 < m; c0 += 64) {
         const uint32_t c = c0 + lane;
-        const uint32_t pw = wave_incl_sum(c < m ? wk[c] : 0u), pb = wave_incl_sum(c < m ? bt[c] : 0u);
-        uint32_t subw = 0, subb = 0;                  // window sums up to the last cut inside the window
+        const uint32_t pw = wave_incl_sum(c < m ? wk[c] : 0u);
+        uint32_t subw = 0;                            // window sum up to the last cut inside the window
         for (;;) {
-            const unsigned long long accw = carry_w + (pw - subw), accb = carry_b + (pb - subb);
+            const unsigned long long accw = carry_w + (pw - subw);
             const unsigned long long len = (unsigned long long)(c + 1 - start) * XZAMD_EST_CHUNK;
             const bool cut = c + 1 < m && c >= start && ns < a.max_spb
-                    && (len >= XZAMD_SPAN_MAX || (accw >= Tb && accb >= bits_min && len >= min_len));
+                    && (len >= XZAMD_SPAN_MAX || (accw >= Tb && len >= min_len));
             const uint64_t mask = __builtin_amdgcn_ballot_w64(cut);
             if (!mask) break;
             const uint32_t L = (uint32_t)__builtin_ctzll(mask);
             start = c0 + L + 1;
-            subw = lane_of(pw, L); subb = lane_of(pb, L);
-            carry_w = 0; carry_b = 0;
+            const unsigned long long closed = carry_w + (lane_of(pw, L) - subw);      // estimated work of the span just closed
+            subw = lane_of(pw, L);
+            carry_w = 0;
             if (lane == 0) {
                 const uint32_t p = bs + start * XZAMD_EST_CHUNK;
                 tab[2 * ns - 1] = p;                  // end of the span just closed
                 tab[2 * ns] = p;
+                // launch-order key: heaviest first (ascending sort of ~work); unused slots keep 0xFFFFFFFF = last
+                span_key[(uint64_t)b * a.max_spb + ns - 1] = ~(uint32_t)min(closed ? closed : 1ull, 0xFFFFFFFEull);
             }
             ++ns;
         }
         carry_w += lane_of(pw, 63) - subw;
-        carry_b += lane_of(pb, 63) - subb;
     }
     if (lane == 0) {
         tab[2 * ns - 1] = be;
         span_cnt[b] = ns;
+        span_key[(uint64_t)b * a.max_spb + ns - 1] = ~(uint32_t)min(carry_w ? carry_w : 1ull, 0xFFFFFFFEull);
     }
 }
 
@@ -3550,18 +3565,38 @@ int xzk_find_matches(const xzamd_span_args* a, const uint32_t* sa, const uint32_
 
 int xzk_span_plan(const xzamd_span_args* a, uint32_t nblocks, uint32_t* est, unsigned long long* totals,
         uint32_t* span_tab, uint32_t* span_cnt, uint32_t cost_min, uint32_t bits_min, uint32_t min_len, uint32_t slots,
-        void* stream_)
+        uint32_t* order_bufs, void* sort_tmp, uint64_t sort_tmp_bytes, uint32_t** order_out, void* stream_)
 {
     hipStream_t st = (hipStream_t)stream_;
+    if (order_out) *order_out = nullptr;
     if (nblocks == 0 || a->n == 0) return 0;
-    if (!a->mtop || a->max_spb == 0 || slots == 0 || cost_min == 0) return (int)hipErrorInvalidValue;
+    if (!a->mtop || a->max_spb == 0 || slots == 0 || cost_min == 0 || !order_bufs || !order_out) return (int)hipErrorInvalidValue;
     const uint32_t cpb = (a->block_size + XZAMD_EST_CHUNK - 1) / XZAMD_EST_CHUNK;
+    const uint32_t nslots = nblocks * a->max_spb;
+    uint32_t* key_a = order_bufs;
+    uint32_t* key_b = order_bufs + nslots;
+    uint32_t* val_a = order_bufs + 2ull * nslots;
+    uint32_t* val_b = order_bufs + 3ull * nslots;
     hipError_t e = hipMemsetAsync(totals, 0, (size_t)(nblocks + 2) * sizeof(unsigned long long), st);
+    if (e == hipSuccess) e = hipMemsetAsync(key_a, 0xFF, (size_t)nslots * 4, st);
     if (e != hipSuccess) return (int)e;
     const uint64_t nch = (uint64_t)nblocks * cpb;
     hipLaunchKernelGGL(k_span_est, dim3((uint32_t)((nch + 255) / 256)), dim3(256), 0, st, *a, nblocks, cpb, est, totals);
     hipLaunchKernelGGL(k_span_cut, dim3(nblocks), dim3(64), 0, st, *a, nblocks, cpb, est, totals, span_tab, span_cnt,
-            cost_min, bits_min, min_len, slots);
+            cost_min, bits_min, min_len, slots, key_a);
+    // launch order: span slots by estimated work, heaviest first (a launch then ends with its short spans instead of
+    // waiting for a heavy one that happened to start late); the order does not change a byte of the output
+    hipLaunchKernelGGL(k_iota, dim3(grid_for(nslots, 256, 4096)), dim3(256), 0, st, val_a, nslots);
+    rocprim::double_buffer<uint32_t> kb(key_a, key_b);
+    rocprim::double_buffer<uint32_t> vb(val_a, val_b);
+    size_t need = 0;
+    e = rocprim::radix_sort_pairs(nullptr, need, kb, vb, (size_t)nslots, 0u, 32u, st);
+    if (e != hipSuccess) return (int)e;
+    if (need > sort_tmp_bytes) return (int)hipErrorOutOfMemory;
+    size_t tb = (size_t)sort_tmp_bytes;
+    e = rocprim::radix_sort_pairs(sort_tmp, tb, kb, vb, (size_t)nslots, 0u, 32u, st);
+    if (e != hipSuccess) return (int)e;
+    *order_out = vb.current();
     return (int)hipGetLastError();
 }
 
@@ -3577,7 +3612,8 @@ int xzk_span_encode(const xzamd_span_args* a, uint32_t nspans, uint32_t waves, u
     uint32_t* cnt = persist ? counter : nullptr;
     if (a->parser) {
         if ((!a->mlen && !a->list_packed) || !a->mdist) return (int)hipErrorInvalidValue;
-        if (a->nice_len > 128)
+        const char* const wenv = getenv("XZAMD_WMAX_STD");          // measurement knob: 1 = the 232-node window for every nice_len (not the oracle's bytes)
+        if (a->nice_len > 128 && !(wenv && *wenv == '1'))
             hipLaunchKernelGGL((k_span_encode_t<2, true, WMAX_LONG>), dim3(grid), dim3(64), 0, st, *a, nspans, cnt);
         else
             hipLaunchKernelGGL((k_span_encode_t<2, true>), dim3(grid), dim3(64), 0, st, *a, nspans, cnt);
@@ -3589,12 +3625,12 @@ int xzk_span_encode(const xzamd_span_args* a, uint32_t nspans, uint32_t waves, u
 }
 
 // wavefronts of the span kernel one CU holds at once (what the launch geometry of the span plan is sized for)
-int xzk_span_occupancy(int parser, int* waves_per_cu)
+int xzk_span_occupancy(int parser, uint32_t nice_len, int* waves_per_cu)
 {
     int nb = 0;
-    hipError_t e = parser
-            ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_span_encode_t<2, true>, 64, 0)
-            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_span_encode_t<0, false>, 64, 0);
+    hipError_t e = !parser ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_span_encode_t<0, false>, 64, 0)
+            : nice_len > 128 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_span_encode_t<2, true, WMAX_LONG>, 64, 0)
+            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_span_encode_t<2, true>, 64, 0);
     *waves_per_cu = nb;
     return (int)e;
 }

@@ -208,11 +208,10 @@ void xzamd_sn_defaults(xzamd_lzma_options *o)
 	o->gpu_sa_window = XZAMD_SA_WINDOW_MAX;
 	o->gpu_parser = 1;
 	o->gpu_sa_depth = o->gpu_nice_len <= 32 ? 32 : o->gpu_nice_len <= 64 ? 64 : 256;
-	/* nice_len > 128 (the extreme presets) asks for ratio first: spans twice as long (half the state resets; whole
-	 * batches are cut to the GPU's size anyway) and the 464-node parser window (kernels: WMAX_LONG) */
-	const uint32_t k = o->gpu_nice_len > 128 ? 2 : 1;
-	o->span_cost = k * XZAMD_SPAN_COST_DEFAULT;
-	o->span_bits = k * XZAMD_SPAN_BITS_DEFAULT;
+	/* nice_len > 128 (the extreme presets) asks for ratio first: twice the output per span on compressible Blocks,
+	 * and the longer parser window (kernels: WMAX_LONG) */
+	o->span_cost = XZAMD_SPAN_COST_DEFAULT;
+	o->span_bits = (o->gpu_nice_len > 128 ? 2 : 1) * XZAMD_SPAN_BITS_DEFAULT;
 }
 
 int xzamd_lzma_preset(xzamd_lzma_options *o, uint32_t preset)
@@ -285,7 +284,8 @@ struct xzamd_ctx {
 	void *lo_stream;             /* lowest priority: the next batch's chain build runs here, under the span kernel */
 	void *ev_lo[2][4];           /* per list buffer: find done (hi), chains begin / end (lo), prefetched find done (lo) */
 	uint64_t batch_bytes;
-	uint32_t wave_slots;         /* span wavefronts resident at once (CUs x 16) */
+	uint32_t wave_slots;         /* span wavefronts resident at once (CUs x occupancy of the standard span kernel) */
+	uint32_t cus;
 	uint32_t span_waves;         /* != 0: persistent span kernel with this many wavefronts */
 	int prefetch_after;          /* XZAMD_PREFETCH_AFTER=1: enqueue the next batch's build behind the span kernel launch instead of in front of it */
 	int sha_early;               /* this batch's SHA-256 was launched on the second stream */
@@ -296,7 +296,7 @@ struct xzamd_ctx {
 	/* device buffers */
 	dbuf keys_a, keys_b, vals_a, vals_b, rank, sorted_pos, prev2, prev3, prev4, prev8, prev16, key64_a, key64_b, sa, sa_rank, sort_tmp;
 	dbuf scratch, span_bytes, strip_crc, block_crc, segs, lits, trace, errw, litp, mlen, mdist, mlen2, mdist2, bcj;
-	dbuf est, totals, span_tab, span_cnt, mtop, mtop2;      /* span plan (kernels_api.h) */
+	dbuf est, totals, span_tab, span_cnt, mtop, mtop2, order;      /* span plan (kernels_api.h) */
 	/* pinned host buffers */
 	dbuf h_span_bytes, h_block_crc, h_segs, h_lits, h_span_tab, h_span_cnt;
 	void *ev[10];
@@ -363,7 +363,8 @@ int xzamd_ctx_create(xzamd_ctx **out, int device)
 		int cus = 0;
 		if (xzk_cu_count(device, &cus) || cus <= 0) cus = 256;
 		int occ = 0;
-		if (xzk_span_occupancy(1, &occ) || occ <= 0 || occ > 32) occ = 16;     /* the span kernels are built for 4 waves per SIMD */
+		if (xzk_span_occupancy(1, 64, &occ) || occ <= 0 || occ > 32) occ = 16;     /* the span kernels are built for 4 waves per SIMD */
+		c->cus = (uint32_t)cus;
 		c->wave_slots = (uint32_t)cus * (uint32_t)occ;
 		/* XZAMD_SPAN_WAVES_PER_CU = k: persistent span kernel with k wavefronts per CU (k < 16 leaves
 		 * register space for the low-priority stream's kernels); 0 / unset: one wavefront per span */
@@ -388,7 +389,7 @@ void xzamd_ctx_destroy(xzamd_ctx *c)
 		&c->prev2, &c->prev3, &c->prev4, &c->prev8, &c->prev16, &c->key64_a, &c->key64_b, &c->sa, &c->sa_rank, &c->sort_tmp,
 		&c->scratch, &c->span_bytes, &c->strip_crc,
 		&c->block_crc, &c->segs, &c->lits, &c->trace, &c->errw, &c->litp, &c->mlen, &c->mdist, &c->mlen2, &c->mdist2, &c->bcj,
-		&c->est, &c->totals, &c->span_tab, &c->span_cnt, &c->mtop, &c->mtop2 };
+		&c->est, &c->totals, &c->span_tab, &c->span_cnt, &c->mtop, &c->mtop2, &c->order };
 	for (size_t i = 0; i < sizeof(d) / sizeof(d[0]); ++i)
 		if (d[i]->p) xzk_free(d[i]->p);
 	dbuf *h[] = { &c->h_span_bytes, &c->h_block_crc, &c->h_segs, &c->h_lits, &c->h_span_tab, &c->h_span_cnt };
@@ -718,6 +719,7 @@ int xzamd_stream_encode_device(xzamd_ctx *c,
 		if (adaptive) {
 			GROW(est, 8ull * nb * cpb, 0);
 			GROW(totals, 8ull * (nb + 2), 0);
+			GROW(order, 16ull * nspans, 0);
 		}
 		GROW(strip_crc, 8ull * spb_crc * nb, 0);
 		GROW(block_crc, 32ull * nb, 0);
@@ -827,10 +829,17 @@ int xzamd_stream_encode_device(xzamd_ctx *c,
 			uint32_t *const htab = (uint32_t *)c->h_span_tab.p, *const hcnt = (uint32_t *)c->h_span_cnt.p;
 			xzk_event_record(c->ev[7], st);
 			if (adaptive) {
+				/* the rounds of the launch are those of the kernel variant that will run (464-node windows: 10 per CU) */
+				int occ = 0;
+				uint32_t *launch_order = NULL;
+				const uint32_t plan_slots = (xzk_span_occupancy(1, opt->gpu_nice_len, &occ) || occ <= 0 || occ > 32)
+						? c->wave_slots : c->cus * (uint32_t)occ;
+				c->stats.wave_slots = plan_slots;
 				e = xzk_span_plan(&a, (uint32_t)nb, (uint32_t *)c->est.p, (unsigned long long *)c->totals.p,
 						(uint32_t *)c->span_tab.p, (uint32_t *)c->span_cnt.p, opt->span_cost, opt->span_bits,
-						XZAMD_SPAN_MIN_LEN, c->wave_slots, st);
+						XZAMD_SPAN_MIN_LEN, plan_slots, (uint32_t *)c->order.p, c->sort_tmp.p, c->sort_tmp.cap, &launch_order, st);
 				if (e) { rc = fail(c, XZAMD_DEVICE_ERROR, "span plan launch", e); goto done; }
+				a.order = launch_order;
 				/* the host lays the Blocks out from the plan: fetched with the span sizes below */
 				e = xzk_d2h(htab, c->span_tab.p, 8ull * nspans, st);
 				if (!e) e = xzk_d2h(hcnt, c->span_cnt.p, 4ull * nb, st);
