@@ -152,6 +152,29 @@ int main(int argc, char **argv)
 		pos = 5;
 		CHECK(lzma_easy_buffer_encode(6, LZMA_CHECK_CRC64, NULL, in, 600000, out, &pos, 100) == LZMA_BUF_ERROR && pos == 5);
 	}
+	/* 7. a device failure in the middle of a Stream (XZAMD_TEST_FAIL_JOB: the job with that sequence number fails):
+	 * by default the Stream fails and the error latches (common.c:368-372); with XZAMD_STORED_ON_DEVICE_ERROR=1 the
+	 * job's Blocks are stored and the Stream stays valid */
+	{
+		setenv("XZAMD_BATCH_MIB", "1", 1);
+		setenv("XZAMD_TEST_FAIL_JOB", "1", 1);
+		memset(&mt, 0, sizeof(mt));
+		mt.threads = 1; mt.preset = 1; mt.check = LZMA_CHECK_CRC64; mt.block_size = 256u << 10;
+		lzma_stream s = LZMA_STREAM_INIT;
+		CHECK(lzma_stream_encoder_mt(&s, &mt) == LZMA_OK);
+		s.next_in = in; s.avail_in = n2; s.next_out = out; s.avail_out = n1;
+		lzma_ret r;
+		do r = lzma_code(&s, LZMA_FINISH); while (r == LZMA_OK);
+		CHECK(r == LZMA_PROG_ERROR);
+		CHECK(lzma_code(&s, LZMA_FINISH) == LZMA_PROG_ERROR);
+		lzma_end(&s);
+		setenv("XZAMD_STORED_ON_DEVICE_ERROR", "1", 1);
+		w = stream_encode(&mt, in, n2, 1u << 20, 1u << 20, 0, LZMA_RUN, out, n1 + (n1 >> 2) + (1u << 20));
+		save(dir, "case7.in", in, n2);
+		save(dir, "case7.xz", out, w);
+		unsetenv("XZAMD_STORED_ON_DEVICE_ERROR");
+		unsetenv("XZAMD_TEST_FAIL_JOB");
+	}
 	xzamd_release_parked();
 	free(in);
 	free(out);

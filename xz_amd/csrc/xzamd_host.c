@@ -198,6 +198,77 @@ uint64_t xzamd_stream_buffer_bound(uint64_t in_size, uint64_t block_size)
 	return (tot + 15) & ~15ull;
 }
 
+/* Stored Blocks made on the host (block_buffer_encoder.c:88-162 block_encode_uncompressed: uncompressed LZMA2 chunks
+ * of 64 KiB, filter chain reduced to LZMA2), laid out like the device path's XZAMD_F_BLOCKS_ONLY output.  Not an
+ * encoder: the error path of the lzma_* front end for a device failure in the middle of a Stream (SURVEY.md section
+ * 5: "uncompressed-chunk fallback keeps output valid"), taken only when the client asked for it
+ * (XZAMD_STORED_ON_DEVICE_ERROR=1; the default is LZMA_PROG_ERROR).  Checks none / CRC32 / CRC64. */
+static uint64_t crc64_buf(const uint8_t *p, uint64_t n)
+{
+	static uint64_t t[256];
+	static int ready;
+	if (!ready) {
+		for (uint32_t i = 0; i < 256; ++i) {
+			uint64_t r = i;
+			for (int k = 0; k < 8; ++k) r = (r >> 1) ^ ((r & 1) ? 0xC96C5795D7870F42ull : 0);
+			t[i] = r;
+		}
+		__atomic_store_n(&ready, 1, __ATOMIC_RELEASE);      /* racing initialisers write identical tables */
+	}
+	uint64_t c = ~0ull;
+	for (uint64_t i = 0; i < n; ++i) c = t[(c ^ p[i]) & 0xFF] ^ (c >> 8);
+	return ~c;
+}
+
+int xzamd_stored_blocks_host_(const uint8_t *in, uint64_t n, uint64_t block_size, int check,
+		uint8_t *out, uint64_t out_cap, uint64_t *out_size, xzamd_block_info *binfo, uint64_t binfo_cap, uint64_t *nblocks)
+{
+	const uint32_t cbytes = check_bytes(check);
+	if (block_size == 0 || (check != XZAMD_CHECK_NONE && check != XZAMD_CHECK_CRC32 && check != XZAMD_CHECK_CRC64))
+		return XZAMD_OPTIONS_ERROR;
+	uint64_t opos = 0, nb = 0;
+	for (uint64_t bs = 0; bs < n; bs += block_size, ++nb) {
+		const uint64_t usize = n - bs < block_size ? n - bs : block_size;
+		const uint64_t csz = usize + ((usize + 65535) / 65536) * 3 + 1;
+		const uint32_t hs = block_header_size(csz, usize, 0);
+		const uint64_t pad = (4 - (csz & 3)) & 3;
+		if (opos + hs + csz + pad + cbytes > out_cap)
+			return XZAMD_BUF_ERROR;
+		const uint64_t bstart = opos;
+		block_header_put(out + opos, hs, csz, usize, 0x00, 0);
+		opos += hs;
+		uint8_t ctl = 0x01;
+		for (uint64_t ip = 0; ip < usize; ip += 65536) {
+			const uint64_t cs = usize - ip < 65536 ? usize - ip : 65536;
+			out[opos++] = ctl;
+			out[opos++] = (uint8_t)((cs - 1) >> 8);
+			out[opos++] = (uint8_t)(cs - 1);
+			memcpy(out + opos, in + bs + ip, cs);
+			opos += cs;
+			ctl = 0x02;
+		}
+		out[opos++] = 0x00;
+		for (uint64_t i = 0; i < pad; ++i) out[opos++] = 0;
+		if (check == XZAMD_CHECK_CRC64) {
+			const uint64_t v = crc64_buf(in + bs, usize);
+			le32(out + opos, (uint32_t)v);
+			le32(out + opos + 4, (uint32_t)(v >> 32));
+		} else if (check == XZAMD_CHECK_CRC32) {
+			le32(out + opos, crc32_buf(in + bs, usize));
+		}
+		opos += cbytes;
+		if (binfo && nb < binfo_cap) {
+			binfo[nb].unpadded_size = hs + csz + cbytes;
+			binfo[nb].uncompressed_size = usize;
+			binfo[nb].out_offset = bstart;
+			binfo[nb].total_size = opos - bstart;
+		}
+	}
+	*out_size = opos;
+	if (nblocks) *nblocks = nb;
+	return XZAMD_OK;
+}
+
 /* ------------------------------------------------------------------ */
 /* presets                                                              */
 /* ------------------------------------------------------------------ */

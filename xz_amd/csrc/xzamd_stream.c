@@ -31,6 +31,7 @@
 #include "../../include/xz_amd.h"
 #include "../../include/xz_amd_lzma.h"
 #include "kernels_api.h"
+#include "xzamd_internal.h"
 
 #include <pthread.h>
 #include <stdint.h>
@@ -293,16 +294,33 @@ static lzma_ret run_job(lzma_internal *in, devslot *d, job *j)
 	}
 	lzma_ret r = grow_pinned(&j->out, &j->out_cap, 0, bound);
 	if (r != LZMA_OK) return r;
-	if (xzk_h2d(d->d_in, j->stage, n, NULL) || xzk_sync(NULL))
-		return LZMA_PROG_ERROR;
 	uint64_t out_size = 0, nblocks = 0;
-	int rc = xzamd_stream_encode_device(d->ctx, d->d_in, n, in->block_size, &j->opt, in->check,
-			XZAMD_F_BLOCKS_ONLY, d->d_out, d->d_out_cap, &out_size, j->binfo, j->binfo_cap,
-			&nblocks, NULL);
+	int rc = XZAMD_DEVICE_ERROR;
+	{
+		/* XZAMD_TEST_FAIL_JOB=k (tests): the k-th job behaves as if the device had failed */
+		const char *tf = getenv("XZAMD_TEST_FAIL_JOB");
+		const int injected = tf && *tf && (uint64_t)atoll(tf) == j->seq;
+		if (!injected && !(xzk_h2d(d->d_in, j->stage, n, NULL) || xzk_sync(NULL))) {
+			rc = xzamd_stream_encode_device(d->ctx, d->d_in, n, in->block_size, &j->opt, in->check,
+					XZAMD_F_BLOCKS_ONLY, d->d_out, d->d_out_cap, &out_size, j->binfo, j->binfo_cap,
+					&nblocks, NULL);
+			if (rc == XZAMD_OK && (xzk_d2h(j->out, d->d_out, out_size, NULL) || xzk_sync(NULL)))
+				rc = XZAMD_DEVICE_ERROR;
+		}
+	}
+	if (rc == XZAMD_DEVICE_ERROR || rc == XZAMD_PROG_ERROR) {
+		/* A device failure in the middle of a Stream.  Default: the Stream fails (LZMA_PROG_ERROR, latched).  With
+		 * XZAMD_STORED_ON_DEVICE_ERROR=1 the job's Blocks are stored instead (the reference's own way out when a
+		 * Block cannot be coded, block_buffer_encoder.c:88-162), so what the client has written so far stays a
+		 * valid .xz Stream -- no encoding happens on the host. */
+		const char *sf = getenv("XZAMD_STORED_ON_DEVICE_ERROR");
+		if (sf && *sf == '1'
+				&& xzamd_stored_blocks_host_(j->stage, n, in->block_size, in->check, j->out, j->out_cap, &out_size,
+						j->binfo, j->binfo_cap, &nblocks) == XZAMD_OK)
+			rc = XZAMD_OK;
+	}
 	if (rc != XZAMD_OK)
 		return map_rc(rc);
-	if (xzk_d2h(j->out, d->d_out, out_size, NULL) || xzk_sync(NULL))
-		return LZMA_PROG_ERROR;
 	j->out_len = out_size;
 	j->out_pos = 0;
 	j->nblocks = nblocks;
