@@ -900,7 +900,7 @@ int xzamd_stream_encode_device(xzamd_ctx *c,
 			uint32_t *const htab = (uint32_t *)c->h_span_tab.p, *const hcnt = (uint32_t *)c->h_span_cnt.p;
 			xzk_event_record(c->ev[7], st);
 			if (adaptive) {
-				/* the rounds of the launch are those of the kernel variant that will run (464-node windows: 10 per CU) */
+				/* the rounds of the launch are those of the kernel variant that will run (360-node windows: 12 waves per CU) */
 				int occ = 0;
 				uint32_t *launch_order = NULL;
 				const uint32_t plan_slots = (xzk_span_occupancy(1, opt->gpu_nice_len, &occ) || occ <= 0 || occ > 32)
