@@ -51,8 +51,8 @@ def span_kernel_name(opts, pmc=False):
     finder = 2 if opts.gpu_parser else 0
     sep = ", " if pmc else ","
     wm = 360 if (opts.gpu_parser and opts.gpu_nice_len > 128) else 232
-    if pmc:          # prefix as rocprofv3 prints it (the window argument follows)
-        return "k_span_encode_t<%d%s%s" % (finder, sep, "true" if opts.gpu_parser else "false")
+    if pmc:          # as rocprofv3 prints it
+        return "k_span_encode_t<%d%s%s%s%du>" % (finder, sep, "true" if opts.gpu_parser else "false", sep, wm)
     return "k_span_encode_t<%d,%s,%d>" % (finder, "true" if opts.gpu_parser else "false", wm)
 
 

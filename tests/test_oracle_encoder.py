@@ -206,3 +206,27 @@ def test_span_plan_properties():
     _, _, starts2 = o.orc_span_plan(data, prm2)
     assert len(starts2) < len(starts)
     assert int(work.sum()) >= (len(data) - (3 << 20)) // 2
+
+
+def test_tar_corpus_is_a_deterministic_ustar_stream(tmp_path):
+    """xzamd_corpus_tar (BASELINE config C4's input): the same bytes every time, a stream `tar` itself accepts, cycled
+    with a perturbation once the roots are exhausted (so that cycles are not identical)."""
+    import subprocess
+    import xz_amd
+    root = tmp_path / "tree"
+    (root / "b").mkdir(parents=True)
+    (root / "a.txt").write_bytes(b"alpha\n" * 1000)
+    (root / "b" / "c.h").write_bytes(b"#define X 1\n" * 700)
+    (root / "b" / ("long_name_" * 12 + ".py")).write_bytes(b"print('x')\n" * 500)
+    n = 200000
+    a = xz_amd.corpus_tar(n, str(root), seed=7).tobytes()
+    assert a == xz_amd.corpus_tar(n, str(root), seed=7).tobytes()
+    first_cycle = 512 * 3 + 6144 + 8704 + 5632          # three headers + the bodies padded to 512
+    assert a[:first_cycle] == xz_amd.corpus_tar(first_cycle, str(root), seed=8).tobytes()     # the first cycle is unperturbed
+    assert a[first_cycle:2 * first_cycle] != a[:first_cycle]                                  # later cycles differ
+    t = tmp_path / "c.tar"
+    t.write_bytes(a[:first_cycle] + b"\0" * 1024)
+    names = subprocess.run(["tar", "tf", str(t)], capture_output=True, text=True)
+    assert names.returncode == 0 and len(names.stdout.split()) == 3, (names.stdout, names.stderr)
+    with pytest.raises(RuntimeError):
+        xz_amd.corpus_tar(1000, str(tmp_path / "missing"))
