@@ -776,6 +776,24 @@ static lzma_ret stream_code(lzma_internal *in, const uint8_t *inb, size_t *in_po
 						break;                   /* every job is with a worker or waits to be drained */
 				}
 				job *j = &in->jobs[in->fill];
+				/* Size of this job.  With LZMA_RUN the end of the input is unknown: full jobs.  With FINISH / FULL_FLUSH /
+				 * FULL_BARRIER the caller has shown everything that ends this unit (the same avail_in is repeated until it
+				 * is done, common.c:253-281): the rest is dealt in EVEN jobs, so that the last one is not a sliver that
+				 * cannot fill the GPU (4 GiB at 24 MiB Blocks: 35+34+34+34+34 Blocks instead of 42+42+42+42+3). */
+				uint64_t job_max = in->stage_max;
+				if (action != LZMA_RUN) {
+					const uint64_t rem = (in_size - *in_pos) + j->stage_len;
+					const uint64_t nbr = (rem + in->block_size - 1) / in->block_size;
+					const uint64_t maxb = in->stage_max / in->block_size;
+					if (nbr > maxb && maxb > 0) {
+						const uint64_t nj = (nbr + maxb - 1) / maxb;
+						job_max = ((nbr + nj - 1) / nj) * in->block_size;
+					}
+				}
+				if (j->stage_len >= job_max) {          /* (a job filled under LZMA_RUN beyond what FINISH would deal) */
+					queue_fill_job(in);
+					continue;
+				}
 				if (j->stage_len == j->stage_cap) {
 					/* second growth step goes straight to the full batch: each step is a pinned allocation + copy */
 					uint64_t nc = j->stage_cap ? in->stage_max : in->block_size;
@@ -784,13 +802,13 @@ static lzma_ret stream_code(lzma_internal *in, const uint8_t *inb, size_t *in_po
 					lzma_ret r = grow_pinned(&j->stage, &j->stage_cap, j->stage_len, nc);
 					if (r != LZMA_OK) return r;
 				}
-				uint64_t room = (j->stage_cap < in->stage_max ? j->stage_cap : in->stage_max) - j->stage_len;
+				uint64_t room = (j->stage_cap < job_max ? j->stage_cap : job_max) - j->stage_len;
 				uint64_t take = in_size - *in_pos;
 				if (take > room) take = room;
 				memcpy(j->stage + j->stage_len, inb + *in_pos, take);
 				j->stage_len += take;
 				*in_pos += take;
-				if (j->stage_len == in->stage_max)
+				if (j->stage_len == job_max)
 					queue_fill_job(in);
 			}
 			const int input_done = *in_pos == in_size;
