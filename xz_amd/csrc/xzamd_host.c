@@ -203,20 +203,22 @@ uint64_t xzamd_stream_buffer_bound(uint64_t in_size, uint64_t block_size)
  * encoder: the error path of the lzma_* front end for a device failure in the middle of a Stream (SURVEY.md section
  * 5: "uncompressed-chunk fallback keeps output valid"), taken only when the client asked for it
  * (XZAMD_STORED_ON_DEVICE_ERROR=1; the default is LZMA_PROG_ERROR).  Checks none / CRC32 / CRC64. */
+static uint64_t crc64_tab[256];
+static pthread_once_t crc64_once = PTHREAD_ONCE_INIT;
+static void crc64_init(void)
+{
+	for (uint32_t i = 0; i < 256; ++i) {
+		uint64_t r = i;
+		for (int k = 0; k < 8; ++k) r = (r >> 1) ^ ((r & 1) ? 0xC96C5795D7870F42ull : 0);
+		crc64_tab[i] = r;
+	}
+}
+
 static uint64_t crc64_buf(const uint8_t *p, uint64_t n)
 {
-	static uint64_t t[256];
-	static int ready;
-	if (!ready) {
-		for (uint32_t i = 0; i < 256; ++i) {
-			uint64_t r = i;
-			for (int k = 0; k < 8; ++k) r = (r >> 1) ^ ((r & 1) ? 0xC96C5795D7870F42ull : 0);
-			t[i] = r;
-		}
-		__atomic_store_n(&ready, 1, __ATOMIC_RELEASE);      /* racing initialisers write identical tables */
-	}
+	pthread_once(&crc64_once, crc64_init);
 	uint64_t c = ~0ull;
-	for (uint64_t i = 0; i < n; ++i) c = t[(c ^ p[i]) & 0xFF] ^ (c >> 8);
+	for (uint64_t i = 0; i < n; ++i) c = crc64_tab[(c ^ p[i]) & 0xFF] ^ (c >> 8);
 	return ~c;
 }
 
@@ -800,8 +802,9 @@ int xzamd_stream_encode_device(xzamd_ctx *c,
 			/* per-position match lists: 8 x u32 (7 entries + trailer), + 8 x u16 lengths when not packed */
 			if (!list_packed) GROW(mlen, 16ull * n, 0);
 			GROW(mdist, 32ull * n, 0);
-			if (opt->gpu_sa_window) GROW(mtop, 2ull * n, 0);
-			if (overlap && opt->gpu_sa_window) GROW(mtop2, 2ull * n, 0);
+			/* + 32: k_span_est reads the summaries eight at a time (16 bytes) and may look past the last position */
+			if (opt->gpu_sa_window) GROW(mtop, 2ull * n + 32, 0);
+			if (overlap && opt->gpu_sa_window) GROW(mtop2, 2ull * n + 32, 0);
 			if (overlap) {
 				/* second list buffer: the next batch's finder runs underneath this batch's span kernel */
 				if (!list_packed) GROW(mlen2, 16ull * n, 0);
