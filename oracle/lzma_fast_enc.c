@@ -160,6 +160,11 @@ typedef struct {
 	uint32_t cnt_len, cnt_match, cnt_align;
 	int tables_valid;
 	orc_trace *trace;
+	/* two-phase mode: the recorded parse (valid at symbol starts) */
+	uint16_t *sy_len;           /* 0 = literal, else the length of the match / rep (1 = short rep) */
+	uint32_t *sy_dist;          /* zero-based distance; literal: byte | previous byte << 8 | match byte << 16 |
+	                             * (parser state >= 7) << 24 -- what the device's coder reads instead of the input */
+	int rc_off;                 /* phase 1: adapt the model, code nothing */
 } enc;
 
 static const uint32_t *crc_table0(void)
@@ -558,6 +563,11 @@ static void rc_shift_low(enc *e)
 
 static inline void rc_bit(enc *e, uint16_t *prob, uint32_t bit)
 {
+	if (e->rc_off) {            /* phase 1 of the two-phase mode: the price model adapts, nothing is coded */
+		uint32_t p = *prob;
+		*prob = (uint16_t)(bit ? p - (p >> 5) : p + ((2048 - p) >> 5));
+		return;
+	}
 	if (e->range < (1u << 24)) {
 		rc_shift_low(e);
 		e->range <<= 8;
@@ -598,6 +608,7 @@ static void rc_tree_rev(enc *e, uint16_t *probs, uint32_t nbits, uint32_t sym)
 
 static void rc_direct(enc *e, uint32_t value, uint32_t nbits)
 {
+	if (e->rc_off) return;
 	do {
 		if (e->range < (1u << 24)) {
 			rc_shift_low(e);
@@ -1298,45 +1309,66 @@ static void est_chunk(enc *e, uint32_t c0, uint32_t c1, uint32_t *work, uint32_t
 	*bits = b;
 }
 
-static uint32_t plan_spans(enc *e, uint32_t *chunk_cost, uint32_t *span_start, uint32_t span_cap)
+static uint32_t plan_spans_ex(enc *e, uint32_t *chunk_cost, uint32_t *span_start, uint32_t span_cap,
+		uint32_t *enc_start, uint32_t enc_cap, uint32_t *n_enc)
 {
 	const uint32_t n = e->n;
 	const uint32_t m = (n + ORC_EST_CHUNK - 1) / ORC_EST_CHUNK;
 	const uint32_t T = e->prm.span_cost;
 	const uint32_t min_len = e->prm.span_size ? e->prm.span_size : 65536u;
+	const int two = e->prm.enc_bits != 0;
+	/* two-phase: the first ORC_SEED_LEN bytes are the seed piece, the plan covers the rest */
+	const uint32_t seed_chunks = two && n > ORC_SEED_LEN ? ORC_SEED_LEN / ORC_EST_CHUNK : 0;
 	uint32_t *cc = chunk_cost ? chunk_cost : (uint32_t *)malloc((size_t)(m + 1) * 8);
 	uint32_t *cb = cc + m;      /* chunk_cost: m work estimates, then m bit estimates */
-	uint64_t total = 0;
+	uint64_t total = 0, total_bits = 0, all_bits = 0;
 	for (uint32_t c = 0; c < m; ++c) {
 		const uint32_t c0 = c * ORC_EST_CHUNK, c1 = n - c0 < ORC_EST_CHUNK ? n : c0 + ORC_EST_CHUNK;
 		est_chunk(e, c0, c1, &cc[c], &cb[c]);
-		total += cc[c];
+		all_bits += cb[c];
+		if (c >= seed_chunks) { total += cc[c]; total_bits += cb[c]; }
 	}
 	/* k spans of equal estimated work: k = floor(total / T), but no more than the Block's estimated coded size
-	 * allows at span_bits per span (a state reset costs a few hundred bytes whatever the data, so what bounds the
-	 * number of resets is the Block's OUTPUT), at least one; threshold = ceil(total / k) */
-	uint64_t total_bits = 0;
-	for (uint32_t c = 0; c < m; ++c) total_bits += cb[c];
+	 * allows at span_bits per span, at least one; threshold = ceil(total / k) */
 	uint64_t k = total / T;
 	if (e->prm.span_bits && total_bits / e->prm.span_bits < k) k = total_bits / e->prm.span_bits;
 	if (k == 0) k = 1;
 	const uint64_t Tb = (total + k - 1) / k;
-	uint32_t ns = 0, start = 0;
-	uint64_t acc = 0;
+	/* encode spans (two-phase): ke of about equal estimated coded size, closed at piece ends */
+	uint64_t ke = two ? all_bits / e->prm.enc_bits : 1;
+	if (ke > n / ORC_ENC_MIN_LEN) ke = n / ORC_ENC_MIN_LEN;
+	if (ke == 0) ke = 1;
+	const uint64_t Eb = (all_bits + ke - 1) / ke;
+	uint32_t ns = 0, start = 0, ne = 0, estart = 0;
+	uint64_t acc = 0, accb = 0;
 	if (n && span_start && ns < span_cap) span_start[0] = 0;
-	if (n) ns = 1;
+	if (n && enc_start && ne < enc_cap) enc_start[0] = 0;
+	if (n) { ns = 1; ne = 1; }
 	for (uint32_t c = 0; c + 1 < m; ++c) {
 		acc += cc[c];
+		accb += cb[c];
 		const uint64_t len = (uint64_t)(c + 1 - start) * ORC_EST_CHUNK;
-		if (len >= ORC_SPAN_MAX || (acc >= Tb && len >= min_len)) {
+		if (len >= ORC_SPAN_MAX || (acc >= Tb && len >= min_len) || c + 1 == seed_chunks) {
 			acc = 0;
 			start = c + 1;
 			if (span_start && ns < span_cap) span_start[ns] = start * ORC_EST_CHUNK;
 			++ns;
+			if (two && accb >= Eb && (uint64_t)(c + 1 - estart) * ORC_EST_CHUNK >= ORC_ENC_MIN_LEN) {
+				accb = 0;
+				estart = c + 1;
+				if (enc_start && ne < enc_cap) enc_start[ne] = estart * ORC_EST_CHUNK;
+				++ne;
+			}
 		}
 	}
+	if (n_enc) *n_enc = ne;
 	if (!chunk_cost) free(cc);
 	return ns;
+}
+
+static uint32_t plan_spans(enc *e, uint32_t *chunk_cost, uint32_t *span_start, uint32_t span_cap)
+{
+	return plan_spans_ex(e, chunk_cost, span_start, span_cap, NULL, 0, NULL);
 }
 
 /* ---- per-span chunk loop: lzma_encoder.c:313-436 + lzma2_encoder.c:135-259 - */
@@ -1463,6 +1495,147 @@ static int encode_span_(enc *e, uint32_t start, uint32_t end, int first_in_block
 	return 0;
 }
 
+/* ---- two-phase mode (OUR definition; the device: k_parse_pieces / k_encode_syms) --------------------
+ * The optimal parser is the expensive part and needs many independent units to fill the GPU; the range coder
+ * is cheap but every model reset costs output bytes.  So the two are decoupled: phase 1 parses independent
+ * PIECES (own adaptive model for the prices, reset at the piece start, nothing coded) and records the symbols
+ * in a form that does not depend on the coder state -- (length, distance) or literal; phase 2 codes the
+ * recorded symbols of a whole ENCODE SPAN with one continuous model, choosing rep / short rep / match from
+ * its own rep distances.  A recorded one-byte rep0 whose distance is not the coder's rep0 becomes a literal
+ * (the byte equality it relied on does not matter to a literal). */
+static void record_literal(enc *e, uint32_t pos)
+{
+	const uint32_t cur = e->in[pos], prev = pos ? e->in[pos - 1] : 0;
+	const uint32_t matched = e->state >= 7;
+	const uint32_t mb = matched ? e->in[pos - e->reps[0] - 1] : 0;
+	e->sy_len[pos] = 0;
+	e->sy_dist[pos] = cur | (prev << 8) | (mb << 16) | (matched << 24);
+}
+
+static void parse_piece(enc *e, uint32_t start, uint32_t end, int first_in_block, const uint16_t *prior)
+{
+	uint32_t cur = start;
+	int cached = 0;
+	e->span_end = end;
+	e->q_count = e->q_head = 0;
+	lzma_state_reset(e);
+	if (prior)
+		memcpy(e->probs, prior, sizeof(e->probs));
+	e->rc_off = 1;
+	if (first_in_block && cur < end) {
+		record_literal(e, 0);
+		rc_bit(e, &e->probs[P_IS_MATCH], 0);
+		rc_tree(e, e->probs + P_LITERAL, 8, e->in[0]);
+		trace_sym(e, 0, LIT, 1);
+		cur = 1;
+	}
+	while (cur < end) {
+		if (e->q_head == e->q_count)
+			cached = optimum_window(e, cur, cached);
+		const uint32_t back = e->q_back[e->q_head], len = e->q_len[e->q_head];
+		++e->q_head;
+		if (back == LIT) record_literal(e, cur);
+		else {
+			e->sy_len[cur] = (uint16_t)len;
+			e->sy_dist[cur] = back < 4 ? e->reps[back] : back - 4;
+		}
+		enc_symbol(e, cur, back, len);
+		ST_SYM();
+		cur += len;
+	}
+	e->rc_off = 0;
+}
+
+/* phase 1 of a whole Block: the seed piece, then every other piece from the seed's model */
+static int parse_block(enc *e, const uint32_t *piece_start, uint32_t np)
+{
+	const uint32_t n = e->n;
+	e->sy_len = (uint16_t *)calloc((size_t)n + 1, 2);
+	e->sy_dist = (uint32_t *)calloc((size_t)n + 1, 4);
+	uint16_t *prior = (uint16_t *)malloc(sizeof(e->probs));
+	if (!e->sy_len || !e->sy_dist || !prior) { free(prior); return -3; }
+	orc_trace *const tr = e->trace;
+	for (uint32_t k = 0; k < np; ++k) {
+		parse_piece(e, piece_start[k], k + 1 < np ? piece_start[k + 1] : n, k == 0, k == 0 ? NULL : prior);
+		if (k == 0) memcpy(prior, e->probs, sizeof(e->probs));
+	}
+	e->trace = tr;
+	free(prior);
+	return 0;
+}
+
+static int encode_syms(enc *e, uint32_t start, uint32_t end, int first_in_block,
+		uint8_t *out, uint64_t cap, uint64_t *opos)
+{
+	int need_props = 1, need_dict_reset = first_in_block, need_state_reset = 0;
+	uint32_t cur = start;
+	lzma_state_reset(e);
+	int initialized = !first_in_block;
+	while (cur < end) {
+		if (need_state_reset)
+			lzma_state_reset(e);
+		const uint32_t chunk_start = cur;
+		e->cpos = 0;
+		if (!initialized) {
+			rc_bit(e, &e->probs[P_IS_MATCH], 0);
+			rc_tree(e, e->probs + P_LITERAL, 8, e->in[0]);
+			trace_sym(e, 0, LIT, 1);
+			cur = 1;
+			initialized = 1;
+		}
+		for (;;) {
+			if (cur - chunk_start >= (1u << 21) - MATCH_LEN_MAX
+					|| e->cpos + e->cache_size + 4 >= 65536 - 4097)
+				break;
+			if (cur >= end)
+				break;
+			uint32_t len = e->sy_len[cur];
+			const uint32_t d = e->sy_dist[cur];
+			uint32_t back;
+			if (len == 0) { back = LIT; len = 1; }
+			else if (len == 1) back = d == e->reps[0] ? 0 : LIT;
+			else if (d == e->reps[0]) back = 0;
+			else if (d == e->reps[1]) back = 1;
+			else if (d == e->reps[2]) back = 2;
+			else if (d == e->reps[3]) back = 3;
+			else back = d + 4;
+			enc_symbol(e, cur, back, len);
+			cur += len;
+		}
+		rc_flush(e);
+		const uint32_t usize = cur - chunk_start, csize = e->cpos;
+		uint8_t hdr[6];
+		if (csize >= usize) {
+			hdr[0] = need_dict_reset ? 1 : 2;
+			need_dict_reset = 0;
+			hdr[1] = (uint8_t)((usize - 1) >> 8);
+			hdr[2] = (uint8_t)(usize - 1);
+			need_state_reset = 1;
+			if (put(out, cap, opos, hdr, 3) || put(out, cap, opos, e->in + chunk_start, usize))
+				return -1;
+			if (e->trace) ++e->trace->chunks_uncompressed;
+			continue;
+		}
+		uint32_t hl = 0;
+		if (need_props)
+			hdr[hl] = need_dict_reset ? 0x80 + (3 << 5) : 0x80 + (2 << 5);
+		else
+			hdr[hl] = need_state_reset ? 0x80 + (1 << 5) : 0x80;
+		hdr[hl++] += (uint8_t)((usize - 1) >> 16);
+		hdr[hl++] = (uint8_t)((usize - 1) >> 8);
+		hdr[hl++] = (uint8_t)(usize - 1);
+		hdr[hl++] = (uint8_t)((csize - 1) >> 8);
+		hdr[hl++] = (uint8_t)(csize - 1);
+		if (need_props)
+			hdr[hl++] = (uint8_t)((e->prm.pb * 5 + e->prm.lp) * 9 + e->prm.lc);
+		need_props = need_state_reset = need_dict_reset = 0;
+		if (put(out, cap, opos, hdr, hl) || put(out, cap, opos, e->cbuf, csize))
+			return -1;
+		if (e->trace) ++e->trace->chunks_lzma;
+	}
+	return 0;
+}
+
 static uint32_t hash_mask_for(uint32_t dict_size, uint32_t hash_bytes)
 {
 	/* lz/lz_encoder.c:306-327 */
@@ -1482,7 +1655,7 @@ static uint32_t hash_mask_for(uint32_t dict_size, uint32_t hash_bytes)
 static void enc_free(enc *e)
 {
 	if (!e) return;
-	free(e->prev2); free(e->prev3); free(e->son); free(e->prev4); free(e->prev8); free(e->prev16); free(e->sa); free(e->sa_rank); free(e->cbuf); free(e->nodes); free(e);
+	free(e->prev2); free(e->prev3); free(e->son); free(e->prev4); free(e->prev8); free(e->prev16); free(e->sa); free(e->sa_rank); free(e->cbuf); free(e->nodes); free(e->sy_len); free(e->sy_dist); free(e);
 }
 
 static enc *enc_new(const uint8_t *in, uint32_t n, const orc_enc_params *p)
@@ -1532,7 +1705,17 @@ int orc_lzma2_encode_block(const uint8_t *in, uint32_t n, const orc_enc_params *
 	e->trace = trace;
 	uint64_t opos = 0;
 	int r = 0;
-	if (p->span_cost && p->sa_window) {
+	if (p->enc_bits && p->span_cost && p->sa_window && p->parser == 1) {
+		const uint32_t scap = n / 4096 + 2;
+		uint32_t *ss = (uint32_t *)malloc((size_t)scap * 8), *es = ss + scap, ne = 0;
+		const uint32_t np = plan_spans_ex(e, NULL, ss, scap, es, scap, &ne);
+		r = parse_block(e, ss, np);
+		e->trace = NULL;            /* the trace is the parser's */
+		for (uint32_t k = 0; k < ne && !r; ++k)
+			r = encode_syms(e, es[k], k + 1 < ne ? es[k + 1] : n, k == 0, out, cap, &opos);
+		e->trace = trace;
+		free(ss);
+	} else if (p->span_cost && p->sa_window) {
 		const uint32_t scap = n / 4096 + 2;
 		uint32_t *ss = (uint32_t *)malloc((size_t)scap * 4);
 		const uint32_t ns = plan_spans(e, NULL, ss, scap);
@@ -1588,6 +1771,37 @@ uint32_t orc_span_plan(const uint8_t *in, uint32_t n, const orc_enc_params *p, u
 	const uint32_t ns = plan_spans(e, chunk_cost, span_start, span_cap);
 	enc_free(e);
 	return ns;
+}
+
+uint32_t orc_piece_plan(const uint8_t *in, uint32_t n, const orc_enc_params *p, uint32_t *chunk_cost,
+		uint32_t *span_start, uint32_t span_cap, uint32_t *enc_start, uint32_t enc_cap, uint32_t *n_enc)
+{
+	if (!p->sa_window || !p->span_cost || !p->enc_bits)
+		return 0;
+	enc *e = enc_new(in, n, p);
+	if (!e) return 0;
+	const uint32_t ns = plan_spans_ex(e, chunk_cost, span_start, span_cap, enc_start, enc_cap, n_enc);
+	enc_free(e);
+	return ns;
+}
+
+int orc_parse_dump(const uint8_t *in, uint32_t n, const orc_enc_params *p, uint16_t *sym_len, uint32_t *sym_dist)
+{
+	if (!p->sa_window || !p->span_cost || !p->enc_bits || p->parser != 1)
+		return -2;
+	enc *e = enc_new(in, n, p);
+	if (!e) return -3;
+	const uint32_t scap = n / 4096 + 2;
+	uint32_t *ss = (uint32_t *)malloc((size_t)scap * 4);
+	const uint32_t np = plan_spans_ex(e, NULL, ss, scap, NULL, 0, NULL);
+	const int r = parse_block(e, ss, np);
+	if (!r) {
+		memcpy(sym_len, e->sy_len, (size_t)n * 2);
+		memcpy(sym_dist, e->sy_dist, (size_t)n * 4);
+	}
+	free(ss);
+	enc_free(e);
+	return r;
 }
 
 /* Debug/test hooks for the device parity tests: the suffix order and the per-position match-list

@@ -133,15 +133,35 @@ typedef struct {
 	                       boundary where its estimate reaches ceil(total / k) and it is >= span_size bytes long (span_size 0: 64 KiB) */
 	uint32_t span_bits; /* with span_cost: a Block of estimated coded size `bits` (greedy parse over the match lists) gets
 	                       at most bits / span_bits spans: the number of state resets is bounded by the Block's OUTPUT */
+	uint32_t enc_bits;  /* != 0 (needs span_cost and parser 1): TWO-PHASE encode (OUR definition; the device: k_parse_pieces /
+	                       k_encode_syms).  The spans of the plan become parse PIECES: phase 1 runs the optimal parser over
+	                       every piece on its own, with an adaptive price model that codes nothing, and records the symbols in a
+	                       coder-independent form (length, distance) / literal; symbols never cross a piece end.  The first
+	                       ORC_SEED_LEN bytes of the Block are a piece of their own, parsed from the flat model; the model they
+	                       leave is the PRIOR every other piece of the Block starts its prices from.  Phase 2 range-codes the
+	                       recorded symbols with ONE continuous model per ENCODE SPAN (state reset only there), choosing rep /
+	                       short rep / match from its own rep distances.  Encode spans end at piece ends: a Block of estimated
+	                       coded size `bits` gets ke = max(1, min(n / ORC_ENC_MIN_LEN, bits / enc_bits)) of them, closed at the
+	                       first piece end where the estimate reaches ceil(bits / ke) and the span is >= ORC_ENC_MIN_LEN long */
 } orc_enc_params;
 #define ORC_EST_CHUNK 4096u
 #define ORC_SPAN_MAX (16u << 20)
+#define ORC_SEED_LEN 65536u
+#define ORC_ENC_MIN_LEN (512u << 10)
 
 /* The span plan of one Block under p->span_cost: chunk_cost (optional, 2 * ceil(n / ORC_EST_CHUNK) entries: work
  * estimates, then bit estimates) receives the per-chunk estimates, span_start (optional, capacity span_cap) the first byte of every span; returns the
  * number of spans (0 on error). */
 uint32_t orc_span_plan(const uint8_t *in, uint32_t n, const orc_enc_params *p, uint32_t *chunk_cost,
 		uint32_t *span_start, uint32_t span_cap);
+/* Two-phase mode: the same plan plus the encode spans (enc_start: first byte of each, capacity enc_cap; *n_enc their
+ * number).  Returns the number of pieces. */
+uint32_t orc_piece_plan(const uint8_t *in, uint32_t n, const orc_enc_params *p, uint32_t *chunk_cost,
+		uint32_t *span_start, uint32_t span_cap, uint32_t *enc_start, uint32_t enc_cap, uint32_t *n_enc);
+/* Two-phase mode: the recorded parse of one Block as the device stores it: per position (valid at symbol starts)
+ * sym_len (0 = literal, else the match length) and sym_dist (zero-based distance; literal: byte | previous byte << 8 |
+ * match byte << 16 | (parser state >= 7) << 24). */
+int orc_parse_dump(const uint8_t *in, uint32_t n, const orc_enc_params *p, uint16_t *sym_len, uint32_t *sym_dist);
 
 int orc_preset(uint32_t preset, orc_enc_params *p, uint32_t *mode_normal);
 

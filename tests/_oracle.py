@@ -41,7 +41,7 @@ class OrcParams(C.Structure):
                 ("pb", C.c_uint32), ("nice_len", C.c_uint32), ("mf", C.c_uint32),
                 ("depth", C.c_uint32), ("span_size", C.c_uint32), ("sa_window", C.c_uint32),
                 ("parser", C.c_uint32), ("sa_depth", C.c_uint32), ("span_cost", C.c_uint32),
-                ("span_bits", C.c_uint32)]
+                ("span_bits", C.c_uint32), ("enc_bits", C.c_uint32)]
 
 
 class OrcSymbol(C.Structure):

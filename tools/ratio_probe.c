@@ -87,6 +87,7 @@ int main(int argc, char **argv)
 	if (argc > 8) g_prm.span_cost = (uint32_t)strtoul(argv[8], NULL, 10);
 	if (argc > 9) g_prm.span_bits = (uint32_t)strtoul(argv[9], NULL, 10);
 	g_verify = getenv("PROBE_VERIFY") != NULL;
+	if (getenv("PROBE_ENC_BITS")) g_prm.enc_bits = (uint32_t)strtoul(getenv("PROBE_ENC_BITS"), NULL, 10);
 	void *h = dlopen("/root/repo/oracle/_ref/libref_shim.so", RTLD_NOW);
 	if (!h) { fprintf(stderr, "%s\n", dlerror()); return 1; }
 	g_ref = (ref_raw_fn)dlsym(h, "ref_raw_lzma2_encode");
@@ -99,8 +100,8 @@ int main(int argc, char **argv)
 	for (int t = 0; t < nt; ++t) pthread_join(th[t], NULL);
 	uint64_t so = 0, sr = 0;
 	for (uint64_t b = 0; b < g_nb; ++b) { so += g_ours[b]; sr += g_refsz[b]; }
-	printf("%s preset %s span %u W %u depth %u cost %u block %llu: ours %llu ref %llu", argv[1], argv[2], g_prm.span_size, g_prm.sa_window,
-			g_prm.sa_depth, g_prm.span_cost, (unsigned long long)g_block, (unsigned long long)so, (unsigned long long)sr);
+	printf("%s preset %s span %u W %u depth %u cost %u bits %u enc_bits %u block %llu: ours %llu ref %llu", argv[1], argv[2], g_prm.span_size, g_prm.sa_window,
+			g_prm.sa_depth, g_prm.span_cost, g_prm.span_bits, g_prm.enc_bits, (unsigned long long)g_block, (unsigned long long)so, (unsigned long long)sr);
 	if (sr) printf("  delta %+.2f%%  (ratio ours %.4f ref %.4f)", 100.0 * ((double)so / (double)sr - 1.0), (double)so / g_n, (double)sr / g_n);
 	printf("\n");
 	return 0;
