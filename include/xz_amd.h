@@ -104,9 +104,17 @@ typedef struct {
 	                        gets at most bits / span_bits spans: a state reset costs a few hundred bytes whatever the data,
 	                        so what bounds the number of resets is the Block's OUTPUT (highly compressible Blocks: fewer,
 	                        longer spans) */
+	uint32_t enc_span_bits; /* != 0 with cost-balanced spans: TWO-PHASE encode.  The spans of the plan are
+	                        parse PIECES: the optimal parser runs over each with an adaptive price model that codes nothing
+	                        (the first 64 KiB of a Block are the seed piece, parsed from the flat model; what it leaves is
+	                        the prior of every other piece) and records (length, distance) / literal symbols; a second
+	                        kernel range-codes them with ONE continuous model per encode span -- state resets only there.
+	                        A Block of estimated coded size `bits` gets max(1, min(size / 512 KiB, bits / enc_span_bits))
+	                        encode spans, closed at piece ends.  0: single phase, every span of the plan resets the state */
 } xzamd_lzma_options;
 #define XZAMD_SPAN_COST_DEFAULT 131072u   /* text: 128 KiB spans */
 #define XZAMD_SPAN_BITS_DEFAULT 400000u
+#define XZAMD_ENC_SPAN_BITS_DEFAULT 1600000u   /* about 200 KB of output per encode span */
 #define XZAMD_SPAN_MIN_LEN 65536u         /* shortest cost-balanced span */
 #define XZAMD_BCJ_X86 4u    /* LZMA_FILTER_X86, api/lzma/bcj.h:20 */
 #define XZAMD_BCJ_ARM64 0x0Au   /* LZMA_FILTER_ARM64, api/lzma/bcj.h (simple/arm64.c), start offset 0 */
@@ -162,6 +170,10 @@ typedef struct {
 	uint32_t span_cost_used;     /* cost-balanced spans: work target of the LAST batch (>= span_cost) */
 	float ms_plan;               /* span plan (k_span_est + k_span_cut) */
 	uint32_t wave_slots;         /* span wavefronts the GPU holds at once (CUs x occupancy of the span kernel) */
+	uint64_t enc_spans;          /* two-phase: encode spans (= state resets + 1 per Block); `spans` counts the parse pieces */
+	float ms_seed;               /* two-phase: the seed pieces (one wavefront per Block, part of ms_encode) */
+	float ms_parse;              /* two-phase: every other piece */
+	float ms_code;               /* two-phase: k_encode_syms */
 } xzamd_stats;
 void xzamd_get_stats(const xzamd_ctx *ctx, xzamd_stats *out);
 
@@ -226,6 +238,10 @@ int xzamd_trace_read(xzamd_ctx *ctx, uint32_t *out, uint32_t cap, uint32_t *coun
 #define XZAMD_DEBUG_SPAN_CNT 6      /* spans per Block */
 #define XZAMD_DEBUG_LITP 8          /* literal-coder slices of the span slots (timing builds leave a per-span record there) */
 #define XZAMD_DEBUG_SPAN_EST 7      /* per 4 KiB chunk: work estimates of every Block, then the bit estimates */
+#define XZAMD_DEBUG_SYM_LEN 9       /* two-phase: u16 per position, valid at symbol starts (0 = literal) */
+#define XZAMD_DEBUG_SYM_DIST 10     /* two-phase: u32 per position (distance / literal bytes) */
+#define XZAMD_DEBUG_ENC_TAB 11      /* two-phase: (first byte, end) per encode-span slot, slots = Block * (block_size / 512 KiB + 1) + j */
+#define XZAMD_DEBUG_ENC_CNT 12      /* encode spans per Block */
 int xzamd_debug_fetch(xzamd_ctx *ctx, int what, void *host_out, uint64_t bytes);
 
 /* Seeded synthetic corpora used by bench.py and the tests (host memory). */

@@ -471,6 +471,7 @@ def params_for_gpu_options(opts, span_size=None, span_cost_used=None):
         p.span_size = 65536                         # XZAMD_SPAN_MIN_LEN
         p.span_cost = span_cost_used if span_cost_used else opts.span_cost
         p.span_bits = opts.span_bits
+        p.enc_bits = opts.enc_span_bits                # != 0: two-phase (parse pieces + encode spans)
         return p
     if sp in (0, 1):
         sp = 131072 if opts.gpu_parser else 65536    # xzamd_host.c DEFAULT_SPAN_OPT / DEFAULT_SPAN
@@ -491,6 +492,35 @@ def orc_span_plan(data, prm):
     ns = f(_ptr(data), n, C.byref(prm), _ptr(cc, u32p), _ptr(ss, u32p), len(ss))
     assert ns > 0
     return cc[:m], cc[m:2 * m], ss[:ns]
+
+
+def orc_piece_plan(data, prm):
+    """Two-phase plan of one Block: (piece starts, encode-span starts)."""
+    data = as_u8(data)
+    n = len(data)
+    ss = np.zeros(n // 4096 + 2, dtype=np.uint32)
+    es = np.zeros(n // 4096 + 2, dtype=np.uint32)
+    ne = C.c_uint32(0)
+    f = orc().orc_piece_plan
+    f.restype = C.c_uint32
+    f.argtypes = [u8p, C.c_uint32, C.POINTER(OrcParams), u32p, u32p, C.c_uint32, u32p, C.c_uint32, u32p]
+    ns = f(_ptr(data), n, C.byref(prm), None, _ptr(ss, u32p), len(ss), _ptr(es, u32p), len(es), C.byref(ne))
+    assert ns > 0
+    return ss[:ns], es[:ne.value]
+
+
+def orc_parse_dump(data, prm):
+    """Two-phase: the recorded parse of one Block (sym_len u16, sym_dist u32 per position, valid at symbol starts)."""
+    data = as_u8(data)
+    n = len(data)
+    sl = np.zeros(n, dtype=np.uint16)
+    sd = np.zeros(n, dtype=np.uint32)
+    f = orc().orc_parse_dump
+    f.restype = C.c_int
+    f.argtypes = [u8p, C.c_uint32, C.POINTER(OrcParams), C.POINTER(C.c_uint16), u32p]
+    r = f(_ptr(data), n, C.byref(prm), _ptr(sl, C.POINTER(C.c_uint16)), _ptr(sd, u32p))
+    assert r == 0, r
+    return sl, sd
 
 
 def first_diff(a, b):

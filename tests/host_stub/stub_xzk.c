@@ -65,10 +65,11 @@ int xzk_find_matches(const xzamd_span_args *a, const uint32_t *sa, const uint32_
 
 /* a plan with the documented shape: spans of 192 KiB (a multiple of the estimate chunk), at least min_len long */
 int xzk_span_plan(const xzamd_span_args *a, uint32_t nblocks, uint32_t *est, unsigned long long *totals,
-		uint32_t *span_tab, uint32_t *span_cnt, uint32_t cost_min, uint32_t bits_min, uint32_t min_len, uint32_t slots,
+		uint32_t *span_tab, uint32_t *span_cnt, uint32_t cost_min, uint32_t bits_min, uint32_t min_len,
+		uint32_t *enc_tab, uint32_t *enc_cnt,
 		uint32_t *order_bufs, void *sort_tmp, uint64_t sort_tmp_bytes, uint32_t **order_out, void *stream)
 {
-	(void)est; (void)bits_min; (void)slots; (void)stream; (void)order_bufs; (void)sort_tmp; (void)sort_tmp_bytes;
+	(void)est; (void)bits_min; (void)stream; (void)order_bufs; (void)sort_tmp; (void)sort_tmp_bytes;
 	*order_out = NULL;
 	uint32_t span = 192u << 10;
 	if (span < min_len) span = min_len;
@@ -82,6 +83,16 @@ int xzk_span_plan(const xzamd_span_args *a, uint32_t nblocks, uint32_t *est, uns
 		}
 		span_cnt[b] = k;
 		totals[b] = be - bs;
+		if (a->enc_bits) {
+			/* two-phase: encode spans of 768 KiB (four spans of the plan above), the last one takes the rest */
+			const uint32_t es = 768u << 10;
+			uint32_t j = 0;
+			for (uint64_t p = bs; p < be && j < a->max_esb; p += es, ++j) {
+				enc_tab[2 * ((uint64_t)b * a->max_esb + j)] = (uint32_t)p;
+				enc_tab[2 * ((uint64_t)b * a->max_esb + j) + 1] = (uint32_t)(be - p < es || j + 1 == a->max_esb ? be : p + es);
+			}
+			enc_cnt[b] = j;
+		}
 	}
 	totals[nblocks] = a->n;
 	totals[nblocks + 1] = cost_min;
@@ -103,6 +114,39 @@ int xzk_span_encode(const xzamd_span_args *a, uint32_t nslots, uint32_t waves, u
 		for (uint32_t p = start; p < end; ) {
 			const uint32_t c = end - p < 65536 ? end - p : 65536;
 			out[o++] = first ? 1 : 2;               /* lzma2_header_uncompressed: 0x01 resets the dictionary */
+			out[o++] = (uint8_t)((c - 1) >> 8);
+			out[o++] = (uint8_t)(c - 1);
+			memcpy(out + o, a->in + p, c);
+			o += c;
+			p += c;
+			first = 0;
+		}
+		a->span_bytes[s] = o;
+	}
+	return 0;
+}
+
+/* two-phase: the pieces record nothing here, the encode spans are stored chunks of the input */
+int xzk_parse_pieces(const xzamd_span_args *a, uint32_t nblocks, int phase, uint32_t waves, uint32_t *counter, void *stream)
+{
+	(void)a; (void)nblocks; (void)phase; (void)waves; (void)counter; (void)stream;
+	return 0;
+}
+
+int xzk_encode_syms(const xzamd_span_args *a, uint32_t nblocks, void *stream)
+{
+	(void)stream;
+	for (uint32_t s = 0; s < nblocks * a->max_esb; ++s) {
+		const uint32_t b = s / a->max_esb, k = s - b * a->max_esb;
+		if ((uint64_t)b * a->block_size >= a->n || k >= a->enc_cnt[b])
+			continue;
+		const uint32_t start = a->enc_tab[2 * s], end = a->enc_tab[2 * s + 1];
+		uint8_t *out = a->scratch + ((((uint64_t)start + (start >> 3)) + 15) & ~15ull) + (uint64_t)s * XZAMD_SPAN_SLACK;
+		uint32_t o = 0;
+		int first = start == b * a->block_size;
+		for (uint32_t p = start; p < end; ) {
+			const uint32_t c = end - p < 65536 ? end - p : 65536;
+			out[o++] = first ? 1 : 2;
 			out[o++] = (uint8_t)((c - 1) >> 8);
 			out[o++] = (uint8_t)(c - 1);
 			memcpy(out + o, a->in + p, c);

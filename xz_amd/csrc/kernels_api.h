@@ -49,7 +49,21 @@ typedef struct {
 	uint32_t lc, lp, pb;
 	uint32_t sa_window;          /* suffix-neighbourhood finder: slots examined on either side (0 = exact HC3/HC4 finder) */
 	uint32_t parser;             /* 0 = optimum_fast, 1 = windowed optimal parser */
+	/* Two-phase mode (oracle: parse_piece / encode_syms): the spans of the plan are parse PIECES (xzk_parse_pieces: the
+	 * optimal parser with an adaptive price model that codes nothing; the seed piece = slot 0 of every Block starts flat
+	 * and leaves the prior of the others), the recorded symbols are range-coded per ENCODE SPAN (xzk_encode_syms). */
+	uint16_t *sym_len;           /* per position, valid at symbol starts: 0 = literal, else the match / rep length (1 = short rep) */
+	uint32_t *sym_dist;          /* zero-based distance; literal: byte | previous byte << 8 | match byte << 16 | (parser state >= 7) << 24 */
+	uint32_t *prior;             /* XZAMD_PRIOR_WORDS x u32 per Block: the LDS part of the model its seed piece leaves
+	                                (the literal part stays in the seed's `lit` slice) */
+	const uint32_t *enc_tab;     /* encode spans: (first byte, end) per slot b * max_esb + j, offsets into the batch */
+	const uint32_t *enc_cnt;     /* encode spans per Block */
+	uint32_t max_esb;            /* encode span slots per Block */
+	uint32_t enc_bits;           /* != 0: two-phase plan (seed cut + encode spans of about enc_bits estimated bits) */
 } xzamd_span_args;
+#define XZAMD_PRIOR_WORDS 928u      /* 1856 x u16 >= the 1846 non-literal probabilities */
+#define XZAMD_SEED_LEN 65536u       /* two-phase: the first piece of every Block (oracle: ORC_SEED_LEN) */
+#define XZAMD_ENC_MIN_LEN (512u << 10)  /* shortest encode span (but the last of a Block) */
 #define XZAMD_SPAN_SLACK 4112u      /* 4096 + 16 bytes of scratch per span slot on top of 9/8 of the input */
 #define XZAMD_EST_CHUNK 4096u       /* positions per work estimate of the span plan */
 #define XZAMD_SPAN_MAX (16u << 20)  /* longest cost-balanced span */
@@ -78,13 +92,20 @@ int xzk_find_matches(const xzamd_span_args *a, const uint32_t *sa, const uint32_
 /* Cost-balanced span plan of a batch from its match lists (oracle: plan_spans): est[0 .. 2 * nblocks * cpb) receives
  * the per-chunk work and bit estimates (cpb = chunks per Block), totals[0 .. nblocks] the per-Block work and, last,
  * the batch total (u64 each); then span_tab / span_cnt as described in xzamd_span_args.  The work target of a span is
- * cost_min, or, for a batch of more than `slots` such spans, what makes the rounds of the launch full (k_span_cut);
- * totals[nblocks + 1] receives the target used. */
+ * cost_min: the plan of a Block depends on the Block and the options only, never on the batch or the GPU.  With
+ * a->enc_bits (two-phase): the first XZAMD_SEED_LEN bytes of a Block are a span of their own and enc_tab / enc_cnt receive
+ * the encode spans (a->max_esb slots per Block). */
 int xzk_span_plan(const xzamd_span_args *a, uint32_t nblocks, uint32_t *est, unsigned long long *totals,
-		uint32_t *span_tab, uint32_t *span_cnt, uint32_t cost_min, uint32_t bits_min, uint32_t min_len, uint32_t slots,
+		uint32_t *span_tab, uint32_t *span_cnt, uint32_t cost_min, uint32_t bits_min, uint32_t min_len,
+		uint32_t *enc_tab, uint32_t *enc_cnt,
 		uint32_t *order_bufs, void *sort_tmp, uint64_t sort_tmp_bytes, uint32_t **order_out, void *stream);
 /* order_bufs: 4 x (nblocks * max_spb) u32 of scratch; *order_out = where the launch order ends up (inside order_bufs) */
 int xzk_span_encode(const xzamd_span_args *a, uint32_t nslots, uint32_t waves, uint32_t *counter, void *stream);
+/* Two-phase mode.  xzk_parse_pieces: phase 0 = the seed pieces (one wavefront per Block), phase 1 = every other piece
+ * (nslots = nblocks * max_spb slots in a->order, heaviest first; persistent with `waves` wavefronts when waves != 0).
+ * xzk_encode_syms: one wavefront per encode-span slot (nblocks * max_esb), bytes produced into a->span_bytes[slot]. */
+int xzk_parse_pieces(const xzamd_span_args *a, uint32_t nblocks, int phase, uint32_t waves, uint32_t *counter, void *stream);
+int xzk_encode_syms(const xzamd_span_args *a, uint32_t nblocks, void *stream);
 /* wavefronts of the span kernel variant for (parser, nice_len) one CU holds at once */
 int xzk_span_occupancy(int parser, uint32_t nice_len, int *waves_per_cu);
 /* x86 BCJ encoder: d_out = filtered copy of d_in, every Block filtered independently (simple/x86.c). */

@@ -857,6 +857,9 @@ __device__ __forceinline__ void rc_run(RC& rc, uint32_t packed, uint32_t n, uint
     }
 }
 
+// CODE: run the range coder (false: the parse pieces of the two-phase mode only adapt their price model);
+// LITG: literal-coder probabilities live in global memory (u32 each, `lit`), else in LDS behind P_LITERAL (u16).
+template <bool CODE, bool LITG>
 __device__ __forceinline__ void rc_emit(RC& rc, uint16_t* probs, uint32_t* lit, const SegSel& s, uint32_t total,
         uint32_t d0, uint32_t d1)
 {
@@ -886,7 +889,7 @@ __device__ __forceinline__ void rc_emit(RC& rc, uint16_t* probs, uint32_t* lit, 
     }
     uint32_t p = 0;
     if (s.hit && !direct) {
-        if (idx >= P_LITERAL) {
+        if (LITG && idx >= P_LITERAL) {
             uint32_t* g = lit + (idx - P_LITERAL);
             p = lit_load(g);
             lit_store(g, bit ? p - (p >> 5) : p + ((2048 - p) >> 5));
@@ -895,23 +898,27 @@ __device__ __forceinline__ void rc_emit(RC& rc, uint16_t* probs, uint32_t* lit, 
             probs[idx] = (uint16_t)(bit ? p - (p >> 5) : p + ((2048 - p) >> 5));
         }
     }
-    const uint32_t packed = p | (bit << 12) | (direct ? 0x2000u : 0u);
-    rc_run(rc, packed, total, d0, d1);
+    if constexpr (CODE) {
+        const uint32_t packed = p | (bit << 12) | (direct ? 0x2000u : 0u);
+        rc_run(rc, packed, total, d0, d1);
+    }
 }
 
-// g = global offset of the byte, upos = its offset inside the Block
-__device__ __forceinline__ void encode_symbol(RC& rc, uint16_t* probs, Lz& z, const uint8_t* __restrict__ in,
-        uint32_t g, uint32_t upos, uint32_t back, uint32_t len)
+// upos = offset of the symbol inside the Block; lit3 (literals only) = byte | previous byte << 8 | match byte << 16
+// (the match byte is read only in states >= 7)
+template <bool CODE, bool LITG>
+__device__ __forceinline__ void encode_symbol_t(RC& rc, uint16_t* probs, Lz& z, uint32_t upos, uint32_t back, uint32_t len,
+        uint32_t lit3)
 {
     const uint32_t ps = upos & ((1u << z.pb) - 1);
     SegSel s;
     s.type = 0; s.base = 0; s.sym = 0; s.i = 0; s.n = 0; s.hit = false;
     uint32_t off = 0;
     if (back == LITERAL) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // previous literal's probability scatter
+        if (LITG) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // previous literal's probability scatter
         seg_add(s, off, 1, SEG_BIT, P_IS_MATCH + z.state * 16 + ps, 0);
-        const uint32_t cur = uni(in[g]);
-        const uint32_t prev = upos ? uni(in[g - 1]) : 0;
+        const uint32_t cur = lit3 & 0xFFu;
+        const uint32_t prev = (lit3 >> 8) & 0xFFu;
         const uint32_t mask = (0x100u << z.lp) - (0x100u >> z.lc);
         const uint32_t sub = P_LITERAL + 3u * ((((upos << 8) + prev) & mask) << z.lc);
         if (z.state < 7) {
@@ -919,10 +926,10 @@ __device__ __forceinline__ void encode_symbol(RC& rc, uint16_t* probs, Lz& z, co
             seg_add(s, off, 8, SEG_TREE, sub, cur);
         } else {
             z.state = z.state <= 9 ? z.state - 3 : z.state - 6;
-            const uint32_t mb = uni(in[g - z.rep0 - 1]);
+            const uint32_t mb = (lit3 >> 16) & 0xFFu;
             seg_add(s, off, 8, SEG_MATCHED, sub, cur | (mb << 8));
         }
-        rc_emit(rc, probs, z.lit, s, off, off, off);
+        rc_emit<CODE, LITG>(rc, probs, z.lit, s, off, off, off);
         return;
     }
     seg_add(s, off, 1, SEG_BIT, P_IS_MATCH + z.state * 16 + ps, 1);
@@ -950,7 +957,7 @@ __device__ __forceinline__ void encode_symbol(RC& rc, uint16_t* probs, Lz& z, co
         }
         if (len == 1) {
             z.state = z.state < 7 ? 9 : 11;
-            rc_emit(rc, probs, z.lit, s, off, off, off);
+            rc_emit<CODE, LITG>(rc, probs, z.lit, s, off, off, off);
             return;
         }
         len_base = P_REP_LEN;
@@ -1002,7 +1009,23 @@ __device__ __forceinline__ void encode_symbol(RC& rc, uint16_t* probs, Lz& z, co
         z.rep3 = z.rep2; z.rep2 = z.rep1; z.rep1 = z.rep0; z.rep0 = dist;
     }
     if (dir0 == ~0u) dir0 = dir1 = off;
-    rc_emit(rc, probs, z.lit, s, off, dir0, dir1);
+    rc_emit<CODE, LITG>(rc, probs, z.lit, s, off, dir0, dir1);
+}
+
+// the bytes a literal at global offset g needs, for encode_symbol_t
+__device__ __forceinline__ uint32_t literal_bytes(const uint8_t* __restrict__ in, uint32_t g, uint32_t upos, const Lz& z)
+{
+    const uint32_t cur = uni(in[g]);
+    const uint32_t prev = upos ? uni(in[g - 1]) : 0;
+    const uint32_t mb = z.state >= 7 ? uni(in[g - z.rep0 - 1]) : 0;
+    return cur | (prev << 8) | (mb << 16);
+}
+
+// g = global offset of the byte, upos = its offset inside the Block (single-phase kernels: code while parsing)
+__device__ __forceinline__ void encode_symbol(RC& rc, uint16_t* probs, Lz& z, const uint8_t* __restrict__ in,
+        uint32_t g, uint32_t upos, uint32_t back, uint32_t len)
+{
+    encode_symbol_t<true, true>(rc, probs, z, upos, back, len, back == LITERAL ? literal_bytes(in, g, upos, z) : 0u);
 }
 
 __device__ __forceinline__ bool change_pair(uint32_t small_dist, uint32_t big_dist)
@@ -2187,6 +2210,362 @@ void k_span_encode_t(xzamd_span_args a, uint32_t nspans, uint32_t* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------
+// Two-phase mode (oracle: parse_piece / parse_block / encode_syms).  The optimal parser is the expensive part and
+// needs thousands of independent units to fill the GPU; the range coder is cheap, but every reset of its model costs
+// output bytes -- and, worse, a parser that prices with a freshly reset model chooses badly for tens of KiB (measured
+// through the oracle: that, not the coded resets, was most of the span overhead).  So the two are decoupled:
+//   k_parse_pieces   one wavefront per PIECE of the span plan: optimum_window with an adaptive price model that codes
+//                    nothing.  The first XZAMD_SEED_LEN bytes of every Block are the seed piece (phase 0, flat model);
+//                    the model it leaves is the prior every other piece of the Block starts from (phase 1).  Symbols
+//                    are recorded per position in a coder-independent form: (length, distance) or literal bytes.
+//   k_encode_syms    one wavefront per ENCODE SPAN (>= 512 KiB of input, about enc_bits of output): the recorded
+//                    symbols are range-coded with one continuous model (all of it in LDS), rep / short rep / match
+//                    chosen from the coder's own rep distances; LZMA2 chunking as in the single-phase kernel.
+// ------------------------------------------------------------------------------------------
+template <uint32_t WMAX>
+__device__ __forceinline__ void parse_piece_one(const xzamd_span_args& a, const uint32_t span)
+{
+    constexpr uint32_t W_PROBS = XZAMD_PRIOR_WORDS;                      // 1856 x u16 >= P_LITERAL (1846): all but the literal coders
+    constexpr uint32_t W_NODES = 6 * (WMAX + 1) + 2;                     // reps[4], price, info (16-byte multiple)
+    constexpr uint32_t W_TABS = 128 + 72 + 32;                           // dsp, xt + ap (u16), ptab (u8)
+    __shared__ __attribute__((aligned(16))) uint32_t pool[W_PROBS + W_NODES + W_TABS];
+    uint16_t* const probs = reinterpret_cast<uint16_t*>(pool);
+    const uint32_t lane = threadIdx.x;
+    const uint32_t blk = span / a.max_spb;
+    const uint32_t k = span - blk * a.max_spb;
+    if (k >= a.span_cnt[blk]) return;                  // an unused slot of the span plan
+    const uint32_t block_start = blk * a.block_size;
+    const uint32_t block_end = min(a.n, block_start + a.block_size);
+    const uint32_t span_start = uni(a.span_tab[2 * span]), span_end = uni(a.span_tab[2 * span + 1]);
+    const uint8_t* __restrict__ in = a.in;
+
+    Env e;
+    e.in = in; e.rank = a.rank; e.sorted_pos = a.sorted_pos; e.prev2 = a.prev2; e.prev3 = a.prev3;
+    e.nice = a.nice_len; e.depth = a.depth; e.hb = a.hash_bytes; e.cyclic = a.dict_size + 1;
+    e.block_end = block_end; e.n_last = a.n - 1;
+    e.mlen = a.mlen; e.mdist = a.mdist; e.packed = a.list_packed;
+    ListPre LP;
+    LP.valid = false; LP.pos = 0; LP.sl = LP.sd = LP.tr = 0;
+
+    Work w{};
+    {
+        uint32_t* nb = pool + W_PROBS;
+        w.n_reps4 = reinterpret_cast<uint4*>(nb);
+        w.n_price = nb + 4 * (WMAX + 1);
+        w.n_info = nb + 5 * (WMAX + 1);
+        uint32_t* tb = nb + W_NODES;
+        w.dsp = reinterpret_cast<uint16_t*>(tb);
+        w.xt = reinterpret_cast<uint16_t*>(tb + 128);
+        w.ap = w.xt + 128;
+        w.ptab = reinterpret_cast<uint8_t*>(tb + 200);
+        w.err = a.err;
+        for (uint32_t t = lane; t < 128; t += 64) {     // bit price table (price_tablegen.c:31-58)
+            uint32_t wv = t * 16 + 8, bit_count = 0;
+            for (int jj = 0; jj < 4; ++jj) {
+                wv *= wv;
+                bit_count <<= 1;
+                while (wv >= (1u << 16)) { wv >>= 1; ++bit_count; }
+            }
+            w.ptab[t] = (uint8_t)((11 << 4) - 15 - bit_count);
+        }
+        wave_sync();
+        w.ptv = reinterpret_cast<const uint32_t*>(w.ptab)[lane & 31];
+    }
+
+    Lz z;
+    z.lc = a.lc; z.lp = a.lp; z.pb = a.pb;
+    z.cnt_len = z.cnt_match = z.cnt_align = 0;
+    const uint32_t lit_size = 0x300u << (a.lc + a.lp);
+    z.lit = a.lit + (uint64_t)span * lit_size;
+    z.state = 0; z.rep0 = z.rep1 = z.rep2 = z.rep3 = 0;
+    RC rc;                                              // never codes: encode_symbol_t<false, .> only adapts the model
+    rc.cpos = 0; rc.out = nullptr; rc.reset();
+
+    // price model: flat for the seed piece (slot 0 of the Block), else the model the seed left
+    {
+        uint32_t* p32 = reinterpret_cast<uint32_t*>(probs);
+        uint4* l4 = reinterpret_cast<uint4*>(z.lit);
+        if (k == 0) {
+            for (uint32_t i = lane; i < W_PROBS; i += 64) p32[i] = 0x04000400u;
+            const uint4 v = make_uint4(1024u, 1024u, 1024u, 1024u);
+            for (uint32_t i = lane; i < lit_size / 4; i += 64) l4[i] = v;
+        } else {
+            const uint32_t* pr = a.prior + (uint64_t)blk * XZAMD_PRIOR_WORDS;
+            for (uint32_t i = lane; i < W_PROBS; i += 64) p32[i] = pr[i];
+            const uint4* s4 = reinterpret_cast<const uint4*>(a.lit + (uint64_t)blk * a.max_spb * lit_size);
+            for (uint32_t i = lane; i < lit_size / 4; i += 64) l4[i] = s4[i];
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        wave_sync();
+    }
+
+    uint32_t cur = span_start;
+    bool cached = false;
+    RoundL RL;
+    RL.L = 0; RL.SL = 0; RL.SD = 0; RL.cnt = 0; RL.longest = 0; RL.l2a = RL.l2b = 0;
+    RL.rp[0] = RL.rp[1] = RL.rp[2] = RL.rp[3] = 0;
+    RL.rm[0] = RL.rm[1] = RL.rm[2] = RL.rm[3] = 0;
+    RL.rl[0] = RL.rl[1] = RL.rl[2] = RL.rl[3] = 0;
+    RL.pre = 0;
+    LenTab lt;
+    uint32_t q_pos = 0, q_end = 0;
+    bool tables_valid = false;
+
+    if (span_start == block_start) {
+        // encode_init (lzma_encoder.c:267-293): the first byte of a Block is a literal in the initial contexts
+        const uint32_t l3 = literal_bytes(in, block_start, 0, z);
+        if (lane == 0) { a.sym_len[block_start] = 0; a.sym_dist[block_start] = l3; }
+        encode_symbol_t<false, true>(rc, probs, z, 0, LITERAL, 1, l3);
+        cur = block_start + 1;
+    }
+    while (cur < span_end) {
+        uint32_t back = LITERAL, len = 1;
+        if (q_pos == q_end) {
+            if (!tables_valid || z.cnt_len >= 64) { refresh_len_tables(probs, w.ptab, lt, 1u << z.pb, reinterpret_cast<uint32_t*>(w.n_reps4)); z.cnt_len = 0; }
+            if (!tables_valid || z.cnt_match >= 128) { refresh_dist_tables(probs, w); z.cnt_match = 0; }
+            if (!tables_valid || z.cnt_align >= 16) { refresh_align_table(probs, w); z.cnt_align = 0; }
+            tables_valid = true;
+            if (!cached) {
+                round_lists(e, LP, cur, span_end, z.rep0, z.rep1, z.rep2, z.rep3, RL);
+                cached = true;
+            }
+            uint32_t sb = LITERAL, sl = 0;
+            if (RL.rp[0] >= e.nice) { sb = 0; sl = RL.rp[0]; }
+            else if (RL.rp[1] >= e.nice) { sb = 1; sl = RL.rp[1]; }
+            else if (RL.rp[2] >= e.nice) { sb = 2; sl = RL.rp[2]; }
+            else if (RL.rp[3] >= e.nice) { sb = 3; sl = RL.rp[3]; }
+            else if (RL.longest >= e.nice) { sb = lane_of(RL.SD, RL.cnt - 1) + 4; sl = RL.longest; }
+            if (sl) {
+                back = sb; len = sl;
+                cached = false;
+                q_pos = q_end = 0;
+            } else if (RL.cnt == 0 && RL.rp[0] == 0 && RL.rp[1] < 2 && RL.rp[2] < 2 && RL.rp[3] < 2
+                    && mask_run_after(RL.rm[0], 0) < 2) {
+                cached = false;                         // nothing but a literal can leave this node
+                q_pos = q_end = 0;
+            } else {
+                cached = optimum_window<WMAX>(e, w, LP, probs, z, lt, in, cur, block_start, span_end, cached, RL, q_end);
+                q_pos = 0;
+                if (q_end == 0) {                       // consistency failure reported by the parser
+                    if (lane == 0 && a.err) atomicCAS(a.err, 0u, 2u);
+                    return;
+                }
+            }
+        }
+        if (q_pos != q_end) {
+            back = uni(w.n_price[q_pos]);
+            len = (uni(w.n_info[q_pos]) >> 13) & 0x1FF;
+            q_pos += len;
+        }
+        if (len == 0 || len > MATCH_LEN_MAX || cur + len > span_end
+                || (back != LITERAL && back >= 4 && back - 4 >= cur - block_start)) {
+            if (lane == 0 && a.err) {
+                if (atomicCAS(a.err, 0u, 1u) == 0u) {
+                    a.err[1] = span; a.err[2] = cur - block_start; a.err[3] = back; a.err[4] = len;
+                    a.err[5] = q_pos; a.err[6] = q_end; a.err[7] = 0;
+                }
+            }
+            return;
+        }
+        uint32_t l3 = 0;
+        if (back == LITERAL) {
+            l3 = literal_bytes(in, cur, cur - block_start, z) | (z.state >= 7 ? 1u << 24 : 0u);
+            if (lane == 0) { a.sym_len[cur] = 0; a.sym_dist[cur] = l3; }
+        } else if (lane == 0) {
+            a.sym_len[cur] = (uint16_t)len;
+            a.sym_dist[cur] = back >= 4 ? back - 4 : back == 0 ? z.rep0 : back == 1 ? z.rep1 : back == 2 ? z.rep2 : z.rep3;
+        }
+        encode_symbol_t<false, true>(rc, probs, z, cur - block_start, back, len, l3);
+        if (a.trace && lane == 0) {
+            const uint32_t ti = atomicAdd(a.trace_count, 1u);
+            if (ti < a.trace_cap) {
+                a.trace[4 * ti] = span;
+                a.trace[4 * ti + 1] = cur - block_start;
+                a.trace[4 * ti + 2] = back;
+                a.trace[4 * ti + 3] = len;
+            }
+        }
+        cur += len;
+    }
+    if (k == 0) {
+        // the seed piece leaves the prior of the Block: the LDS part here, the literal part is this slot's `lit`
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        wave_sync();
+        uint32_t* pr = a.prior + (uint64_t)blk * XZAMD_PRIOR_WORDS;
+        const uint32_t* p32 = reinterpret_cast<const uint32_t*>(probs);
+        for (uint32_t i = lane; i < W_PROBS; i += 64) pr[i] = p32[i];
+    }
+}
+
+template <uint32_t WMAX = WMAX_STD>
+__global__ __launch_bounds__(64)
+__attribute__((amdgpu_waves_per_eu(WMAX > WMAX_STD ? 3 : XZAMD_WAVES_OPT, WMAX > WMAX_STD ? 3 : XZAMD_WAVES_OPT)))
+void k_parse_pieces(xzamd_span_args a, uint32_t nslots, int phase, uint32_t* __restrict__ counter)
+{
+    for (;;) {
+        uint32_t s = blockIdx.x;
+        if (counter != nullptr) {
+            if (threadIdx.x == 0) s = atomicAdd(counter, 1u);
+            s = uni(s);
+        }
+        if (s >= nslots) break;
+        if (phase == 0) {
+            parse_piece_one<WMAX>(a, s * a.max_spb);                 // s = Block: its seed piece
+        } else {
+            const uint32_t slot = a.order ? a.order[s] : s;
+            if (slot % a.max_spb != 0) parse_piece_one<WMAX>(a, slot);
+        }
+        if (counter == nullptr) break;
+        __builtin_amdgcn_s_waitcnt(0);
+        wave_sync();
+    }
+}
+
+// ---- phase 2: range-code the recorded symbols of one encode span ----
+struct SymRow {
+    uint32_t base;          // position of lane 0 of `l` / `d`
+    uint32_t l, d;          // records of positions base + lane
+    uint32_t nl, nd;        // records of positions base + 64 + lane (in flight)
+};
+
+__device__ __forceinline__ void symrow_load(const xzamd_span_args& a, uint32_t pos, uint32_t& l, uint32_t& d)
+{
+    uint32_t x = pos + threadIdx.x;
+    x = x < a.n ? x : a.n - 1;
+    l = a.sym_len[x];
+    d = a.sym_dist[x];
+}
+
+__global__ __launch_bounds__(64) void k_encode_syms(xzamd_span_args a, uint32_t nslots)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t enc_pool[];
+    uint16_t* const probs = reinterpret_cast<uint16_t*>(enc_pool);
+    const uint32_t lane = threadIdx.x;
+    const uint32_t slot = blockIdx.x;
+    if (slot >= nslots) return;
+    const uint32_t blk = slot / a.max_esb;
+    const uint32_t k = slot - blk * a.max_esb;
+    if (k >= a.enc_cnt[blk]) return;
+    const uint32_t block_start = blk * a.block_size;
+    const uint32_t span_start = uni(a.enc_tab[2 * slot]), span_end = uni(a.enc_tab[2 * slot + 1]);
+    uint8_t* const outp = a.scratch + ((((uint64_t)span_start + (span_start >> 3)) + 15) & ~15ull) + (uint64_t)slot * XZAMD_SPAN_SLACK;
+    const uint32_t span_cap = (span_end - span_start) + ((span_end - span_start) >> 3) + 4096;
+    const uint8_t* __restrict__ in = a.in;
+    const uint32_t model_words = (P_LITERAL + (0x300u << (a.lc + a.lp)) + 1) / 2;
+
+    Lz z;
+    z.lc = a.lc; z.lp = a.lp; z.pb = a.pb;
+    z.cnt_len = z.cnt_match = z.cnt_align = 0;
+    z.lit = nullptr;
+    z.state = 0; z.rep0 = z.rep1 = z.rep2 = z.rep3 = 0;
+    RC rc;
+    rc.cpos = 0; rc.out = outp; rc.reset();
+
+    bool need_props = true, need_dict_reset = (span_start == block_start), need_state_reset = true;
+    uint32_t cur = span_start;
+    uint32_t out_off = 0;
+    SymRow R;
+    R.base = span_start;
+    symrow_load(a, span_start, R.l, R.d);
+    symrow_load(a, span_start + 64, R.nl, R.nd);
+
+    while (cur < span_end) {
+        if (need_state_reset) {
+            // lzma_lzma_encoder_reset (lzma_encoder.c:529-598); the flag stays set until a chunk header has announced it
+            for (uint32_t i = lane; i < model_words; i += 64) enc_pool[i] = 0x04000400u;
+            wave_sync();
+            z.state = 0; z.rep0 = z.rep1 = z.rep2 = z.rep3 = 0;
+        }
+        const uint32_t chunk_start = cur;
+        const uint32_t hl = need_props ? 6 : 5;
+        rc.out = outp + out_off + hl;
+        rc.cpos = 0;
+        rc.reset();
+        for (;;) {
+            // lzma_encoder.c:346-351 (limit from lzma2_encoder.c:167-181)
+            if (cur - chunk_start >= (1u << 21) - MATCH_LEN_MAX
+                    || rc.cpos + rc.cache_size + 4 >= 65536 - 4097)
+                break;
+            if (cur >= span_end)
+                break;
+            uint32_t off = cur - R.base;
+            if (off >= 64) {
+                if (off < 128) {
+                    R.l = R.nl; R.d = R.nd; R.base += 64; off -= 64;
+                } else {
+                    R.base = cur; off = 0;
+                    symrow_load(a, cur, R.l, R.d);
+                }
+                symrow_load(a, R.base + 64, R.nl, R.nd);
+            }
+            uint32_t len = lane_of(R.l, off);
+            const uint32_t d = lane_of(R.d, off);
+            uint32_t back, l3 = 0;
+            if (len == 0) {
+                back = LITERAL; len = 1; l3 = d;
+                if (z.state >= 7 && !(d >> 24))          // the parser was not in a matched state here (piece start): fetch the match byte
+                    l3 = (d & 0xFFFFu) | (uni(in[cur - z.rep0 - 1]) << 16);
+            } else if (len == 1) {
+                if (d == z.rep0) back = 0;
+                else { back = LITERAL; l3 = literal_bytes(in, cur, cur - block_start, z); }   // a short rep0 of another distance: code the byte
+            } else if (d == z.rep0) back = 0;
+            else if (d == z.rep1) back = 1;
+            else if (d == z.rep2) back = 2;
+            else if (d == z.rep3) back = 3;
+            else back = d + 4;
+            if (len > MATCH_LEN_MAX || cur + len > span_end
+                    || (back != LITERAL && back >= 4 && back - 4 >= cur - block_start)
+                    || out_off + hl + rc.cpos + 64 > span_cap) {
+                if (lane == 0 && a.err) {
+                    if (atomicCAS(a.err, 0u, 3u) == 0u) {
+                        a.err[1] = slot; a.err[2] = cur - block_start; a.err[3] = back; a.err[4] = len;
+                        a.err[5] = d; a.err[6] = 0; a.err[7] = out_off + rc.cpos;
+                    }
+                }
+                if (lane == 0) a.span_bytes[slot] = 0;
+                return;
+            }
+            encode_symbol_t<true, false>(rc, probs, z, cur - block_start, back, len, l3);
+            cur += len;
+        }
+        rc.flush();
+
+        const uint32_t usize = cur - chunk_start;
+        const uint32_t csize = rc.cpos;
+        uint8_t* const hdr = outp + out_off;
+        if (csize >= usize) {
+            // lzma2_encoder.c:205-214: store the chunk raw, the next LZMA chunk resets the state
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            for (uint32_t i = lane; i < usize; i += 64) hdr[3 + i] = in[chunk_start + i];
+            if (lane == 0) {
+                hdr[0] = need_dict_reset ? 1 : 2;
+                hdr[1] = (uint8_t)((usize - 1) >> 8);
+                hdr[2] = (uint8_t)(usize - 1);
+            }
+            need_dict_reset = false;
+            need_state_reset = true;
+            out_off += 3 + usize;
+            continue;
+        }
+        // lzma2_header_lzma (lzma2_encoder.c:54-106)
+        if (lane == 0) {
+            uint32_t c;
+            if (need_props) c = need_dict_reset ? 0xE0 : 0xC0;
+            else c = need_state_reset ? 0xA0 : 0x80;
+            hdr[0] = (uint8_t)(c + ((usize - 1) >> 16));
+            hdr[1] = (uint8_t)((usize - 1) >> 8);
+            hdr[2] = (uint8_t)(usize - 1);
+            hdr[3] = (uint8_t)((csize - 1) >> 8);
+            hdr[4] = (uint8_t)(csize - 1);
+            if (need_props) hdr[5] = (uint8_t)((a.pb * 5 + a.lp) * 9 + a.lc);
+        }
+        need_props = false; need_dict_reset = false; need_state_reset = false;
+        out_off += hl + csize;
+    }
+    if (lane == 0) a.span_bytes[slot] = out_off;
+}
+
+// ------------------------------------------------------------------------------------------
 // Batch match finders: one wavefront per run of FIND_RUN consecutive positions.  Because find and
 // skip both insert (lz_encoder_mf.c:366-441), the matches of a position depend on the data only, so
 // they are computed for every position of the batch ahead of the (serial) parser, which streams
@@ -2565,8 +2944,8 @@ __device__ __forceinline__ uint32_t wave_incl_sum(uint32_t v)
 
 __global__ __launch_bounds__(64) void k_span_cut(xzamd_span_args a, uint32_t nblocks, uint32_t cpb,
         const uint32_t* __restrict__ est, unsigned long long* __restrict__ totals, uint32_t* __restrict__ span_tab,
-        uint32_t* __restrict__ span_cnt, uint32_t cost_min, uint32_t bits_min, uint32_t min_len, uint32_t slots,
-        uint32_t* __restrict__ span_key)
+        uint32_t* __restrict__ span_cnt, uint32_t cost_min, uint32_t bits_min, uint32_t min_len,
+        uint32_t* __restrict__ enc_tab, uint32_t* __restrict__ enc_cnt, uint32_t* __restrict__ span_key)
 {
     const uint32_t lane = threadIdx.x;
     const uint32_t b = blockIdx.x;
@@ -2574,50 +2953,53 @@ __global__ __launch_bounds__(64) void k_span_cut(xzamd_span_args a, uint32_t nbl
     const uint32_t bs = b * a.block_size;
     const uint32_t be = min(a.n, bs + a.block_size);
     const uint32_t m = (be - bs + XZAMD_EST_CHUNK - 1) / XZAMD_EST_CHUNK;      // chunks of this Block
-    const unsigned long long batch_total = totals[nblocks], total = totals[b];
-    // Work target of a span.  A launch runs in rounds of `slots` wavefronts, so the spans of a batch that fills the GPU
-    // are sized for FULL rounds: R = ceil(rounds at cost_min) rounds of slightly lighter spans (down to 0.8 cost_min),
-    // else one round less of heavier ones.  A batch below one round keeps cost_min.
-    unsigned long long T = cost_min;
-    {
-        const unsigned long long denom = (unsigned long long)cost_min * slots;
-        if (batch_total > denom) {
-            unsigned long long R = (batch_total + denom - 1) / denom;
-            T = (batch_total + R * slots - 1) / (R * slots);
-            if (T * 5 < (unsigned long long)cost_min * 4 && R > 1) {
-                --R;
-                T = (batch_total + R * slots - 1) / (R * slots);
-            }
-        }
-    }
+    // Work target of a span: cost_min, whatever the batch or the GPU -- the plan (and with it the output) of a Block is
+    // a function of the Block and the options alone.
+    const unsigned long long T = cost_min;
     if (b == 0 && lane == 0) totals[nblocks + 1] = T;
     const uint32_t* wk = est + (uint64_t)b * cpb;
     const uint32_t* bt = est + nch + (uint64_t)b * cpb;
+    // two-phase: the first XZAMD_SEED_LEN bytes are the seed piece and the plan covers the rest
+    const bool two = a.enc_bits != 0;
+    const uint32_t seed_chunks = two && be - bs > XZAMD_SEED_LEN ? XZAMD_SEED_LEN / XZAMD_EST_CHUNK : 0u;
     // spans of this Block: total / T of equal estimated work, but no more than its estimated coded size allows at
-    // bits_min per span -- a state reset costs a few hundred bytes whatever the data, so what bounds the number of
-    // resets of a Block is its OUTPUT (highly compressible Blocks get fewer, longer spans)
-    unsigned long long total_bits = 0;
+    // bits_min per span (highly compressible Blocks get fewer, longer spans)
+    unsigned long long total = 0, total_bits = 0, all_bits = 0;
     for (uint32_t c0 = 0; c0 < m; c0 += 64) {
         const uint32_t c = c0 + lane;
-        total_bits += lane_of(wave_incl_sum(c < m ? bt[c] : 0u), 63);
+        const uint32_t vb = c < m ? bt[c] : 0u, vw = c < m ? wk[c] : 0u;
+        const bool planned = c >= seed_chunks;
+        all_bits += lane_of(wave_incl_sum(vb), 63);
+        total_bits += lane_of(wave_incl_sum(planned ? vb : 0u), 63);
+        total += lane_of(wave_incl_sum(planned ? vw : 0u), 63);
     }
     unsigned long long k = total / T;
     if (bits_min && total_bits / bits_min < k) k = total_bits / bits_min;
     if (k == 0) k = 1;
     const unsigned long long Tb = (total + k - 1) / k;
+    // encode spans (two-phase): ke of about equal estimated coded size, each closed at a piece end
+    unsigned long long ke = two ? all_bits / a.enc_bits : 1ull;
+    if (ke > (be - bs) / XZAMD_ENC_MIN_LEN) ke = (be - bs) / XZAMD_ENC_MIN_LEN;
+    if (ke == 0) ke = 1;
+    const unsigned long long Eb = (all_bits + ke - 1) / ke;
     uint32_t* tab = span_tab + 2ull * b * a.max_spb;
+    uint32_t* etab = two ? enc_tab + 2ull * b * a.max_esb : nullptr;
     uint32_t ns = 1, start = 0;                       // spans so far, first chunk of the open span
+    uint32_t ne = 1, estart = 0;                      // encode spans so far, first chunk of the open one
     unsigned long long carry_w = 0;                   // estimated work of the open span in front of the window
-    if (lane == 0) tab[0] = bs;
+    unsigned long long carry_b = 0;                   // estimated bits of the open encode span in front of the window
+    if (lane == 0) { tab[0] = bs; if (two) etab[0] = bs; }
     for (uint32_t c0 = 0; c0 < m; c0 += 64) {
         const uint32_t c = c0 + lane;
         const uint32_t pw = wave_incl_sum(c < m ? wk[c] : 0u);
+        const uint32_t pb = two ? wave_incl_sum(c < m ? bt[c] : 0u) : 0u;
         uint32_t subw = 0;                            // window sum up to the last cut inside the window
+        uint32_t subb = 0;                            // the same for the bits, up to the last encode cut
         for (;;) {
             const unsigned long long accw = carry_w + (pw - subw);
             const unsigned long long len = (unsigned long long)(c + 1 - start) * XZAMD_EST_CHUNK;
             const bool cut = c + 1 < m && c >= start && ns < a.max_spb
-                    && (len >= XZAMD_SPAN_MAX || (accw >= Tb && len >= min_len));
+                    && (len >= XZAMD_SPAN_MAX || (accw >= Tb && len >= min_len) || c + 1 == seed_chunks);
             const uint64_t mask = __builtin_amdgcn_ballot_w64(cut);
             if (!mask) break;
             const uint32_t L = (uint32_t)__builtin_ctzll(mask);
@@ -2625,21 +3007,33 @@ __global__ __launch_bounds__(64) void k_span_cut(xzamd_span_args a, uint32_t nbl
             const unsigned long long closed = carry_w + (lane_of(pw, L) - subw);      // estimated work of the span just closed
             subw = lane_of(pw, L);
             carry_w = 0;
+            const uint32_t p = bs + start * XZAMD_EST_CHUNK;
             if (lane == 0) {
-                const uint32_t p = bs + start * XZAMD_EST_CHUNK;
                 tab[2 * ns - 1] = p;                  // end of the span just closed
                 tab[2 * ns] = p;
                 // launch-order key: heaviest first (ascending sort of ~work); unused slots keep 0xFFFFFFFF = last
                 span_key[(uint64_t)b * a.max_spb + ns - 1] = ~(uint32_t)min(closed ? closed : 1ull, 0xFFFFFFFEull);
             }
             ++ns;
+            if (two) {
+                const unsigned long long accb = carry_b + (lane_of(pb, L) - subb);
+                if (accb >= Eb && (unsigned long long)(start - estart) * XZAMD_EST_CHUNK >= XZAMD_ENC_MIN_LEN && ne < a.max_esb) {
+                    if (lane == 0) { etab[2 * ne - 1] = p; etab[2 * ne] = p; }
+                    ++ne;
+                    estart = start;
+                    subb = lane_of(pb, L);
+                    carry_b = 0;
+                }
+            }
         }
         carry_w += lane_of(pw, 63) - subw;
+        carry_b += lane_of(pb, 63) - subb;
     }
     if (lane == 0) {
         tab[2 * ns - 1] = be;
         span_cnt[b] = ns;
         span_key[(uint64_t)b * a.max_spb + ns - 1] = ~(uint32_t)min(carry_w ? carry_w : 1ull, 0xFFFFFFFEull);
+        if (two) { etab[2 * ne - 1] = be; enc_cnt[b] = ne; }
     }
 }
 
@@ -3564,13 +3958,15 @@ int xzk_find_matches(const xzamd_span_args* a, const uint32_t* sa, const uint32_
 }
 
 int xzk_span_plan(const xzamd_span_args* a, uint32_t nblocks, uint32_t* est, unsigned long long* totals,
-        uint32_t* span_tab, uint32_t* span_cnt, uint32_t cost_min, uint32_t bits_min, uint32_t min_len, uint32_t slots,
+        uint32_t* span_tab, uint32_t* span_cnt, uint32_t cost_min, uint32_t bits_min, uint32_t min_len,
+        uint32_t* enc_tab, uint32_t* enc_cnt,
         uint32_t* order_bufs, void* sort_tmp, uint64_t sort_tmp_bytes, uint32_t** order_out, void* stream_)
 {
     hipStream_t st = (hipStream_t)stream_;
     if (order_out) *order_out = nullptr;
     if (nblocks == 0 || a->n == 0) return 0;
-    if (!a->mtop || a->max_spb == 0 || slots == 0 || cost_min == 0 || !order_bufs || !order_out) return (int)hipErrorInvalidValue;
+    if (!a->mtop || a->max_spb == 0 || cost_min == 0 || !order_bufs || !order_out) return (int)hipErrorInvalidValue;
+    if (a->enc_bits && (!enc_tab || !enc_cnt || a->max_esb == 0 || min_len < XZAMD_SEED_LEN)) return (int)hipErrorInvalidValue;
     const uint32_t cpb = (a->block_size + XZAMD_EST_CHUNK - 1) / XZAMD_EST_CHUNK;
     const uint32_t nslots = nblocks * a->max_spb;
     uint32_t* key_a = order_bufs;
@@ -3583,7 +3979,7 @@ int xzk_span_plan(const xzamd_span_args* a, uint32_t nblocks, uint32_t* est, uns
     const uint64_t nch = (uint64_t)nblocks * cpb;
     hipLaunchKernelGGL(k_span_est, dim3((uint32_t)((nch + 255) / 256)), dim3(256), 0, st, *a, nblocks, cpb, est, totals);
     hipLaunchKernelGGL(k_span_cut, dim3(nblocks), dim3(64), 0, st, *a, nblocks, cpb, est, totals, span_tab, span_cnt,
-            cost_min, bits_min, min_len, slots, key_a);
+            cost_min, bits_min, min_len, enc_tab, enc_cnt, key_a);
     // launch order: span slots by estimated work, heaviest first (a launch then ends with its short spans instead of
     // waiting for a heavy one that happened to start late); the order does not change a byte of the output
     hipLaunchKernelGGL(k_iota, dim3(grid_for(nslots, 256, 4096)), dim3(256), 0, st, val_a, nslots);
@@ -3621,6 +4017,38 @@ int xzk_span_encode(const xzamd_span_args* a, uint32_t nspans, uint32_t waves, u
         if (a->sa_window) return (int)hipErrorInvalidValue;      // the fast parser runs on the exact finder only
         hipLaunchKernelGGL((k_span_encode_t<0, false>), dim3(grid), dim3(64), 0, st, *a, nspans, cnt);
     }
+    return (int)hipGetLastError();
+}
+
+// Two-phase mode, phase 1 of the pipeline: the parse pieces.  phase 0 = the seed piece of every Block, 1 = the others.
+int xzk_parse_pieces(const xzamd_span_args* a, uint32_t nblocks, int phase, uint32_t waves, uint32_t* counter, void* stream_)
+{
+    hipStream_t st = (hipStream_t)stream_;
+    if (nblocks == 0) return 0;
+    if (!a->span_tab || !a->span_cnt || a->max_spb == 0 || !a->sym_len || !a->sym_dist || !a->prior || !a->lit
+            || (!a->mlen && !a->list_packed) || !a->mdist || !a->parser)
+        return (int)hipErrorInvalidValue;
+    const uint32_t nitems = phase == 0 ? nblocks : nblocks * a->max_spb;
+    const bool persist = phase != 0 && waves != 0 && counter != nullptr && waves < nitems;
+    const uint32_t grid = persist ? waves : nitems;
+    uint32_t* cnt = persist ? counter : nullptr;
+    if (a->nice_len > 128)
+        hipLaunchKernelGGL((k_parse_pieces<WMAX_LONG>), dim3(grid), dim3(64), 0, st, *a, nitems, phase, cnt);
+    else
+        hipLaunchKernelGGL((k_parse_pieces<WMAX_STD>), dim3(grid), dim3(64), 0, st, *a, nitems, phase, cnt);
+    return (int)hipGetLastError();
+}
+
+// Two-phase mode, phase 2: one wavefront per encode-span slot, the whole model in LDS.
+int xzk_encode_syms(const xzamd_span_args* a, uint32_t nblocks, void* stream_)
+{
+    hipStream_t st = (hipStream_t)stream_;
+    if (nblocks == 0) return 0;
+    if (!a->enc_tab || !a->enc_cnt || a->max_esb == 0 || !a->sym_len || !a->sym_dist || !a->scratch || !a->span_bytes)
+        return (int)hipErrorInvalidValue;
+    const uint32_t nslots = nblocks * a->max_esb;
+    const uint32_t lds = (((P_LITERAL + (0x300u << (a->lc + a->lp)) + 1) / 2) * 4 + 15) & ~15u;
+    hipLaunchKernelGGL(k_encode_syms, dim3(nslots), dim3(64), lds, st, *a, nslots);
     return (int)hipGetLastError();
 }
 

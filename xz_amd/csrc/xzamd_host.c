@@ -285,6 +285,7 @@ void xzamd_sn_defaults(xzamd_lzma_options *o)
 	 * and the longer parser window (kernels: WMAX_LONG) */
 	o->span_cost = XZAMD_SPAN_COST_DEFAULT;
 	o->span_bits = (o->gpu_nice_len > 128 ? 2 : 1) * XZAMD_SPAN_BITS_DEFAULT;
+	o->enc_span_bits = XZAMD_ENC_SPAN_BITS_DEFAULT;
 }
 
 int xzamd_lzma_preset(xzamd_lzma_options *o, uint32_t preset)
@@ -370,8 +371,10 @@ struct xzamd_ctx {
 	dbuf keys_a, keys_b, vals_a, vals_b, rank, sorted_pos, prev2, prev3, prev4, prev8, prev16, key64_a, key64_b, sa, sa_rank, sort_tmp;
 	dbuf scratch, span_bytes, strip_crc, block_crc, segs, lits, trace, errw, litp, mlen, mdist, mlen2, mdist2, bcj;
 	dbuf est, totals, span_tab, span_cnt, mtop, mtop2, order;      /* span plan (kernels_api.h) */
+	dbuf sym_len, sym_dist, prior, enc_tab, enc_cnt;               /* two-phase mode */
 	/* pinned host buffers */
-	dbuf h_span_bytes, h_block_crc, h_segs, h_lits, h_span_tab, h_span_cnt;
+	dbuf h_span_bytes, h_block_crc, h_segs, h_lits, h_span_tab, h_span_cnt, h_enc_tab, h_enc_cnt;
+	void *ev2[4];                /* two-phase stage timing: seeds done, pieces done, coded */
 	void *ev[10];
 	uint32_t trace_cap;
 	int trace_on;
@@ -427,6 +430,8 @@ int xzamd_ctx_create(xzamd_ctx **out, int device)
 		if (xzk_event_create(&c->ev_lo[i >> 2][i & 3])) { c->ev_lo[i >> 2][i & 3] = NULL; c->overlap_off = 1; }
 	for (int i = 0; i < 10; ++i)
 		if (xzk_event_create(&c->ev[i])) { c->ev[i] = NULL; xzamd_ctx_destroy(c); return XZAMD_DEVICE_ERROR; }
+	for (int i = 0; i < 4; ++i)
+		if (xzk_event_create(&c->ev2[i])) { c->ev2[i] = NULL; xzamd_ctx_destroy(c); return XZAMD_DEVICE_ERROR; }
 	{
 		const char *lim = getenv("XZAMD_TEST_ALLOC_LIMIT_MIB");
 		c->alloc_limit = (lim && *lim && atoll(lim) > 0) ? (uint64_t)atoll(lim) << 20 : 0;
@@ -462,14 +467,18 @@ void xzamd_ctx_destroy(xzamd_ctx *c)
 		&c->prev2, &c->prev3, &c->prev4, &c->prev8, &c->prev16, &c->key64_a, &c->key64_b, &c->sa, &c->sa_rank, &c->sort_tmp,
 		&c->scratch, &c->span_bytes, &c->strip_crc,
 		&c->block_crc, &c->segs, &c->lits, &c->trace, &c->errw, &c->litp, &c->mlen, &c->mdist, &c->mlen2, &c->mdist2, &c->bcj,
-		&c->est, &c->totals, &c->span_tab, &c->span_cnt, &c->mtop, &c->mtop2, &c->order };
+		&c->est, &c->totals, &c->span_tab, &c->span_cnt, &c->mtop, &c->mtop2, &c->order,
+		&c->sym_len, &c->sym_dist, &c->prior, &c->enc_tab, &c->enc_cnt };
 	for (size_t i = 0; i < sizeof(d) / sizeof(d[0]); ++i)
 		if (d[i]->p) xzk_free(d[i]->p);
-	dbuf *h[] = { &c->h_span_bytes, &c->h_block_crc, &c->h_segs, &c->h_lits, &c->h_span_tab, &c->h_span_cnt };
+	dbuf *h[] = { &c->h_span_bytes, &c->h_block_crc, &c->h_segs, &c->h_lits, &c->h_span_tab, &c->h_span_cnt,
+		&c->h_enc_tab, &c->h_enc_cnt };
 	for (size_t i = 0; i < sizeof(h) / sizeof(h[0]); ++i)
 		if (h[i]->p) xzk_host_free(h[i]->p);
 	for (int i = 0; i < 10; ++i)
 		if (c->ev[i]) xzk_event_destroy(c->ev[i]);
+	for (int i = 0; i < 4; ++i)
+		if (c->ev2[i]) xzk_event_destroy(c->ev2[i]);
 	for (int i = 0; i < 8; ++i)
 		if (c->ev_lo[i >> 2][i & 3]) xzk_event_destroy(c->ev_lo[i >> 2][i & 3]);
 	if (c->lo_stream) xzk_stream_destroy(c->lo_stream);
@@ -537,7 +546,9 @@ int xzamd_debug_fetch(xzamd_ctx *c, int what, void *out, uint64_t bytes)
 	const dbuf *b = what == XZAMD_DEBUG_SA ? &c->sa : what == XZAMD_DEBUG_SA_RANK ? &c->sa_rank
 			: what == XZAMD_DEBUG_LISTS ? &c->mdist : what == XZAMD_DEBUG_LIST_LENS ? &c->mlen
 			: what == XZAMD_DEBUG_SPAN_TAB ? &c->span_tab : what == XZAMD_DEBUG_SPAN_CNT ? &c->span_cnt
-			: what == XZAMD_DEBUG_SPAN_EST ? &c->est : what == XZAMD_DEBUG_LITP ? &c->litp : NULL;
+			: what == XZAMD_DEBUG_SPAN_EST ? &c->est : what == XZAMD_DEBUG_LITP ? &c->litp
+			: what == XZAMD_DEBUG_SYM_LEN ? &c->sym_len : what == XZAMD_DEBUG_SYM_DIST ? &c->sym_dist
+			: what == XZAMD_DEBUG_ENC_TAB ? &c->enc_tab : what == XZAMD_DEBUG_ENC_CNT ? &c->enc_cnt : NULL;
 	if (!b || !b->p || b->cap < bytes)
 		return XZAMD_PROG_ERROR;
 	xzk_set_device(c->device);
@@ -725,6 +736,9 @@ int xzamd_stream_encode_device(xzamd_ctx *c,
 	const int adaptive = opt->gpu_parser && opt->gpu_sa_window && opt->span_cost != 0
 			&& (opt->span_size == XZAMD_SPAN_DEFAULT || opt->span_size == XZAMD_SPAN_AUTO);
 	const uint32_t spb = adaptive ? (uint32_t)(block_size / XZAMD_SPAN_MIN_LEN + 2) : (uint32_t)((block_size + span - 1) / span);   /* span slots per Block */
+	/* Two-phase: the spans of the plan are parse pieces, the symbols they record are coded per encode span (esb slots per Block) */
+	const int two = adaptive && opt->enc_span_bits != 0;
+	const uint32_t esb = two ? (uint32_t)(block_size / XZAMD_ENC_MIN_LEN + 1) : 0;
 	const uint32_t cpb = (uint32_t)((block_size + XZAMD_EST_CHUNK - 1) / XZAMD_EST_CHUNK);
 	const uint64_t bound = xzamd_block_buffer_bound(block_size);
 	const int x86 = opt->bcj != 0;          /* any filter in front of LZMA2: the encoder reads a filtered copy */
@@ -765,6 +779,9 @@ int xzamd_stream_encode_device(xzamd_ctx *c,
 		const uint32_t n = g.n;
 		const uint64_t sort_bytes = g.sort_bytes;
 		const uint32_t nspans = (uint32_t)(nb * spb);
+		const uint32_t nenc = (uint32_t)(nb * esb);
+		const uint32_t nout = two ? nenc : nspans;            /* slots that write coded bytes */
+		const uint32_t opb = two ? esb : spb;
 		const uint32_t spb_crc = (uint32_t)((block_size + CRC_STRIP - 1) / CRC_STRIP);
 
 		/* Out of device memory: retry this batch with half the Blocks (retry_smaller releases every per-batch
@@ -783,8 +800,17 @@ int xzamd_stream_encode_device(xzamd_ctx *c,
 			GROW(rank, 4ull * n, 0); GROW(sorted_pos, 4ull * n, 0);
 		}
 		GROW(sort_tmp, sort_bytes + 256, 0);
-		GROW(scratch, (uint64_t)n + (n >> 3) + 32 + (uint64_t)XZAMD_SPAN_SLACK * nspans, 0);
-		GROW(span_bytes, 4ull * nspans, 0);
+		GROW(scratch, (uint64_t)n + (n >> 3) + 32 + (uint64_t)XZAMD_SPAN_SLACK * nout, 0);
+		GROW(span_bytes, 4ull * nout, 0);
+		if (two) {
+			GROW(sym_len, 2ull * n + 64, 0);
+			GROW(sym_dist, 4ull * n + 64, 0);
+			GROW(prior, 4ull * XZAMD_PRIOR_WORDS * nb, 0);
+			GROW(enc_tab, 8ull * nenc, 0);
+			GROW(enc_cnt, 4ull * nb, 0);
+			GROW(h_enc_tab, 8ull * nenc, 1);
+			GROW(h_enc_cnt, 4ull * nb + 16, 1);
+		}
 		GROW(span_tab, 8ull * nspans, 0);
 		GROW(span_cnt, 4ull * nb, 0);
 		GROW(h_span_tab, 8ull * nspans, 1);
@@ -811,10 +837,10 @@ int xzamd_stream_encode_device(xzamd_ctx *c,
 				GROW(mdist2, 32ull * n, 0);
 			}
 		}
-		GROW(h_span_bytes, 4ull * nspans, 1);
+		GROW(h_span_bytes, 4ull * nout, 1);
 		GROW(h_block_crc, 32ull * nb, 1);
 		/* plan capacity: per Block header + spans + trailer, or the stored form */
-		const uint64_t segs_per_block = spb + 2 + 2 * ((block_size + 65535) / 65536) + 2;
+		const uint64_t segs_per_block = opb + 2 + 2 * ((block_size + 65535) / 65536) + 2;
 		const uint64_t max_segs = nb * segs_per_block + 4;
 		const uint64_t max_lits = nb * (64 + 3 * ((block_size + 65535) / 65536) + 32) + 64;
 		GROW(segs, max_segs * sizeof(xzamd_copy_seg), 0);
@@ -883,6 +909,15 @@ int xzamd_stream_encode_device(xzamd_ctx *c,
 			a.depth = opt->gpu_depth;
 			a.hash_bytes = hb;
 			a.lc = opt->lc; a.lp = opt->lp; a.pb = opt->pb;
+			if (two) {
+				a.sym_len = (uint16_t *)c->sym_len.p;
+				a.sym_dist = (uint32_t *)c->sym_dist.p;
+				a.prior = (uint32_t *)c->prior.p;
+				a.enc_tab = (const uint32_t *)c->enc_tab.p;
+				a.enc_cnt = (const uint32_t *)c->enc_cnt.p;
+				a.max_esb = esb;
+				a.enc_bits = opt->enc_span_bits;
+			}
 			int e = 0;
 			uint16_t *const ml_cur = list_packed ? NULL : (uint16_t *)(lists_cur ? c->mlen2.p : c->mlen.p);
 			uint32_t *const md_cur = (uint32_t *)(lists_cur ? c->mdist2.p : c->mdist.p);
@@ -903,21 +938,24 @@ int xzamd_stream_encode_device(xzamd_ctx *c,
 			uint32_t *const htab = (uint32_t *)c->h_span_tab.p, *const hcnt = (uint32_t *)c->h_span_cnt.p;
 			xzk_event_record(c->ev[7], st);
 			if (adaptive) {
-				/* the rounds of the launch are those of the kernel variant that will run (360-node windows: 12 waves per CU) */
-				int occ = 0;
 				uint32_t *launch_order = NULL;
-				const uint32_t plan_slots = (xzk_span_occupancy(1, opt->gpu_nice_len, &occ) || occ <= 0 || occ > 32)
-						? c->wave_slots : c->cus * (uint32_t)occ;
-				c->stats.wave_slots = plan_slots;
+				{
+					int occ = 0;
+					c->stats.wave_slots = (xzk_span_occupancy(1, opt->gpu_nice_len, &occ) || occ <= 0 || occ > 32)
+							? c->wave_slots : c->cus * (uint32_t)occ;
+				}
 				e = xzk_span_plan(&a, (uint32_t)nb, (uint32_t *)c->est.p, (unsigned long long *)c->totals.p,
 						(uint32_t *)c->span_tab.p, (uint32_t *)c->span_cnt.p, opt->span_cost, opt->span_bits,
-						XZAMD_SPAN_MIN_LEN, plan_slots, (uint32_t *)c->order.p, c->sort_tmp.p, c->sort_tmp.cap, &launch_order, st);
+						XZAMD_SPAN_MIN_LEN, two ? (uint32_t *)c->enc_tab.p : NULL, two ? (uint32_t *)c->enc_cnt.p : NULL,
+						(uint32_t *)c->order.p, c->sort_tmp.p, c->sort_tmp.cap, &launch_order, st);
 				if (e) { rc = fail(c, XZAMD_DEVICE_ERROR, "span plan launch", e); goto done; }
 				a.order = launch_order;
 				/* the host lays the Blocks out from the plan: fetched with the span sizes below */
 				e = xzk_d2h(htab, c->span_tab.p, 8ull * nspans, st);
 				if (!e) e = xzk_d2h(hcnt, c->span_cnt.p, 4ull * nb, st);
 				if (!e) e = xzk_d2h(hcnt + 2 * ((nb + 1) / 2), (uint8_t *)c->totals.p + 8ull * (nb + 1), 8, st);   /* target used, behind the counts */
+				if (!e && two) e = xzk_d2h(c->h_enc_tab.p, c->enc_tab.p, 8ull * nenc, st);
+				if (!e && two) e = xzk_d2h(c->h_enc_cnt.p, c->enc_cnt.p, 4ull * nb, st);
 				if (e) { rc = fail(c, XZAMD_DEVICE_ERROR, "d2h span plan", e); goto done; }
 			} else {
 				for (uint64_t b = 0; b < nb; ++b) {
@@ -952,7 +990,17 @@ int xzamd_stream_encode_device(xzamd_ctx *c,
 			const int pf_after = c->prefetch_after;
 			for (int phase = 0; phase < 2; ++phase) {
 				if (phase == (pf_after ? 0 : 1)) {
-					e = xzk_span_encode(&a, nspans, c->span_waves, (uint32_t *)c->errw.p + 60, st);
+					if (two) {
+						/* seed pieces -> every other piece -> the coder */
+						xzk_event_record(c->ev2[0], st);
+						e = xzk_parse_pieces(&a, (uint32_t)nb, 0, 0, NULL, st);
+						xzk_event_record(c->ev2[1], st);
+						if (!e) e = xzk_parse_pieces(&a, (uint32_t)nb, 1, c->span_waves, (uint32_t *)c->errw.p + 60, st);
+						xzk_event_record(c->ev2[2], st);
+						if (!e) e = xzk_encode_syms(&a, (uint32_t)nb, st);
+						xzk_event_record(c->ev2[3], st);
+					} else
+						e = xzk_span_encode(&a, nspans, c->span_waves, (uint32_t *)c->errw.p + 60, st);
 					if (e) { rc = fail(c, XZAMD_DEVICE_ERROR, "span_encode launch", e); goto done; }
 					continue;
 				}
@@ -1000,7 +1048,7 @@ int xzamd_stream_encode_device(xzamd_ctx *c,
 		xzk_event_record(c->ev[3], st);
 		{
 			uint32_t herr[64] = { 0 };
-			int e = xzk_d2h(c->h_span_bytes.p, c->span_bytes.p, 4ull * nspans, st);
+			int e = xzk_d2h(c->h_span_bytes.p, c->span_bytes.p, 4ull * nout, st);
 			if (!e) e = xzk_d2h(herr, c->errw.p, 256, st);
 			if (!e) e = xzk_sync(st);
 			if (e) { rc = fail(c, XZAMD_DEVICE_ERROR, "span encode / d2h sizes", e); goto done; }
@@ -1032,16 +1080,19 @@ int xzamd_stream_encode_device(xzamd_ctx *c,
 		pl.lits = (uint8_t *)c->h_lits.p; pl.lits_len = 0; pl.lits_cap = max_lits;
 		pl.segs = (xzamd_copy_seg *)c->h_segs.p; pl.nsegs = 0; pl.segs_cap = max_segs;
 		const uint32_t *sb = (const uint32_t *)c->h_span_bytes.p;
-		const uint32_t *htab = (const uint32_t *)c->h_span_tab.p, *hcnt = (const uint32_t *)c->h_span_cnt.p;
+		const uint32_t *hcnt = (const uint32_t *)c->h_span_cnt.p;
+		/* the slots that hold coded bytes: the spans of the plan, or (two-phase) the encode spans */
+		const uint32_t *otab = (const uint32_t *)(two ? c->h_enc_tab.p : c->h_span_tab.p);
+		const uint32_t *ocnt = (const uint32_t *)(two ? c->h_enc_cnt.p : c->h_span_cnt.p);
 		const uint64_t *bcrc = (const uint64_t *)c->h_block_crc.p;
 		for (uint64_t b = 0; b < nb; ++b) {
 			const uint64_t boff = b * block_size;                 /* in batch */
 			const uint64_t usize = n64 - boff < block_size ? n64 - boff : block_size;
 			uint64_t payload = 1;                                 /* end marker */
-			const uint32_t nsp = hcnt[b];                         /* spans of this Block (slots b * spb ...) */
-			if (nsp == 0 || nsp > spb) { rc = fail(c, XZAMD_PROG_ERROR, "span plan out of range", 0); goto done; }
+			const uint32_t nsp = ocnt[b];                         /* coded spans of this Block (slots b * opb ...) */
+			if (nsp == 0 || nsp > opb || hcnt[b] == 0 || hcnt[b] > spb) { rc = fail(c, XZAMD_PROG_ERROR, "span plan out of range", 0); goto done; }
 			for (uint32_t s = 0; s < nsp; ++s)
-				payload += sb[b * spb + s];
+				payload += sb[b * opb + s];
 			const uint64_t pad = (4 - (payload & 3)) & 3;
 			const uint64_t bstart = opos;
 			uint64_t unp;
@@ -1071,7 +1122,7 @@ int xzamd_stream_encode_device(xzamd_ctx *c,
 				block_header_put(small, hs_fixed, payload, usize, dbyte, opt->bcj);
 				opos = plan_lit(&pl, small, hs_fixed, opos);
 				for (uint32_t s = 0; s < nsp; ++s) {
-					const uint64_t slot = b * spb + s, start = htab[2 * slot];
+					const uint64_t slot = b * opb + s, start = otab[2 * slot];
 					opos = plan_seg(&pl, 0, ((start + (start >> 3) + 15) & ~15ull) + slot * XZAMD_SPAN_SLACK, sb[slot], opos);
 				}
 				tail[tl++] = 0x00;
@@ -1124,6 +1175,12 @@ int xzamd_stream_encode_device(xzamd_ctx *c,
 		if (!xzk_event_elapsed_ms(c->ev[7], c->ev[6], &ms)) c->stats.ms_plan += ms;
 		c->stats.blocks += nb;
 		for (uint64_t b = 0; b < nb; ++b) c->stats.spans += hcnt[b];
+		if (two) {
+			for (uint64_t b = 0; b < nb; ++b) c->stats.enc_spans += ocnt[b];
+			if (!xzk_event_elapsed_ms(c->ev2[0], c->ev2[1], &ms)) c->stats.ms_seed += ms;
+			if (!xzk_event_elapsed_ms(c->ev2[1], c->ev2[2], &ms)) c->stats.ms_parse += ms;
+			if (!xzk_event_elapsed_ms(c->ev2[2], c->ev2[3], &ms)) c->stats.ms_code += ms;
+		}
 		if (adaptive) {
 			uint64_t tgt;
 			memcpy(&tgt, hcnt + 2 * ((nb + 1) / 2), 8);
@@ -1143,7 +1200,8 @@ retry_smaller:
 		{
 			dbuf *d[] = { &c->keys_a, &c->keys_b, &c->vals_a, &c->vals_b, &c->rank, &c->sorted_pos,
 				&c->prev2, &c->prev3, &c->prev4, &c->prev8, &c->prev16, &c->key64_a, &c->key64_b, &c->sa, &c->sa_rank,
-				&c->sort_tmp, &c->scratch, &c->litp, &c->mlen, &c->mdist, &c->mlen2, &c->mdist2, &c->bcj, &c->est, &c->mtop, &c->mtop2 };
+				&c->sort_tmp, &c->scratch, &c->litp, &c->mlen, &c->mdist, &c->mlen2, &c->mdist2, &c->bcj, &c->est, &c->mtop, &c->mtop2,
+				&c->order, &c->sym_len, &c->sym_dist };
 			for (size_t i = 0; i < sizeof(d) / sizeof(d[0]); ++i)
 				if (d[i]->p) { xzk_free(d[i]->p); d[i]->p = NULL; d[i]->cap = 0; }
 		}
