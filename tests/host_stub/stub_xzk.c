@@ -57,9 +57,9 @@ int xzk_build_chains(const uint8_t *d_in, uint32_t n, uint32_t block_size, uint3
 }
 
 int xzk_find_matches(const xzamd_span_args *a, const uint32_t *sa, const uint32_t *sa_rank, const uint32_t *prev4,
-		const uint64_t *rp8, const uint64_t *rp16, uint16_t *mlen, uint32_t *mdist, void *stream)
+		const uint64_t *rp8, const uint64_t *rp16, uint16_t *mlen, uint32_t *mdist, int part, void *stream)
 {
-	(void)a; (void)sa; (void)sa_rank; (void)prev4; (void)rp8; (void)rp16; (void)mlen; (void)mdist; (void)stream;
+	(void)a; (void)sa; (void)sa_rank; (void)prev4; (void)rp8; (void)rp16; (void)mlen; (void)mdist; (void)part; (void)stream;
 	return 0;
 }
 

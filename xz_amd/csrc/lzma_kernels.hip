@@ -81,6 +81,10 @@ __device__ __forceinline__ void wave_sync()
 }
 
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+// A wave-uniform value the compiler must keep in a scalar register from here on (no instruction is emitted when it is
+// there already): without the pin a loop-carried uniform chain can end up on the vector ALU as a whole.
+__device__ __forceinline__ void pin_s(uint32_t& v) { asm volatile("" : "+s"(v)); }
+__device__ __forceinline__ void pin_s(uint64_t& v) { asm volatile("" : "+s"(v)); }
 __device__ __forceinline__ uint32_t lane_of(uint32_t v, uint32_t l) { return __builtin_amdgcn_readlane(v, uni(l)); }
 
 // CRC32 table[0] entry for one byte (lz_encoder_hash.h:31-39 uses lzma_crc32_table[0]).
@@ -482,6 +486,10 @@ struct RC {
     uint32_t cache;
     uint32_t cpos;      // payload bytes written for the current chunk
     uint8_t* out;       // payload base of the current chunk
+#ifdef XZAMD_TIMING
+    uint64_t tm_run;    // cycles inside rc_run (profiling builds only)
+    uint64_t tm_bits;
+#endif
 
     __device__ __forceinline__ void reset()
     {
@@ -834,8 +842,13 @@ __device__ __forceinline__ void seg_add(SegSel& s, uint32_t& off, uint32_t n, ui
 // serial part: t = p (12 bits) | bit << 12 | direct << 13, one entry per lane 0..n-1
 // Entries [d0, d1) are direct bits (rc_direct), all others probability-coded; the latter are
 // written without data-dependent branches (the bit only selects via a mask).
+template <bool PIN>
 __device__ __forceinline__ void rc_run(RC& rc, uint32_t packed, uint32_t n, uint32_t d0, uint32_t d1)
 {
+#ifdef XZAMD_TIMING
+    const uint64_t t0_ = __builtin_amdgcn_s_memtime();
+    rc.tm_bits += n;
+#endif
     uint32_t k = 0;
     for (;;) {
         const uint32_t stop = k < d0 ? d0 : n;
@@ -846,6 +859,7 @@ __device__ __forceinline__ void rc_run(RC& rc, uint32_t packed, uint32_t n, uint
             const uint32_t bound = (rc.range >> 11) * (t & 0xFFFu);
             rc.low += bound & m;
             rc.range = bound + ((rc.range - 2 * bound) & m);   // 1: range - bound, 0: bound
+            if constexpr (PIN) { pin_s(rc.range); pin_s(rc.low); }
         }
         if (k >= n) break;
         for (; k < d1; ++k) {
@@ -853,8 +867,12 @@ __device__ __forceinline__ void rc_run(RC& rc, uint32_t packed, uint32_t n, uint
             rc.normalize();
             rc.range >>= 1;
             rc.low += rc.range & (0u - ((t >> 12) & 1u));
+            if constexpr (PIN) { pin_s(rc.range); pin_s(rc.low); }
         }
     }
+#ifdef XZAMD_TIMING
+    rc.tm_run += __builtin_amdgcn_s_memtime() - t0_;
+#endif
 }
 
 // CODE: run the range coder (false: the parse pieces of the two-phase mode only adapt their price model);
@@ -900,7 +918,7 @@ __device__ __forceinline__ void rc_emit(RC& rc, uint16_t* probs, uint32_t* lit, 
     }
     if constexpr (CODE) {
         const uint32_t packed = p | (bit << 12) | (direct ? 0x2000u : 0u);
-        rc_run(rc, packed, total, d0, d1);
+        rc_run<!LITG>(rc, packed, total, d0, d1);
     }
 }
 
@@ -2229,14 +2247,26 @@ __device__ __forceinline__ void parse_piece_one(const xzamd_span_args& a, const 
     constexpr uint32_t W_NODES = 6 * (WMAX + 1) + 2;                     // reps[4], price, info (16-byte multiple)
     constexpr uint32_t W_TABS = 128 + 72 + 32;                           // dsp, xt + ap (u16), ptab (u8)
     __shared__ __attribute__((aligned(16))) uint32_t pool[W_PROBS + W_NODES + W_TABS];
+#ifdef XZAMD_TIMING
+    __shared__ unsigned long long tm_lds[16];
+    if (threadIdx.x < 16) tm_lds[threadIdx.x] = 0;
+    const uint64_t tm_start = __builtin_amdgcn_s_memtime();
+#endif
     uint16_t* const probs = reinterpret_cast<uint16_t*>(pool);
     const uint32_t lane = threadIdx.x;
     const uint32_t blk = span / a.max_spb;
     const uint32_t k = span - blk * a.max_spb;
-    if (k >= a.span_cnt[blk]) return;                  // an unused slot of the span plan
     const uint32_t block_start = blk * a.block_size;
     const uint32_t block_end = min(a.n, block_start + a.block_size);
-    const uint32_t span_start = uni(a.span_tab[2 * span]), span_end = uni(a.span_tab[2 * span + 1]);
+    uint32_t span_start, span_end;
+    if (k == 0) {
+        // the seed piece is the same whatever the plan says (k_span_cut: seed_chunks), so it can run before the plan exists
+        span_start = block_start;
+        span_end = block_end - block_start > XZAMD_SEED_LEN ? block_start + XZAMD_SEED_LEN : block_end;
+    } else {
+        if (k >= a.span_cnt[blk]) return;              // an unused slot of the span plan
+        span_start = uni(a.span_tab[2 * span]); span_end = uni(a.span_tab[2 * span + 1]);
+    }
     const uint8_t* __restrict__ in = a.in;
 
     Env e;
@@ -2248,6 +2278,9 @@ __device__ __forceinline__ void parse_piece_one(const xzamd_span_args& a, const 
     LP.valid = false; LP.pos = 0; LP.sl = LP.sd = LP.tr = 0;
 
     Work w{};
+#ifdef XZAMD_TIMING
+    w.tm = tm_lds;
+#endif
     {
         uint32_t* nb = pool + W_PROBS;
         w.n_reps4 = reinterpret_cast<uint4*>(nb);
@@ -2321,10 +2354,12 @@ __device__ __forceinline__ void parse_piece_one(const xzamd_span_args& a, const 
     while (cur < span_end) {
         uint32_t back = LITERAL, len = 1;
         if (q_pos == q_end) {
+            TM_BEGIN(t_refresh);
             if (!tables_valid || z.cnt_len >= 64) { refresh_len_tables(probs, w.ptab, lt, 1u << z.pb, reinterpret_cast<uint32_t*>(w.n_reps4)); z.cnt_len = 0; }
             if (!tables_valid || z.cnt_match >= 128) { refresh_dist_tables(probs, w); z.cnt_match = 0; }
             if (!tables_valid || z.cnt_align >= 16) { refresh_align_table(probs, w); z.cnt_align = 0; }
             tables_valid = true;
+            TM_END(w, 7, t_refresh);
             if (!cached) {
                 round_lists(e, LP, cur, span_end, z.rep0, z.rep1, z.rep2, z.rep3, RL);
                 cached = true;
@@ -2375,7 +2410,12 @@ __device__ __forceinline__ void parse_piece_one(const xzamd_span_args& a, const 
             a.sym_len[cur] = (uint16_t)len;
             a.sym_dist[cur] = back >= 4 ? back - 4 : back == 0 ? z.rep0 : back == 1 ? z.rep1 : back == 2 ? z.rep2 : z.rep3;
         }
-        encode_symbol_t<false, true>(rc, probs, z, cur - block_start, back, len, l3);
+        {
+            TM_BEGIN(t_sym);
+            encode_symbol_t<false, true>(rc, probs, z, cur - block_start, back, len, l3);
+            TM_END(w, 6, t_sym);
+            TM_COUNT(w, 10);
+        }
         if (a.trace && lane == 0) {
             const uint32_t ti = atomicAdd(a.trace_count, 1u);
             if (ti < a.trace_cap) {
@@ -2395,6 +2435,17 @@ __device__ __forceinline__ void parse_piece_one(const xzamd_span_args& a, const 
         const uint32_t* p32 = reinterpret_cast<const uint32_t*>(probs);
         for (uint32_t i = lane; i < W_PROBS; i += 64) pr[i] = p32[i];
     }
+#ifdef XZAMD_TIMING
+    if (lane == 0 && a.err) {
+        tm_lds[8] = __builtin_amdgcn_s_memtime() - tm_start;
+        unsigned long long* g = reinterpret_cast<unsigned long long*>(a.err + 16);
+        for (int i = 0; i < 12; ++i) atomicAdd(g + i, tm_lds[i]);
+        atomicMax(g + 12, tm_lds[8]);
+        atomicAdd(g + 13, tm_lds[13]);
+        atomicAdd(g + 14, tm_lds[14]);
+        atomicAdd(g + 15, tm_lds[15]);
+    }
+#endif
 }
 
 template <uint32_t WMAX = WMAX_STD>
@@ -2460,8 +2511,15 @@ __global__ __launch_bounds__(64) void k_encode_syms(xzamd_span_args a, uint32_t 
     z.state = 0; z.rep0 = z.rep1 = z.rep2 = z.rep3 = 0;
     RC rc;
     rc.cpos = 0; rc.out = outp; rc.reset();
+#ifdef XZAMD_TIMING
+    rc.tm_run = 0; rc.tm_bits = 0;
+    uint64_t tm_sym = 0, tm_nsym = 0;
+    const uint64_t tm_start = __builtin_amdgcn_s_memtime();
+#endif
 
     bool need_props = true, need_dict_reset = (span_start == block_start), need_state_reset = true;
+    bool failed = false;
+    uint32_t f_pos = 0, f_back = 0, f_len = 0, f_d = 0;
     uint32_t cur = span_start;
     uint32_t out_off = 0;
     SymRow R;
@@ -2516,16 +2574,21 @@ __global__ __launch_bounds__(64) void k_encode_syms(xzamd_span_args a, uint32_t 
             if (len > MATCH_LEN_MAX || cur + len > span_end
                     || (back != LITERAL && back >= 4 && back - 4 >= cur - block_start)
                     || out_off + hl + rc.cpos + 64 > span_cap) {
-                if (lane == 0 && a.err) {
-                    if (atomicCAS(a.err, 0u, 3u) == 0u) {
-                        a.err[1] = slot; a.err[2] = cur - block_start; a.err[3] = back; a.err[4] = len;
-                        a.err[5] = d; a.err[6] = 0; a.err[7] = out_off + rc.cpos;
-                    }
-                }
-                if (lane == 0) a.span_bytes[slot] = 0;
-                return;
+                // internal consistency failure: report it and leave through the loop conditions (an early return from
+                // inside the loops costs the compiler its proof that the coder state is wave-uniform)
+                f_pos = cur - block_start; f_back = back; f_len = len; f_d = d;
+                failed = true;
+                cur = span_end;
+                break;
             }
+#ifdef XZAMD_TIMING
+            const uint64_t ts0 = __builtin_amdgcn_s_memtime();
+#endif
             encode_symbol_t<true, false>(rc, probs, z, cur - block_start, back, len, l3);
+#ifdef XZAMD_TIMING
+            tm_sym += __builtin_amdgcn_s_memtime() - ts0;
+            ++tm_nsym;
+#endif
             cur += len;
         }
         rc.flush();
@@ -2562,7 +2625,21 @@ __global__ __launch_bounds__(64) void k_encode_syms(xzamd_span_args a, uint32_t 
         need_props = false; need_dict_reset = false; need_state_reset = false;
         out_off += hl + csize;
     }
-    if (lane == 0) a.span_bytes[slot] = out_off;
+    if (failed && lane == 0 && a.err) {
+        if (atomicCAS(a.err, 0u, 3u) == 0u) {
+            a.err[1] = slot; a.err[2] = f_pos; a.err[3] = f_back; a.err[4] = f_len;
+            a.err[5] = f_d; a.err[6] = 0; a.err[7] = out_off;
+        }
+    }
+    if (lane == 0) a.span_bytes[slot] = failed ? 0u : out_off;
+#ifdef XZAMD_TIMING
+    if (lane == 0 && a.err) {
+        unsigned long long* g = reinterpret_cast<unsigned long long*>(a.err + 48);      // [0] total [1] in encode_symbol [2] in rc_run [3] symbols [4] bits [5] max span
+        const uint64_t tot = __builtin_amdgcn_s_memtime() - tm_start;
+        atomicAdd(g + 0, tot); atomicAdd(g + 1, tm_sym); atomicAdd(g + 2, rc.tm_run); atomicAdd(g + 3, tm_nsym); atomicAdd(g + 4, rc.tm_bits);
+        atomicMax(g + 5, tot);
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2622,7 +2699,12 @@ struct SnArgs {
     const uint32_t* __restrict__ prev4;
     const uint32_t* __restrict__ prev8;
     const uint32_t* __restrict__ prev16;
+    // Which runs a launch covers: 0 = all; 1 = the runs that touch the first XZAMD_SEED_LEN bytes of a Block (workgroup =
+    // Block * SEED_RUNS + j); 2 = all the others.  The two-phase mode parses the seed pieces (k_parse_pieces phase 0)
+    // underneath launch 2.
+    uint32_t mode;
 };
+constexpr uint32_t SEED_RUNS = XZAMD_SEED_LEN / 256 + 1;
 constexpr uint32_t SN_WMAX = 5;
 
 // Suffix-neighbourhood finder (oracle: find_sn).  Both hot kernels of this path are bound by instruction
@@ -2675,7 +2757,20 @@ __global__ __launch_bounds__(64) void k_find_sn(xzamd_span_args a, SnArgs sn, ui
 {
     const uint32_t lane = threadIdx.x;
     const uint32_t t = lane & 15, row = lane >> 4;
-    const uint32_t xr0 = blockIdx.x * FIND_RUN + row * ROW_RUN;          // first position of this row
+    uint32_t run = blockIdx.x;
+    if (sn.mode == 1) {
+        const uint32_t b = blockIdx.x / SEED_RUNS, j = blockIdx.x - b * SEED_RUNS;
+        const uint32_t bs = b * a.block_size;
+        run = bs / FIND_RUN + j;
+        if ((uint64_t)run * FIND_RUN >= (uint64_t)bs + XZAMD_SEED_LEN || (uint64_t)run * FIND_RUN >= a.n) return;
+    } else if (sn.mode == 2) {
+        // a run belongs to launch 1 when it starts inside the seed region of its Block or reaches into the next Block
+        const uint32_t x0 = run * FIND_RUN;
+        const uint32_t b = x0 / a.block_size, bs = b * a.block_size;
+        const uint64_t be = (uint64_t)bs + a.block_size;
+        if (x0 < bs + XZAMD_SEED_LEN || ((uint64_t)x0 + FIND_RUN > be && be < a.n)) return;
+    }
+    const uint32_t xr0 = run * FIND_RUN + row * ROW_RUN;                 // first position of this row
     const uint8_t* __restrict__ in = sn.in;
     const uint32_t W = a.sa_window;
     const uint32_t cyclic = a.dict_size + 1;
@@ -3939,18 +4034,21 @@ int xzk_build_chains(const uint8_t* d_in, uint32_t n, uint32_t block_size, uint3
 }
 
 int xzk_find_matches(const xzamd_span_args* a, const uint32_t* sa, const uint32_t* sa_rank, const uint32_t* prev4,
-        const uint64_t* rp8, const uint64_t* rp16, uint16_t* mlen, uint32_t* mdist, void* stream_)
+        const uint64_t* rp8, const uint64_t* rp16, uint16_t* mlen, uint32_t* mdist, int part, void* stream_)
 {
     hipStream_t st = (hipStream_t)stream_;
     const uint32_t runs = (a->n + FIND_RUN - 1) / FIND_RUN;
     if (runs == 0) return 0;
     if (a->sa_window) {
         if (!sa || !sa_rank || !prev4 || !rp8 || !rp16 || !a->mtop || a->sa_window > SN_WMAX) return (int)hipErrorInvalidValue;
+        if (part != 0 && a->block_size < XZAMD_SEED_LEN + 2 * FIND_RUN) return (int)hipErrorInvalidValue;
         SnArgs sn;
         sn.in = a->in; sn.sa = sa; sn.sa_rank = sa_rank; sn.prev2 = a->prev2; sn.prev4 = prev4;
         sn.prev8 = reinterpret_cast<const uint32_t*>(rp8) + a->n;     // second array of the round's (rank, distance) pair
         sn.prev16 = reinterpret_cast<const uint32_t*>(rp16) + a->n;
-        hipLaunchKernelGGL(k_find_sn, dim3(runs), dim3(64), 0, st, *a, sn, mlen, mdist);
+        sn.mode = (uint32_t)part;
+        const uint32_t nblocks = (a->n + a->block_size - 1) / a->block_size;
+        hipLaunchKernelGGL(k_find_sn, dim3(part == 1 ? nblocks * SEED_RUNS : runs), dim3(64), 0, st, *a, sn, mlen, mdist);
     } else {
         hipLaunchKernelGGL(k_find_exact, dim3(runs), dim3(64), 0, st, *a, mlen, mdist);
     }
@@ -4025,7 +4123,7 @@ int xzk_parse_pieces(const xzamd_span_args* a, uint32_t nblocks, int phase, uint
 {
     hipStream_t st = (hipStream_t)stream_;
     if (nblocks == 0) return 0;
-    if (!a->span_tab || !a->span_cnt || a->max_spb == 0 || !a->sym_len || !a->sym_dist || !a->prior || !a->lit
+    if ((phase != 0 && (!a->span_tab || !a->span_cnt)) || a->max_spb == 0 || !a->sym_len || !a->sym_dist || !a->prior || !a->lit
             || (!a->mlen && !a->list_packed) || !a->mdist || !a->parser)
         return (int)hipErrorInvalidValue;
     const uint32_t nitems = phase == 0 ? nblocks : nblocks * a->max_spb;

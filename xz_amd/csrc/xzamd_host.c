@@ -352,32 +352,36 @@ typedef struct {
 	uint64_t cap;
 } dbuf;
 
+/* stage events of one batch (one set per parity of the two-stream pipeline) */
+enum { EV_START, EV_CHAINS, EV_FIND, EV_PLAN0, EV_PLAN1, EV_SEED, EV_PARSE, EV_FRONT, EV_BACK0, EV_CODE, EV_CRC, EV_ASM, EV_COUNT };
+
 struct xzamd_ctx {
 	int device;
 	void *own_stream;
-	void *lo_stream;             /* lowest priority: the next batch's chain build runs here, under the span kernel */
-	void *ev_lo[2][4];           /* per list buffer: find done (hi), chains begin / end (lo), prefetched find done (lo) */
+	void *st2;                   /* back-end stream: range coder, checks and gather of batch i run here while the front end
+	                                (match structures, plan, parse) of batch i + 1 runs on the caller's stream */
+	void *st3;                   /* the seed pieces of a batch run here, underneath the rest of its match finder */
+	void *ev_seed[2][3];            /* seed lists ready (caller's stream), seeds begin / done (st3) */
+	void *ev_sha;                /* SHA-256 of the batch (second stream) done */
 	uint64_t batch_bytes;
 	uint32_t wave_slots;         /* span wavefronts resident at once (CUs x occupancy of the standard span kernel) */
 	uint32_t cus;
 	uint32_t span_waves;         /* != 0: persistent span kernel with this many wavefronts */
-	int prefetch_after;          /* XZAMD_PREFETCH_AFTER=1: enqueue the next batch's build behind the span kernel launch instead of in front of it */
-	int sha_early;               /* this batch's SHA-256 was launched on the second stream */
-	int overlap_off;             /* an event of the low-priority pipeline could not be created: no prefetch */
 	uint64_t alloc_limit;        /* test hook (XZAMD_TEST_ALLOC_LIMIT_MIB, read once at creation): larger allocations fail; 0 = none */
 	char err[256];
 	char err_msg_buf[200];
 	/* device buffers */
 	dbuf keys_a, keys_b, vals_a, vals_b, rank, sorted_pos, prev2, prev3, prev4, prev8, prev16, key64_a, key64_b, sa, sa_rank, sort_tmp;
-	dbuf scratch, span_bytes, strip_crc, block_crc, segs, lits, trace, errw, litp, mlen, mdist, mlen2, mdist2, bcj;
-	dbuf est, totals, span_tab, span_cnt, mtop, mtop2, order;      /* span plan (kernels_api.h) */
-	dbuf sym_len, sym_dist, prior, enc_tab, enc_cnt;               /* two-phase mode */
+	dbuf scratch, span_bytes, strip_crc, block_crc, segs, lits, trace, errw, errw2, litp, mlen, mdist, bcj[2];
+	dbuf est, totals, span_tab, span_cnt, mtop, order;             /* span plan (kernels_api.h) */
+	dbuf sym_len[2], sym_dist[2], prior, enc_tab[2], enc_cnt[2];   /* two-phase mode ([2]: one set per pipeline parity) */
 	/* pinned host buffers */
-	dbuf h_span_bytes, h_block_crc, h_segs, h_lits, h_span_tab, h_span_cnt, h_enc_tab, h_enc_cnt;
-	void *ev2[4];                /* two-phase stage timing: seeds done, pieces done, coded */
-	void *ev[10];
+	dbuf h_span_bytes, h_block_crc, h_segs, h_lits, h_span_tab, h_span_cnt[2], h_enc_tab[2], h_enc_cnt[2], h_err[2];
+	void *evp[2][EV_COUNT];
+	void *ev_total[2];
 	uint32_t trace_cap;
 	int trace_on;
+	int last_par;                /* pipeline parity of the last batch (debug fetches) */
 	xzamd_stats stats;
 };
 
@@ -425,13 +429,15 @@ int xzamd_ctx_create(xzamd_ctx **out, int device)
 	c->device = device;
 	/* from here on every failure goes through xzamd_ctx_destroy (streams and events already made are released) */
 	if (xzk_stream_create(&c->own_stream)) { c->own_stream = NULL; xzamd_ctx_destroy(c); return XZAMD_DEVICE_ERROR; }
-	if (xzk_stream_create_low(&c->lo_stream)) c->lo_stream = NULL;      /* no overlap then */
-	for (int i = 0; i < 8; ++i)
-		if (xzk_event_create(&c->ev_lo[i >> 2][i & 3])) { c->ev_lo[i >> 2][i & 3] = NULL; c->overlap_off = 1; }
-	for (int i = 0; i < 10; ++i)
-		if (xzk_event_create(&c->ev[i])) { c->ev[i] = NULL; xzamd_ctx_destroy(c); return XZAMD_DEVICE_ERROR; }
-	for (int i = 0; i < 4; ++i)
-		if (xzk_event_create(&c->ev2[i])) { c->ev2[i] = NULL; xzamd_ctx_destroy(c); return XZAMD_DEVICE_ERROR; }
+	if (xzk_stream_create(&c->st2)) { c->st2 = NULL; xzamd_ctx_destroy(c); return XZAMD_DEVICE_ERROR; }
+	if (xzk_event_create(&c->ev_sha)) { c->ev_sha = NULL; xzamd_ctx_destroy(c); return XZAMD_DEVICE_ERROR; }
+	if (xzk_stream_create(&c->st3)) { c->st3 = NULL; xzamd_ctx_destroy(c); return XZAMD_DEVICE_ERROR; }
+	for (int i = 0; i < 6; ++i)
+		if (xzk_event_create(&c->ev_seed[i / 3][i % 3])) { c->ev_seed[i / 3][i % 3] = NULL; xzamd_ctx_destroy(c); return XZAMD_DEVICE_ERROR; }
+	for (int i = 0; i < 2 * EV_COUNT; ++i)
+		if (xzk_event_create(&c->evp[i / EV_COUNT][i % EV_COUNT])) { c->evp[i / EV_COUNT][i % EV_COUNT] = NULL; xzamd_ctx_destroy(c); return XZAMD_DEVICE_ERROR; }
+	for (int i = 0; i < 2; ++i)
+		if (xzk_event_create(&c->ev_total[i])) { c->ev_total[i] = NULL; xzamd_ctx_destroy(c); return XZAMD_DEVICE_ERROR; }
 	{
 		const char *lim = getenv("XZAMD_TEST_ALLOC_LIMIT_MIB");
 		c->alloc_limit = (lim && *lim && atoll(lim) > 0) ? (uint64_t)atoll(lim) << 20 : 0;
@@ -448,8 +454,6 @@ int xzamd_ctx_create(xzamd_ctx **out, int device)
 		 * register space for the low-priority stream's kernels); 0 / unset: one wavefront per span */
 		const char *pw = getenv("XZAMD_SPAN_WAVES_PER_CU");
 		c->span_waves = (pw && atoi(pw) > 0) ? (uint32_t)cus * (uint32_t)atoi(pw) : 0;
-		const char *pa = getenv("XZAMD_PREFETCH_AFTER");
-		c->prefetch_after = pa && *pa == '1';
 	}
 	const char *env = getenv("XZAMD_BATCH_MIB");
 	if (env && atoll(env) > 0)
@@ -458,30 +462,43 @@ int xzamd_ctx_create(xzamd_ctx **out, int device)
 	return XZAMD_OK;
 }
 
+static void ctx_device_bufs(xzamd_ctx *c, dbuf **d, size_t *nd)
+{
+	dbuf *all[] = { &c->keys_a, &c->keys_b, &c->vals_a, &c->vals_b, &c->rank, &c->sorted_pos,
+		&c->prev2, &c->prev3, &c->prev4, &c->prev8, &c->prev16, &c->key64_a, &c->key64_b, &c->sa, &c->sa_rank, &c->sort_tmp,
+		&c->scratch, &c->litp, &c->mlen, &c->mdist, &c->bcj[0], &c->bcj[1], &c->est, &c->mtop, &c->order,
+		&c->sym_len[0], &c->sym_len[1], &c->sym_dist[0], &c->sym_dist[1],
+		/* small ones */
+		&c->span_bytes, &c->strip_crc, &c->block_crc, &c->segs, &c->lits, &c->trace, &c->errw, &c->errw2,
+		&c->totals, &c->span_tab, &c->span_cnt, &c->prior, &c->enc_tab[0], &c->enc_tab[1], &c->enc_cnt[0], &c->enc_cnt[1] };
+	*nd = sizeof(all) / sizeof(all[0]);
+	memcpy(d, all, sizeof(all));
+}
+#define CTX_NBIG 29      /* the first CTX_NBIG entries of ctx_device_bufs scale with the batch */
+
 void xzamd_ctx_destroy(xzamd_ctx *c)
 {
 	if (!c)
 		return;
 	xzk_set_device(c->device);
-	dbuf *d[] = { &c->keys_a, &c->keys_b, &c->vals_a, &c->vals_b, &c->rank, &c->sorted_pos,
-		&c->prev2, &c->prev3, &c->prev4, &c->prev8, &c->prev16, &c->key64_a, &c->key64_b, &c->sa, &c->sa_rank, &c->sort_tmp,
-		&c->scratch, &c->span_bytes, &c->strip_crc,
-		&c->block_crc, &c->segs, &c->lits, &c->trace, &c->errw, &c->litp, &c->mlen, &c->mdist, &c->mlen2, &c->mdist2, &c->bcj,
-		&c->est, &c->totals, &c->span_tab, &c->span_cnt, &c->mtop, &c->mtop2, &c->order,
-		&c->sym_len, &c->sym_dist, &c->prior, &c->enc_tab, &c->enc_cnt };
-	for (size_t i = 0; i < sizeof(d) / sizeof(d[0]); ++i)
+	dbuf *d[64];
+	size_t nd = 0;
+	ctx_device_bufs(c, d, &nd);
+	for (size_t i = 0; i < nd; ++i)
 		if (d[i]->p) xzk_free(d[i]->p);
-	dbuf *h[] = { &c->h_span_bytes, &c->h_block_crc, &c->h_segs, &c->h_lits, &c->h_span_tab, &c->h_span_cnt,
-		&c->h_enc_tab, &c->h_enc_cnt };
+	dbuf *h[] = { &c->h_span_bytes, &c->h_block_crc, &c->h_segs, &c->h_lits, &c->h_span_tab, &c->h_span_cnt[0], &c->h_span_cnt[1],
+		&c->h_enc_tab[0], &c->h_enc_tab[1], &c->h_enc_cnt[0], &c->h_enc_cnt[1], &c->h_err[0], &c->h_err[1] };
 	for (size_t i = 0; i < sizeof(h) / sizeof(h[0]); ++i)
 		if (h[i]->p) xzk_host_free(h[i]->p);
-	for (int i = 0; i < 10; ++i)
-		if (c->ev[i]) xzk_event_destroy(c->ev[i]);
-	for (int i = 0; i < 4; ++i)
-		if (c->ev2[i]) xzk_event_destroy(c->ev2[i]);
-	for (int i = 0; i < 8; ++i)
-		if (c->ev_lo[i >> 2][i & 3]) xzk_event_destroy(c->ev_lo[i >> 2][i & 3]);
-	if (c->lo_stream) xzk_stream_destroy(c->lo_stream);
+	for (int i = 0; i < 2 * EV_COUNT; ++i)
+		if (c->evp[i / EV_COUNT][i % EV_COUNT]) xzk_event_destroy(c->evp[i / EV_COUNT][i % EV_COUNT]);
+	for (int i = 0; i < 2; ++i)
+		if (c->ev_total[i]) xzk_event_destroy(c->ev_total[i]);
+	if (c->ev_sha) xzk_event_destroy(c->ev_sha);
+	for (int i = 0; i < 6; ++i)
+		if (c->ev_seed[i / 3][i % 3]) xzk_event_destroy(c->ev_seed[i / 3][i % 3]);
+	if (c->st3) xzk_stream_destroy(c->st3);
+	if (c->st2) xzk_stream_destroy(c->st2);
 	if (c->own_stream) xzk_stream_destroy(c->own_stream);
 	free(c);
 }
@@ -547,8 +564,8 @@ int xzamd_debug_fetch(xzamd_ctx *c, int what, void *out, uint64_t bytes)
 			: what == XZAMD_DEBUG_LISTS ? &c->mdist : what == XZAMD_DEBUG_LIST_LENS ? &c->mlen
 			: what == XZAMD_DEBUG_SPAN_TAB ? &c->span_tab : what == XZAMD_DEBUG_SPAN_CNT ? &c->span_cnt
 			: what == XZAMD_DEBUG_SPAN_EST ? &c->est : what == XZAMD_DEBUG_LITP ? &c->litp
-			: what == XZAMD_DEBUG_SYM_LEN ? &c->sym_len : what == XZAMD_DEBUG_SYM_DIST ? &c->sym_dist
-			: what == XZAMD_DEBUG_ENC_TAB ? &c->enc_tab : what == XZAMD_DEBUG_ENC_CNT ? &c->enc_cnt : NULL;
+			: what == XZAMD_DEBUG_SYM_LEN ? &c->sym_len[c->last_par] : what == XZAMD_DEBUG_SYM_DIST ? &c->sym_dist[c->last_par]
+			: what == XZAMD_DEBUG_ENC_TAB ? &c->enc_tab[c->last_par] : what == XZAMD_DEBUG_ENC_CNT ? &c->enc_cnt[c->last_par] : NULL;
 	if (!b || !b->p || b->cap < bytes)
 		return XZAMD_PROG_ERROR;
 	xzk_set_device(c->device);
@@ -670,6 +687,193 @@ static int launch_chains(xzamd_ctx *c, const xzamd_lzma_options *opt, const uint
 
 #define HIPCHK(call, what) do { int e_ = (call); if (e_) return fail(c, XZAMD_DEVICE_ERROR, what, e_); } while (0)
 
+/* What the front end of a batch (match structures, plan, parse -- the caller's stream) hands to its back end (range
+ * coder of the two-phase mode, Block checks, sizes, layout, gather -- the second stream when the two are pipelined). */
+typedef struct {
+	int active;
+	uint64_t b0, nb, in_off, n64;
+	uint32_t n, nspans, nout, opb;
+	int par;                     /* which set of the double-buffered tables / events this batch uses */
+	const uint8_t *enc_in;       /* what LZMA2 reads (the filtered copy when a filter runs in front of it) */
+	int find_timed, seeds_early;
+	uint64_t max_segs, max_lits;
+} batch_run;
+
+/* constants of one xzamd_stream_encode_device call */
+typedef struct {
+	const xzamd_lzma_options *opt;
+	const uint8_t *d_in;
+	uint8_t *d_out;
+	uint64_t block_size, out_cap, bound, binfo_cap;
+	uint32_t spb, esb, cbytes, hs_fixed;
+	int check, two, adaptive, whole;
+	uint8_t dbyte;
+	void *st, *stb;
+	uint64_t *rec_unp, *rec_unc;
+	xzamd_block_info *binfo;
+	uint64_t opos;
+} job_env;
+
+/* Second half of a batch's back end: wait for the sizes, lay the Blocks out (the ordered output queue of the
+ * reference, outqueue.c) and gather them into the Stream. */
+static int back_finish(xzamd_ctx *c, job_env *J, batch_run *B)
+{
+	const xzamd_lzma_options *opt = J->opt;
+	const uint64_t nb = B->nb, block_size = J->block_size, n64 = B->n64;
+	const uint32_t spb = J->spb, opb = B->opb, cbytes = J->cbytes;
+	const int two = J->two, check = J->check, par = B->par;
+	uint8_t small[64];
+	B->active = 0;
+	{
+		int e = xzk_sync(J->stb);
+		if (e) return fail(c, XZAMD_DEVICE_ERROR, "span encode / d2h sizes", e);
+		const uint32_t *herr = (const uint32_t *)c->h_err[par].p;           /* front end: parser / single-phase span kernel */
+		const uint32_t *herr2 = herr + 128;                                /* back end: coder of the two-phase mode */
+		if (getenv("XZAMD_TIMING") && herr[8])
+			fprintf(stderr, "[timing span0] total %u round1 %u round2 %u encode %u (x256 clk) rounds %u symbols %u\n",
+					herr[8], herr[9], herr[10], herr[11], herr[12], herr[13]);
+		if (getenv("XZAMD_TIMING")) {
+			const uint64_t *t = (const uint64_t *)(herr + 16);
+			if (t[8])
+				fprintf(stderr, "[timing opt, Mcycles summed over spans] total %llu | derive %llu round %llu bits %llu lit %llu relax %llu "
+						"backtrack %llu encode %llu refresh %llu | nodes %llu symbols %llu windows %llu | span max %llu Mcyc | compound nodes %llu price %llu gather %llu\n",
+						(unsigned long long)(t[8] >> 20), (unsigned long long)(t[0] >> 20), (unsigned long long)(t[1] >> 20),
+						(unsigned long long)(t[2] >> 20), (unsigned long long)(t[3] >> 20), (unsigned long long)(t[4] >> 20),
+						(unsigned long long)(t[5] >> 20), (unsigned long long)(t[6] >> 20), (unsigned long long)(t[7] >> 20),
+						(unsigned long long)t[9], (unsigned long long)t[10], (unsigned long long)t[11],
+						(unsigned long long)(t[12] >> 20), (unsigned long long)t[13], (unsigned long long)(t[14] >> 20), (unsigned long long)(t[15] >> 20));
+			const uint64_t *t2 = (const uint64_t *)(herr2 + 48);
+			if (t2[0])
+				fprintf(stderr, "[timing coder, Mcycles summed over encode spans] total %llu | encode_symbol %llu of which rc_run %llu | "
+						"symbols %llu bits %llu | span max %llu Mcyc\n", (unsigned long long)(t2[0] >> 20), (unsigned long long)(t2[1] >> 20),
+						(unsigned long long)(t2[2] >> 20), (unsigned long long)t2[3], (unsigned long long)t2[4], (unsigned long long)(t2[5] >> 20));
+		}
+		const uint32_t *he = herr[0] ? herr : herr2[0] ? herr2 : NULL;
+		if (he) {
+			snprintf(c->err_msg_buf, sizeof(c->err_msg_buf),
+					"span encoder consistency check %u failed: %u %u %u %u %u %u %u",
+					he[0], he[1], he[2], he[3], he[4], he[5], he[6], he[7]);
+			return fail(c, XZAMD_PROG_ERROR, c->err_msg_buf, 0);
+		}
+	}
+
+	plan pl;
+	pl.lits = (uint8_t *)c->h_lits.p; pl.lits_len = 0; pl.lits_cap = B->max_lits;
+	pl.segs = (xzamd_copy_seg *)c->h_segs.p; pl.nsegs = 0; pl.segs_cap = B->max_segs;
+	const uint32_t *sb = (const uint32_t *)c->h_span_bytes.p;
+	const uint32_t *hcnt = (const uint32_t *)c->h_span_cnt[par].p;
+	/* the slots that hold coded bytes: the spans of the plan, or (two-phase) the encode spans */
+	const uint32_t *otab = (const uint32_t *)(two ? c->h_enc_tab[par].p : c->h_span_tab.p);
+	const uint32_t *ocnt = (const uint32_t *)(two ? c->h_enc_cnt[par].p : c->h_span_cnt[par].p);
+	const uint64_t *bcrc = (const uint64_t *)c->h_block_crc.p;
+	uint64_t opos = J->opos;
+	for (uint64_t b = 0; b < nb; ++b) {
+		const uint64_t boff = b * block_size;                 /* in batch */
+		const uint64_t usize = n64 - boff < block_size ? n64 - boff : block_size;
+		uint64_t payload = 1;                                 /* end marker */
+		const uint32_t nsp = ocnt[b];                         /* coded spans of this Block (slots b * opb ...) */
+		if (nsp == 0 || nsp > opb || hcnt[b] == 0 || hcnt[b] > spb)
+			return fail(c, XZAMD_PROG_ERROR, "span plan out of range", 0);
+		for (uint32_t s = 0; s < nsp; ++s)
+			payload += sb[b * opb + s];
+		const uint64_t pad = (4 - (payload & 3)) & 3;
+		const uint64_t bstart = opos;
+		uint64_t unp;
+		uint8_t tail[48];
+		uint32_t tl = 0;
+		if (J->hs_fixed + payload + pad + cbytes > J->bound) {
+			/* stream_encoder_mt.c:298,316-344 -> block_buffer_encoder.c:88-162 */
+			const uint64_t csz = usize + ((usize + 65535) / 65536) * 3 + 1;
+			const uint32_t hs = block_header_size(csz, usize, 0);      /* stored Blocks drop the BCJ filter */
+			if (opos + hs + csz + 3 + cbytes > J->out_cap) return fail(c, XZAMD_BUF_ERROR, "output buffer too small", 0);
+			block_header_put(small, hs, csz, usize, 0x00, 0);
+			opos = plan_lit(&pl, small, hs, opos);
+			uint8_t ctl = 0x01;
+			for (uint64_t ip = 0; ip < usize; ip += 65536) {
+				const uint64_t cs = usize - ip < 65536 ? usize - ip : 65536;
+				uint8_t ch[3] = { ctl, (uint8_t)((cs - 1) >> 8), (uint8_t)(cs - 1) };
+				ctl = 0x02;
+				opos = plan_lit(&pl, ch, 3, opos);
+				opos = plan_seg(&pl, 2, boff + ip, cs, opos);
+			}
+			tail[tl++] = 0x00;
+			while ((csz + (tl - 1)) & 3) tail[tl++] = 0;
+			unp = hs + csz + cbytes;
+			++c->stats.blocks_stored;
+		} else {
+			if (opos + J->hs_fixed + payload + pad + cbytes > J->out_cap) return fail(c, XZAMD_BUF_ERROR, "output buffer too small", 0);
+			block_header_put(small, J->hs_fixed, payload, usize, J->dbyte, opt->bcj);
+			opos = plan_lit(&pl, small, J->hs_fixed, opos);
+			for (uint32_t s = 0; s < nsp; ++s) {
+				const uint64_t slot = b * opb + s, start = otab[2 * slot];
+				opos = plan_seg(&pl, 0, ((start + (start >> 3) + 15) & ~15ull) + slot * XZAMD_SPAN_SLACK, sb[slot], opos);
+			}
+			tail[tl++] = 0x00;
+			for (uint64_t i = 0; i < pad; ++i) tail[tl++] = 0;
+			unp = J->hs_fixed + payload + cbytes;
+		}
+		if (check == XZAMD_CHECK_CRC64) {
+			const uint64_t v = bcrc[b];
+			le32(tail + tl, (uint32_t)v);
+			le32(tail + tl + 4, (uint32_t)(v >> 32));
+			tl += 8;
+		} else if (check == XZAMD_CHECK_CRC32) {
+			le32(tail + tl, (uint32_t)bcrc[b]);
+			tl += 4;
+		} else if (check == XZAMD_CHECK_SHA256) {
+			memcpy(tail + tl, (const uint8_t *)c->h_block_crc.p + 32 * b, 32);
+			tl += 32;
+		}
+		opos = plan_lit(&pl, tail, tl, opos);
+		const uint64_t gi = B->b0 + b;
+		if (J->whole) { J->rec_unp[gi] = unp; J->rec_unc[gi] = usize; }
+		if (J->binfo && gi < J->binfo_cap) {
+			J->binfo[gi].unpadded_size = unp;
+			J->binfo[gi].uncompressed_size = usize;
+			J->binfo[gi].out_offset = bstart;
+			J->binfo[gi].total_size = opos - bstart;
+		}
+	}
+	J->opos = opos;
+	if (pl.nsegs > pl.segs_cap || pl.lits_len > pl.lits_cap) return fail(c, XZAMD_PROG_ERROR, "plan overflow", 0);
+
+	/* gather (the literal pieces and the segment table leave the pinned buffers before the call returns) */
+	{
+		int e = xzk_h2d(c->segs.p, pl.segs, pl.nsegs * sizeof(xzamd_copy_seg), J->stb);
+		if (!e) e = xzk_h2d(c->lits.p, pl.lits, pl.lits_len ? pl.lits_len : 1, J->stb);
+		if (!e) e = xzk_assemble((const xzamd_copy_seg *)c->segs.p, (uint32_t)pl.nsegs,
+				(const uint8_t *)c->scratch.p, (const uint8_t *)c->lits.p, J->d_in + B->in_off, J->d_out, J->stb);
+		xzk_event_record(c->evp[par][EV_ASM], J->stb);
+		if (!e) e = xzk_sync(J->stb);
+		if (e) return fail(c, XZAMD_DEVICE_ERROR, "assemble", e);
+	}
+	float ms;
+	void **ev = c->evp[par];
+	if (!xzk_event_elapsed_ms(ev[EV_START], ev[EV_CHAINS], &ms)) c->stats.ms_chains += ms;
+	if (!xzk_event_elapsed_ms(ev[EV_CHAINS], ev[EV_FRONT], &ms)) c->stats.ms_encode += ms;
+	if (B->find_timed && !xzk_event_elapsed_ms(ev[EV_CHAINS], ev[EV_FIND], &ms)) c->stats.ms_find += ms;
+	if (!xzk_event_elapsed_ms(ev[EV_PLAN0], ev[EV_PLAN1], &ms)) c->stats.ms_plan += ms;
+	if (!xzk_event_elapsed_ms(ev[EV_CODE], ev[EV_CRC], &ms)) c->stats.ms_crc += ms;
+	if (!xzk_event_elapsed_ms(ev[EV_CRC], ev[EV_ASM], &ms)) c->stats.ms_assemble += ms;
+	c->stats.blocks += nb;
+	for (uint64_t b = 0; b < nb; ++b) c->stats.spans += hcnt[b];
+	if (two) {
+		for (uint64_t b = 0; b < nb; ++b) c->stats.enc_spans += ocnt[b];
+		if (B->seeds_early) { if (!xzk_event_elapsed_ms(c->ev_seed[par][1], c->ev_seed[par][2], &ms)) c->stats.ms_seed += ms; }
+		else if (!xzk_event_elapsed_ms(ev[EV_PLAN1], ev[EV_SEED], &ms)) c->stats.ms_seed += ms;
+		if (!xzk_event_elapsed_ms(ev[EV_SEED], ev[EV_PARSE], &ms)) c->stats.ms_parse += ms;
+		if (!xzk_event_elapsed_ms(ev[EV_BACK0], ev[EV_CODE], &ms)) { c->stats.ms_code += ms; c->stats.ms_encode += ms; }
+	}
+	if (J->adaptive) {
+		uint64_t tgt;
+		memcpy(&tgt, hcnt + 2 * ((nb + 1) / 2), 8);
+		c->stats.span_cost_used = tgt > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)tgt;
+	}
+	c->stats.batches += 1;
+	c->stats.encode_launches += 1;
+	return XZAMD_OK;
+}
+
 int xzamd_stream_encode_device(xzamd_ctx *c,
 		const void *d_in_, uint64_t in_size, uint64_t block_size,
 		const xzamd_lzma_options *opt, int check, uint32_t flags,
@@ -740,37 +944,46 @@ int xzamd_stream_encode_device(xzamd_ctx *c,
 	const int two = adaptive && opt->enc_span_bits != 0;
 	const uint32_t esb = two ? (uint32_t)(block_size / XZAMD_ENC_MIN_LEN + 1) : 0;
 	const uint32_t cpb = (uint32_t)((block_size + XZAMD_EST_CHUNK - 1) / XZAMD_EST_CHUNK);
-	const uint64_t bound = xzamd_block_buffer_bound(block_size);
 	const int x86 = opt->bcj != 0;          /* any filter in front of LZMA2: the encoder reads a filtered copy */
-	const uint32_t hs_fixed = block_header_size(bound, block_size, opt->bcj);
-	const uint8_t dbyte = dict_size_byte(opt->dict_size);
+	/* Two-stream pipeline (two-phase mode): the back end of batch i -- range coder, checks, sizes, gather -- runs on the
+	 * second stream while the front end of batch i + 1 -- match structures, plan, parse -- runs on the caller's: the coder
+	 * is a few thousand latency-bound wavefronts, the structure build is HBM-bound, they share the GPU well.  The
+	 * single-phase kernels read the match structures while they code, so their batches stay serial. */
+	const int pipelined = two && total_blocks > max_blocks && getenv("XZAMD_NO_OVERLAP") == NULL;
+
+	job_env J;
+	memset(&J, 0, sizeof(J));
+	J.opt = opt; J.d_in = d_in; J.d_out = d_out; J.block_size = block_size; J.out_cap = out_cap;
+	J.bound = xzamd_block_buffer_bound(block_size);
+	J.binfo = binfo; J.binfo_cap = binfo_cap;
+	J.spb = spb; J.esb = esb; J.cbytes = cbytes; J.hs_fixed = block_header_size(J.bound, block_size, opt->bcj);
+	J.check = check; J.two = two; J.adaptive = adaptive;
+	J.dbyte = dict_size_byte(opt->dict_size);
+	J.st = st; J.stb = pipelined ? c->st2 : st;
+	J.whole = !(flags & XZAMD_F_BLOCKS_ONLY);
 
 	memset(&c->stats, 0, sizeof(c->stats));
 	c->stats.span_size = adaptive ? 0 : span;
 	c->stats.wave_slots = c->wave_slots;
-	uint64_t opos = 0;
 	uint8_t small[64];
-	uint64_t *rec_unp = NULL, *rec_unc = NULL;
-	const int whole = !(flags & XZAMD_F_BLOCKS_ONLY);
-	if (whole) {
-		rec_unp = (uint64_t *)malloc(sizeof(uint64_t) * (total_blocks + 1) * 2);
-		if (!rec_unp)
+	if (J.whole) {
+		J.rec_unp = (uint64_t *)malloc(sizeof(uint64_t) * (total_blocks + 1) * 2);
+		if (!J.rec_unp)
 			return fail(c, XZAMD_MEM_ERROR, "malloc", 0);
-		rec_unc = rec_unp + total_blocks + 1;
-		if (out_cap < 12) { free(rec_unp); return fail(c, XZAMD_BUF_ERROR, "output buffer too small", 0); }
+		J.rec_unc = J.rec_unp + total_blocks + 1;
+		if (out_cap < 12) { free(J.rec_unp); return fail(c, XZAMD_BUF_ERROR, "output buffer too small", 0); }
 		xzamd_frame_header(small, check);
 		int e = xzk_h2d(d_out, small, 12, st);
 		if (!e) e = xzk_sync(st);
-		if (e) { free(rec_unp); return fail(c, XZAMD_DEVICE_ERROR, "h2d header", e); }
-		opos = 12;
+		if (e) { free(J.rec_unp); return fail(c, XZAMD_DEVICE_ERROR, "h2d header", e); }
+		J.opos = 12;
 	}
 
 	int rc = XZAMD_OK;
-	/* chain-build overlap: more than one batch, no BCJ copy to double-buffer, not disabled */
-	const int overlap = c->lo_stream != NULL && !c->overlap_off && !x86 && total_blocks > max_blocks && getenv("XZAMD_NO_OVERLAP") == NULL;
-	int prefetched = 0, chains_on_lo = 0, lists_cur = 0, find_on_lo = 0;
-	uint64_t prefetched_b0 = 0;
-	xzk_event_record(c->ev[8], st);
+	batch_run prev;
+	memset(&prev, 0, sizeof(prev));
+	uint64_t batch_index = 0;
+	xzk_event_record(c->ev_total[0], st);
 	for (uint64_t b0 = 0; b0 < total_blocks && rc == XZAMD_OK; ) {
 		batch_geo g;
 		rc = batch_geometry(c, opt, b0, total_blocks, max_blocks, block_size, in_size, hbits, &g);
@@ -783,6 +996,8 @@ int xzamd_stream_encode_device(xzamd_ctx *c,
 		const uint32_t nout = two ? nenc : nspans;            /* slots that write coded bytes */
 		const uint32_t opb = two ? esb : spb;
 		const uint32_t spb_crc = (uint32_t)((block_size + CRC_STRIP - 1) / CRC_STRIP);
+		const int par = pipelined ? (int)(batch_index & 1) : 0;
+		void **ev = c->evp[par];
 
 		/* Out of device memory: retry this batch with half the Blocks (retry_smaller releases every per-batch
 		 * buffer first). */
@@ -802,19 +1017,19 @@ int xzamd_stream_encode_device(xzamd_ctx *c,
 		GROW(sort_tmp, sort_bytes + 256, 0);
 		GROW(scratch, (uint64_t)n + (n >> 3) + 32 + (uint64_t)XZAMD_SPAN_SLACK * nout, 0);
 		GROW(span_bytes, 4ull * nout, 0);
-		if (two) {
-			GROW(sym_len, 2ull * n + 64, 0);
-			GROW(sym_dist, 4ull * n + 64, 0);
-			GROW(prior, 4ull * XZAMD_PRIOR_WORDS * nb, 0);
-			GROW(enc_tab, 8ull * nenc, 0);
-			GROW(enc_cnt, 4ull * nb, 0);
-			GROW(h_enc_tab, 8ull * nenc, 1);
-			GROW(h_enc_cnt, 4ull * nb + 16, 1);
-		}
 		GROW(span_tab, 8ull * nspans, 0);
 		GROW(span_cnt, 4ull * nb, 0);
 		GROW(h_span_tab, 8ull * nspans, 1);
-		GROW(h_span_cnt, 4ull * nb + 16, 1);
+		GROW(h_span_cnt[par], 4ull * nb + 16, 1);
+		if (two) {
+			GROW(sym_len[par], 2ull * n + 64, 0);
+			GROW(sym_dist[par], 4ull * n + 64, 0);
+			GROW(prior, 4ull * XZAMD_PRIOR_WORDS * nb, 0);
+			GROW(enc_tab[par], 8ull * nenc, 0);
+			GROW(enc_cnt[par], 4ull * nb, 0);
+			GROW(h_enc_tab[par], 8ull * nenc, 1);
+			GROW(h_enc_cnt[par], 4ull * nb + 16, 1);
+		}
 		if (adaptive) {
 			GROW(est, 8ull * nb * cpb, 0);
 			GROW(totals, 8ull * (nb + 2), 0);
@@ -822,7 +1037,9 @@ int xzamd_stream_encode_device(xzamd_ctx *c,
 		}
 		GROW(strip_crc, 8ull * spb_crc * nb, 0);
 		GROW(block_crc, 32ull * nb, 0);
-		GROW(errw, 256, 0);
+		GROW(errw, 512, 0);
+		GROW(errw2, 512, 0);
+		GROW(h_err[par], 1024, 1);
 		GROW(litp, (uint64_t)nspans * (0x300ull << (opt->lc + opt->lp)) * 4ull, 0);
 		if (opt->gpu_parser) {
 			/* per-position match lists: 8 x u32 (7 entries + trailer), + 8 x u16 lengths when not packed */
@@ -830,12 +1047,6 @@ int xzamd_stream_encode_device(xzamd_ctx *c,
 			GROW(mdist, 32ull * n, 0);
 			/* + 32: k_span_est reads the summaries eight at a time (16 bytes) and may look past the last position */
 			if (opt->gpu_sa_window) GROW(mtop, 2ull * n + 32, 0);
-			if (overlap && opt->gpu_sa_window) GROW(mtop2, 2ull * n + 32, 0);
-			if (overlap) {
-				/* second list buffer: the next batch's finder runs underneath this batch's span kernel */
-				if (!list_packed) GROW(mlen2, 16ull * n, 0);
-				GROW(mdist2, 32ull * n, 0);
-			}
 		}
 		GROW(h_span_bytes, 4ull * nout, 1);
 		GROW(h_block_crc, 32ull * nb, 1);
@@ -847,96 +1058,109 @@ int xzamd_stream_encode_device(xzamd_ctx *c,
 		GROW(lits, max_lits, 0);
 		GROW(h_segs, max_segs * sizeof(xzamd_copy_seg), 1);
 		GROW(h_lits, max_lits, 1);
+		if (x86) GROW(bcj[par], (uint64_t)n + 16, 0);
 
+		batch_run cur;
+		memset(&cur, 0, sizeof(cur));
+		cur.active = 1; cur.b0 = b0; cur.nb = nb; cur.in_off = in_off; cur.n64 = n64; cur.n = n;
+		cur.nspans = nspans; cur.nout = nout; cur.opb = opb; cur.par = par;
+		cur.max_segs = max_segs; cur.max_lits = max_lits;
+		c->last_par = par;
+
+		/* ================= front end, on the caller's stream ================= */
 		/* 0. BCJ pre-pass: LZMA2 sees the filtered copy, the Check and stored Blocks the original */
 		const uint8_t *enc_in = d_in + in_off;
-		xzk_event_record(c->ev[0], st);
+		xzk_event_record(ev[EV_START], st);
+		int sha_early = 0;
+		if (check == XZAMD_CHECK_SHA256 && !pipelined) {
+			/* SHA-256 is a serial hash per Block: on the second stream, underneath everything else of the batch */
+			int e3 = xzk_stream_wait_event(c->st2, ev[EV_START]);
+			if (!e3) e3 = xzk_sha256_blocks(d_in + in_off, n, (uint32_t)block_size, (uint32_t)nb, (uint8_t *)c->block_crc.p, c->st2);
+			if (!e3) e3 = xzk_event_record(c->ev_sha, c->st2);
+			if (e3) { rc = fail(c, XZAMD_DEVICE_ERROR, "sha256 launch", e3); goto done; }
+			sha_early = 1;
+		}
 		if (x86) {
-			GROW(bcj, (uint64_t)n + 16, 0);
 			int e = opt->bcj == XZAMD_BCJ_X86
-					? xzk_x86_bcj(d_in + in_off, (uint8_t *)c->bcj.p, n, (uint32_t)block_size, (uint32_t)nb, st)
-					: xzk_prefilter(d_in + in_off, (uint8_t *)c->bcj.p, n, (uint32_t)block_size, (uint32_t)nb, opt->bcj & 0xFF,
+					? xzk_x86_bcj(d_in + in_off, (uint8_t *)c->bcj[par].p, n, (uint32_t)block_size, (uint32_t)nb, st)
+					: xzk_prefilter(d_in + in_off, (uint8_t *)c->bcj[par].p, n, (uint32_t)block_size, (uint32_t)nb, opt->bcj & 0xFF,
 							(opt->bcj >> 8) + 1, st);
 			if (e) { rc = fail(c, XZAMD_DEVICE_ERROR, "filter in front of LZMA2", e); goto done; }
-			enc_in = (const uint8_t *)c->bcj.p;
+			enc_in = (const uint8_t *)c->bcj[par].p;
 		}
-		/* 1. match-finder structure: built on the caller's stream, unless the previous iteration already
-		 * started it on the low-priority stream underneath its span kernel */
-		if (prefetched && prefetched_b0 == b0) {
-			/* chains AND match lists of this batch were produced on the low-priority stream (into the other
-			 * list buffer) while the previous span kernel ran */
-			lists_cur ^= 1;
-			if (xzk_stream_wait_event(st, c->ev_lo[lists_cur][3])) { rc = fail(c, XZAMD_DEVICE_ERROR, "wait chains", 1); goto done; }
-			chains_on_lo = 1;
-			find_on_lo = 1;
-		} else {
-			rc = launch_chains(c, opt, enc_in, &g, block_size, hb, hmask, hbits, st);
-			if (rc != XZAMD_OK) goto done;
-			chains_on_lo = 0;
-			find_on_lo = 0;
+		cur.enc_in = enc_in;
+		/* 1. match-finder structure */
+		rc = launch_chains(c, opt, enc_in, &g, block_size, hb, hmask, hbits, st);
+		if (rc != XZAMD_OK) goto done;
+		xzk_event_record(ev[EV_CHAINS], st);
+		xzamd_span_args a;
+		memset(&a, 0, sizeof(a));
+		a.in = enc_in;
+		a.rank = (const uint32_t *)c->rank.p;
+		a.sorted_pos = (const uint32_t *)c->sorted_pos.p;
+		a.prev2 = (const uint32_t *)c->prev2.p;
+		a.prev3 = (const uint32_t *)c->prev3.p;
+		a.sa_window = opt->gpu_sa_window;
+		a.parser = opt->gpu_parser;
+		a.scratch = (uint8_t *)c->scratch.p;
+		a.span_tab = (const uint32_t *)c->span_tab.p;
+		a.span_cnt = (const uint32_t *)c->span_cnt.p;
+		a.max_spb = spb;
+		a.span_bytes = (uint32_t *)c->span_bytes.p;
+		a.err = (uint32_t *)c->errw.p;
+		a.lit = (uint32_t *)c->litp.p;
+		if (xzk_memset(c->errw.p, 0, 512, st)) { rc = fail(c, XZAMD_DEVICE_ERROR, "memset", 1); goto done; }
+		if (c->trace_on) {
+			a.trace_count = (uint32_t *)c->trace.p;
+			a.trace = (uint32_t *)((uint8_t *)c->trace.p + 16);
+			a.trace_cap = c->trace_cap;
 		}
-		prefetched = 0;
-		xzk_event_record(c->ev[1], st);
-		/* 2. span encode */
+		a.n = n;
+		a.block_size = (uint32_t)block_size;
+		a.span_size = span;
+		a.dict_size = opt->dict_size;
+		a.nice_len = opt->gpu_nice_len;
+		a.depth = opt->gpu_depth;
+		a.hash_bytes = hb;
+		a.lc = opt->lc; a.lp = opt->lp; a.pb = opt->pb;
+		if (two) {
+			a.sym_len = (uint16_t *)c->sym_len[par].p;
+			a.sym_dist = (uint32_t *)c->sym_dist[par].p;
+			a.prior = (uint32_t *)c->prior.p;
+			a.enc_tab = (const uint32_t *)c->enc_tab[par].p;
+			a.enc_cnt = (const uint32_t *)c->enc_cnt[par].p;
+			a.max_esb = esb;
+			a.enc_bits = opt->enc_span_bits;
+		}
 		{
-			xzamd_span_args a;
-			memset(&a, 0, sizeof(a));
-			a.in = enc_in;
-			a.rank = (const uint32_t *)c->rank.p;
-			a.sorted_pos = (const uint32_t *)c->sorted_pos.p;
-			a.prev2 = (const uint32_t *)c->prev2.p;
-			a.prev3 = (const uint32_t *)c->prev3.p;
-			a.sa_window = opt->gpu_sa_window;
-			a.parser = opt->gpu_parser;
-			a.scratch = (uint8_t *)c->scratch.p;
-			a.span_tab = (const uint32_t *)c->span_tab.p;
-			a.span_cnt = (const uint32_t *)c->span_cnt.p;
-			a.max_spb = spb;
-			a.span_bytes = (uint32_t *)c->span_bytes.p;
-			a.err = (uint32_t *)c->errw.p;
-			a.lit = (uint32_t *)c->litp.p;
-			if (xzk_memset(c->errw.p, 0, 256, st)) { rc = fail(c, XZAMD_DEVICE_ERROR, "memset", 1); goto done; }
-			if (c->trace_on) {
-				a.trace_count = (uint32_t *)c->trace.p;
-				a.trace = (uint32_t *)((uint8_t *)c->trace.p + 16);
-				a.trace_cap = c->trace_cap;
-			}
-			a.n = n;
-			a.block_size = (uint32_t)block_size;
-			a.span_size = span;
-			a.dict_size = opt->dict_size;
-			a.nice_len = opt->gpu_nice_len;
-			a.depth = opt->gpu_depth;
-			a.hash_bytes = hb;
-			a.lc = opt->lc; a.lp = opt->lp; a.pb = opt->pb;
-			if (two) {
-				a.sym_len = (uint16_t *)c->sym_len.p;
-				a.sym_dist = (uint32_t *)c->sym_dist.p;
-				a.prior = (uint32_t *)c->prior.p;
-				a.enc_tab = (const uint32_t *)c->enc_tab.p;
-				a.enc_cnt = (const uint32_t *)c->enc_cnt.p;
-				a.max_esb = esb;
-				a.enc_bits = opt->enc_span_bits;
-			}
-			int e = 0;
-			uint16_t *const ml_cur = list_packed ? NULL : (uint16_t *)(lists_cur ? c->mlen2.p : c->mlen.p);
-			uint32_t *const md_cur = (uint32_t *)(lists_cur ? c->mdist2.p : c->mdist.p);
+			int e = 0, seeds_early = 0;
 			if (opt->gpu_parser) {
-				/* 2a. batch match finder -> lists the parser streams (unless already made on the low-priority stream) */
-				a.mlen = ml_cur;
+				/* 2a. batch match finder -> lists the parser streams */
+				a.mlen = list_packed ? NULL : (uint16_t *)c->mlen.p;
 				a.list_packed = (uint32_t)list_packed;
-				a.mdist = md_cur;
-				a.mtop = (uint16_t *)(lists_cur ? c->mtop2.p : c->mtop.p);
-				if (!find_on_lo) {
+				a.mdist = (uint32_t *)c->mdist.p;
+				a.mtop = (uint16_t *)c->mtop.p;
+				/* two-phase: the lists of the seed regions first, so that the seed pieces (one wavefront per Block, latency
+				 * bound) can be parsed on a third stream underneath the rest of the finder (HBM bound) */
+				seeds_early = two && block_size >= XZAMD_SEED_LEN + 1024 && getenv("XZAMD_NO_OVERLAP") == NULL;
+				if (seeds_early) {
 					e = xzk_find_matches(&a, (const uint32_t *)c->sa.p, (const uint32_t *)c->sa_rank.p, (const uint32_t *)c->prev4.p,
-							(const uint64_t *)c->prev8.p, (const uint64_t *)c->prev16.p, ml_cur, md_cur, st);
-					if (e) { rc = fail(c, XZAMD_DEVICE_ERROR, "find_matches launch", e); goto done; }
+							(const uint64_t *)c->prev8.p, (const uint64_t *)c->prev16.p, (uint16_t *)a.mlen, (uint32_t *)a.mdist, 1, st);
+					if (!e) e = xzk_event_record(c->ev_seed[par][0], st);
+					if (!e) e = xzk_stream_wait_event(c->st3, c->ev_seed[par][0]);
+					if (!e) e = xzk_event_record(c->ev_seed[par][1], c->st3);
+					if (!e) e = xzk_parse_pieces(&a, (uint32_t)nb, 0, 0, NULL, c->st3);
+					if (!e) e = xzk_event_record(c->ev_seed[par][2], c->st3);
 				}
-				xzk_event_record(c->ev[5], st);
+				if (!e) e = xzk_find_matches(&a, (const uint32_t *)c->sa.p, (const uint32_t *)c->sa_rank.p, (const uint32_t *)c->prev4.p,
+						(const uint64_t *)c->prev8.p, (const uint64_t *)c->prev16.p, (uint16_t *)a.mlen, (uint32_t *)a.mdist, seeds_early ? 2 : 0, st);
+				if (e) { rc = fail(c, XZAMD_DEVICE_ERROR, "find_matches launch", e); goto done; }
+				cur.find_timed = 1;
 			}
+			xzk_event_record(ev[EV_FIND], st);
 			/* 2b. span plan */
-			uint32_t *const htab = (uint32_t *)c->h_span_tab.p, *const hcnt = (uint32_t *)c->h_span_cnt.p;
-			xzk_event_record(c->ev[7], st);
+			uint32_t *const htab = (uint32_t *)c->h_span_tab.p, *const hcnt = (uint32_t *)c->h_span_cnt[par].p;
+			xzk_event_record(ev[EV_PLAN0], st);
 			if (adaptive) {
 				uint32_t *launch_order = NULL;
 				{
@@ -946,16 +1170,16 @@ int xzamd_stream_encode_device(xzamd_ctx *c,
 				}
 				e = xzk_span_plan(&a, (uint32_t)nb, (uint32_t *)c->est.p, (unsigned long long *)c->totals.p,
 						(uint32_t *)c->span_tab.p, (uint32_t *)c->span_cnt.p, opt->span_cost, opt->span_bits,
-						XZAMD_SPAN_MIN_LEN, two ? (uint32_t *)c->enc_tab.p : NULL, two ? (uint32_t *)c->enc_cnt.p : NULL,
+						XZAMD_SPAN_MIN_LEN, two ? (uint32_t *)c->enc_tab[par].p : NULL, two ? (uint32_t *)c->enc_cnt[par].p : NULL,
 						(uint32_t *)c->order.p, c->sort_tmp.p, c->sort_tmp.cap, &launch_order, st);
 				if (e) { rc = fail(c, XZAMD_DEVICE_ERROR, "span plan launch", e); goto done; }
 				a.order = launch_order;
 				/* the host lays the Blocks out from the plan: fetched with the span sizes below */
-				e = xzk_d2h(htab, c->span_tab.p, 8ull * nspans, st);
+				if (!two) e = xzk_d2h(htab, c->span_tab.p, 8ull * nspans, st);
 				if (!e) e = xzk_d2h(hcnt, c->span_cnt.p, 4ull * nb, st);
 				if (!e) e = xzk_d2h(hcnt + 2 * ((nb + 1) / 2), (uint8_t *)c->totals.p + 8ull * (nb + 1), 8, st);   /* target used, behind the counts */
-				if (!e && two) e = xzk_d2h(c->h_enc_tab.p, c->enc_tab.p, 8ull * nenc, st);
-				if (!e && two) e = xzk_d2h(c->h_enc_cnt.p, c->enc_cnt.p, 4ull * nb, st);
+				if (!e && two) e = xzk_d2h(c->h_enc_tab[par].p, c->enc_tab[par].p, 8ull * nenc, st);
+				if (!e && two) e = xzk_d2h(c->h_enc_cnt[par].p, c->enc_cnt[par].p, 4ull * nb, st);
 				if (e) { rc = fail(c, XZAMD_DEVICE_ERROR, "d2h span plan", e); goto done; }
 			} else {
 				for (uint64_t b = 0; b < nb; ++b) {
@@ -971,268 +1195,121 @@ int xzamd_stream_encode_device(xzamd_ctx *c,
 				if (!e) e = xzk_h2d(c->span_cnt.p, hcnt, 4ull * nb, st);
 				if (e) { rc = fail(c, XZAMD_DEVICE_ERROR, "h2d span plan", e); goto done; }
 			}
-			xzk_event_record(c->ev[6], st);
-			/* The chain arrays are free once the finder is done (the fast kernels read them, so they keep
-			 * them): build the NEXT batch's chains and match lists now, on the lowest-priority stream, into
-			 * the other list buffer.  The span kernel takes every slot it can use; the sorts and the finder
-			 * fill what its rounds leave idle. */
-			/* SHA-256 is one serial hash per Block (a single wavefront for the whole batch, hundreds of ms): it runs on
-			 * the second stream underneath the span kernel instead of behind it */
-			int sha_early = 0;
-			if (check == XZAMD_CHECK_SHA256 && c->lo_stream != NULL && c->ev_lo[0][0] != NULL) {
-				int e3 = xzk_stream_wait_event(c->lo_stream, c->ev[0]);
-				if (!e3) e3 = xzk_sha256_blocks(d_in + in_off, n, (uint32_t)block_size, (uint32_t)nb, (uint8_t *)c->block_crc.p, c->lo_stream);
-				if (!e3) e3 = xzk_event_record(c->ev_lo[0][0], c->lo_stream);
-				if (e3) { rc = fail(c, XZAMD_DEVICE_ERROR, "sha256 launch", e3); goto done; }
-				sha_early = 1;
-			}
-			c->sha_early = sha_early;
-			const int pf_after = c->prefetch_after;
-			for (int phase = 0; phase < 2; ++phase) {
-				if (phase == (pf_after ? 0 : 1)) {
-					if (two) {
-						/* seed pieces -> every other piece -> the coder */
-						xzk_event_record(c->ev2[0], st);
-						e = xzk_parse_pieces(&a, (uint32_t)nb, 0, 0, NULL, st);
-						xzk_event_record(c->ev2[1], st);
-						if (!e) e = xzk_parse_pieces(&a, (uint32_t)nb, 1, c->span_waves, (uint32_t *)c->errw.p + 60, st);
-						xzk_event_record(c->ev2[2], st);
-						if (!e) e = xzk_encode_syms(&a, (uint32_t)nb, st);
-						xzk_event_record(c->ev2[3], st);
-					} else
-						e = xzk_span_encode(&a, nspans, c->span_waves, (uint32_t *)c->errw.p + 60, st);
-					if (e) { rc = fail(c, XZAMD_DEVICE_ERROR, "span_encode launch", e); goto done; }
-					continue;
-				}
-				if (overlap && opt->gpu_parser && b0 + nb < total_blocks) {
-					batch_geo g2;
-					if (batch_geometry(c, opt, b0 + nb, total_blocks, max_blocks, block_size, in_size, hbits, &g2) == XZAMD_OK
-							&& g2.n <= n && g2.sort_bytes + 256 <= c->sort_tmp.cap) {
-						xzamd_span_args a2 = a;
-						a2.in = d_in + g2.in_off;
-						a2.n = g2.n;
-						a2.mtop = (uint16_t *)(lists_cur ? c->mtop.p : c->mtop2.p);
-						uint16_t *const ml_nx = list_packed ? NULL : (uint16_t *)(lists_cur ? c->mlen.p : c->mlen2.p);
-						uint32_t *const md_nx = (uint32_t *)(lists_cur ? c->mdist.p : c->mdist2.p);
-						void **evn = c->ev_lo[lists_cur ^ 1];
-						/* the chain arrays are free once the finder and the span plan of this batch are done: ev[6] */
-						int e2 = xzk_stream_wait_event(c->lo_stream, c->ev[6]);
-						if (!e2) e2 = xzk_event_record(evn[1], c->lo_stream);
-						if (!e2 && launch_chains(c, opt, d_in + g2.in_off, &g2, block_size, hb, hmask, hbits, c->lo_stream) != XZAMD_OK) e2 = 1;
-						if (!e2) e2 = xzk_event_record(evn[2], c->lo_stream);
-						if (!e2) e2 = xzk_find_matches(&a2, (const uint32_t *)c->sa.p, (const uint32_t *)c->sa_rank.p, (const uint32_t *)c->prev4.p,
-								(const uint64_t *)c->prev8.p, (const uint64_t *)c->prev16.p, ml_nx, md_nx, c->lo_stream);
-						if (!e2) e2 = xzk_event_record(evn[3], c->lo_stream);
-						if (e2) { rc = fail(c, XZAMD_DEVICE_ERROR, "chain prefetch", e2); goto done; }
-						prefetched = 1;
-						prefetched_b0 = b0 + nb;
-					}
-				}
-			}
-		}
-		xzk_event_record(c->ev[2], st);
-		/* 3. Block checks */
-		if (check == XZAMD_CHECK_CRC64 || check == XZAMD_CHECK_CRC32) {
-			int e = xzk_crc_blocks(d_in + in_off, n, (uint32_t)block_size, (uint32_t)nb, CRC_STRIP,
-					check == XZAMD_CHECK_CRC32, (uint64_t *)c->strip_crc.p, (uint64_t *)c->block_crc.p, st);
-			if (e) { rc = fail(c, XZAMD_DEVICE_ERROR, "crc64 launch", e); goto done; }
-			e = xzk_d2h(c->h_block_crc.p, c->block_crc.p, 8ull * nb, st);
-			if (e) { rc = fail(c, XZAMD_DEVICE_ERROR, "d2h crc", e); goto done; }
-		} else if (check == XZAMD_CHECK_SHA256) {
-			int e = c->sha_early ? xzk_stream_wait_event(st, c->ev_lo[0][0])
-					: xzk_sha256_blocks(d_in + in_off, n, (uint32_t)block_size, (uint32_t)nb, (uint8_t *)c->block_crc.p, st);
-			if (e) { rc = fail(c, XZAMD_DEVICE_ERROR, "sha256 launch", e); goto done; }
-			e = xzk_d2h(c->h_block_crc.p, c->block_crc.p, 32ull * nb, st);
-			if (e) { rc = fail(c, XZAMD_DEVICE_ERROR, "d2h sha256", e); goto done; }
-		}
-		xzk_event_record(c->ev[3], st);
-		{
-			uint32_t herr[64] = { 0 };
-			int e = xzk_d2h(c->h_span_bytes.p, c->span_bytes.p, 4ull * nout, st);
-			if (!e) e = xzk_d2h(herr, c->errw.p, 256, st);
-			if (!e) e = xzk_sync(st);
-			if (e) { rc = fail(c, XZAMD_DEVICE_ERROR, "span encode / d2h sizes", e); goto done; }
-			if (getenv("XZAMD_TIMING") && herr[8])
-				fprintf(stderr, "[timing span0] total %u round1 %u round2 %u encode %u (x256 clk) rounds %u symbols %u\n",
-						herr[8], herr[9], herr[10], herr[11], herr[12], herr[13]);
-			if (getenv("XZAMD_TIMING")) {
-				const uint64_t *t = (const uint64_t *)(herr + 16);
-				if (t[8])
-					fprintf(stderr, "[timing opt, Mcycles summed over spans] total %llu | derive %llu round %llu bits %llu lit %llu relax %llu "
-							"backtrack %llu encode %llu refresh %llu | nodes %llu symbols %llu windows %llu | span max %llu Mcyc | compound nodes %llu price %llu gather %llu\n",
-							(unsigned long long)(t[8] >> 20), (unsigned long long)(t[0] >> 20), (unsigned long long)(t[1] >> 20),
-							(unsigned long long)(t[2] >> 20), (unsigned long long)(t[3] >> 20), (unsigned long long)(t[4] >> 20),
-							(unsigned long long)(t[5] >> 20), (unsigned long long)(t[6] >> 20), (unsigned long long)(t[7] >> 20),
-							(unsigned long long)t[9], (unsigned long long)t[10], (unsigned long long)t[11],
-							(unsigned long long)(t[12] >> 20), (unsigned long long)t[13], (unsigned long long)(t[14] >> 20), (unsigned long long)(t[15] >> 20));
-			}
-			if (herr[0]) {
-				snprintf(c->err_msg_buf, sizeof(c->err_msg_buf),
-						"span encoder consistency check %u failed: %u %u %u %u %u %u %u",
-						herr[0], herr[1], herr[2], herr[3], herr[4], herr[5], herr[6], herr[7]);
-				rc = fail(c, XZAMD_PROG_ERROR, c->err_msg_buf, 0);
-				goto done;
-			}
-		}
-
-		/* 4. layout (the ordered output queue of the reference, outqueue.c) */
-		plan pl;
-		pl.lits = (uint8_t *)c->h_lits.p; pl.lits_len = 0; pl.lits_cap = max_lits;
-		pl.segs = (xzamd_copy_seg *)c->h_segs.p; pl.nsegs = 0; pl.segs_cap = max_segs;
-		const uint32_t *sb = (const uint32_t *)c->h_span_bytes.p;
-		const uint32_t *hcnt = (const uint32_t *)c->h_span_cnt.p;
-		/* the slots that hold coded bytes: the spans of the plan, or (two-phase) the encode spans */
-		const uint32_t *otab = (const uint32_t *)(two ? c->h_enc_tab.p : c->h_span_tab.p);
-		const uint32_t *ocnt = (const uint32_t *)(two ? c->h_enc_cnt.p : c->h_span_cnt.p);
-		const uint64_t *bcrc = (const uint64_t *)c->h_block_crc.p;
-		for (uint64_t b = 0; b < nb; ++b) {
-			const uint64_t boff = b * block_size;                 /* in batch */
-			const uint64_t usize = n64 - boff < block_size ? n64 - boff : block_size;
-			uint64_t payload = 1;                                 /* end marker */
-			const uint32_t nsp = ocnt[b];                         /* coded spans of this Block (slots b * opb ...) */
-			if (nsp == 0 || nsp > opb || hcnt[b] == 0 || hcnt[b] > spb) { rc = fail(c, XZAMD_PROG_ERROR, "span plan out of range", 0); goto done; }
-			for (uint32_t s = 0; s < nsp; ++s)
-				payload += sb[b * opb + s];
-			const uint64_t pad = (4 - (payload & 3)) & 3;
-			const uint64_t bstart = opos;
-			uint64_t unp;
-			uint8_t tail[48];
-			uint32_t tl = 0;
-			if (hs_fixed + payload + pad + cbytes > bound) {
-				/* stream_encoder_mt.c:298,316-344 -> block_buffer_encoder.c:88-162 */
-				const uint64_t csz = usize + ((usize + 65535) / 65536) * 3 + 1;
-				const uint32_t hs = block_header_size(csz, usize, 0);      /* stored Blocks drop the BCJ filter */
-				if (opos + hs + csz + 3 + cbytes > out_cap) { rc = fail(c, XZAMD_BUF_ERROR, "output buffer too small", 0); goto done; }
-				block_header_put(small, hs, csz, usize, 0x00, 0);
-				opos = plan_lit(&pl, small, hs, opos);
-				uint8_t ctl = 0x01;
-				for (uint64_t ip = 0; ip < usize; ip += 65536) {
-					const uint64_t cs = usize - ip < 65536 ? usize - ip : 65536;
-					uint8_t ch[3] = { ctl, (uint8_t)((cs - 1) >> 8), (uint8_t)(cs - 1) };
-					ctl = 0x02;
-					opos = plan_lit(&pl, ch, 3, opos);
-					opos = plan_seg(&pl, 2, boff + ip, cs, opos);
-				}
-				tail[tl++] = 0x00;
-				while ((csz + (tl - 1)) & 3) tail[tl++] = 0;
-				unp = hs + csz + cbytes;
-				++c->stats.blocks_stored;
+			xzk_event_record(ev[EV_PLAN1], st);
+			/* 2c. parse (two-phase: seed pieces, then every other piece) or the single-phase span kernel */
+			if (two) {
+				if (seeds_early) e = xzk_stream_wait_event(st, c->ev_seed[par][2]);
+				else e = xzk_parse_pieces(&a, (uint32_t)nb, 0, 0, NULL, st);
+				xzk_event_record(ev[EV_SEED], st);
+				cur.seeds_early = seeds_early;
+				if (!e) e = xzk_parse_pieces(&a, (uint32_t)nb, 1, c->span_waves, (uint32_t *)c->errw.p + 60, st);
+				xzk_event_record(ev[EV_PARSE], st);
 			} else {
-				if (opos + hs_fixed + payload + pad + cbytes > out_cap) { rc = fail(c, XZAMD_BUF_ERROR, "output buffer too small", 0); goto done; }
-				block_header_put(small, hs_fixed, payload, usize, dbyte, opt->bcj);
-				opos = plan_lit(&pl, small, hs_fixed, opos);
-				for (uint32_t s = 0; s < nsp; ++s) {
-					const uint64_t slot = b * opb + s, start = otab[2 * slot];
-					opos = plan_seg(&pl, 0, ((start + (start >> 3) + 15) & ~15ull) + slot * XZAMD_SPAN_SLACK, sb[slot], opos);
-				}
-				tail[tl++] = 0x00;
-				for (uint64_t i = 0; i < pad; ++i) tail[tl++] = 0;
-				unp = hs_fixed + payload + cbytes;
+				e = xzk_span_encode(&a, nspans, c->span_waves, (uint32_t *)c->errw.p + 60, st);
 			}
-			if (check == XZAMD_CHECK_CRC64) {
-				const uint64_t v = bcrc[b];
-				le32(tail + tl, (uint32_t)v);
-				le32(tail + tl + 4, (uint32_t)(v >> 32));
-				tl += 8;
-			} else if (check == XZAMD_CHECK_CRC32) {
-				le32(tail + tl, (uint32_t)bcrc[b]);
-				tl += 4;
-			} else if (check == XZAMD_CHECK_SHA256) {
-				memcpy(tail + tl, (const uint8_t *)c->h_block_crc.p + 32 * b, 32);
-				tl += 32;
-			}
-			opos = plan_lit(&pl, tail, tl, opos);
-			const uint64_t gi = b0 + b;
-			if (whole) { rec_unp[gi] = unp; rec_unc[gi] = usize; }
-			if (binfo && gi < binfo_cap) {
-				binfo[gi].unpadded_size = unp;
-				binfo[gi].uncompressed_size = usize;
-				binfo[gi].out_offset = bstart;
-				binfo[gi].total_size = opos - bstart;
-			}
+			if (e) { rc = fail(c, XZAMD_DEVICE_ERROR, "span_encode launch", e); goto done; }
+			e = xzk_d2h(c->h_err[par].p, c->errw.p, 512, st);
+			if (e) { rc = fail(c, XZAMD_DEVICE_ERROR, "d2h", e); goto done; }
+			xzk_event_record(ev[EV_FRONT], st);
 		}
-		if (pl.nsegs > pl.segs_cap || pl.lits_len > pl.lits_cap) { rc = fail(c, XZAMD_PROG_ERROR, "plan overflow", 0); goto done; }
 
-		/* 5. gather */
+		/* ================= back end ================= */
+		/* the previous batch's sizes, layout and gather: its coder has had the whole front end above to finish */
+		if (pipelined && prev.active) {
+			rc = back_finish(c, &J, &prev);
+			if (rc != XZAMD_OK) goto done;
+		}
 		{
-			int e = xzk_h2d(c->segs.p, pl.segs, pl.nsegs * sizeof(xzamd_copy_seg), st);
-			if (!e) e = xzk_h2d(c->lits.p, pl.lits, pl.lits_len ? pl.lits_len : 1, st);
-			if (!e) e = xzk_assemble((const xzamd_copy_seg *)c->segs.p, (uint32_t)pl.nsegs,
-					(const uint8_t *)c->scratch.p, (const uint8_t *)c->lits.p, d_in + in_off, d_out, st);
-			xzk_event_record(c->ev[4], st);
-			if (!e) e = xzk_sync(st);
-			if (e) { rc = fail(c, XZAMD_DEVICE_ERROR, "assemble", e); goto done; }
+			void *stb = J.stb;
+			int e = 0;
+			if (stb != st) e = xzk_stream_wait_event(stb, ev[EV_FRONT]);
+			xzk_event_record(ev[EV_BACK0], stb);
+			if (!e) e = xzk_memset(c->errw2.p, 0, 512, stb);
+			if (!e && two) {
+				xzamd_span_args a2 = a;
+				a2.err = (uint32_t *)c->errw2.p;
+				e = xzk_encode_syms(&a2, (uint32_t)nb, stb);
+			}
+			xzk_event_record(ev[EV_CODE], stb);
+			if (e) { rc = fail(c, XZAMD_DEVICE_ERROR, "encode_syms launch", e); goto done; }
+			/* Block checks */
+			if (check == XZAMD_CHECK_CRC64 || check == XZAMD_CHECK_CRC32) {
+				e = xzk_crc_blocks(d_in + in_off, n, (uint32_t)block_size, (uint32_t)nb, CRC_STRIP,
+						check == XZAMD_CHECK_CRC32, (uint64_t *)c->strip_crc.p, (uint64_t *)c->block_crc.p, stb);
+				if (e) { rc = fail(c, XZAMD_DEVICE_ERROR, "crc64 launch", e); goto done; }
+				e = xzk_d2h(c->h_block_crc.p, c->block_crc.p, 8ull * nb, stb);
+				if (e) { rc = fail(c, XZAMD_DEVICE_ERROR, "d2h crc", e); goto done; }
+			} else if (check == XZAMD_CHECK_SHA256) {
+				e = sha_early ? xzk_stream_wait_event(stb, c->ev_sha)
+						: xzk_sha256_blocks(d_in + in_off, n, (uint32_t)block_size, (uint32_t)nb, (uint8_t *)c->block_crc.p, stb);
+				if (e) { rc = fail(c, XZAMD_DEVICE_ERROR, "sha256 launch", e); goto done; }
+				e = xzk_d2h(c->h_block_crc.p, c->block_crc.p, 32ull * nb, stb);
+				if (e) { rc = fail(c, XZAMD_DEVICE_ERROR, "d2h sha256", e); goto done; }
+			}
+			xzk_event_record(ev[EV_CRC], stb);
+			e = xzk_d2h(c->h_span_bytes.p, c->span_bytes.p, 4ull * nout, stb);
+			if (!e) e = xzk_d2h((uint8_t *)c->h_err[par].p + 512, c->errw2.p, 512, stb);
+			if (e) { rc = fail(c, XZAMD_DEVICE_ERROR, "d2h sizes", e); goto done; }
 		}
-		float ms;
-		if (chains_on_lo) {
-			if (!xzk_event_elapsed_ms(c->ev_lo[lists_cur][1], c->ev_lo[lists_cur][2], &ms)) c->stats.ms_chains += ms;
-			if (!xzk_event_elapsed_ms(c->ev_lo[lists_cur][2], c->ev_lo[lists_cur][3], &ms)) c->stats.ms_find_overlapped += ms;
-		} else if (!xzk_event_elapsed_ms(c->ev[0], c->ev[1], &ms)) c->stats.ms_chains += ms;
-		if (!xzk_event_elapsed_ms(c->ev[1], c->ev[2], &ms)) c->stats.ms_encode += ms;
-		if (opt->gpu_parser && !find_on_lo && !xzk_event_elapsed_ms(c->ev[1], c->ev[5], &ms)) c->stats.ms_find += ms;
-		if (!xzk_event_elapsed_ms(c->ev[2], c->ev[3], &ms)) c->stats.ms_crc += ms;
-		if (!xzk_event_elapsed_ms(c->ev[3], c->ev[4], &ms)) c->stats.ms_assemble += ms;
-		if (!xzk_event_elapsed_ms(c->ev[7], c->ev[6], &ms)) c->stats.ms_plan += ms;
-		c->stats.blocks += nb;
-		for (uint64_t b = 0; b < nb; ++b) c->stats.spans += hcnt[b];
-		if (two) {
-			for (uint64_t b = 0; b < nb; ++b) c->stats.enc_spans += ocnt[b];
-			if (!xzk_event_elapsed_ms(c->ev2[0], c->ev2[1], &ms)) c->stats.ms_seed += ms;
-			if (!xzk_event_elapsed_ms(c->ev2[1], c->ev2[2], &ms)) c->stats.ms_parse += ms;
-			if (!xzk_event_elapsed_ms(c->ev2[2], c->ev2[3], &ms)) c->stats.ms_code += ms;
+		if (pipelined) {
+			prev = cur;
+		} else {
+			rc = back_finish(c, &J, &cur);
+			if (rc != XZAMD_OK) goto done;
 		}
-		if (adaptive) {
-			uint64_t tgt;
-			memcpy(&tgt, hcnt + 2 * ((nb + 1) / 2), 8);
-			c->stats.span_cost_used = tgt > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)tgt;
-		}
-		c->stats.batches += 1;
-		c->stats.encode_launches += 1;
 		b0 += nb;
+		++batch_index;
 		continue;
 retry_smaller:
 		c->err[0] = 0;
-		if (prefetched) { xzk_sync(c->lo_stream); prefetched = 0; }
 		/* The buffers grown so far have full-batch capacity: a retry that kept them would fight for what is left.
-		 * Nothing of this batch has been launched; earlier batches may still be assembling, so wait, then release
-		 * every per-batch device buffer and let the smaller geometry allocate afresh. */
+		 * Nothing of this batch has been launched; an earlier batch may still be in its back end: finish it, then
+		 * release every per-batch device buffer and let the smaller geometry allocate afresh. */
+		if (prev.active) {
+			rc = back_finish(c, &J, &prev);
+			if (rc != XZAMD_OK) goto done;
+		}
 		xzk_sync(st);
+		xzk_sync(c->st2);
 		{
-			dbuf *d[] = { &c->keys_a, &c->keys_b, &c->vals_a, &c->vals_b, &c->rank, &c->sorted_pos,
-				&c->prev2, &c->prev3, &c->prev4, &c->prev8, &c->prev16, &c->key64_a, &c->key64_b, &c->sa, &c->sa_rank,
-				&c->sort_tmp, &c->scratch, &c->litp, &c->mlen, &c->mdist, &c->mlen2, &c->mdist2, &c->bcj, &c->est, &c->mtop, &c->mtop2,
-				&c->order, &c->sym_len, &c->sym_dist };
-			for (size_t i = 0; i < sizeof(d) / sizeof(d[0]); ++i)
+			dbuf *d[64];
+			size_t nd = 0;
+			ctx_device_bufs(c, d, &nd);
+			for (size_t i = 0; i < CTX_NBIG && i < nd; ++i)
 				if (d[i]->p) { xzk_free(d[i]->p); d[i]->p = NULL; d[i]->cap = 0; }
 		}
 	}
+	if (rc == XZAMD_OK && prev.active)
+		rc = back_finish(c, &J, &prev);
 done:
-	if (rc == XZAMD_OK && whole) {
+	xzk_sync(st);
+	xzk_sync(c->st3);
+	xzk_sync(c->st2);          /* a back end abandoned by an error path */
+	if (rc == XZAMD_OK && J.whole) {
 		const uint64_t isz_cap = 32 + total_blocks * 18 + 16;
 		uint8_t *ib = (uint8_t *)malloc(isz_cap);
 		if (!ib) rc = fail(c, XZAMD_MEM_ERROR, "malloc", 0);
 		else {
-			const uint64_t w = xzamd_frame_index_footer(ib, isz_cap, check, rec_unp, rec_unc, total_blocks);
-			if (w == 0 || opos + w > out_cap) rc = fail(c, XZAMD_BUF_ERROR, "output buffer too small", 0);
+			const uint64_t w = xzamd_frame_index_footer(ib, isz_cap, check, J.rec_unp, J.rec_unc, total_blocks);
+			if (w == 0 || J.opos + w > out_cap) rc = fail(c, XZAMD_BUF_ERROR, "output buffer too small", 0);
 			else {
-				int e = xzk_h2d(d_out + opos, ib, w, st);
+				int e = xzk_h2d(d_out + J.opos, ib, w, st);
 				if (!e) e = xzk_sync(st);
 				if (e) rc = fail(c, XZAMD_DEVICE_ERROR, "h2d index", e);
-				opos += w;
+				J.opos += w;
 			}
 			free(ib);
 		}
 	}
-	xzk_event_record(c->ev[9], st);
+	xzk_event_record(c->ev_total[1], st);
 	xzk_sync(st);
-	if (c->lo_stream) xzk_sync(c->lo_stream);      /* a prefetched chain build abandoned by an error path */
 	{
 		float ms;
-		if (!xzk_event_elapsed_ms(c->ev[8], c->ev[9], &ms)) c->stats.ms_total = ms;
+		if (!xzk_event_elapsed_ms(c->ev_total[0], c->ev_total[1], &ms)) c->stats.ms_total = ms;
 	}
-	free(rec_unp);
+	free(J.rec_unp);
 	c->stats.in_bytes = in_size;
-	c->stats.out_bytes = opos;
-	*out_size = opos;
+	c->stats.out_bytes = J.opos;
+	*out_size = J.opos;
 	return rc;
 }
