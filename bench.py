@@ -14,8 +14,8 @@ CRC64, assembly into a complete .xz Stream) over the batch already resident in H
 GPU).  Every rank encodes its own shard of Blocks on its own GPU (no data-path collective), then the
 encoded Blocks are gathered to rank 0 over RCCL (send/recv of variable-length byte tensors + the 16-byte
 Index records) and rank 0 frames the Stream.  The gather is inside the timed region.
---scaling weak (default): --size-mib per GPU; --scaling strong: --size-mib in total, whole Blocks dealt
-to the ranks in order (north_star's 4 GiB on 8 GPUs).  Prints ONE JSON line on rank 0, with `roofline`,
+--scaling strong (default): --size-mib in total, whole Blocks dealt to the ranks in order (the metric's 4 GiB
+at 1/2/4/8 GPUs); --scaling weak: --size-mib per GPU.  Prints ONE JSON line on rank 0, with `roofline`,
 `cpu_baseline` (reference liblzma -T0 on the host cores, bounded wall time) and `host_to_host` (the same
 job through lzma_code on host buffers, PCIe inclusive).
 """
@@ -46,21 +46,29 @@ def baseline_metric():
         return "compress MB/s + ratio vs xz -T0 -6, 4 GiB input, 1/2/4/8 MI355X"
 
 
+def two_phase(opts):
+    """Parse pieces + encode spans (the default of the optimal-parser presets) instead of the single-phase span kernel."""
+    return bool(opts.gpu_parser and opts.gpu_sa_window and opts.span_cost and opts.enc_span_bits
+                and opts.span_size in (xz_amd.SPAN_DEFAULT, xz_amd.SPAN_AUTO))
+
+
 def span_kernel_name(opts, pmc=False):
     """Name of the dominant kernel for these options (template args: finder source, parser, parser window)."""
+    wm = 360 if (opts.gpu_parser and opts.gpu_nice_len > 128) else 232
+    if two_phase(opts):
+        return "k_parse_pieces<%du>" % wm if pmc else "k_parse_pieces<%d>" % wm
     finder = 2 if opts.gpu_parser else 0
     sep = ", " if pmc else ","
-    wm = 360 if (opts.gpu_parser and opts.gpu_nice_len > 128) else 232
     if pmc:          # as rocprofv3 prints it
         return "k_span_encode_t<%d%s%s%s%du>" % (finder, sep, "true" if opts.gpu_parser else "false", sep, wm)
     return "k_span_encode_t<%d,%s,%d>" % (finder, "true" if opts.gpu_parser else "false", wm)
 
 
-def pmc_traffic(opts):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
-    (FETCH_SIZE and WRITE_SIZE in separate passes, tools/prof_bench.sh -> profiles/*pmc_summary.json).
-    PMC counters cannot be collected from inside this process; None when no profile of the same
-    kernel variant is present."""
+def pmc_traffic(opts, corpus, preset, bcj):
+    """HBM bytes per BIG launch (a full timed batch) of the dominant kernel from the committed rocprofv3 --pmc passes
+    (FETCH_SIZE and WRITE_SIZE in separate passes, tools/prof_bench.sh -> tools/pmc_summary.py ->
+    profiles/*pmc_summary.json).  PMC counters cannot be collected from inside this process.  A figure is quoted only
+    from a profile of the SAME kernel variant, corpus, preset and filter chain (`_meta` of the summary); else None."""
     import glob
     want = span_kernel_name(opts, pmc=True)
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_summary.json")), reverse=True):
@@ -68,9 +76,12 @@ def pmc_traffic(opts):
             d = json.load(open(f))
         except Exception:  # noqa: BLE001
             continue
+        meta = d.get("_meta") or {}
+        if not meta or meta.get("corpus") != corpus or int(str(meta.get("preset", "6")), 0) != preset or bool(meta.get("bcj")) != bool(bcj):
+            continue
         for k, e in d.items():
-            if want in k and "hbm_bytes_per_dispatch_uncorrected" in e:
-                return int(e["hbm_bytes_per_dispatch_uncorrected"]), os.path.basename(f)
+            if want in k and isinstance(e, dict) and "hbm_bytes_per_big_launch_uncorrected" in e:
+                return int(e["hbm_bytes_per_big_launch_uncorrected"]), os.path.basename(f)
     return None, None
 
 
@@ -145,14 +156,18 @@ def cpu_baseline(host, preset, bcj, block_size, seconds=20.0):
             return {"value": None, "unit": "MB/s", "cores": 0, "kind": "reference", "sample": f"lzma_code failed: {r}"}
         nblocks = (host.size + block_size - 1) // block_size
         busy = min(int(th.value), int(nblocks))
+        # what the workers can actually run on: the affinity mask and the cgroup CPU quota bound the cores in use
+        usable = min(x for x in (busy, lim.get("sched_getaffinity") or busy, int(lim["cgroup_quota_cpus"] + 0.5) if lim.get("cgroup_quota_cpus") else busy))
         mt = pin.value / el.value / 1e6
         pin1, el1, th1 = C.c_uint64(), C.c_double(), C.c_uint32()
         f(host.ctypes.data, host.size, preset, 1 if bcj else 0, 1, 0, min(seconds, 6.0), C.byref(pin1), C.byref(el1), C.byref(th1))
         t1 = pin1.value / max(el1.value, 1e-9) / 1e6
-        return {"value": round(mt, 2), "unit": "MB/s", "cores": busy, "kind": "reference",
+        return {"value": round(mt, 2), "unit": "MB/s", "cores": usable, "kind": "reference",
                 "sample": (f"liblzma 5.8.3 lzma_stream_encoder_mt preset {preset & 31}{'e' if preset >> 31 else ''}{' + x86 BCJ' if bcj else ''}, "
                            f"threads={int(th.value)} (lzma_cputhreads, as xz -T0), whole {host.size >> 20} MiB input of rank 0 on offer = {nblocks} Blocks "
-                           f"-> {busy} busy workers, timed {el.value:.1f} s wall, {pin.value >> 20} MiB processed (lzma_get_progress)"),
+                           f"-> {busy} worker threads with a Block each on {usable} usable CPUs (affinity mask / cgroup quota), "
+                           f"timed {el.value:.1f} s wall, {pin.value >> 20} MiB processed (lzma_get_progress)"),
+                "worker_threads": busy,
                 "per_core_T1": round(t1, 3), "scaling_vs_T1": round(mt / t1, 1) if t1 > 0 else None,
                 "host": lim}
     except Exception as e:  # noqa: BLE001
@@ -256,8 +271,11 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--size-mib", type=int, default=4096, help="input MiB per GPU (weak) or in total (strong)")
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
-                    help="weak: --size-mib per GPU; strong: --size-mib in total, whole Blocks dealt to the ranks in order")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="strong",
+                    help="strong (default; BASELINE's metric: 4 GiB at 1/2/4/8 GPUs): --size-mib in total, whole Blocks dealt to "
+                         "the ranks in order; weak: --size-mib per GPU (BASELINE config 4's shape).  With more than one GPU the "
+                         "line also carries one untimed-warm pass of the other mode (`other_scaling`)")
+    ap.add_argument("--no-ratio", action="store_true", help="skip the ratio sample and the round trips (profiling runs)")
     ap.add_argument("--preset", type=lambda v: int(v, 0), default=6, help="0-9, | 0x80000000 for -e")
     ap.add_argument("--span-kib", type=int, default=0, help="0 = library default")
     ap.add_argument("--block-mib", type=int, default=0, help="0 = lzma_mt_block_size of the preset (BASELINE configs[1]: 16)")
@@ -279,12 +297,20 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # XZAMD_BENCH_OVERSUBSCRIBE=1: more ranks than GPUs (a 1-GPU box exercising the N-rank code path): the ranks share the
+    # devices round robin and the gather runs over gloo on host tensors (RCCL refuses two ranks on one device)
+    oversub = os.environ.get("XZAMD_BENCH_OVERSUBSCRIBE") == "1" and local_rank >= torch.cuda.device_count()
+    oversub = oversub or (os.environ.get("XZAMD_BENCH_OVERSUBSCRIBE") == "1" and world > torch.cuda.device_count())
+    dev_index = local_rank % torch.cuda.device_count() if oversub else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if oversub:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=dev)
         assert dist.get_world_size() == args.gpus
 
     opts = xz_amd.preset_options(args.preset)
@@ -314,7 +340,7 @@ def main():
         host = xz_amd.corpus_text(max(n, 1), seed=1000 + rank)
     host = host[:n]
     data = torch.from_numpy(host).to(dev)
-    enc = xz_amd.Encoder(local_rank)
+    enc = xz_amd.Encoder(dev_index)
     out_buf = torch.empty(xz_amd.lib().xzamd_stream_buffer_bound(n, block_size) + 64, dtype=torch.uint8, device=dev)
 
     def step():
@@ -322,7 +348,7 @@ def main():
             out, binfo = enc.encode(data, opts=opts, block_size=block_size, out=out_buf)
             return out, binfo
         out, binfo = enc.encode(data, opts=opts, block_size=block_size, out=out_buf, blocks_only=True)
-        stream = parallel.gather_stream(out, binfo, check=xz_amd.CHECK_CRC64)
+        stream = parallel.gather_stream(out.cpu() if oversub else out, binfo, check=xz_amd.CHECK_CRC64)
         return stream, binfo
 
     for _ in range(args.warmup):
@@ -338,7 +364,9 @@ def main():
     for _ in range(args.steps):
         out, binfo = step()
         st = enc.stats()
-        enc_ms += st.ms_encode - st.ms_find - st.ms_plan      # the span kernel alone (finder and span plan are timed separately)
+        # the dominant kernel alone: the parse pieces (two-phase) or the single-phase span kernel (finder, span plan, seed
+        # pieces and range coder are timed separately)
+        enc_ms += st.ms_parse if two_phase(opts) else st.ms_encode - st.ms_find - st.ms_plan
         launches += st.encode_launches
     torch.cuda.synchronize()
     if world > 1:
@@ -346,11 +374,41 @@ def main():
         torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if oversub else dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
     st = enc.stats()
+    other = None
+    if world > 1:
+        # one pass of the OTHER scaling mode (report both: the metric's strong form and config 4's weak form)
+        o_mode = "weak" if args.scaling == "strong" else "strong"
+        if o_mode == "strong":
+            nb2 = (total + block_size - 1) // block_size
+            lo2, hi2 = parallel.shard_blocks(nb2, rank, world)
+            n2 = min(total, hi2 * block_size) - lo2 * block_size if hi2 > lo2 else 0
+        else:
+            n2 = total
+        del data, out_buf
+        torch.cuda.empty_cache()
+        host2 = (corpus_elf(max(n2, 1), rank) if args.corpus == "elf" else
+                 xz_amd.corpus_tar(max(n2, 1), seed=2000 + rank) if args.corpus == "tar" else xz_amd.corpus_text(max(n2, 1), seed=2000 + rank))[:n2]
+        data = torch.from_numpy(host2).to(dev)
+        out_buf = torch.empty(xz_amd.lib().xzamd_stream_buffer_bound(n2, block_size) + 64, dtype=torch.uint8, device=dev)
+        step()                                   # warm
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        step()
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        e2 = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device="cpu" if oversub else dev)
+        dist.all_reduce(e2, op=dist.ReduceOp.MAX)
+        jb2 = total if o_mode == "strong" else total * world
+        other = {"scaling": o_mode, "value": round(jb2 / float(e2.item()) / 1e6, 2), "unit": "MB/s", "job_mib": jb2 >> 20,
+                 "ms_per_step": round(float(e2.item()) * 1e3, 2), "steps": 1}
     job_bytes = total if args.scaling == "strong" else total * world
     total_in = job_bytes * args.steps
     value = total_in / elapsed / 1e6
@@ -388,9 +446,12 @@ def main():
                 "device_parser": (f"windowed optimal parser ({360 if opts.gpu_nice_len > 128 else 232}-node DP, exact prices, compound edges) over per-position match lists" if opts.gpu_parser
                                   else "lzma_lzma_optimum_fast semantics (greedy + 1-byte lazy)"),
                 "span_bytes": int(st.span_size) if st.span_size else f"cost-balanced (work target {int(st.span_cost_used)} per span, >= 64 KiB)",
-                "parallelism": f"{world} x (one wavefront per span, {int(st.spans)} spans on rank 0)",
+                "parallelism": (f"{world} x (two-phase: one wavefront per parse piece, {int(st.spans)} pieces on rank 0 incl. one 64 KiB seed piece per Block; "
+                                f"one wavefront per encode span, {int(st.enc_spans)} encode spans = coder state resets)" if two_phase(opts)
+                                else f"{world} x (one wavefront per span, {int(st.spans)} spans on rank 0)"),
             },
             "ratio": {"ours": round(local_out_bytes / max(n, 1), 5)},
+            **({"other_scaling": other} if other else {}),
             "roofline": {
                 "bound": "hbm",
                 "kernel": span_kernel_name(opts),
@@ -398,29 +459,31 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 6),
-                "traffic": pmc_traffic(opts)[0],
-                "traffic_source": pmc_traffic(opts)[1],
+                "traffic": pmc_traffic(opts, args.corpus, args.preset, args.bcj)[0],
+                "traffic_source": pmc_traffic(opts, args.corpus, args.preset, args.bcj)[1],
                 "algorithmic_bytes_per_launch": int(alg_bytes / max(launches, 1)),
                 "avg_launch_ms": round(enc_ms / max(launches, 1), 3),
                 "launches": launches,
             },
             "stage_ms_last_step": {"chains": round(st.ms_chains, 2), "find": round(st.ms_find, 2),
-                                   "find_under_previous_span": round(st.ms_find_overlapped, 2),
                                    "span_plan": round(st.ms_plan, 2),
-                                   "span_encode": round(st.ms_encode - st.ms_find - st.ms_plan, 2),
-                                   "crc": round(st.ms_crc, 2), "assemble": round(st.ms_assemble, 2),
+                                   **({"seed_pieces_under_the_finder": round(st.ms_seed, 2), "parse_pieces": round(st.ms_parse, 2),
+                                       "range_coder_second_stream": round(st.ms_code, 2)} if two_phase(opts)
+                                      else {"span_encode": round(st.ms_encode - st.ms_find - st.ms_plan, 2)}),
+                                   "crc": round(st.ms_crc, 2), "layout_and_assemble": round(st.ms_assemble, 2),
                                    "total": round(st.ms_total, 2)},
         }
         if world == 1 and n:
             import _oracle as o
             # ratio vs the reference on the same Blocks + bit-exact round trip through the REAL reference decoder
             try:
-                if o.have_ref():
+                if args.no_ratio:
+                    pass
+                elif o.have_ref():
                     sample_n = min(n, 4 * block_size)
                     ref_size = reference_ratio(host[:sample_n], args.preset, args.bcj, block_size)
-                    opts.span_size = int(st.span_size)        # the span plan the timed run used
-                    if not st.span_size:
-                        opts.span_cost = int(st.span_cost_used)
+                    # (the span plan of a Block depends on the Block and the options only: the sample's Blocks are coded
+                    # exactly as in the timed run)
                     s_out, _ = enc.encode(data[:sample_n], opts=opts, block_size=block_size)
                     res["ratio"]["sample_mib"] = sample_n >> 20
                     res["ratio"]["ours_on_sample"] = round(s_out.numel() / sample_n, 5)
@@ -431,7 +494,7 @@ def main():
                     rr, dec = o.ref_decode(v_out.cpu().numpy().tobytes(), vn + 16)
                     res["roundtrip_reference_decoder"] = bool(rr == 1 and dec == host[:vn].tobytes())
                 # the WHOLE job back through the device decoder (Block checks verified, bytes compared with the input)
-                if not args.bcj:
+                if not args.bcj and not args.no_ratio:
                     full, _ = enc.encode(data, opts=opts, block_size=block_size, out=out_buf)
                     torch.cuda.synchronize()
                     td = time.perf_counter()

@@ -67,8 +67,10 @@
 #define MATCH_LEN_MAX 273u
 #define LIT 0xFFFFFFFFu
 #define NO_DELTA 0xFFFFFFFFu
+#ifndef WMAX_STD
 #define WMAX_STD 232u             /* optimal-parser window (nodes 0..WMAX); sized so the GPU's node arrays +
                                    * model + price tables fit 10 KiB of LDS per wavefront */
+#endif
 #ifndef WTAIL
 #define WTAIL 16u
 #endif
@@ -1271,6 +1273,9 @@ static int optimum_window(enc *e, uint32_t pos, int cached)
  * match reaches nice_len costs ORC_EST_LONG units and the walk jumps over the match (it may run past the
  * chunk end), any other position costs one unit. */
 #define ORC_EST_LONG 4u
+#ifndef ORC_PREROLL
+#define ORC_PREROLL 0u
+#endif
 
 /* The same walk also makes a rough estimate of the coded size in bits (a greedy parse: at a symbol
  * boundary take the longest match when it is >= 3 bytes long, or 2 bytes at a distance < 128, for 14 bits +
@@ -1522,6 +1527,26 @@ static void parse_piece(enc *e, uint32_t start, uint32_t end, int first_in_block
 	if (prior)
 		memcpy(e->probs, prior, sizeof(e->probs));
 	e->rc_off = 1;
+#if ORC_PREROLL
+	if (prior && start > ORC_PREROLL) {
+		/* pre-roll: the last ORC_PREROLL bytes in front of the piece are parsed once more, from the prior, and thrown
+		 * away: the piece proper then starts with a price model that has seen the local data, and with rep distances
+		 * and a coder state like the ones the previous piece ends with */
+		cur = start - ORC_PREROLL;
+		e->span_end = start;
+		while (cur < start) {
+			if (e->q_head == e->q_count)
+				cached = optimum_window(e, cur, cached);
+			const uint32_t back = e->q_back[e->q_head], len = e->q_len[e->q_head];
+			++e->q_head;
+			enc_symbol(e, cur, back, len);
+			cur += len;
+		}
+		e->span_end = end;
+		e->q_count = e->q_head = 0;
+		cached = 0;
+	}
+#endif
 	if (first_in_block && cur < end) {
 		record_literal(e, 0);
 		rc_bit(e, &e->probs[P_IS_MATCH], 0);
@@ -1693,8 +1718,25 @@ static enc *enc_new(const uint8_t *in, uint32_t n, const orc_enc_params *p)
 	return e;
 }
 
+static int encode_block_impl(const uint8_t *in, uint32_t n, const orc_enc_params *p,
+		uint8_t *out, uint64_t cap, uint64_t *out_size, orc_trace *trace, uint16_t *sym_len, uint32_t *sym_dist);
+
 int orc_lzma2_encode_block(const uint8_t *in, uint32_t n, const orc_enc_params *p,
 		uint8_t *out, uint64_t cap, uint64_t *out_size, orc_trace *trace)
+{
+	return encode_block_impl(in, n, p, out, cap, out_size, trace, NULL, NULL);
+}
+
+int orc_lzma2_encode_block_syms(const uint8_t *in, uint32_t n, const orc_enc_params *p,
+		uint8_t *out, uint64_t cap, uint64_t *out_size, uint16_t *sym_len, uint32_t *sym_dist)
+{
+	if (!p->enc_bits || !sym_len || !sym_dist)
+		return -2;
+	return encode_block_impl(in, n, p, out, cap, out_size, NULL, sym_len, sym_dist);
+}
+
+static int encode_block_impl(const uint8_t *in, uint32_t n, const orc_enc_params *p,
+		uint8_t *out, uint64_t cap, uint64_t *out_size, orc_trace *trace, uint16_t *sym_len, uint32_t *sym_dist)
 {
 	if ((p->mf != 3 && p->mf != 4) || p->lc + p->lp > 4 || p->pb > 4
 			|| (p->sa_window && (p->mf != 4 || p->sa_window > SA_WMAX))
@@ -1710,6 +1752,10 @@ int orc_lzma2_encode_block(const uint8_t *in, uint32_t n, const orc_enc_params *
 		uint32_t *ss = (uint32_t *)malloc((size_t)scap * 8), *es = ss + scap, ne = 0;
 		const uint32_t np = plan_spans_ex(e, NULL, ss, scap, es, scap, &ne);
 		r = parse_block(e, ss, np);
+		if (!r && sym_len && sym_dist) {
+			memcpy(sym_len, e->sy_len, (size_t)n * 2);
+			memcpy(sym_dist, e->sy_dist, (size_t)n * 4);
+		}
 		e->trace = NULL;            /* the trace is the parser's */
 		for (uint32_t k = 0; k < ne && !r; ++k)
 			r = encode_syms(e, es[k], k + 1 < ne ? es[k + 1] : n, k == 0, out, cap, &opos);

@@ -162,6 +162,9 @@ uint32_t orc_piece_plan(const uint8_t *in, uint32_t n, const orc_enc_params *p, 
  * sym_len (0 = literal, else the match length) and sym_dist (zero-based distance; literal: byte | previous byte << 8 |
  * match byte << 16 | (parser state >= 7) << 24). */
 int orc_parse_dump(const uint8_t *in, uint32_t n, const orc_enc_params *p, uint16_t *sym_len, uint32_t *sym_dist);
+/* Two-phase mode: orc_lzma2_encode_block and orc_parse_dump in one pass (full-size parity tests). */
+int orc_lzma2_encode_block_syms(const uint8_t *in, uint32_t n, const orc_enc_params *p,
+		uint8_t *out, uint64_t out_cap, uint64_t *out_size, uint16_t *sym_len, uint32_t *sym_dist);
 
 int orc_preset(uint32_t preset, orc_enc_params *p, uint32_t *mode_normal);
 

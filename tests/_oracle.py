@@ -434,11 +434,12 @@ def corpus_mixed(n, seed=1):
 
 
 # ---------------------------------------------------------------- stream-level helpers
-def orc_xz_stream(data, prm, block_size, check=4):
-    """Whole .xz Stream in the reference MT layout from the oracle's per-Block payloads."""
+def orc_xz_stream(data, prm, block_size, check=4, payloads=None):
+    """Whole .xz Stream in the reference MT layout from the oracle's per-Block payloads (computed here unless given)."""
     data = bytes(data)
     blocks = [data[i:i + block_size] for i in range(0, len(data), block_size)]
-    payloads = [orc_encode_block(b, prm) for b in blocks]
+    if payloads is None:
+        payloads = [orc_encode_block(b, prm) for b in blocks]
     nb = len(blocks)
     pay = [as_u8(p) for p in payloads]
     inp = [as_u8(b) for b in blocks]
@@ -521,6 +522,23 @@ def orc_parse_dump(data, prm):
     r = f(_ptr(data), n, C.byref(prm), _ptr(sl, C.POINTER(C.c_uint16)), _ptr(sd, u32p))
     assert r == 0, r
     return sl, sd
+
+
+def orc_encode_block_syms(data, prm):
+    """Two-phase: (raw LZMA2 payload, sym_len, sym_dist) of one Block in one pass of the oracle."""
+    data = as_u8(data)
+    n = len(data)
+    cap = n + n // 8 + 4096
+    out = np.empty(cap, dtype=np.uint8)
+    sl = np.zeros(n, dtype=np.uint16)
+    sd = np.zeros(n, dtype=np.uint32)
+    sz = C.c_uint64(0)
+    f = orc().orc_lzma2_encode_block_syms
+    f.restype = C.c_int
+    f.argtypes = [u8p, C.c_uint32, C.POINTER(OrcParams), u8p, C.c_uint64, u64p, C.POINTER(C.c_uint16), u32p]
+    r = f(_ptr(data), n, C.byref(prm), _ptr(out), cap, C.byref(sz), _ptr(sl, C.POINTER(C.c_uint16)), _ptr(sd, u32p))
+    assert r == 0, r
+    return out[: sz.value].tobytes(), sl, sd
 
 
 def first_diff(a, b):

@@ -137,7 +137,7 @@ def test_optimal_parser_beats_fast_parser():
         assert opt <= ref6 * (1 + SIZE_TOLERANCE), (opt, ref6)
 
 
-SIZE_TOLERANCE = 0.03     # stated tolerance: device output <= 1.03 x liblzma at the same preset and block size
+SIZE_TOLERANCE = 0.025     # stated tolerance: device output <= 1.03 x liblzma at the same preset and block size
 
 
 def _elf_mix(n):
@@ -155,7 +155,8 @@ def _elf_mix(n):
 
 
 @pytest.mark.parametrize("corpus,n", [("lorem", 4 << 20), ("text", 4 << 20), ("elf", 4 << 20), ("tar", 6 << 20),
-                                      ("rocm_headers", 6 << 20)])
+                                      ("rocm_headers", 6 << 20), ("logs", 4 << 20), ("json", 4 << 20),
+                                      ("sqlite", 4 << 20), ("dpkg_tar", 6 << 20)])
 def test_size_within_tolerance_of_reference_preset6(corpus, n):
     """Oracle restatement of what the device runs for preset 6 (64-byte suffix order, cost-balanced spans) against
     the REAL liblzma at preset 6 on the same Block: compressed size within the stated tolerance.  (The GPU test
@@ -171,12 +172,18 @@ def test_size_within_tolerance_of_reference_preset6(corpus, n):
         data = xz_amd.corpus_tar(n).tobytes()
     elif corpus == "rocm_headers":
         data = xz_amd.corpus_tar(n, "/opt/rocm/include").tobytes()
+    elif corpus in ("logs", "json", "sqlite", "dpkg_tar"):
+        import _corpora
+        data = {"logs": _corpora.logs, "json": _corpora.json_records, "sqlite": _corpora.sqlite_file,
+                "dpkg_tar": _corpora.dpkg_tar}[corpus](n)
+        if data is None:
+            pytest.skip("no /var/lib/dpkg on this box")
     else:
         data = _elf_mix(n)
         if len(data) < n:
             pytest.skip("not enough ELF files on this box")
     prm = o.params_for_gpu_options(xz_amd.preset_options(6))
-    assert prm.span_cost and prm.sa_depth == 64
+    assert prm.span_cost and prm.sa_depth == 64 and prm.enc_bits        # two-phase: parse pieces + encode spans
     ours_raw = o.orc_encode_block(data, prm)
     r, dec = o.ref_raw_decode(ours_raw, prm.dict_size, len(data) + 16)
     assert r == 1 and dec == data

@@ -19,6 +19,10 @@ def main():
     enc = xz_amd.Encoder(0)
     t = torch.from_numpy(data).to("cuda:0")
     opts = xz_amd.preset_options(preset)
+    if len(sys.argv) > 4:
+        opts.span_cost = int(sys.argv[4])
+    if len(sys.argv) > 5:
+        opts.enc_span_bits = int(sys.argv[5])
     for it in range(2):
         out, _ = enc.encode(t, opts=opts)
         st = enc.stats()

@@ -70,14 +70,19 @@ def gather_stream(blocks, binfo, check, dst=0, group=None):
     total = 12 + sum(sizes) + len(tail)
     out = torch.empty(total, dtype=torch.uint8, device=dev)
     out[:12] = torch.from_numpy(frame_header(check)).to(dev)
+    # every peer's Blocks land straight in their place of the Stream: all receives are posted up front (one per peer
+    # link of the xGMI mesh), then waited for together
     off = 12
+    pending = []
     for r in range(world):
         if sizes[r] == 0:
             continue
         if r == rank:
             out[off:off + sizes[r]] = blocks
         else:
-            dist.recv(out[off:off + sizes[r]], src=r, group=group)
+            pending.append(dist.irecv(out[off:off + sizes[r]], src=r, group=group))
         off += sizes[r]
     out[off:] = torch.from_numpy(tail.copy()).to(dev)
+    for req in pending:
+        req.wait()
     return out
