@@ -167,6 +167,11 @@ typedef struct {
 	uint32_t *sy_dist;          /* zero-based distance; literal: byte | previous byte << 8 | match byte << 16 |
 	                             * (parser state >= 7) << 24 -- what the device's coder reads instead of the input */
 	int rc_off;                 /* phase 1: adapt the model, code nothing */
+	uint32_t lit_rec;           /* phase 2: != 0: the record of the literal being coded | 1 << 31 */
+#ifdef ORC_XPREV
+	uint32_t *xprev[8];
+	int xprev_n;
+#endif
 } enc;
 
 static const uint32_t *crc_table0(void)
@@ -441,6 +446,41 @@ static void find_sn(enc *e, uint32_t p)
 		uint32_t L = cmplen(cur - d16, cur, 0, len_limit);
 		if (L >= 4) { cd[nc] = d16; cl[nc] = L; ++nc; }
 	}
+#ifdef ORC_CHAIN4
+	{       /* experiment: further steps along the hash4 / 8-byte / 16-byte chains */
+		uint32_t q = p;
+		for (int st = 0; st < ORC_CHAIN4 + 1; ++st) {
+			const uint32_t d = e->prev4[q];
+			if (!d) break;
+			q -= d;
+			if (p - q >= e->cyclic_size) break;
+			if (st == 0) continue;
+			uint32_t L = cmplen(cur - (p - q), cur, 0, len_limit);
+			if (L >= 4 && nc < 60) { cd[nc] = p - q; cl[nc] = L; ++nc; }
+		}
+#ifdef ORC_CHAIN8
+		q = p;
+		for (int st = 0; st < ORC_CHAIN8 + 1; ++st) {
+			const uint32_t d = e->prev8[q];
+			if (!d) break;
+			q -= d;
+			if (p - q >= e->cyclic_size) break;
+			if (st == 0) continue;
+			uint32_t L = cmplen(cur - (p - q), cur, 0, len_limit);
+			if (L >= 4 && nc < 60) { cd[nc] = p - q; cl[nc] = L; ++nc; }
+		}
+#endif
+	}
+#endif
+#ifdef ORC_XPREV
+	for (int xi = 0; xi < e->xprev_n; ++xi) {        /* experiment: nearest earlier position with the same K bytes */
+		const uint32_t dx = e->xprev[xi][p];
+		if (dx && dx < e->cyclic_size) {
+			uint32_t L = cmplen(cur - dx, cur, 0, len_limit);
+			if (L >= 2) { cd[nc] = dx; cl[nc] = L; ++nc; }
+		}
+	}
+#endif
 	const uint32_t r = e->sa_rank[p];
 	for (int side = 0; side < 2; ++side) {
 		uint32_t recent = 0;        /* most recent eligible position seen so far on this side, + 1 */
@@ -689,6 +729,32 @@ static void enc_literal(enc *e, uint32_t pos)
 {
 	const uint8_t cur = e->in[pos];
 	uint16_t *sub = e->probs + literal_sub(e, pos);
+	if (e->lit_rec) {
+		/* two-phase coder: the literal is coded from its RECORD, as the device does (k_encode_syms never reads the
+		 * input for a literal): byte, previous byte (context), and the match byte when the record carries one */
+		const uint32_t r = e->lit_rec;
+		const uint32_t lc = e->prm.lc, mask = (0x100u << e->prm.lp) - (0x100u >> lc);
+		const uint8_t c2 = (uint8_t)r;
+		sub = e->probs + P_LITERAL + 3u * ((((pos << 8) + ((r >> 8) & 0xFF)) & mask) << lc);
+		if (e->state < 7) {
+			e->state = e->state <= 3 ? 0 : e->state - 3;
+			rc_tree(e, sub, 8, c2);
+		} else {
+			e->state = e->state <= 9 ? e->state - 3 : e->state - 6;
+			uint32_t mb = (r >> 24) & 1 ? (r >> 16) & 0xFF : e->in[pos - e->reps[0] - 1];
+			uint32_t off = 0x100, sym = 0x100u + c2;
+			do {
+				mb <<= 1;
+				const uint32_t mbit = mb & off;
+				const uint32_t idx = off + mbit + (sym >> 8);
+				const uint32_t b = (sym >> 7) & 1;
+				rc_bit(e, &sub[idx], b);
+				sym <<= 1;
+				off &= ~(mb ^ sym);
+			} while (sym < 0x10000);
+		}
+		return;
+	}
 	if (e->state < 7) {
 		e->state = e->state <= 3 ? 0 : e->state - 3;
 		rc_tree(e, sub, 8, cur);
@@ -1274,7 +1340,7 @@ static int optimum_window(enc *e, uint32_t pos, int cached)
  * chunk end), any other position costs one unit. */
 #define ORC_EST_LONG 4u
 #ifndef ORC_PREROLL
-#define ORC_PREROLL 0u
+#define ORC_PREROLL 2048u         /* two-phase: bytes in front of a piece that are parsed twice (the device: XZAMD_PREROLL) */
 #endif
 
 /* The same walk also makes a rough estimate of the coded size in bits (a greedy parse: at a symbol
@@ -1508,10 +1574,12 @@ static int encode_span_(enc *e, uint32_t start, uint32_t end, int first_in_block
  * recorded symbols of a whole ENCODE SPAN with one continuous model, choosing rep / short rep / match from
  * its own rep distances.  A recorded one-byte rep0 whose distance is not the coder's rep0 becomes a literal
  * (the byte equality it relied on does not matter to a literal). */
-static void record_literal(enc *e, uint32_t pos)
+static void record_literal(enc *e, uint32_t pos, int first_of_piece)
 {
 	const uint32_t cur = e->in[pos], prev = pos ? e->in[pos - 1] : 0;
-	const uint32_t matched = e->state >= 7;
+	/* the first symbol of a piece never carries a match byte: what precedes it in the parser (the pre-roll) is not
+	 * what the coder has coded there, so the coder looks the byte up itself */
+	const uint32_t matched = e->state >= 7 && !first_of_piece;
 	const uint32_t mb = matched ? e->in[pos - e->reps[0] - 1] : 0;
 	e->sy_len[pos] = 0;
 	e->sy_dist[pos] = cur | (prev << 8) | (mb << 16) | (matched << 24);
@@ -1532,6 +1600,8 @@ static void parse_piece(enc *e, uint32_t start, uint32_t end, int first_in_block
 		/* pre-roll: the last ORC_PREROLL bytes in front of the piece are parsed once more, from the prior, and thrown
 		 * away: the piece proper then starts with a price model that has seen the local data, and with rep distances
 		 * and a coder state like the ones the previous piece ends with */
+		orc_trace *const tr = e->trace;
+		e->trace = NULL;                 /* the discarded symbols are not part of the parse */
 		cur = start - ORC_PREROLL;
 		e->span_end = start;
 		while (cur < start) {
@@ -1545,10 +1615,11 @@ static void parse_piece(enc *e, uint32_t start, uint32_t end, int first_in_block
 		e->span_end = end;
 		e->q_count = e->q_head = 0;
 		cached = 0;
+		e->trace = tr;
 	}
 #endif
 	if (first_in_block && cur < end) {
-		record_literal(e, 0);
+		record_literal(e, 0, 1);
 		rc_bit(e, &e->probs[P_IS_MATCH], 0);
 		rc_tree(e, e->probs + P_LITERAL, 8, e->in[0]);
 		trace_sym(e, 0, LIT, 1);
@@ -1559,7 +1630,7 @@ static void parse_piece(enc *e, uint32_t start, uint32_t end, int first_in_block
 			cached = optimum_window(e, cur, cached);
 		const uint32_t back = e->q_back[e->q_head], len = e->q_len[e->q_head];
 		++e->q_head;
-		if (back == LIT) record_literal(e, cur);
+		if (back == LIT) record_literal(e, cur, cur == start);
 		else {
 			e->sy_len[cur] = (uint16_t)len;
 			e->sy_dist[cur] = back < 4 ? e->reps[back] : back - 4;
@@ -1617,7 +1688,8 @@ static int encode_syms(enc *e, uint32_t start, uint32_t end, int first_in_block,
 			uint32_t len = e->sy_len[cur];
 			const uint32_t d = e->sy_dist[cur];
 			uint32_t back;
-			if (len == 0) { back = LIT; len = 1; }
+			e->lit_rec = 0;
+			if (len == 0) { back = LIT; len = 1; e->lit_rec = d | (1u << 31); }
 			else if (len == 1) back = d == e->reps[0] ? 0 : LIT;
 			else if (d == e->reps[0]) back = 0;
 			else if (d == e->reps[1]) back = 1;
@@ -1625,6 +1697,7 @@ static int encode_syms(enc *e, uint32_t start, uint32_t end, int first_in_block,
 			else if (d == e->reps[3]) back = 3;
 			else back = d + 4;
 			enc_symbol(e, cur, back, len);
+			e->lit_rec = 0;
 			cur += len;
 		}
 		rc_flush(e);
@@ -1714,6 +1787,28 @@ static enc *enc_new(const uint8_t *in, uint32_t n, const orc_enc_params *p)
 		enc_free(e);
 		return NULL;
 	}
+#ifdef ORC_XPREV
+	if (p->sa_window) {
+		static const uint32_t ks[] = { ORC_XPREV };
+		e->xprev_n = (int)(sizeof(ks) / sizeof(ks[0]));
+		const uint32_t hb = 22, hm = (1u << hb) - 1;
+		uint32_t *head = (uint32_t *)malloc((size_t)(hm + 1) * 4);
+		for (int xi = 0; xi < e->xprev_n; ++xi) {
+			const uint32_t K = ks[xi];
+			e->xprev[xi] = (uint32_t *)calloc((size_t)n + 1, 4);
+			memset(head, 0, (size_t)(hm + 1) * 4);
+			for (uint32_t x = 0; x + K <= n; ++x) {
+				uint64_t h = 1469598103934665603ull;
+				for (uint32_t i = 0; i < K; ++i) h = (h ^ in[x + i]) * 1099511628211ull;
+				const uint32_t b = (uint32_t)(h >> 20) & hm;
+				const uint32_t q1 = head[b];
+				if (q1 && memcmp(in + q1 - 1, in + x, K) == 0) e->xprev[xi][x] = x - (q1 - 1);
+				head[b] = x + 1;
+			}
+		}
+		free(head);
+	}
+#endif
 	price_table_init(e);
 	return e;
 }

@@ -237,3 +237,27 @@ def test_tar_corpus_is_a_deterministic_ustar_stream(tmp_path):
     assert names.returncode == 0 and len(names.stdout.split()) == 3, (names.stdout, names.stderr)
     with pytest.raises(RuntimeError):
         xz_amd.corpus_tar(1000, str(tmp_path / "missing"))
+
+
+def test_two_phase_round_trip_many_small_pieces():
+    """Two-phase semantics under stress (oracle level; the device is pinned to the oracle byte for byte by the GPU tests):
+    4 KiB parse pieces -- thousands of piece starts, each with a pre-roll whose rep distances and coder state are the
+    parser's guess, not what the coder has there -- and small encode spans.  The coder takes every literal from its
+    record (byte, context byte, match byte when the record may carry one), exactly as k_encode_syms does; a record that
+    carried a match byte across a piece start would decode to different bytes here (found at 10,000 pieces on the GPU)."""
+    if not o.have_ref():
+        pytest.skip("oracle/_ref not built")
+    import xz_amd
+    rng = np.random.default_rng(11)
+    data = (xz_amd.corpus_text(3 << 20, seed=5).tobytes() + o.corpus_lorem(1 << 20) + xz_amd.corpus_tar(2 << 20).tobytes()
+            + bytes(rng.integers(0, 4, size=300000, dtype=np.uint8)) + o.corpus_lorem(700000)[::-1])
+    prm = o.params_for_gpu_options(xz_amd.preset_options(6))
+    prm.span_size = 4096            # shortest piece (the device: 64 KiB)
+    prm.span_cost = 4096
+    prm.span_bits = 0
+    prm.enc_bits = 200000
+    starts, estarts = o.orc_piece_plan(data, prm)
+    assert len(starts) > 700 and len(estarts) > 4
+    raw = o.orc_encode_block(data, prm)
+    r, dec = o.ref_raw_decode(raw, prm.dict_size, len(data) + 16)
+    assert r == 1 and dec == data

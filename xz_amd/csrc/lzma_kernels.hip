@@ -2333,6 +2333,17 @@ __device__ __forceinline__ void parse_piece_one(const xzamd_span_args& a, const 
     }
 
     uint32_t cur = span_start;
+    // Pre-roll (oracle: parse_piece, ORC_PREROLL): every piece but the seed first parses the XZAMD_PREROLL bytes in front
+    // of it once more, from the prior, and throws the symbols away: the piece proper then starts with prices that have seen
+    // the local data and with rep distances / a coder state like the ones the previous piece ends with.  `lim` is what the
+    // parser may not cross: the piece start while pre-rolling, then the piece end.
+    uint32_t lim = span_end;
+    bool rec = true;
+    if (k != 0 && span_start - block_start > XZAMD_PREROLL) {
+        cur = span_start - XZAMD_PREROLL;
+        lim = span_start;
+        rec = false;
+    }
     bool cached = false;
     RoundL RL;
     RL.L = 0; RL.SL = 0; RL.SD = 0; RL.cnt = 0; RL.longest = 0; RL.l2a = RL.l2b = 0;
@@ -2351,7 +2362,15 @@ __device__ __forceinline__ void parse_piece_one(const xzamd_span_args& a, const 
         encode_symbol_t<false, true>(rc, probs, z, 0, LITERAL, 1, l3);
         cur = block_start + 1;
     }
-    while (cur < span_end) {
+    for (;;) {
+        if (cur >= lim) {
+            if (rec) break;
+            rec = true;                                  // the pre-roll is over: the piece proper
+            lim = span_end;
+            cached = false;
+            q_pos = q_end = 0;
+            continue;
+        }
         uint32_t back = LITERAL, len = 1;
         if (q_pos == q_end) {
             TM_BEGIN(t_refresh);
@@ -2361,7 +2380,7 @@ __device__ __forceinline__ void parse_piece_one(const xzamd_span_args& a, const 
             tables_valid = true;
             TM_END(w, 7, t_refresh);
             if (!cached) {
-                round_lists(e, LP, cur, span_end, z.rep0, z.rep1, z.rep2, z.rep3, RL);
+                round_lists(e, LP, cur, lim, z.rep0, z.rep1, z.rep2, z.rep3, RL);
                 cached = true;
             }
             uint32_t sb = LITERAL, sl = 0;
@@ -2379,7 +2398,7 @@ __device__ __forceinline__ void parse_piece_one(const xzamd_span_args& a, const 
                 cached = false;                         // nothing but a literal can leave this node
                 q_pos = q_end = 0;
             } else {
-                cached = optimum_window<WMAX>(e, w, LP, probs, z, lt, in, cur, block_start, span_end, cached, RL, q_end);
+                cached = optimum_window<WMAX>(e, w, LP, probs, z, lt, in, cur, block_start, lim, cached, RL, q_end);
                 q_pos = 0;
                 if (q_end == 0) {                       // consistency failure reported by the parser
                     if (lane == 0 && a.err) atomicCAS(a.err, 0u, 2u);
@@ -2392,7 +2411,7 @@ __device__ __forceinline__ void parse_piece_one(const xzamd_span_args& a, const 
             len = (uni(w.n_info[q_pos]) >> 13) & 0x1FF;
             q_pos += len;
         }
-        if (len == 0 || len > MATCH_LEN_MAX || cur + len > span_end
+        if (len == 0 || len > MATCH_LEN_MAX || cur + len > lim
                 || (back != LITERAL && back >= 4 && back - 4 >= cur - block_start)) {
             if (lane == 0 && a.err) {
                 if (atomicCAS(a.err, 0u, 1u) == 0u) {
@@ -2405,8 +2424,12 @@ __device__ __forceinline__ void parse_piece_one(const xzamd_span_args& a, const 
         uint32_t l3 = 0;
         if (back == LITERAL) {
             l3 = literal_bytes(in, cur, cur - block_start, z) | (z.state >= 7 ? 1u << 24 : 0u);
-            if (lane == 0) { a.sym_len[cur] = 0; a.sym_dist[cur] = l3; }
-        } else if (lane == 0) {
+            // the match byte of the record is the coder's only when the coder has coded the symbol in front of it, i.e. not
+            // for the first symbol of a piece (the pre-roll in front of it is the parser's alone): there the coder fetches
+            // the byte itself
+            const uint32_t l3r = cur == span_start ? (l3 & 0xFFFFu) : l3;
+            if (lane == 0 && rec) { a.sym_len[cur] = 0; a.sym_dist[cur] = l3r; }
+        } else if (lane == 0 && rec) {
             a.sym_len[cur] = (uint16_t)len;
             a.sym_dist[cur] = back >= 4 ? back - 4 : back == 0 ? z.rep0 : back == 1 ? z.rep1 : back == 2 ? z.rep2 : z.rep3;
         }
@@ -2416,7 +2439,7 @@ __device__ __forceinline__ void parse_piece_one(const xzamd_span_args& a, const 
             TM_END(w, 6, t_sym);
             TM_COUNT(w, 10);
         }
-        if (a.trace && lane == 0) {
+        if (a.trace && lane == 0 && rec) {
             const uint32_t ti = atomicAdd(a.trace_count, 1u);
             if (ti < a.trace_cap) {
                 a.trace[4 * ti] = span;

@@ -47,6 +47,7 @@
 #include <time.h>
 #include <execinfo.h>
 #include <signal.h>
+#include <stdio.h>
 #include <unistd.h>
 
 /* XZAMD_DEBUG_SEGV=1: print a backtrace on SIGSEGV (debug aid for the interposed-client case) */
@@ -308,16 +309,21 @@ static lzma_ret run_job(lzma_internal *in, devslot *d, job *j)
 				rc = XZAMD_DEVICE_ERROR;
 		}
 	}
-	if (rc == XZAMD_DEVICE_ERROR || rc == XZAMD_PROG_ERROR) {
-		/* A device failure in the middle of a Stream.  Default: the Stream fails (LZMA_PROG_ERROR, latched).  With
-		 * XZAMD_STORED_ON_DEVICE_ERROR=1 the job's Blocks are stored instead (the reference's own way out when a
-		 * Block cannot be coded, block_buffer_encoder.c:88-162), so what the client has written so far stays a
-		 * valid .xz Stream -- no encoding happens on the host. */
+	if (rc == XZAMD_DEVICE_ERROR) {
+		/* A device (HIP runtime / kernel launch) failure in the middle of a Stream.  Default: the Stream fails
+		 * (LZMA_PROG_ERROR, latched).  With XZAMD_STORED_ON_DEVICE_ERROR=1 the job's Blocks are stored instead (the
+		 * reference's own way out when a Block cannot be coded, block_buffer_encoder.c:88-162), so what the client has
+		 * written so far stays a valid .xz Stream -- no encoding happens on the host.  The encoder's own consistency
+		 * failures (XZAMD_PROG_ERROR) are never papered over this way. */
 		const char *sf = getenv("XZAMD_STORED_ON_DEVICE_ERROR");
 		if (sf && *sf == '1'
 				&& xzamd_stored_blocks_host_(j->stage, n, in->block_size, in->check, j->out, j->out_cap, &out_size,
-						j->binfo, j->binfo_cap, &nblocks) == XZAMD_OK)
+						j->binfo, j->binfo_cap, &nblocks) == XZAMD_OK) {
+			if (getenv("XZAMD_VERBOSE"))
+				fprintf(stderr, "xz_amd: job of %llu bytes stored after a device error: %s\n", (unsigned long long)n,
+						xzamd_last_error(d->ctx));
 			rc = XZAMD_OK;
+		}
 	}
 	if (rc != XZAMD_OK)
 		return map_rc(rc);
