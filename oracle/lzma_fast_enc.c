@@ -131,6 +131,8 @@ typedef struct {
 	uint32_t *prev4;            /* delta to the previous position with equal hash4 (sa_window != 0) */
 	uint32_t *prev8, *prev16;   /* delta to the previous position with the same 8 / 16 bytes: by-products of the
 	                             * suffix-order build (left neighbour inside the group of equal keys) */
+	uint32_t *prev24, *prev32;  /* the same for 24 bytes (one extra sort of the 16-byte groups by the 8 bytes behind
+	                             * them) and 32 bytes (by-product of round h = 16) */
 	uint32_t *sa, *sa_rank;     /* suffix-neighbourhood finder: slot -> position, position -> slot */
 	uint32_t span_end;          /* exclusive end for avail computations */
 	/* result of the last find */
@@ -270,8 +272,9 @@ static int build_sa(enc *e)
 	const uint32_t n = e->n;
 	uint64_t *key = (uint64_t *)malloc((size_t)(n + 1) * 8), *key2 = (uint64_t *)malloc((size_t)(n + 1) * 8);
 	uint32_t *val2 = (uint32_t *)malloc((size_t)(n + 1) * 4);
+	uint32_t *rk8 = (uint32_t *)malloc((size_t)(n + 1) * 4);
 	uint32_t *sa = e->sa, *rk = e->sa_rank;
-	if (!key || !key2 || !val2) { free(key); free(key2); free(val2); return -1; }
+	if (!key || !key2 || !val2 || !rk8) { free(key); free(key2); free(val2); free(rk8); return -1; }
 	for (uint32_t p = 0; p < n; ++p) {
 		uint64_t v = 0;
 		for (uint32_t i = 0; i < 8; ++i)
@@ -284,7 +287,7 @@ static int build_sa(enc *e)
 		/* rank = 1 + first slot of the group; inside a group positions ascend, so the left neighbour of a
 		 * group member is the nearest earlier position with the same 8 (round 0) / 16 (round 1) bytes */
 		uint32_t g = 0;
-		uint32_t *prevx = h == 8 ? e->prev8 : (h == 16 ? e->prev16 : NULL);
+		uint32_t *prevx = h == 8 ? e->prev8 : (h == 16 ? e->prev16 : (h == 32 ? e->prev32 : NULL));
 		for (uint32_t i = 0; i < n; ++i) {
 			if (i && key[i] != key[i - 1]) g = i;
 			rk[sa[i]] = g + 1;
@@ -299,6 +302,24 @@ static int build_sa(enc *e)
 			fprintf(stderr, "SA after %u bytes: %.2f%% of positions in groups of >= 2\n", h, 100.0 * unres / (n ? n : 1));
 		}
 #endif
+		if (h == 8)
+			memcpy(rk8, rk, (size_t)n * 4);
+		if (h == 16) {
+			/* prev24: the positions ordered by (16-byte group, rank after 8 bytes of p + 16); stable from the
+			 * current order, so equal keys keep ascending positions */
+			uint64_t *k24 = (uint64_t *)malloc((size_t)(n + 1) * 8);
+			uint32_t *v24 = (uint32_t *)malloc((size_t)(n + 1) * 4);
+			if (!k24 || !v24) { free(k24); free(v24); free(key); free(key2); free(val2); free(rk8); return -1; }
+			for (uint32_t i = 0; i < n; ++i) {
+				const uint32_t p = sa[i];
+				k24[i] = ((uint64_t)rk[p] << 32) | (p + 16 < n ? rk8[p + 16] : 0);
+				v24[i] = p;
+			}
+			radix_sort_u64(k24, v24, key2, val2, n);
+			for (uint32_t i = 0; i < n; ++i)
+				e->prev24[v24[i]] = (i && k24[i] == k24[i - 1]) ? v24[i] - v24[i - 1] : 0;
+			free(k24); free(v24);
+		}
 		if (h >= (e->prm.sa_depth ? e->prm.sa_depth : 32u))
 			break;
 		for (uint32_t i = 0; i < n; ++i) {
@@ -308,7 +329,7 @@ static int build_sa(enc *e)
 	}
 	for (uint32_t i = 0; i < n; ++i)
 		rk[sa[i]] = i;              /* position -> slot */
-	free(key); free(key2); free(val2);
+	free(key); free(key2); free(val2); free(rk8);
 	return 0;
 }
 
@@ -430,6 +451,7 @@ static void find_sn(enc *e, uint32_t p)
 	 * and on the GPU it costs a sort and an inversion of the whole batch.) */
 	uint32_t cd[64], cl[64], nc = 0;
 	const uint32_t d2 = e->prev2[p], d4 = e->prev4[p], d8 = e->prev8[p], d16 = e->prev16[p];
+	const uint32_t d24 = e->prev24[p], d32 = e->prev32[p];
 	if (d2 && d2 < e->cyclic_size) {
 		uint32_t L = cmplen(cur - d2, cur, 0, len_limit);
 		if (L >= 2) { cd[nc] = d2; cl[nc] = L; ++nc; }
@@ -445,6 +467,14 @@ static void find_sn(enc *e, uint32_t p)
 	if (d16 && d16 < e->cyclic_size) {
 		uint32_t L = cmplen(cur - d16, cur, 0, len_limit);
 		if (L >= 4) { cd[nc] = d16; cl[nc] = L; ++nc; }
+	}
+	if (d24 && d24 < e->cyclic_size) {
+		uint32_t L = cmplen(cur - d24, cur, 0, len_limit);
+		if (L >= 4) { cd[nc] = d24; cl[nc] = L; ++nc; }
+	}
+	if (d32 && d32 < e->cyclic_size) {
+		uint32_t L = cmplen(cur - d32, cur, 0, len_limit);
+		if (L >= 4) { cd[nc] = d32; cl[nc] = L; ++nc; }
 	}
 #ifdef ORC_CHAIN4
 	{       /* experiment: further steps along the hash4 / 8-byte / 16-byte chains */
@@ -1753,7 +1783,7 @@ static uint32_t hash_mask_for(uint32_t dict_size, uint32_t hash_bytes)
 static void enc_free(enc *e)
 {
 	if (!e) return;
-	free(e->prev2); free(e->prev3); free(e->son); free(e->prev4); free(e->prev8); free(e->prev16); free(e->sa); free(e->sa_rank); free(e->cbuf); free(e->nodes); free(e->sy_len); free(e->sy_dist); free(e);
+	free(e->prev2); free(e->prev3); free(e->son); free(e->prev4); free(e->prev8); free(e->prev16); free(e->prev24); free(e->prev32); free(e->sa); free(e->sa_rank); free(e->cbuf); free(e->nodes); free(e->sy_len); free(e->sy_dist); free(e);
 }
 
 static enc *enc_new(const uint8_t *in, uint32_t n, const orc_enc_params *p)
@@ -1775,6 +1805,8 @@ static enc *enc_new(const uint8_t *in, uint32_t n, const orc_enc_params *p)
 		e->prev4 = (uint32_t *)calloc((size_t)n + 1, 4);
 		e->prev8 = (uint32_t *)calloc((size_t)n + 1, 4);
 		e->prev16 = (uint32_t *)calloc((size_t)n + 1, 4);
+		e->prev24 = (uint32_t *)calloc((size_t)n + 1, 4);
+		e->prev32 = (uint32_t *)calloc((size_t)n + 1, 4);
 		e->sa = (uint32_t *)calloc((size_t)n + 1, 4);
 		e->sa_rank = (uint32_t *)calloc((size_t)n + 1, 4);
 	}
@@ -1782,7 +1814,7 @@ static enc *enc_new(const uint8_t *in, uint32_t n, const orc_enc_params *p)
 	e->nodes = (node *)calloc(WMAX_CAP + MATCH_LEN_MAX + 2, sizeof(node));
 	e->wmax = e->prm.nice_len > 128 ? WMAX_LONG : WMAX_STD;
 	if (!e->prev2 || !e->prev3 || !e->son || !e->cbuf || !e->nodes
-			|| (p->sa_window && (!e->prev4 || !e->prev8 || !e->prev16 || !e->sa || !e->sa_rank))
+			|| (p->sa_window && (!e->prev4 || !e->prev8 || !e->prev16 || !e->prev24 || !e->prev32 || !e->sa || !e->sa_rank))
 			|| build_links(e) || (p->sa_window && build_sa(e))) {
 		enc_free(e);
 		return NULL;

@@ -48,8 +48,9 @@ int xzk_build_chains(const uint8_t *d_in, uint32_t n, uint32_t block_size, uint3
 		void *sort_tmp, uint64_t sort_tmp_bytes,
 		uint32_t *rank, uint32_t *sorted_pos, uint32_t *prev2, uint32_t *prev3,
 		uint32_t *prev4, uint64_t *rp8, uint64_t *rp16, uint64_t *key64_a, uint64_t *key64_b,
-		uint32_t *sa, uint32_t *sa_rank, void *stream)
+		uint32_t *sa, uint32_t *sa_rank, uint32_t *prev24, uint32_t *prev32, void *stream)
 {
+	(void)prev24; (void)prev32;
 	(void)d_in; (void)n; (void)block_size; (void)nblocks; (void)hash_bytes; (void)hash_mask; (void)hash_bits; (void)sa_depth;
 	(void)keys_a; (void)keys_b; (void)vals_a; (void)vals_b; (void)sort_tmp; (void)sort_tmp_bytes; (void)rank; (void)sorted_pos;
 	(void)prev2; (void)prev3; (void)prev4; (void)rp8; (void)rp16; (void)key64_a; (void)key64_b; (void)sa; (void)sa_rank; (void)stream;
@@ -57,8 +58,10 @@ int xzk_build_chains(const uint8_t *d_in, uint32_t n, uint32_t block_size, uint3
 }
 
 int xzk_find_matches(const xzamd_span_args *a, const uint32_t *sa, const uint32_t *sa_rank, const uint32_t *prev4,
-		const uint64_t *rp8, const uint64_t *rp16, uint16_t *mlen, uint32_t *mdist, int part, void *stream)
+		const uint64_t *rp8, const uint64_t *rp16, const uint32_t *prev24, const uint32_t *prev32,
+		uint16_t *mlen, uint32_t *mdist, int part, void *stream)
 {
+	(void)prev24; (void)prev32;
 	(void)a; (void)sa; (void)sa_rank; (void)prev4; (void)rp8; (void)rp16; (void)mlen; (void)mdist; (void)part; (void)stream;
 	return 0;
 }

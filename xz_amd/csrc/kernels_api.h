@@ -86,13 +86,14 @@ int xzk_build_chains(const uint8_t *d_in, uint32_t n, uint32_t block_size, uint3
 		void *sort_tmp, uint64_t sort_tmp_bytes,
 		uint32_t *rank, uint32_t *sorted_pos, uint32_t *prev2, uint32_t *prev3,
 		uint32_t *prev4, uint64_t *rp8, uint64_t *rp16, uint64_t *key64_a, uint64_t *key64_b,
-		uint32_t *sa, uint32_t *sa_rank, void *stream);
+		uint32_t *sa, uint32_t *sa_rank, uint32_t *prev24, uint32_t *prev32, void *stream);
 int xzk_sa_temp_bytes(uint32_t n, uint64_t *bytes);
 /* part: 0 = every position; 1 = the positions of the seed regions (the first XZAMD_SEED_LEN bytes of every Block, in
  * whole runs of 256), 2 = all the others (suffix-neighbourhood finder with block_size >= XZAMD_SEED_LEN + 512 only):
  * the two-phase mode parses the seed pieces underneath launch 2 */
 int xzk_find_matches(const xzamd_span_args *a, const uint32_t *sa, const uint32_t *sa_rank, const uint32_t *prev4,
-		const uint64_t *rp8, const uint64_t *rp16, uint16_t *mlen, uint32_t *mdist, int part, void *stream);
+		const uint64_t *rp8, const uint64_t *rp16, const uint32_t *prev24, const uint32_t *prev32,
+		uint16_t *mlen, uint32_t *mdist, int part, void *stream);
 /* Cost-balanced span plan of a batch from its match lists (oracle: plan_spans): est[0 .. 2 * nblocks * cpb) receives
  * the per-chunk work and bit estimates (cpb = chunks per Block), totals[0 .. nblocks] the per-Block work and, last,
  * the batch total (u64 each); then span_tab / span_cnt as described in xzamd_span_args.  The work target of a span is

@@ -444,6 +444,18 @@ __global__ __launch_bounds__(256) void k_sa_writeback(const uint32_t* __restrict
     }
 }
 
+// By-product of a sorted round: inside a run of equal keys the positions ascend, so the left neighbour of a member is the
+// nearest earlier position of its group; d[position] = distance to it (0: first of its group).  A scatter of m elements.
+__global__ __launch_bounds__(256) void k_sa_prev_scatter(const uint64_t* __restrict__ key, const uint32_t* __restrict__ val,
+        uint32_t m, uint32_t* __restrict__ d)
+{
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < m; j += stride) {
+        const uint32_t p = val[j];
+        d[p] = (j > 0 && key[j] == key[j - 1]) ? p - val[j - 1] : 0u;
+    }
+}
+
 // doubling key of every position, in position order: (rank[p], rank[p + h]) with 0 for a second half that
 // starts past the Block end; vals = iota.  The second rank is taken relative to the Block (sbits = bits of
 // block_size + 1), so the key is 31 + sbits bits wide instead of 62: one radix pass less for Blocks up to 32 MiB.  (The radix sort is stable and the members of a group ascend by
@@ -2722,6 +2734,8 @@ struct SnArgs {
     const uint32_t* __restrict__ prev4;
     const uint32_t* __restrict__ prev8;
     const uint32_t* __restrict__ prev16;
+    const uint32_t* __restrict__ prev24;    // nearest earlier position with the same 24 / 32 bytes
+    const uint32_t* __restrict__ prev32;
     // Which runs a launch covers: 0 = all; 1 = the runs that touch the first XZAMD_SEED_LEN bytes of a Block (workgroup =
     // Block * SEED_RUNS + j); 2 = all the others.  The two-phase mode parses the seed pieces (k_parse_pieces phase 0)
     // underneath launch 2.
@@ -2805,8 +2819,13 @@ __global__ __launch_bounds__(64) void k_find_sn(xzamd_span_args a, SnArgs sn, ui
     const bool win_lane = (left || right) && k < W;
     // hash2 / hash4 heads and the 8- / 16-byte left neighbours.  (A hash3 head, lane 11, was measured to be worth
     // nothing on text and 0.1 % on executables next to these: its sort and inversion are not built for this finder.)
-    const bool hash_lane = t == 10 || (t >= 12 && t < 15);
-    const uint32_t* __restrict__ hp = t == 10 ? sn.prev2 : t == 12 ? sn.prev4 : t == 13 ? sn.prev8 : sn.prev16;
+    // Lanes 11 / 15: the nearest earlier position with the same 24 / 32 bytes (by-products of the suffix-order rounds):
+    // between "same 16 bytes" and the suffix-order neighbours (which share the LONGEST prefixes, at any distance) these
+    // are the near candidates of medium length BT4's descent finds (measured through the oracle: -0.6 points of size on
+    // a SQLite file, -0.45 on C headers, -0.9 at 9e).
+    const bool hash_lane = t >= 10;
+    const uint32_t* __restrict__ hp = t == 10 ? sn.prev2 : t == 11 ? sn.prev24 : t == 12 ? sn.prev4 : t == 13 ? sn.prev8
+            : t == 14 ? sn.prev16 : sn.prev32;
     const uint32_t hstride = 1u;
     const uint32_t minlen = t == 10 ? 2u : 4u;
     // masks for the prefix maximum inside a side (the right side must not look into the left one)
@@ -2845,8 +2864,18 @@ __global__ __launch_bounds__(64) void k_find_sn(xzamd_span_args a, SnArgs sn, ui
         const uint32_t ex = sh1 ? o1 : 0u;
         valid = elig && v > ex;
         q = elig ? wq : 0u;
+        // The six hash / prefix lanes often name the same position (the nearest earlier position with the same 8 bytes is
+        // usually also the one with the same 16, 24, 32): the candidate stays in the lowest of those lanes only -- which is
+        // the one the Pareto rule below would keep -- and the others do not fetch its bytes again.  (hw is 0 in the
+        // window lanes; computed by every lane so that the row shifts see all their source lanes.)
+        bool dup = false;
+        { const uint32_t o = row_shr<1>(hw); dup = dup || (t >= 11 && o == hw); }
+        { const uint32_t o = row_shr<2>(hw); dup = dup || (t >= 12 && o == hw); }
+        { const uint32_t o = row_shr<3>(hw); dup = dup || (t >= 13 && o == hw); }
+        { const uint32_t o = row_shr<4>(hw); dup = dup || (t >= 14 && o == hw); }
+        { const uint32_t o = row_shr<5>(hw); dup = dup || (t >= 15 && o == hw); }
         if (hash_lane) {
-            valid = hw != 0 && hw < cyclic && hw <= p;
+            valid = hw != 0 && hw < cyclic && hw <= p && !dup;
             q = valid ? p - hw : 0u;
         }
     };
@@ -3829,7 +3858,7 @@ int xzk_build_chains(const uint8_t* d_in, uint32_t n, uint32_t block_size, uint3
         void* sort_tmp, uint64_t sort_tmp_bytes,
         uint32_t* rank, uint32_t* sorted_pos, uint32_t* prev2, uint32_t* prev3,
         uint32_t* prev4, uint64_t* rp8, uint64_t* rp16, uint64_t* key64_a, uint64_t* key64_b,
-        uint32_t* sa, uint32_t* sa_rank, void* stream_)
+        uint32_t* sa, uint32_t* sa_rank, uint32_t* prev24, uint32_t* prev32, void* stream_)
 {
     hipStream_t st = (hipStream_t)stream_;
     const uint32_t g = grid_for(n, 256, 256 * 16);
@@ -3874,6 +3903,8 @@ int xzk_build_chains(const uint8_t* d_in, uint32_t n, uint32_t block_size, uint3
     if (sa == nullptr) return (int)hipGetLastError();
 
     // ---- suffix order ----
+    if (prev24 != nullptr && hipMemsetAsync(prev24, 0, (size_t)n * 4, st) != hipSuccess) return (int)hipErrorUnknown;
+    if (prev32 != nullptr && hipMemsetAsync(prev32, 0, (size_t)n * 4, st) != hipSuccess) return (int)hipErrorUnknown;
     uint32_t* grp = keys_a;                       // group-start scan buffer (the hash sorts above are done with it)
     hipError_t e;
     size_t need = 0;
@@ -4019,6 +4050,22 @@ int xzk_build_chains(const uint8_t* d_in, uint32_t n, uint32_t block_size, uint3
             if (e != hipSuccess) return (int)e;
             if (m == 0) break;                        // every suffix is distinguished: the order is final
         }
+        if (h == 16 && prev24 != nullptr && compact_on && n >= 2) {
+            // prev24 (the nearest earlier position with the same 24 bytes): the members of the 16-byte groups once more,
+            // ordered by (group, rank after 8 bytes of p + 16) -- an extra sort of the m undecided slots only; the key,
+            // value and slot buffers of the compact round below are free until it runs
+            uint32_t* const cslot = pos_alt;
+            hipLaunchKernelGGL(k_sa_compact, dim3(g), dim3(256), 0, st, pos, grp, idx, reinterpret_cast<const uint32_t*>(rp8), n,
+                    block_size, 16u, sbits, key64_a, sa, cslot);
+            rocprim::double_buffer<uint64_t> kk(key64_a, key64_b);
+            rocprim::double_buffer<uint32_t> vv(sa, sa_rank);
+            e = rocprim::radix_sort_pairs(nullptr, need, kk, vv, (size_t)m, 0u, sbits + fbits, st);
+            if (e != hipSuccess) return (int)e;
+            if (need > tb) return (int)hipErrorOutOfMemory;
+            e = rocprim::radix_sort_pairs(sort_tmp, tb, kk, vv, (size_t)m, 0u, sbits + fbits, st);
+            if (e != hipSuccess) return (int)e;
+            hipLaunchKernelGGL(k_sa_prev_scatter, dim3(grid_for(m, 256, 256 * 16)), dim3(256), 0, st, kk.current(), vv.current(), m, prev24);
+        }
         if (compact_on && n >= 2 && (uint64_t)m * 10 <= (uint64_t)n * 6) {
             uint32_t* const cslot = pos_alt;
             const uint32_t gm = grid_for(m, 256, 256 * 16);
@@ -4028,6 +4075,8 @@ int xzk_build_chains(const uint8_t* d_in, uint32_t n, uint32_t block_size, uint3
             rocprim::double_buffer<uint32_t> vv(sa, sa_rank);
             e = rocprim::radix_sort_pairs(sort_tmp, tb, kk, vv, (size_t)m, 0u, sbits + fbits, st);
             if (e != hipSuccess) return (int)e;
+            if (h == 16 && prev32 != nullptr)         // by-product: the 32-byte groups' left neighbours
+                hipLaunchKernelGGL(k_sa_prev_scatter, dim3(gm), dim3(256), 0, st, kk.current(), vv.current(), m, prev32);
             hipLaunchKernelGGL(k_sa_newgrp, dim3(gm), dim3(256), 0, st, kk.current(), cslot, m, idx);
             e = rocprim::inclusive_scan(sort_tmp, tb, idx, idx, (size_t)m, rocprim::maximum<uint32_t>(), st);
             if (e != hipSuccess) return (int)e;
@@ -4041,6 +4090,8 @@ int xzk_build_chains(const uint8_t* d_in, uint32_t n, uint32_t block_size, uint3
             if (e != hipSuccess) return (int)e;
             pos = vv.current();
             pos_alt = vv.alternate();
+            if (h == 16 && prev32 != nullptr)
+                hipLaunchKernelGGL(k_sa_prev_scatter, dim3(g), dim3(256), 0, st, kk.current(), pos, n, prev32);
             if (more) {            // another round follows: its ranks need the groups of this order
                 hipLaunchKernelGGL(k_sa_flags64, dim3(g), dim3(256), 0, st, kk.current(), n, 0u, grp);
                 e = rocprim::inclusive_scan(sort_tmp, tb, grp, grp, (size_t)n, rocprim::maximum<uint32_t>(), st);
@@ -4057,18 +4108,21 @@ int xzk_build_chains(const uint8_t* d_in, uint32_t n, uint32_t block_size, uint3
 }
 
 int xzk_find_matches(const xzamd_span_args* a, const uint32_t* sa, const uint32_t* sa_rank, const uint32_t* prev4,
-        const uint64_t* rp8, const uint64_t* rp16, uint16_t* mlen, uint32_t* mdist, int part, void* stream_)
+        const uint64_t* rp8, const uint64_t* rp16, const uint32_t* prev24, const uint32_t* prev32,
+        uint16_t* mlen, uint32_t* mdist, int part, void* stream_)
 {
     hipStream_t st = (hipStream_t)stream_;
     const uint32_t runs = (a->n + FIND_RUN - 1) / FIND_RUN;
     if (runs == 0) return 0;
     if (a->sa_window) {
-        if (!sa || !sa_rank || !prev4 || !rp8 || !rp16 || !a->mtop || a->sa_window > SN_WMAX) return (int)hipErrorInvalidValue;
+        if (!sa || !sa_rank || !prev4 || !rp8 || !rp16 || !prev24 || !prev32 || !a->mtop || a->sa_window > SN_WMAX)
+            return (int)hipErrorInvalidValue;
         if (part != 0 && a->block_size < XZAMD_SEED_LEN + 2 * FIND_RUN) return (int)hipErrorInvalidValue;
         SnArgs sn;
         sn.in = a->in; sn.sa = sa; sn.sa_rank = sa_rank; sn.prev2 = a->prev2; sn.prev4 = prev4;
         sn.prev8 = reinterpret_cast<const uint32_t*>(rp8) + a->n;     // second array of the round's (rank, distance) pair
         sn.prev16 = reinterpret_cast<const uint32_t*>(rp16) + a->n;
+        sn.prev24 = prev24; sn.prev32 = prev32;
         sn.mode = (uint32_t)part;
         const uint32_t nblocks = (a->n + a->block_size - 1) / a->block_size;
         hipLaunchKernelGGL(k_find_sn, dim3(part == 1 ? nblocks * SEED_RUNS : runs), dim3(64), 0, st, *a, sn, mlen, mdist);

@@ -371,7 +371,7 @@ struct xzamd_ctx {
 	char err[256];
 	char err_msg_buf[200];
 	/* device buffers */
-	dbuf keys_a, keys_b, vals_a, vals_b, rank, sorted_pos, prev2, prev3, prev4, prev8, prev16, key64_a, key64_b, sa, sa_rank, sort_tmp;
+	dbuf keys_a, keys_b, vals_a, vals_b, rank, sorted_pos, prev2, prev3, prev4, prev8, prev16, prev24, prev32, key64_a, key64_b, sa, sa_rank, sort_tmp;
 	dbuf scratch, span_bytes, strip_crc, block_crc, segs, lits, trace, errw, errw2, litp, mlen, mdist, bcj[2];
 	dbuf est, totals, span_tab, span_cnt, mtop, order;             /* span plan (kernels_api.h) */
 	dbuf sym_len[2], sym_dist[2], prior, enc_tab[2], enc_cnt[2];   /* two-phase mode ([2]: one set per pipeline parity) */
@@ -465,7 +465,7 @@ int xzamd_ctx_create(xzamd_ctx **out, int device)
 static void ctx_device_bufs(xzamd_ctx *c, dbuf **d, size_t *nd)
 {
 	dbuf *all[] = { &c->keys_a, &c->keys_b, &c->vals_a, &c->vals_b, &c->rank, &c->sorted_pos,
-		&c->prev2, &c->prev3, &c->prev4, &c->prev8, &c->prev16, &c->key64_a, &c->key64_b, &c->sa, &c->sa_rank, &c->sort_tmp,
+		&c->prev2, &c->prev3, &c->prev4, &c->prev8, &c->prev16, &c->prev24, &c->prev32, &c->key64_a, &c->key64_b, &c->sa, &c->sa_rank, &c->sort_tmp,
 		&c->scratch, &c->litp, &c->mlen, &c->mdist, &c->bcj[0], &c->bcj[1], &c->est, &c->mtop, &c->order,
 		&c->sym_len[0], &c->sym_len[1], &c->sym_dist[0], &c->sym_dist[1],
 		/* small ones */
@@ -474,7 +474,7 @@ static void ctx_device_bufs(xzamd_ctx *c, dbuf **d, size_t *nd)
 	*nd = sizeof(all) / sizeof(all[0]);
 	memcpy(d, all, sizeof(all));
 }
-#define CTX_NBIG 29      /* the first CTX_NBIG entries of ctx_device_bufs scale with the batch */
+#define CTX_NBIG 31      /* the first CTX_NBIG entries of ctx_device_bufs scale with the batch */
 
 void xzamd_ctx_destroy(xzamd_ctx *c)
 {
@@ -681,7 +681,9 @@ static int launch_chains(xzamd_ctx *c, const xzamd_lzma_options *opt, const uint
 			opt->gpu_sa_window ? (uint64_t *)c->key64_a.p : NULL,
 			opt->gpu_sa_window ? (uint64_t *)c->key64_b.p : NULL,
 			opt->gpu_sa_window ? (uint32_t *)c->sa.p : NULL,
-			opt->gpu_sa_window ? (uint32_t *)c->sa_rank.p : NULL, st);
+			opt->gpu_sa_window ? (uint32_t *)c->sa_rank.p : NULL,
+			opt->gpu_sa_window ? (uint32_t *)c->prev24.p : NULL,
+			opt->gpu_sa_window ? (uint32_t *)c->prev32.p : NULL, st);
 	return e ? fail(c, XZAMD_DEVICE_ERROR, "build_chains", e) : XZAMD_OK;
 }
 
@@ -1009,6 +1011,7 @@ int xzamd_stream_encode_device(xzamd_ctx *c,
 		GROW(prev2, 4ull * n, 0); GROW(prev3, 4ull * n, 0);
 		if (opt->gpu_sa_window) {
 			GROW(prev4, 4ull * n, 0); GROW(prev8, 8ull * n, 0); GROW(prev16, 8ull * n, 0);   /* prev8/16: (rank, distance) pairs */
+			GROW(prev24, 4ull * n, 0); GROW(prev32, 4ull * n, 0);
 			GROW(key64_a, 8ull * n, 0); GROW(key64_b, 8ull * n, 0);
 			GROW(sa, 4ull * n, 0); GROW(sa_rank, 4ull * n, 0);
 		} else {
@@ -1145,7 +1148,8 @@ int xzamd_stream_encode_device(xzamd_ctx *c,
 				seeds_early = two && block_size >= XZAMD_SEED_LEN + 1024 && getenv("XZAMD_NO_OVERLAP") == NULL;
 				if (seeds_early) {
 					e = xzk_find_matches(&a, (const uint32_t *)c->sa.p, (const uint32_t *)c->sa_rank.p, (const uint32_t *)c->prev4.p,
-							(const uint64_t *)c->prev8.p, (const uint64_t *)c->prev16.p, (uint16_t *)a.mlen, (uint32_t *)a.mdist, 1, st);
+							(const uint64_t *)c->prev8.p, (const uint64_t *)c->prev16.p,
+							(const uint32_t *)c->prev24.p, (const uint32_t *)c->prev32.p, (uint16_t *)a.mlen, (uint32_t *)a.mdist, 1, st);
 					if (!e) e = xzk_event_record(c->ev_seed[par][0], st);
 					if (!e) e = xzk_stream_wait_event(c->st3, c->ev_seed[par][0]);
 					if (!e) e = xzk_event_record(c->ev_seed[par][1], c->st3);
@@ -1153,7 +1157,8 @@ int xzamd_stream_encode_device(xzamd_ctx *c,
 					if (!e) e = xzk_event_record(c->ev_seed[par][2], c->st3);
 				}
 				if (!e) e = xzk_find_matches(&a, (const uint32_t *)c->sa.p, (const uint32_t *)c->sa_rank.p, (const uint32_t *)c->prev4.p,
-						(const uint64_t *)c->prev8.p, (const uint64_t *)c->prev16.p, (uint16_t *)a.mlen, (uint32_t *)a.mdist, seeds_early ? 2 : 0, st);
+						(const uint64_t *)c->prev8.p, (const uint64_t *)c->prev16.p,
+							(const uint32_t *)c->prev24.p, (const uint32_t *)c->prev32.p, (uint16_t *)a.mlen, (uint32_t *)a.mdist, seeds_early ? 2 : 0, st);
 				if (e) { rc = fail(c, XZAMD_DEVICE_ERROR, "find_matches launch", e); goto done; }
 				cur.find_timed = 1;
 			}
