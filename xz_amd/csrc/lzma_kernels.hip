@@ -3584,33 +3584,51 @@ __global__ __launch_bounds__(64) void k_sha256_blocks(const uint8_t* __restrict_
     const uint32_t len = min(n, bs + block_size) - bs;
     uint32_t h[8] = { 0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19 };
     const uint32_t nchunks = (len + 9 + 63) / 64;               // message + 0x80 + 64-bit length
+    const uint32_t nfull = len / 64;                            // chunks that are message bytes only
+    // A SHA-256 is one serial chain of 64-byte compressions, so the parallelism is the Blocks: one LANE per Block (a
+    // wavefront hashes 64 Blocks in lockstep).  Message words come in 16-byte loads, the schedule lives in a 16-word
+    // ring in registers, the 64 rounds are unrolled.
     for (uint32_t c = 0; c < nchunks; ++c) {
-        uint32_t w[64];
-        for (int i = 0; i < 16; ++i) {
-            uint32_t v = 0;
-            for (int k = 0; k < 4; ++k) {
-                const uint32_t o = c * 64 + i * 4 + k;
-                uint32_t byte = 0;
-                if (o < len) byte = in[bs + o];
-                else if (o == len) byte = 0x80;
-                else if (c + 1 == nchunks && i >= 14) {
-                    const uint64_t bits = (uint64_t)len * 8;
-                    byte = (uint32_t)(bits >> (8 * (7 - ((i - 14) * 4 + k)))) & 0xFF;
-                }
-                v = (v << 8) | byte;
+        uint32_t w[16];
+        if (c < nfull) {
+            const uint8_t* p = in + bs + (uint64_t)c * 64;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                uint4 v;
+                __builtin_memcpy(&v, p + 16 * q, 16);
+                w[4 * q + 0] = __builtin_bswap32(v.x); w[4 * q + 1] = __builtin_bswap32(v.y);
+                w[4 * q + 2] = __builtin_bswap32(v.z); w[4 * q + 3] = __builtin_bswap32(v.w);
             }
-            w[i] = v;
-        }
-        for (int i = 16; i < 64; ++i) {
-            const uint32_t s0 = rotr32(w[i - 15], 7) ^ rotr32(w[i - 15], 18) ^ (w[i - 15] >> 3);
-            const uint32_t s1 = rotr32(w[i - 2], 17) ^ rotr32(w[i - 2], 19) ^ (w[i - 2] >> 10);
-            w[i] = w[i - 16] + s0 + w[i - 7] + s1;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                uint32_t v = 0;
+                for (int k = 0; k < 4; ++k) {
+                    const uint32_t o = c * 64 + i * 4 + k;
+                    uint32_t byte = 0;
+                    if (o < len) byte = in[bs + o];
+                    else if (o == len) byte = 0x80;
+                    else if (c + 1 == nchunks && i >= 14) {
+                        const uint64_t bits = (uint64_t)len * 8;
+                        byte = (uint32_t)(bits >> (8 * (7 - ((i - 14) * 4 + k)))) & 0xFF;
+                    }
+                    v = (v << 8) | byte;
+                }
+                w[i] = v;
+            }
         }
         uint32_t a = h[0], bb = h[1], cc = h[2], d = h[3], e = h[4], f = h[5], g = h[6], hh = h[7];
+#pragma unroll
         for (int i = 0; i < 64; ++i) {
+            if (i >= 16) {
+                const uint32_t w15 = w[(i - 15) & 15], w2 = w[(i - 2) & 15];
+                const uint32_t s0 = rotr32(w15, 7) ^ rotr32(w15, 18) ^ (w15 >> 3);
+                const uint32_t s1 = rotr32(w2, 17) ^ rotr32(w2, 19) ^ (w2 >> 10);
+                w[i & 15] = w[i & 15] + s0 + w[(i - 7) & 15] + s1;
+            }
             const uint32_t S1 = rotr32(e, 6) ^ rotr32(e, 11) ^ rotr32(e, 25);
             const uint32_t ch = (e & f) ^ (~e & g);
-            const uint32_t t1 = hh + S1 + ch + K[i] + w[i];
+            const uint32_t t1 = hh + S1 + ch + K[i] + w[i & 15];
             const uint32_t S0 = rotr32(a, 2) ^ rotr32(a, 13) ^ rotr32(a, 22);
             const uint32_t mj = (a & bb) ^ (a & cc) ^ (bb & cc);
             const uint32_t t2 = S0 + mj;

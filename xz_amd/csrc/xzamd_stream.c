@@ -102,6 +102,8 @@ struct lzma_internal_s {
 	devslot dev[MAX_DEVS]; int ndev;
 	job jobs[MAX_JOBS]; int njobs;
 	int fill;                    /* job being filled by the calling thread, -1 = none */
+	int ndone;                   /* jobs in J_DONE (written under mu, read without it by the calling thread: a stale 0 only
+	                              * delays the drain by one call) */
 	uint64_t next_seq, drain_seq;
 	pthread_mutex_t mu;
 	pthread_cond_t cv_work, cv_done;
@@ -358,6 +360,7 @@ static void *worker_main(void *arg)
 		pthread_mutex_lock(&in->mu);
 		j->err = r;
 		j->state = J_DONE;
+		__atomic_add_fetch(&in->ndone, 1, __ATOMIC_RELEASE);
 		in->progress_in += j->stage_len;
 		pthread_cond_broadcast(&in->cv_done);
 	}
@@ -556,11 +559,12 @@ lzma_ret lzma_stream_encoder_mt(lzma_stream *strm, const lzma_mt *options)
 	}
 	xzk_set_device(cur);
 	in->njobs = in->ndev + 1;        /* one job is filled while every GPU works on one */
-	/* batch = whole Blocks; several GPUs or a known-small input do not need the full GiB */
-	/* One job = one device batch.  A lone GPU wants it large (full launches); with several workers the jobs must
-	 * be small enough that a typical input deals at least two to every worker (stream_encoder_mt.c:599-665 deals
-	 * Block by Block): 256 MiB, i.e. a 4 GiB input is 16 jobs. */
-	uint64_t batch = in->ndev > 1 ? 256ull << 20 : 1ull << 30;
+	/* One job = one device batch of whole Blocks: 1 GiB, i.e. at least two full rounds of parse pieces at preset 6 on an
+	 * MI355X (4096 resident wavefronts x 128 KiB), whatever the number of workers -- a job that cannot fill its GPU
+	 * wastes it.  While the end of the input is unknown (LZMA_RUN) full jobs are dealt in order; once the caller has shown
+	 * the end (FINISH / FULL_FLUSH / FULL_BARRIER) the rest is dealt evenly over the workers (stream_code, below), as
+	 * stream_encoder_mt.c:599-665 deals Blocks to threads. */
+	uint64_t batch = 1ull << 30;
 	const char *env = getenv("XZAMD_BATCH_MIB");
 	if (env && atoll(env) > 0)
 		batch = (uint64_t)atoll(env) << 20;
@@ -733,6 +737,9 @@ static lzma_ret stream_code(lzma_internal *in, const uint8_t *inb, size_t *in_po
 			/* 1. drain finished jobs in order (lzma_outq_read, outqueue.c:182-260) */
 			for (;;) {
 				job *dj = NULL;
+				/* nothing finished (the common case of xz's 8 KiB lzma_code(LZMA_RUN) calls): no lock, no scan */
+				if (__atomic_load_n(&in->ndone, __ATOMIC_ACQUIRE) == 0)
+					break;
 				pthread_mutex_lock(&in->mu);
 				for (int i = 0; i < in->njobs; ++i)
 					if (in->jobs[i].state == J_DONE && in->jobs[i].seq == in->drain_seq)
@@ -769,6 +776,7 @@ static lzma_ret stream_code(lzma_internal *in, const uint8_t *inb, size_t *in_po
 				dj->state = J_FREE;
 				dj->stage_len = 0;
 				++in->drain_seq;
+				__atomic_sub_fetch(&in->ndone, 1, __ATOMIC_RELEASE);
 				pthread_mutex_unlock(&in->mu);
 			}
 			/* 2. take input (stream_encode_in: :599-664) */
@@ -791,9 +799,19 @@ static lzma_ret stream_code(lzma_internal *in, const uint8_t *inb, size_t *in_po
 					const uint64_t rem = (in_size - *in_pos) + j->stage_len;
 					const uint64_t nbr = (rem + in->block_size - 1) / in->block_size;
 					const uint64_t maxb = in->stage_max / in->block_size;
-					if (nbr > maxb && maxb > 0) {
-						const uint64_t nj = (nbr + maxb - 1) / maxb;
-						job_max = ((nbr + nj - 1) / nj) * in->block_size;
+					if (maxb > 0) {
+						uint64_t nj = (nbr + maxb - 1) / maxb;
+						if (in->ndev > 1) {
+							/* several GPUs: a job for every worker, as long as a job keeps at least 128 MiB (what is left of a
+							 * 4 GiB input on 8 GPUs: 8 jobs of 22 Blocks instead of 4 of 43) */
+							uint64_t minb = (128ull << 20) / in->block_size;
+							if (minb == 0) minb = 1;
+							uint64_t want = nbr / minb;
+							if (want > (uint64_t)in->ndev) want = (uint64_t)in->ndev;
+							if (want > nj) nj = want;
+						}
+						if (nj > 1)
+							job_max = ((nbr + nj - 1) / nj) * in->block_size;
 					}
 				}
 				if (j->stage_len >= job_max) {          /* (a job filled under LZMA_RUN beyond what FINISH would deal) */
