@@ -170,6 +170,8 @@ typedef struct {
 	                             * (parser state >= 7) << 24 -- what the device's coder reads instead of the input */
 	int rc_off;                 /* phase 1: adapt the model, code nothing */
 	uint32_t lit_rec;           /* phase 2: != 0: the record of the literal being coded | 1 << 31 */
+	int est_on;                 /* phase 2: sum the prices of the coded decisions (chunk rule of the two-phase coder) */
+	uint64_t est;               /* in 1/16 bit, from the probabilities before their update */
 #ifdef ORC_XPREV
 	uint32_t *xprev[8];
 	int xprev_n;
@@ -645,6 +647,8 @@ static inline void rc_bit(enc *e, uint16_t *prob, uint32_t bit)
 		e->range <<= 8;
 	}
 	uint32_t p = *prob;
+	if (e->est_on)
+		e->est += e->price_tab[(p ^ ((0u - bit) & 0x7FFu)) >> 4];
 	const uint32_t bound = (e->range >> 11) * p;
 	if (!bit) {
 		e->range = bound;
@@ -681,6 +685,7 @@ static void rc_tree_rev(enc *e, uint16_t *probs, uint32_t nbits, uint32_t sym)
 static void rc_direct(enc *e, uint32_t value, uint32_t nbits)
 {
 	if (e->rc_off) return;
+	if (e->est_on) e->est += 16u * nbits;
 	do {
 		if (e->range < (1u << 24)) {
 			rc_shift_low(e);
@@ -1369,6 +1374,7 @@ static int optimum_window(enc *e, uint32_t pos, int cached)
  * match reaches nice_len costs ORC_EST_LONG units and the walk jumps over the match (it may run past the
  * chunk end), any other position costs one unit. */
 #define ORC_EST_LONG 4u
+#define ORC_CHUNK_EST (56000u * 128u)   /* two-phase coder: a chunk ends when the summed prices reach this (1/16 bit) */
 #ifndef ORC_PREROLL
 #define ORC_PREROLL 2048u         /* two-phase: bytes in front of a piece that are parsed twice (the device: XZAMD_PREROLL) */
 #endif
@@ -1696,12 +1702,20 @@ static int encode_syms(enc *e, uint32_t start, uint32_t end, int first_in_block,
 	int need_props = 1, need_dict_reset = first_in_block, need_state_reset = 0;
 	uint32_t cur = start;
 	lzma_state_reset(e);
+	/* Chunk rule of the two-phase coder (OUR definition; the device: k_model_syms / k_rc_chunks).  The range coder of a
+	 * chunk runs apart from the model pass that decides where chunks end, so that pass cannot look at the coded size:
+	 * it sums the PRICES of the decisions instead (the parser's table, 1/16 bit each, probabilities before their
+	 * update; 16 per direct bit).  A chunk ends in front of the first symbol at which the sum has reached
+	 * ORC_CHUNK_EST (56,000 bytes: the coded size stays far below the format's 65,536) or 2 MiB - 273 bytes of input;
+	 * it is stored raw when the estimate says it would not shrink (est / 128 + 5 >= bytes of input). */
+	e->est_on = 1;
 	int initialized = !first_in_block;
 	while (cur < end) {
 		if (need_state_reset)
 			lzma_state_reset(e);
 		const uint32_t chunk_start = cur;
 		e->cpos = 0;
+		e->est = 0;
 		if (!initialized) {
 			rc_bit(e, &e->probs[P_IS_MATCH], 0);
 			rc_tree(e, e->probs + P_LITERAL, 8, e->in[0]);
@@ -1710,8 +1724,7 @@ static int encode_syms(enc *e, uint32_t start, uint32_t end, int first_in_block,
 			initialized = 1;
 		}
 		for (;;) {
-			if (cur - chunk_start >= (1u << 21) - MATCH_LEN_MAX
-					|| e->cpos + e->cache_size + 4 >= 65536 - 4097)
+			if (cur - chunk_start >= (1u << 21) - MATCH_LEN_MAX || e->est >= ORC_CHUNK_EST)
 				break;
 			if (cur >= end)
 				break;
@@ -1733,14 +1746,17 @@ static int encode_syms(enc *e, uint32_t start, uint32_t end, int first_in_block,
 		rc_flush(e);
 		const uint32_t usize = cur - chunk_start, csize = e->cpos;
 		uint8_t hdr[6];
-		if (csize >= usize) {
+		if (csize > 65536) { e->est_on = 0; return -4; }      /* cannot happen: see ORC_CHUNK_EST */
+		if (e->est / 128 + 5 >= usize) {
 			hdr[0] = need_dict_reset ? 1 : 2;
 			need_dict_reset = 0;
 			hdr[1] = (uint8_t)((usize - 1) >> 8);
 			hdr[2] = (uint8_t)(usize - 1);
 			need_state_reset = 1;
-			if (put(out, cap, opos, hdr, 3) || put(out, cap, opos, e->in + chunk_start, usize))
+			if (put(out, cap, opos, hdr, 3) || put(out, cap, opos, e->in + chunk_start, usize)) {
+				e->est_on = 0;
 				return -1;
+			}
 			if (e->trace) ++e->trace->chunks_uncompressed;
 			continue;
 		}
@@ -1757,10 +1773,13 @@ static int encode_syms(enc *e, uint32_t start, uint32_t end, int first_in_block,
 		if (need_props)
 			hdr[hl++] = (uint8_t)((e->prm.pb * 5 + e->prm.lp) * 9 + e->prm.lc);
 		need_props = need_state_reset = need_dict_reset = 0;
-		if (put(out, cap, opos, hdr, hl) || put(out, cap, opos, e->cbuf, csize))
+		if (put(out, cap, opos, hdr, hl) || put(out, cap, opos, e->cbuf, csize)) {
+			e->est_on = 0;
 			return -1;
+		}
 		if (e->trace) ++e->trace->chunks_lzma;
 	}
+	e->est_on = 0;
 	return 0;
 }
 

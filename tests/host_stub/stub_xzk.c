@@ -139,25 +139,26 @@ int xzk_parse_pieces(const xzamd_span_args *a, uint32_t nblocks, int phase, uint
 int xzk_encode_syms(const xzamd_span_args *a, uint32_t nblocks, void *stream)
 {
 	(void)stream;
-	for (uint32_t s = 0; s < nblocks * a->max_esb; ++s) {
+	const uint32_t nslots = nblocks * a->max_esb;
+	memset(a->chunks, 0, (size_t)XZAMD_CHUNK_SLOTS(a->n, nslots) * sizeof(xzamd_chunk));
+	for (uint32_t s = 0; s < nslots; ++s) {
 		const uint32_t b = s / a->max_esb, k = s - b * a->max_esb;
 		if ((uint64_t)b * a->block_size >= a->n || k >= a->enc_cnt[b])
 			continue;
 		const uint32_t start = a->enc_tab[2 * s], end = a->enc_tab[2 * s + 1];
-		uint8_t *out = a->scratch + ((((uint64_t)start + (start >> 3)) + 15) & ~15ull) + (uint64_t)s * XZAMD_SPAN_SLACK;
-		uint32_t o = 0;
+		uint32_t ci = XZAMD_CHUNK_BASE(start, s);
 		int first = start == b * a->block_size;
-		for (uint32_t p = start; p < end; ) {
-			const uint32_t c = end - p < 65536 ? end - p : 65536;
-			out[o++] = first ? 1 : 2;
-			out[o++] = (uint8_t)((c - 1) >> 8);
-			out[o++] = (uint8_t)(c - 1);
-			memcpy(out + o, a->in + p, c);
-			o += c;
+		for (uint32_t p = start; p < end; ++ci) {           /* raw chunks of 48 KiB: more than 32 KiB each, as the table assumes */
+			const uint32_t c = end - p < 49152 ? end - p : 49152;
+			uint8_t *out = a->scratch + XZAMD_CHUNK_OUT(p, ci);
+			out[0] = first ? 1 : 2;                 /* lzma2_header_uncompressed: 0x01 resets the dictionary */
+			out[1] = (uint8_t)((c - 1) >> 8);
+			out[2] = (uint8_t)(c - 1);
+			memcpy(out + 3, a->in + p, c);
+			a->chunks[ci].in_start = p; a->chunks[ci].usize = c; a->chunks[ci].csize = 3 + c; a->chunks[ci].flags = XZAMD_CH_RAW;
 			p += c;
 			first = 0;
 		}
-		a->span_bytes[s] = o;
 	}
 	return 0;
 }

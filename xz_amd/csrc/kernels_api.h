@@ -60,7 +60,33 @@ typedef struct {
 	const uint32_t *enc_cnt;     /* encode spans per Block */
 	uint32_t max_esb;            /* encode span slots per Block */
 	uint32_t enc_bits;           /* != 0: two-phase plan (seed cut + encode spans of about enc_bits estimated bits) */
+	/* Coder of the two-phase mode (xzk_encode_syms): the model pass of an encode span writes one 16-bit TOKEN per binary
+	 * decision (probability before its update | bit << 12, or bit << 12 | 1 << 15 for a direct bit) and one xzamd_chunk
+	 * per LZMA2 chunk; the range coder then runs one LANE per chunk. */
+	uint16_t *tok;               /* tokens of encode-span slot s (first byte st): from XZAMD_TOK_BASE(st, s) on */
+	struct xzamd_chunk *chunks;  /* chunk slots of encode-span slot s: from XZAMD_CHUNK_BASE(st, s) on; usize 0 = unused */
 } xzamd_span_args;
+/* One LZMA2 chunk of the two-phase coder.  Its bytes (chunk header included) are written at
+ * scratch + XZAMD_CHUNK_OUT(in_start, its slot index). */
+typedef struct xzamd_chunk {
+	uint32_t in_start;           /* first input byte (offset into the batch) */
+	uint32_t usize;              /* input bytes; 0 = unused slot */
+	uint32_t tok_lo, tok_hi;     /* index of its first token */
+	uint32_t ntok;
+	uint32_t csize;              /* out: bytes at its scratch location, header included (raw: 3 + usize) */
+	uint32_t flags;              /* XZAMD_CH_* */
+	uint32_t pad_;
+} xzamd_chunk;
+#define XZAMD_CH_RAW 1u             /* stored uncompressed (lzma2_encoder.c:205-214) */
+#define XZAMD_CH_PROPS 2u           /* header carries the properties byte */
+#define XZAMD_CH_DICT_RESET 4u
+#define XZAMD_CH_STATE_RESET 8u
+#define XZAMD_CHUNK_EST (56000u * 128u)  /* a chunk ends when the summed prices of its decisions reach this (1/16 bit): oracle ORC_CHUNK_EST */
+#define XZAMD_TOK_PER_BYTE 10u      /* token capacity: a literal is 9 decisions */
+#define XZAMD_TOK_BASE(st, slot) ((uint64_t)(st) * XZAMD_TOK_PER_BYTE + (uint64_t)(slot) * 4096u)
+#define XZAMD_CHUNK_BASE(st, slot) (((st) >> 15) + 2u * (slot))     /* a chunk but the last of its span holds > 32 KiB of input */
+#define XZAMD_CHUNK_SLOTS(n, nslots) (((n) >> 15) + 2u * (nslots) + 2u)
+#define XZAMD_CHUNK_OUT(in_start, cidx) (((((uint64_t)(in_start) + ((in_start) >> 3)) + 15) & ~15ull) + (uint64_t)(cidx) * 32u)
 #define XZAMD_PRIOR_WORDS 928u      /* 1856 x u16 >= the 1846 non-literal probabilities */
 #define XZAMD_SEED_LEN 65536u       /* two-phase: the first piece of every Block (oracle: ORC_SEED_LEN) */
 #define XZAMD_ENC_MIN_LEN (512u << 10)  /* shortest encode span (but the last of a Block) */
@@ -108,7 +134,8 @@ int xzk_span_plan(const xzamd_span_args *a, uint32_t nblocks, uint32_t *est, uns
 int xzk_span_encode(const xzamd_span_args *a, uint32_t nslots, uint32_t waves, uint32_t *counter, void *stream);
 /* Two-phase mode.  xzk_parse_pieces: phase 0 = the seed pieces (one wavefront per Block), phase 1 = every other piece
  * (nslots = nblocks * max_spb slots in a->order, heaviest first; persistent with `waves` wavefronts when waves != 0).
- * xzk_encode_syms: one wavefront per encode-span slot (nblocks * max_esb), bytes produced into a->span_bytes[slot]. */
+ * xzk_encode_syms: the model pass (one wavefront per encode-span slot: tokens + chunk table, raw chunks copied) and the
+ * range coder (one lane per chunk slot); the chunk table must be zero on entry (the call clears it). */
 int xzk_parse_pieces(const xzamd_span_args *a, uint32_t nblocks, int phase, uint32_t waves, uint32_t *counter, void *stream);
 int xzk_encode_syms(const xzamd_span_args *a, uint32_t nblocks, void *stream);
 /* wavefronts of the span kernel variant for (parser, nice_len) one CU holds at once */

@@ -81,6 +81,18 @@ __device__ __forceinline__ void wave_sync()
 }
 
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+// Sum over the 64 lanes on the DPP network (no LDS traffic): row-wise shifts, then the two row broadcasts; lane 63 has it.
+__device__ __forceinline__ uint32_t wave_sum_dpp(uint32_t v)
+{
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true);     // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true);     // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true);     // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true);     // row_shr:8   -> lane 15 of a row = row sum
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, true);     // row_bcast:15 into rows 1, 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, true);     // row_bcast:31 into rows 2, 3
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
 // A wave-uniform value the compiler must keep in a scalar register from here on (no instruction is emitted when it is
 // there already): without the pin a loop-carried uniform chain can end up on the vector ALU as a whole.
 __device__ __forceinline__ void pin_s(uint32_t& v) { asm volatile("" : "+s"(v)); }
@@ -498,6 +510,10 @@ struct RC {
     uint32_t cache;
     uint32_t cpos;      // payload bytes written for the current chunk
     uint8_t* out;       // payload base of the current chunk
+    // token sink of the two-phase model pass (rc_emit<.., TOK>): the decisions are written out instead of coded
+    uint16_t* tok;      // next free token of the encode span
+    uint32_t est;       // summed prices of the current chunk's decisions, 1/16 bit
+    const uint8_t* ptab;
 #ifdef XZAMD_TIMING
     uint64_t tm_run;    // cycles inside rc_run (profiling builds only)
     uint64_t tm_bits;
@@ -888,8 +904,10 @@ __device__ __forceinline__ void rc_run(RC& rc, uint32_t packed, uint32_t n, uint
 }
 
 // CODE: run the range coder (false: the parse pieces of the two-phase mode only adapt their price model);
-// LITG: literal-coder probabilities live in global memory (u32 each, `lit`), else in LDS behind P_LITERAL (u16).
-template <bool CODE, bool LITG>
+// LITG: literal-coder probabilities live in global memory (u32 each, `lit`), else in LDS behind P_LITERAL (u16);
+// TOK: the model pass of the two-phase coder: one 16-bit token per decision goes to rc.tok and the price of the
+// decisions (the parser's table, probability before its update) is added to rc.est.
+template <bool CODE, bool LITG, bool TOK = false>
 __device__ __forceinline__ void rc_emit(RC& rc, uint16_t* probs, uint32_t* lit, const SegSel& s, uint32_t total,
         uint32_t d0, uint32_t d1)
 {
@@ -928,7 +946,16 @@ __device__ __forceinline__ void rc_emit(RC& rc, uint16_t* probs, uint32_t* lit, 
             probs[idx] = (uint16_t)(bit ? p - (p >> 5) : p + ((2048 - p) >> 5));
         }
     }
-    if constexpr (CODE) {
+    if constexpr (TOK) {
+        const uint32_t k = threadIdx.x;
+        uint32_t price = 0;
+        if (k < total) {
+            rc.tok[k] = (uint16_t)(p | (bit << 12) | (direct ? 0x8000u : 0u));
+            price = direct ? 16u : (uint32_t)rc.ptab[(p ^ ((0u - bit) & 0x7FFu)) >> 4];
+        }
+        rc.est += wave_sum_dpp(price);
+        rc.tok += total;
+    } else if constexpr (CODE) {
         const uint32_t packed = p | (bit << 12) | (direct ? 0x2000u : 0u);
         rc_run<!LITG>(rc, packed, total, d0, d1);
     }
@@ -936,7 +963,7 @@ __device__ __forceinline__ void rc_emit(RC& rc, uint16_t* probs, uint32_t* lit, 
 
 // upos = offset of the symbol inside the Block; lit3 (literals only) = byte | previous byte << 8 | match byte << 16
 // (the match byte is read only in states >= 7)
-template <bool CODE, bool LITG>
+template <bool CODE, bool LITG, bool TOK = false>
 __device__ __forceinline__ void encode_symbol_t(RC& rc, uint16_t* probs, Lz& z, uint32_t upos, uint32_t back, uint32_t len,
         uint32_t lit3)
 {
@@ -959,7 +986,7 @@ __device__ __forceinline__ void encode_symbol_t(RC& rc, uint16_t* probs, Lz& z, 
             const uint32_t mb = (lit3 >> 16) & 0xFFu;
             seg_add(s, off, 8, SEG_MATCHED, sub, cur | (mb << 8));
         }
-        rc_emit<CODE, LITG>(rc, probs, z.lit, s, off, off, off);
+        rc_emit<CODE, LITG, TOK>(rc, probs, z.lit, s, off, off, off);
         return;
     }
     seg_add(s, off, 1, SEG_BIT, P_IS_MATCH + z.state * 16 + ps, 1);
@@ -987,7 +1014,7 @@ __device__ __forceinline__ void encode_symbol_t(RC& rc, uint16_t* probs, Lz& z, 
         }
         if (len == 1) {
             z.state = z.state < 7 ? 9 : 11;
-            rc_emit<CODE, LITG>(rc, probs, z.lit, s, off, off, off);
+            rc_emit<CODE, LITG, TOK>(rc, probs, z.lit, s, off, off, off);
             return;
         }
         len_base = P_REP_LEN;
@@ -1039,7 +1066,7 @@ __device__ __forceinline__ void encode_symbol_t(RC& rc, uint16_t* probs, Lz& z, 
         z.rep3 = z.rep2; z.rep2 = z.rep1; z.rep1 = z.rep0; z.rep0 = dist;
     }
     if (dir0 == ~0u) dir0 = dir1 = off;
-    rc_emit<CODE, LITG>(rc, probs, z.lit, s, off, dir0, dir1);
+    rc_emit<CODE, LITG, TOK>(rc, probs, z.lit, s, off, dir0, dir1);
 }
 
 // the bytes a literal at global offset g needs, for encode_symbol_t
@@ -2522,8 +2549,11 @@ __device__ __forceinline__ void symrow_load(const xzamd_span_args& a, uint32_t p
     d = a.sym_dist[x];
 }
 
-__global__ __launch_bounds__(64) void k_encode_syms(xzamd_span_args a, uint32_t nslots)
+__global__ __launch_bounds__(64) void k_model_syms(xzamd_span_args a, uint32_t nslots)
 {
+    // Model pass of one encode span (oracle: encode_syms): the recorded symbols go through ONE continuous probability
+    // model (all of it in LDS); every binary decision leaves a token, the chunks are cut by the summed prices of their
+    // decisions (the range coder runs later, one lane per chunk: k_rc_chunks), raw chunks are copied here.
     extern __shared__ __attribute__((aligned(16))) uint32_t enc_pool[];
     uint16_t* const probs = reinterpret_cast<uint16_t*>(enc_pool);
     const uint32_t lane = threadIdx.x;
@@ -2534,10 +2564,19 @@ __global__ __launch_bounds__(64) void k_encode_syms(xzamd_span_args a, uint32_t 
     if (k >= a.enc_cnt[blk]) return;
     const uint32_t block_start = blk * a.block_size;
     const uint32_t span_start = uni(a.enc_tab[2 * slot]), span_end = uni(a.enc_tab[2 * slot + 1]);
-    uint8_t* const outp = a.scratch + ((((uint64_t)span_start + (span_start >> 3)) + 15) & ~15ull) + (uint64_t)slot * XZAMD_SPAN_SLACK;
-    const uint32_t span_cap = (span_end - span_start) + ((span_end - span_start) >> 3) + 4096;
     const uint8_t* __restrict__ in = a.in;
     const uint32_t model_words = (P_LITERAL + (0x300u << (a.lc + a.lp)) + 1) / 2;
+    uint8_t* const ptab = reinterpret_cast<uint8_t*>(enc_pool + model_words);
+    for (uint32_t t = lane; t < 128; t += 64) {         // bit price table (price_tablegen.c:31-58)
+        uint32_t wv = t * 16 + 8, bit_count = 0;
+        for (int jj = 0; jj < 4; ++jj) {
+            wv *= wv;
+            bit_count <<= 1;
+            while (wv >= (1u << 16)) { wv >>= 1; ++bit_count; }
+        }
+        ptab[t] = (uint8_t)((11 << 4) - 15 - bit_count);
+    }
+    wave_sync();
 
     Lz z;
     z.lc = a.lc; z.lp = a.lp; z.pb = a.pb;
@@ -2545,7 +2584,13 @@ __global__ __launch_bounds__(64) void k_encode_syms(xzamd_span_args a, uint32_t 
     z.lit = nullptr;
     z.state = 0; z.rep0 = z.rep1 = z.rep2 = z.rep3 = 0;
     RC rc;
-    rc.cpos = 0; rc.out = outp; rc.reset();
+    rc.cpos = 0; rc.out = nullptr; rc.reset();
+    uint16_t* const tok0 = a.tok + XZAMD_TOK_BASE(span_start, slot);
+    const uint64_t tok_cap = (uint64_t)(span_end - span_start) * XZAMD_TOK_PER_BYTE + 4096u - 64u;
+    rc.tok = tok0; rc.est = 0; rc.ptab = ptab;
+    const uint32_t cbase = XZAMD_CHUNK_BASE(span_start, slot);
+    const uint32_t ccap = ((span_end - span_start) >> 15) + 2u;
+    uint32_t nchunks = 0;
 #ifdef XZAMD_TIMING
     rc.tm_run = 0; rc.tm_bits = 0;
     uint64_t tm_sym = 0, tm_nsym = 0;
@@ -2556,7 +2601,6 @@ __global__ __launch_bounds__(64) void k_encode_syms(xzamd_span_args a, uint32_t 
     bool failed = false;
     uint32_t f_pos = 0, f_back = 0, f_len = 0, f_d = 0;
     uint32_t cur = span_start;
-    uint32_t out_off = 0;
     SymRow R;
     R.base = span_start;
     symrow_load(a, span_start, R.l, R.d);
@@ -2570,14 +2614,12 @@ __global__ __launch_bounds__(64) void k_encode_syms(xzamd_span_args a, uint32_t 
             z.state = 0; z.rep0 = z.rep1 = z.rep2 = z.rep3 = 0;
         }
         const uint32_t chunk_start = cur;
-        const uint32_t hl = need_props ? 6 : 5;
-        rc.out = outp + out_off + hl;
-        rc.cpos = 0;
-        rc.reset();
+        uint16_t* const chunk_tok = rc.tok;
+        rc.est = 0;
         for (;;) {
-            // lzma_encoder.c:346-351 (limit from lzma2_encoder.c:167-181)
-            if (cur - chunk_start >= (1u << 21) - MATCH_LEN_MAX
-                    || rc.cpos + rc.cache_size + 4 >= 65536 - 4097)
+            // the chunk rule of the two-phase coder (oracle: encode_syms): input limit of lzma2_encoder.c:167-181, and
+            // the summed prices in place of the coded size
+            if (cur - chunk_start >= (1u << 21) - MATCH_LEN_MAX || rc.est >= XZAMD_CHUNK_EST)
                 break;
             if (cur >= span_end)
                 break;
@@ -2596,7 +2638,7 @@ __global__ __launch_bounds__(64) void k_encode_syms(xzamd_span_args a, uint32_t 
             uint32_t back, l3 = 0;
             if (len == 0) {
                 back = LITERAL; len = 1; l3 = d;
-                if (z.state >= 7 && !(d >> 24))          // the parser was not in a matched state here (piece start): fetch the match byte
+                if (z.state >= 7 && !(d >> 24))          // no match byte with the record (first symbol of a piece): fetch it
                     l3 = (d & 0xFFFFu) | (uni(in[cur - z.rep0 - 1]) << 16);
             } else if (len == 1) {
                 if (d == z.rep0) back = 0;
@@ -2608,7 +2650,7 @@ __global__ __launch_bounds__(64) void k_encode_syms(xzamd_span_args a, uint32_t 
             else back = d + 4;
             if (len > MATCH_LEN_MAX || cur + len > span_end
                     || (back != LITERAL && back >= 4 && back - 4 >= cur - block_start)
-                    || out_off + hl + rc.cpos + 64 > span_cap) {
+                    || (uint64_t)(rc.tok - tok0) + 64u > tok_cap || nchunks + 1 >= ccap) {
                 // internal consistency failure: report it and leave through the loop conditions (an early return from
                 // inside the loops costs the compiler its proof that the coder state is wave-uniform)
                 f_pos = cur - block_start; f_back = back; f_len = len; f_d = d;
@@ -2619,62 +2661,146 @@ __global__ __launch_bounds__(64) void k_encode_syms(xzamd_span_args a, uint32_t 
 #ifdef XZAMD_TIMING
             const uint64_t ts0 = __builtin_amdgcn_s_memtime();
 #endif
-            encode_symbol_t<true, false>(rc, probs, z, cur - block_start, back, len, l3);
+            encode_symbol_t<false, false, true>(rc, probs, z, cur - block_start, back, len, l3);
 #ifdef XZAMD_TIMING
             tm_sym += __builtin_amdgcn_s_memtime() - ts0;
             ++tm_nsym;
 #endif
             cur += len;
         }
-        rc.flush();
-
+        if (failed) break;
         const uint32_t usize = cur - chunk_start;
-        const uint32_t csize = rc.cpos;
-        uint8_t* const hdr = outp + out_off;
-        if (csize >= usize) {
-            // lzma2_encoder.c:205-214: store the chunk raw, the next LZMA chunk resets the state
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const uint32_t ntok = (uint32_t)(rc.tok - chunk_tok);
+        const bool raw = rc.est / 128u + 5u >= usize;
+        const uint32_t cidx = cbase + nchunks;
+        uint32_t flags = raw ? XZAMD_CH_RAW : 0u;
+        if (raw) {
+            // lzma2_encoder.c:205-214: the chunk is stored, the next LZMA chunk resets the state; its tokens are dropped
+            uint8_t* const hdr = a.scratch + XZAMD_CHUNK_OUT(chunk_start, cidx);
             for (uint32_t i = lane; i < usize; i += 64) hdr[3 + i] = in[chunk_start + i];
             if (lane == 0) {
                 hdr[0] = need_dict_reset ? 1 : 2;
                 hdr[1] = (uint8_t)((usize - 1) >> 8);
                 hdr[2] = (uint8_t)(usize - 1);
             }
+            rc.tok = chunk_tok;
             need_dict_reset = false;
             need_state_reset = true;
-            out_off += 3 + usize;
-            continue;
+        } else {
+            if (need_props) flags |= XZAMD_CH_PROPS;
+            if (need_dict_reset) flags |= XZAMD_CH_DICT_RESET;
+            if (need_state_reset) flags |= XZAMD_CH_STATE_RESET;
+            need_props = false; need_dict_reset = false; need_state_reset = false;
         }
-        // lzma2_header_lzma (lzma2_encoder.c:54-106)
         if (lane == 0) {
-            uint32_t c;
-            if (need_props) c = need_dict_reset ? 0xE0 : 0xC0;
-            else c = need_state_reset ? 0xA0 : 0x80;
-            hdr[0] = (uint8_t)(c + ((usize - 1) >> 16));
-            hdr[1] = (uint8_t)((usize - 1) >> 8);
-            hdr[2] = (uint8_t)(usize - 1);
-            hdr[3] = (uint8_t)((csize - 1) >> 8);
-            hdr[4] = (uint8_t)(csize - 1);
-            if (need_props) hdr[5] = (uint8_t)((a.pb * 5 + a.lp) * 9 + a.lc);
+            const uint64_t tix = (uint64_t)(chunk_tok - a.tok);
+            xzamd_chunk c;
+            c.in_start = chunk_start; c.usize = usize; c.tok_lo = (uint32_t)tix; c.tok_hi = (uint32_t)(tix >> 32);
+            c.ntok = raw ? 0u : ntok; c.csize = raw ? 3u + usize : 0u; c.flags = flags; c.pad_ = 0;
+            a.chunks[cidx] = c;
         }
-        need_props = false; need_dict_reset = false; need_state_reset = false;
-        out_off += hl + csize;
+        ++nchunks;
     }
     if (failed && lane == 0 && a.err) {
         if (atomicCAS(a.err, 0u, 3u) == 0u) {
             a.err[1] = slot; a.err[2] = f_pos; a.err[3] = f_back; a.err[4] = f_len;
-            a.err[5] = f_d; a.err[6] = 0; a.err[7] = out_off;
+            a.err[5] = f_d; a.err[6] = nchunks; a.err[7] = (uint32_t)(rc.tok - tok0);
         }
     }
-    if (lane == 0) a.span_bytes[slot] = failed ? 0u : out_off;
 #ifdef XZAMD_TIMING
     if (lane == 0 && a.err) {
-        unsigned long long* g = reinterpret_cast<unsigned long long*>(a.err + 48);      // [0] total [1] in encode_symbol [2] in rc_run [3] symbols [4] bits [5] max span
+        unsigned long long* g = reinterpret_cast<unsigned long long*>(a.err + 48);      // [0] total [1] in encode_symbol [3] symbols [4] tokens [5] max span
         const uint64_t tot = __builtin_amdgcn_s_memtime() - tm_start;
-        atomicAdd(g + 0, tot); atomicAdd(g + 1, tm_sym); atomicAdd(g + 2, rc.tm_run); atomicAdd(g + 3, tm_nsym); atomicAdd(g + 4, rc.tm_bits);
+        atomicAdd(g + 0, tot); atomicAdd(g + 1, tm_sym); atomicAdd(g + 3, tm_nsym); atomicAdd(g + 4, (unsigned long long)(rc.tok - tok0));
         atomicMax(g + 5, tot);
     }
 #endif
+}
+
+// Range coder of the two-phase mode: one LANE per LZMA2 chunk (rangecoder/range_encoder.h:136-263 per lane).  A chunk's
+// coder starts from the reset state, so the chunks of a batch -- thousands -- are independent given their tokens; the
+// serial recurrence that costs a wavefront ~16 scalar instructions per decision when it runs one span costs a lane of
+// this kernel one vector instruction slot shared with 63 other chunks.
+__global__ __launch_bounds__(64) void k_rc_chunks(xzamd_span_args a, uint32_t nchunk_slots)
+{
+    const uint32_t idx = blockIdx.x * 64 + threadIdx.x;
+    if (idx >= nchunk_slots) return;
+    const xzamd_chunk c = a.chunks[idx];
+    if (c.usize == 0 || (c.flags & XZAMD_CH_RAW)) return;
+    const uint16_t* __restrict__ tk = a.tok + (((uint64_t)c.tok_hi << 32) | c.tok_lo);
+    uint8_t* const hdr = a.scratch + XZAMD_CHUNK_OUT(c.in_start, idx);
+    const uint32_t hl = (c.flags & XZAMD_CH_PROPS) ? 6u : 5u;
+    uint8_t* const out = hdr + hl;
+    uint32_t low_lo = 0, low_hi = 0, range = 0xFFFFFFFFu, cache = 0, cache_size = 1, cpos = 0;
+    const uint32_t cap = c.usize + (c.usize >> 3) + 8u;           // never reached: the chunk was estimated to shrink
+    auto shift_low = [&]() {
+        if (low_lo < 0xFF000000u || low_hi != 0) {
+            uint32_t b = cache + low_hi;
+            for (uint32_t i = 0; i < cache_size; ++i) {
+                if (cpos < cap) out[cpos] = (uint8_t)b;
+                ++cpos;
+                b = 0xFFu + low_hi;
+            }
+            cache_size = 0;
+            cache = low_lo >> 24;
+        }
+        ++cache_size;
+        low_lo <<= 8;
+        low_hi = 0;
+    };
+    auto code = [&](uint32_t t) {
+        if (range < (1u << 24)) { shift_low(); range <<= 8; }
+        const uint32_t bit = (t >> 12) & 1u;
+        uint32_t add;
+        if (t & 0x8000u) {
+            range >>= 1;
+            add = bit ? range : 0u;
+        } else {
+            const uint32_t bound = (range >> 11) * (t & 0xFFFu);
+            add = bit ? bound : 0u;
+            range = bit ? range - bound : bound;
+        }
+        const uint32_t nl = low_lo + add;
+        low_hi += nl < low_lo ? 1u : 0u;
+        low_lo = nl;
+    };
+    // tokens eight at a time (one 16-byte load per lane), the next eight in flight while these are coded: a lane's token
+    // stream is sequential, but a 2-byte load per decision would put the cache latency in front of every one of them
+    auto load8 = [&](uint32_t i) -> uint4 {
+        uint4 v;
+        __builtin_memcpy(&v, tk + i, 16);        // (the token buffer has 64 spare entries behind the last token)
+        return v;
+    };
+    uint4 cur = make_uint4(0, 0, 0, 0);
+    if (c.ntok) cur = load8(0);
+    for (uint32_t i = 0; i < c.ntok; i += 8) {
+        uint4 nxt = cur;
+        if (i + 8 < c.ntok) nxt = load8(i + 8);
+        const uint32_t left = c.ntok - i;
+        code(cur.x & 0xFFFFu);
+        if (left > 1) code(cur.x >> 16);
+        if (left > 2) code(cur.y & 0xFFFFu);
+        if (left > 3) code(cur.y >> 16);
+        if (left > 4) code(cur.z & 0xFFFFu);
+        if (left > 5) code(cur.z >> 16);
+        if (left > 6) code(cur.w & 0xFFFFu);
+        if (left > 7) code(cur.w >> 16);
+        cur = nxt;
+    }
+    if (range < (1u << 24)) { shift_low(); range <<= 8; }     // the queue loop normalizes before the first RC_FLUSH
+    for (int i = 0; i < 5; ++i) shift_low();
+    const uint32_t csize = cpos;
+    uint32_t ctl;
+    if (c.flags & XZAMD_CH_PROPS) ctl = (c.flags & XZAMD_CH_DICT_RESET) ? 0xE0u : 0xC0u;
+    else ctl = (c.flags & XZAMD_CH_STATE_RESET) ? 0xA0u : 0x80u;
+    hdr[0] = (uint8_t)(ctl + ((c.usize - 1) >> 16));
+    hdr[1] = (uint8_t)((c.usize - 1) >> 8);
+    hdr[2] = (uint8_t)(c.usize - 1);
+    hdr[3] = (uint8_t)((csize - 1) >> 8);
+    hdr[4] = (uint8_t)(csize - 1);
+    if (c.flags & XZAMD_CH_PROPS) hdr[5] = (uint8_t)((a.pb * 5 + a.lp) * 9 + a.lc);
+    a.chunks[idx].csize = hl + csize;
+    if ((csize > 65536u || csize >= cap) && a.err) atomicCAS(a.err, 0u, 4u);      // the price sum was far off: cannot happen
 }
 
 // ------------------------------------------------------------------------------------------
@@ -4232,16 +4358,21 @@ int xzk_parse_pieces(const xzamd_span_args* a, uint32_t nblocks, int phase, uint
     return (int)hipGetLastError();
 }
 
-// Two-phase mode, phase 2: one wavefront per encode-span slot, the whole model in LDS.
+// Two-phase mode, phase 2: the model pass (one wavefront per encode-span slot, the whole model in LDS) and the range
+// coder (one lane per chunk slot).
 int xzk_encode_syms(const xzamd_span_args* a, uint32_t nblocks, void* stream_)
 {
     hipStream_t st = (hipStream_t)stream_;
     if (nblocks == 0) return 0;
-    if (!a->enc_tab || !a->enc_cnt || a->max_esb == 0 || !a->sym_len || !a->sym_dist || !a->scratch || !a->span_bytes)
+    if (!a->enc_tab || !a->enc_cnt || a->max_esb == 0 || !a->sym_len || !a->sym_dist || !a->scratch || !a->tok || !a->chunks)
         return (int)hipErrorInvalidValue;
     const uint32_t nslots = nblocks * a->max_esb;
-    const uint32_t lds = (((P_LITERAL + (0x300u << (a->lc + a->lp)) + 1) / 2) * 4 + 15) & ~15u;
-    hipLaunchKernelGGL(k_encode_syms, dim3(nslots), dim3(64), lds, st, *a, nslots);
+    const uint32_t nch = XZAMD_CHUNK_SLOTS(a->n, nslots);
+    hipError_t e = hipMemsetAsync(a->chunks, 0, (size_t)nch * sizeof(xzamd_chunk), st);
+    if (e != hipSuccess) return (int)e;
+    const uint32_t lds = ((((P_LITERAL + (0x300u << (a->lc + a->lp)) + 1) / 2) * 4 + 128) + 15) & ~15u;
+    hipLaunchKernelGGL(k_model_syms, dim3(nslots), dim3(64), lds, st, *a, nslots);
+    hipLaunchKernelGGL(k_rc_chunks, dim3((nch + 63) / 64), dim3(64), 0, st, *a, nch);
     return (int)hipGetLastError();
 }
 

@@ -375,6 +375,7 @@ struct xzamd_ctx {
 	dbuf scratch, span_bytes, strip_crc, block_crc, segs, lits, trace, errw, errw2, litp, mlen, mdist, bcj[2];
 	dbuf est, totals, span_tab, span_cnt, mtop, order;             /* span plan (kernels_api.h) */
 	dbuf sym_len[2], sym_dist[2], prior, enc_tab[2], enc_cnt[2];   /* two-phase mode ([2]: one set per pipeline parity) */
+	dbuf tok, chunks, h_chunks;                                    /* coder of the two-phase mode: tokens, chunk table */
 	/* pinned host buffers */
 	dbuf h_span_bytes, h_block_crc, h_segs, h_lits, h_span_tab, h_span_cnt[2], h_enc_tab[2], h_enc_cnt[2], h_err[2];
 	void *evp[2][EV_COUNT];
@@ -467,14 +468,15 @@ static void ctx_device_bufs(xzamd_ctx *c, dbuf **d, size_t *nd)
 	dbuf *all[] = { &c->keys_a, &c->keys_b, &c->vals_a, &c->vals_b, &c->rank, &c->sorted_pos,
 		&c->prev2, &c->prev3, &c->prev4, &c->prev8, &c->prev16, &c->prev24, &c->prev32, &c->key64_a, &c->key64_b, &c->sa, &c->sa_rank, &c->sort_tmp,
 		&c->scratch, &c->litp, &c->mlen, &c->mdist, &c->bcj[0], &c->bcj[1], &c->est, &c->mtop, &c->order,
-		&c->sym_len[0], &c->sym_len[1], &c->sym_dist[0], &c->sym_dist[1],
+		&c->sym_len[0], &c->sym_len[1], &c->sym_dist[0], &c->sym_dist[1], &c->tok,
 		/* small ones */
+		&c->chunks,
 		&c->span_bytes, &c->strip_crc, &c->block_crc, &c->segs, &c->lits, &c->trace, &c->errw, &c->errw2,
 		&c->totals, &c->span_tab, &c->span_cnt, &c->prior, &c->enc_tab[0], &c->enc_tab[1], &c->enc_cnt[0], &c->enc_cnt[1] };
 	*nd = sizeof(all) / sizeof(all[0]);
 	memcpy(d, all, sizeof(all));
 }
-#define CTX_NBIG 31      /* the first CTX_NBIG entries of ctx_device_bufs scale with the batch */
+#define CTX_NBIG 32      /* the first CTX_NBIG entries of ctx_device_bufs scale with the batch */
 
 void xzamd_ctx_destroy(xzamd_ctx *c)
 {
@@ -487,7 +489,7 @@ void xzamd_ctx_destroy(xzamd_ctx *c)
 	for (size_t i = 0; i < nd; ++i)
 		if (d[i]->p) xzk_free(d[i]->p);
 	dbuf *h[] = { &c->h_span_bytes, &c->h_block_crc, &c->h_segs, &c->h_lits, &c->h_span_tab, &c->h_span_cnt[0], &c->h_span_cnt[1],
-		&c->h_enc_tab[0], &c->h_enc_tab[1], &c->h_enc_cnt[0], &c->h_enc_cnt[1], &c->h_err[0], &c->h_err[1] };
+		&c->h_enc_tab[0], &c->h_enc_tab[1], &c->h_enc_cnt[0], &c->h_enc_cnt[1], &c->h_err[0], &c->h_err[1], &c->h_chunks };
 	for (size_t i = 0; i < sizeof(h) / sizeof(h[0]); ++i)
 		if (h[i]->p) xzk_host_free(h[i]->p);
 	for (int i = 0; i < 2 * EV_COUNT; ++i)
@@ -763,6 +765,7 @@ static int back_finish(xzamd_ctx *c, job_env *J, batch_run *B)
 	pl.lits = (uint8_t *)c->h_lits.p; pl.lits_len = 0; pl.lits_cap = B->max_lits;
 	pl.segs = (xzamd_copy_seg *)c->h_segs.p; pl.nsegs = 0; pl.segs_cap = B->max_segs;
 	const uint32_t *sb = (const uint32_t *)c->h_span_bytes.p;
+	const xzamd_chunk *hch = (const xzamd_chunk *)c->h_chunks.p;
 	const uint32_t *hcnt = (const uint32_t *)c->h_span_cnt[par].p;
 	/* the slots that hold coded bytes: the spans of the plan, or (two-phase) the encode spans */
 	const uint32_t *otab = (const uint32_t *)(two ? c->h_enc_tab[par].p : c->h_span_tab.p);
@@ -776,8 +779,25 @@ static int back_finish(xzamd_ctx *c, job_env *J, batch_run *B)
 		const uint32_t nsp = ocnt[b];                         /* coded spans of this Block (slots b * opb ...) */
 		if (nsp == 0 || nsp > opb || hcnt[b] == 0 || hcnt[b] > spb)
 			return fail(c, XZAMD_PROG_ERROR, "span plan out of range", 0);
-		for (uint32_t s = 0; s < nsp; ++s)
-			payload += sb[b * opb + s];
+		if (two) {
+			/* the chunks of the Block's encode spans, in order (k_model_syms / k_rc_chunks) */
+			for (uint32_t s = 0; s < nsp; ++s) {
+				const uint32_t slot = (uint32_t)(b * opb + s), st0 = otab[2 * slot], en0 = otab[2 * slot + 1];
+				const uint32_t cb = XZAMD_CHUNK_BASE(st0, slot), cc = ((en0 - st0) >> 15) + 2u;
+				uint64_t covered = 0;
+				for (uint32_t k = 0; k < cc && hch[cb + k].usize != 0; ++k) {
+					if (hch[cb + k].csize == 0 || hch[cb + k].in_start != st0 + covered)
+						return fail(c, XZAMD_PROG_ERROR, "chunk table inconsistent", 0);
+					payload += hch[cb + k].csize;
+					covered += hch[cb + k].usize;
+				}
+				if (covered != (uint64_t)en0 - st0)
+					return fail(c, XZAMD_PROG_ERROR, "chunks do not cover their encode span", 0);
+			}
+		} else {
+			for (uint32_t s = 0; s < nsp; ++s)
+				payload += sb[b * opb + s];
+		}
 		const uint64_t pad = (4 - (payload & 3)) & 3;
 		const uint64_t bstart = opos;
 		uint64_t unp;
@@ -808,7 +828,12 @@ static int back_finish(xzamd_ctx *c, job_env *J, batch_run *B)
 			opos = plan_lit(&pl, small, J->hs_fixed, opos);
 			for (uint32_t s = 0; s < nsp; ++s) {
 				const uint64_t slot = b * opb + s, start = otab[2 * slot];
-				opos = plan_seg(&pl, 0, ((start + (start >> 3) + 15) & ~15ull) + slot * XZAMD_SPAN_SLACK, sb[slot], opos);
+				if (two) {
+					const uint32_t cb = XZAMD_CHUNK_BASE((uint32_t)start, (uint32_t)slot), cc = ((otab[2 * slot + 1] - (uint32_t)start) >> 15) + 2u;
+					for (uint32_t k = 0; k < cc && hch[cb + k].usize != 0; ++k)
+						opos = plan_seg(&pl, 0, XZAMD_CHUNK_OUT(hch[cb + k].in_start, cb + k), hch[cb + k].csize, opos);
+				} else
+					opos = plan_seg(&pl, 0, ((start + (start >> 3) + 15) & ~15ull) + slot * XZAMD_SPAN_SLACK, sb[slot], opos);
 			}
 			tail[tl++] = 0x00;
 			for (uint64_t i = 0; i < pad; ++i) tail[tl++] = 0;
@@ -1018,7 +1043,8 @@ int xzamd_stream_encode_device(xzamd_ctx *c,
 			GROW(rank, 4ull * n, 0); GROW(sorted_pos, 4ull * n, 0);
 		}
 		GROW(sort_tmp, sort_bytes + 256, 0);
-		GROW(scratch, (uint64_t)n + (n >> 3) + 32 + (uint64_t)XZAMD_SPAN_SLACK * nout, 0);
+		const uint32_t nch = two ? XZAMD_CHUNK_SLOTS(n, nenc) : 0;      /* chunk slots of the two-phase coder */
+		GROW(scratch, two ? (uint64_t)n + (n >> 3) + 64 + 32ull * nch : (uint64_t)n + (n >> 3) + 32 + (uint64_t)XZAMD_SPAN_SLACK * nout, 0);
 		GROW(span_bytes, 4ull * nout, 0);
 		GROW(span_tab, 8ull * nspans, 0);
 		GROW(span_cnt, 4ull * nb, 0);
@@ -1032,6 +1058,9 @@ int xzamd_stream_encode_device(xzamd_ctx *c,
 			GROW(enc_cnt[par], 4ull * nb, 0);
 			GROW(h_enc_tab[par], 8ull * nenc, 1);
 			GROW(h_enc_cnt[par], 4ull * nb + 16, 1);
+			GROW(tok, 2ull * ((uint64_t)n * XZAMD_TOK_PER_BYTE + 4096ull * nenc + 64), 0);
+			GROW(chunks, (uint64_t)nch * sizeof(xzamd_chunk), 0);
+			GROW(h_chunks, (uint64_t)nch * sizeof(xzamd_chunk), 1);
 		}
 		if (adaptive) {
 			GROW(est, 8ull * nb * cpb, 0);
@@ -1054,7 +1083,7 @@ int xzamd_stream_encode_device(xzamd_ctx *c,
 		GROW(h_span_bytes, 4ull * nout, 1);
 		GROW(h_block_crc, 32ull * nb, 1);
 		/* plan capacity: per Block header + spans + trailer, or the stored form */
-		const uint64_t segs_per_block = opb + 2 + 2 * ((block_size + 65535) / 65536) + 2;
+		const uint64_t segs_per_block = (two ? (block_size >> 15) + 2ull * esb + 2 : opb) + 2 + 2 * ((block_size + 65535) / 65536) + 2;
 		const uint64_t max_segs = nb * segs_per_block + 4;
 		const uint64_t max_lits = nb * (64 + 3 * ((block_size + 65535) / 65536) + 32) + 64;
 		GROW(segs, max_segs * sizeof(xzamd_copy_seg), 0);
@@ -1134,6 +1163,8 @@ int xzamd_stream_encode_device(xzamd_ctx *c,
 			a.enc_cnt = (const uint32_t *)c->enc_cnt[par].p;
 			a.max_esb = esb;
 			a.enc_bits = opt->enc_span_bits;
+			a.tok = (uint16_t *)c->tok.p;
+			a.chunks = (xzamd_chunk *)c->chunks.p;
 		}
 		{
 			int e = 0, seeds_early = 0;
@@ -1252,7 +1283,8 @@ int xzamd_stream_encode_device(xzamd_ctx *c,
 				if (e) { rc = fail(c, XZAMD_DEVICE_ERROR, "d2h sha256", e); goto done; }
 			}
 			xzk_event_record(ev[EV_CRC], stb);
-			e = xzk_d2h(c->h_span_bytes.p, c->span_bytes.p, 4ull * nout, stb);
+			e = two ? xzk_d2h(c->h_chunks.p, c->chunks.p, (uint64_t)nch * sizeof(xzamd_chunk), stb)
+					: xzk_d2h(c->h_span_bytes.p, c->span_bytes.p, 4ull * nout, stb);
 			if (!e) e = xzk_d2h((uint8_t *)c->h_err[par].p + 512, c->errw2.p, 512, stb);
 			if (e) { rc = fail(c, XZAMD_DEVICE_ERROR, "d2h sizes", e); goto done; }
 		}
