@@ -168,10 +168,11 @@ def test_size_within_tolerance_of_reference_preset6(corpus, n):
         data = o.corpus_lorem(n)
     elif corpus == "text":
         data = xz_amd.corpus_text(n, seed=1000).tobytes()
-    elif corpus == "tar":
-        data = xz_amd.corpus_tar(n).tobytes()
-    elif corpus == "rocm_headers":
-        data = xz_amd.corpus_tar(n, "/opt/rocm/include").tobytes()
+    elif corpus in ("tar", "rocm_headers"):
+        try:
+            data = (xz_amd.corpus_tar(n) if corpus == "tar" else xz_amd.corpus_tar(n, "/opt/rocm/include")).tobytes()
+        except RuntimeError:
+            pytest.skip("the image has none of the source trees the tar corpus is made of")
     elif corpus in ("logs", "json", "sqlite", "dpkg_tar"):
         import _corpora
         data = {"logs": _corpora.logs, "json": _corpora.json_records, "sqlite": _corpora.sqlite_file,
