@@ -13,7 +13,7 @@ fails = 0
 t0 = time.time()
 for case in range(ncases):
     kind = int(rng.integers(0, 6))
-    n = int(rng.integers(1, 600000))
+    n = int(rng.integers(1, 600000)) if rng.random() < 0.7 else int(rng.integers(600000, 3500000))
     if kind == 0: data = o.corpus_lorem(n)
     elif kind == 1: data = o.corpus_mixed(n, int(rng.integers(1, 1000)))
     elif kind == 2: data = o.corpus_x86(n, int(rng.integers(1, 1000)))
@@ -28,6 +28,11 @@ for case in range(ncases):
         opts.gpu_parser = int(rng.integers(0, 2))       # exact finder with either parser
     if rng.random() < 0.2 and opts.gpu_sa_window:
         opts.gpu_sa_window = int(rng.integers(1, 6))
+    if opts.gpu_sa_window and span == 0 and rng.random() < 0.6:
+        # two-phase plan under stress: small parse pieces, small (or no) encode spans
+        opts.span_cost = int(rng.choice([20000, 50000, 131072]))
+        opts.span_bits = int(rng.choice([0, 100000]))
+        opts.enc_span_bits = int(rng.choice([0, 100000, 400000, 1600000]))
     if rng.random() < 0.2:
         opts.gpu_nice_len = int(rng.integers(max(4, opts.gpu_mf & 15), 274))
     if rng.random() < 0.15:
@@ -36,7 +41,7 @@ for case in range(ncases):
         lc = int(rng.integers(0, 5)); opts.lc = lc; opts.lp = int(rng.integers(0, 5 - lc)); opts.pb = int(rng.integers(0, 5))
     bcj = rng.random() < 0.2
     if bcj: opts.bcj = xz_amd.BCJ_X86
-    bs = int(rng.choice([1 << 20, 200000, 65537, 1 << 16]))
+    bs = int(rng.choice([1 << 20, 200000, 65537, 1 << 16, 3 << 20]))
     if opts.span_size not in (0, 0xFFFFFFFF) and opts.span_size > bs: opts.span_size = 4096
     check = int(rng.choice([0, 1, 4]))
     t = torch.frombuffer(bytearray(data), dtype=torch.uint8).cuda()
