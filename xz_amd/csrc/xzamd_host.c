@@ -956,6 +956,31 @@ int xzamd_stream_encode_device(xzamd_ctx *c,
 		return fail(c, XZAMD_OPTIONS_ERROR, "block_size too large for one device batch", 0);
 
 	const uint64_t total_blocks = (in_size + block_size - 1) / block_size;
+	/* A batch must fit the device memory with room to spare: the work buffers take 100 - 165 bytes per input byte
+	 * (DESIGN.md section 2), and the runtime allocates kernel scratch (register spills of the parser) lazily at launch --
+	 * an allocation that fails there surfaces as an error of some later call, not as a clean out-of-memory here.  So
+	 * the batch is capped at 80 % of what is free now plus what this context already holds. */
+	{
+		const int two_ = opt->gpu_parser && opt->gpu_sa_window && opt->span_cost != 0 && opt->enc_span_bits != 0
+				&& (opt->span_size == XZAMD_SPAN_DEFAULT || opt->span_size == XZAMD_SPAN_AUTO);
+		double per_byte = 16.0 + 8.0 + 1.2 + 0.5;                        /* sort buffers, two link arrays, scratch, tables */
+		if (opt->gpu_sa_window) per_byte += 4.0 + 16.0 + 8.0 + 16.0 + 8.0;   /* prev4, rp8/16, prev24/32, key64, sa + rank */
+		else per_byte += 8.0;                                            /* rank, sorted_pos */
+		if (opt->gpu_parser) per_byte += 32.0 + 2.0 + (list_packed ? 0.0 : 16.0);
+		if (two_) per_byte += 12.0 + 2.0 * XZAMD_TOK_PER_BYTE;
+		if (opt->bcj) per_byte += 2.0;
+		uint64_t free_b = 0, total_b = 0, held = 0;
+		if (xzk_mem_info(&free_b, &total_b) == 0 && total_b != 0) {
+			dbuf *d[64];
+			size_t nd = 0;
+			ctx_device_bufs(c, d, &nd);
+			for (size_t i = 0; i < nd; ++i) held += d[i]->cap;
+			const double budget = 0.80 * (double)(free_b + held);
+			uint64_t fit = (uint64_t)(budget / per_byte) / block_size;
+			if (fit == 0) fit = 1;
+			if (fit < max_blocks) max_blocks = fit;
+		}
+	}
 	/* even batches: a short last launch cannot fill the GPU (one wavefront per span) */
 	if (total_blocks > max_blocks) {
 		const uint64_t nbatch = (total_blocks + max_blocks - 1) / max_blocks;
