@@ -90,7 +90,8 @@ typedef struct {
 	uint32_t gpu_parser; /* 0 = lzma_lzma_optimum_fast semantics, 1 = windowed optimal parser (232-node DP over
 	                        per-position match lists incl. the reference's compound edges; needs pb <= 2,
 	                        else XZAMD_OPTIONS_ERROR) */
-	uint32_t bcj;        /* 0 = chain {LZMA2}; XZAMD_BCJ_* / XZAMD_FILTER_DELTA(d) = that filter in front of LZMA2 */
+	uint32_t bcj;        /* 0 = chain {LZMA2}; XZAMD_BCJ_* / XZAMD_FILTER_DELTA(d) = that filter in front of LZMA2
+	                        (the FIRST filter of the chain when bcj2 / bcj3 below name more) */
 	uint32_t gpu_sa_depth; /* suffix-neighbourhood finder: prefix bytes the suffix order compares, 32 / 64 / 128 / 256
 	                        (0 = 32); one rank-doubling round more per step.  Presets: 32 for nice_len <= 32, 64 up to
 	                        nice_len 64, 256 above (what lz_encoder_mf.c:450-512 orders by is the whole suffix) */
@@ -111,7 +112,10 @@ typedef struct {
 	                        kernel range-codes them with ONE continuous model per encode span -- state resets only there.
 	                        A Block of estimated coded size `bits` gets max(1, min(size / 512 KiB, bits / enc_span_bits))
 	                        encode spans, closed at piece ends.  0: single phase, every span of the plan resets the state */
+	uint32_t bcj2, bcj3; /* second and third filter in front of LZMA2, same values as `bcj`, applied in that order (a chain
+	                        holds at most 4 filters, LZMA2 last: common/filter_common.c:250-334); bcj3 needs bcj2 needs bcj */
 } xzamd_lzma_options;
+#define XZAMD_PREFILTERS_MAX 3u
 #define XZAMD_SPAN_COST_DEFAULT 131072u   /* text: 128 KiB spans */
 #define XZAMD_SPAN_BITS_DEFAULT 400000u
 #define XZAMD_ENC_SPAN_BITS_DEFAULT 1600000u   /* about 200 KB of output per encode span */

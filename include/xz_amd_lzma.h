@@ -20,7 +20,7 @@
  *     lzma_mt.timeout bounds the time a lzma_code call waits for the workers (0 = no limit), a call
  *     that returns because of it returns LZMA_OK like the reference (stream_encoder_mt.c:667-713);
  *     LZMA_FULL_BARRIER returns once the input has been handed over (:803-807).
- *   - filters: {LZMA2} and {x86 BCJ | ARM64 BCJ | delta, LZMA2} chains; LZMA_SYNC_FLUSH is unsupported
+ *   - filters: {LZMA2} and {up to three BCJ (any of the eight) | delta filters, LZMA2} chains; LZMA_SYNC_FLUSH is unsupported
  *     exactly like the reference MT encoder (stream_encoder_mt.c:1201-1205).
  *   - check: LZMA_CHECK_NONE, LZMA_CHECK_CRC32, LZMA_CHECK_CRC64 (the xz default) and
  *     LZMA_CHECK_SHA256; others return LZMA_UNSUPPORTED_CHECK.

@@ -150,6 +150,48 @@ int ref_encode_mt_chain(const uint8_t *in, size_t in_size, uint32_t preset, uint
 	return (int)r;
 }
 
+/* MT encode with a chain of `nf` (<= 3) filters in front of LZMA2(preset): ids[i] = LZMA_FILTER_* of the i-th filter,
+ * dists[i] = its distance when it is LZMA_FILTER_DELTA (common/filter_common.c:250-334 validates the chain). */
+int ref_encode_mt_chain_n(const uint8_t *in, size_t in_size, uint32_t preset, uint32_t nf, const uint64_t *ids,
+		const uint32_t *dists, uint32_t threads, uint64_t block_size, int check,
+		uint8_t *out, size_t out_cap, size_t *out_size)
+{
+	lzma_options_lzma opt;
+	if (nf > 3 || lzma_lzma_preset(&opt, preset))
+		return (int)LZMA_OPTIONS_ERROR;
+	lzma_options_delta dl[3];
+	lzma_filter f[5];
+	memset(dl, 0, sizeof(dl));
+	for (uint32_t i = 0; i < nf; ++i) {
+		dl[i].type = LZMA_DELTA_TYPE_BYTE;
+		dl[i].dist = dists[i];
+		f[i].id = ids[i];
+		f[i].options = ids[i] == LZMA_FILTER_DELTA ? (void *)&dl[i] : NULL;
+	}
+	f[nf].id = LZMA_FILTER_LZMA2; f[nf].options = &opt;
+	f[nf + 1].id = LZMA_VLI_UNKNOWN; f[nf + 1].options = NULL;
+	lzma_stream strm = LZMA_STREAM_INIT;
+	lzma_mt mt;
+	memset(&mt, 0, sizeof(mt));
+	mt.threads = threads;
+	mt.block_size = block_size;
+	mt.filters = f;
+	mt.check = (lzma_check)check;
+	lzma_ret r = lzma_stream_encoder_mt(&strm, &mt);
+	if (r != LZMA_OK)
+		return (int)r;
+	strm.next_in = in;
+	strm.avail_in = in_size;
+	strm.next_out = out;
+	strm.avail_out = out_cap;
+	do {
+		r = lzma_code(&strm, LZMA_FINISH);
+	} while (r == LZMA_OK && strm.avail_out > 0);
+	*out_size = out_cap - strm.avail_out;
+	lzma_end(&strm);
+	return (int)r;
+}
+
 /* Steady-state throughput of the reference MT encoder: feed `in` through lzma_code(LZMA_RUN) in 4 MiB
  * slices (output discarded) until `seconds` of wall time have passed or the input is used up, then report
  * how many input bytes the workers have actually processed (lzma_get_progress) and the wall time.  With

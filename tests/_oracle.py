@@ -260,6 +260,23 @@ def ref_encode_mt_chain(data, preset, filter_id, delta_dist=1, threads=1, block_
     return out[: n.value].tobytes()
 
 
+def ref_encode_mt_chain_n(data, preset, chain, threads=1, block_size=0, check=4):
+    """Reference MT encoder with up to three filters in front of LZMA2(preset): chain = [(filter_id, delta_dist), ...]."""
+    data = as_u8(data)
+    cap = len(data) + len(data) // 4 + 65536
+    out = np.empty(cap, dtype=np.uint8)
+    n = C.c_size_t(0)
+    ids = (C.c_uint64 * 3)(*([c[0] for c in chain] + [0] * (3 - len(chain))))
+    dists = (C.c_uint32 * 3)(*([c[1] for c in chain] + [0] * (3 - len(chain))))
+    f = ref().ref_encode_mt_chain_n
+    f.restype = C.c_int
+    f.argtypes = [C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64,
+                  C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    r = f(_ptr(data), len(data), preset, len(chain), ids, dists, threads, block_size, check, _ptr(out), cap, C.byref(n))
+    assert r == 1, r
+    return out[: n.value].tobytes()
+
+
 def ref_x86_filter(data):
     """What the reference's x86 BCJ encoder makes of one Block (fresh state, start offset 0)."""
     data = as_u8(data)

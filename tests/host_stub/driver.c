@@ -137,6 +137,43 @@ int main(int argc, char **argv)
 		CHECK(lzma_stream_encoder_mt_memusage(&mt) != UINT64_MAX);
 		mt.preset = 77;
 		CHECK(lzma_stream_encoder_mt_memusage(&mt) == UINT64_MAX);
+		/* filter chains (common/filter_common.c:250-334): up to three BCJ / delta filters in any order in front
+		 * of LZMA2; LZMA2 must be there and must be last; five filters are one too many */
+		lzma_options_lzma lz;
+		memset(&lz, 0, sizeof(lz));      /* preset 1 (lzma_encoder_presets.c:17-63) */
+		lz.dict_size = 1u << 20; lz.lc = 3; lz.lp = 0; lz.pb = 2;
+		lz.mode = LZMA_MODE_FAST; lz.nice_len = 128; lz.mf = LZMA_MF_HC4; lz.depth = 8;
+		lzma_options_delta dl;
+		memset(&dl, 0, sizeof(dl));
+		dl.type = LZMA_DELTA_TYPE_BYTE; dl.dist = 4;
+		lzma_options_bcj off;
+		memset(&off, 0, sizeof(off));
+		off.start_offset = 16;
+		const lzma_filter END = { LZMA_VLI_UNKNOWN, NULL }, L2 = { LZMA_FILTER_LZMA2, &lz }, X86 = { LZMA_FILTER_X86, NULL },
+				DL = { LZMA_FILTER_DELTA, &dl }, A64 = { LZMA_FILTER_ARM64, NULL }, PPC = { LZMA_FILTER_POWERPC, NULL },
+				XOFF = { LZMA_FILTER_X86, &off }, DNULL = { LZMA_FILTER_DELTA, NULL };
+		const struct { lzma_filter f[6]; lzma_ret want; } chains[] = {
+			{ { L2, END }, LZMA_OK },
+			{ { DL, L2, END }, LZMA_OK },
+			{ { X86, DL, L2, END }, LZMA_OK },
+			{ { DL, X86, A64, L2, END }, LZMA_OK },
+			{ { A64, A64, A64, L2, END }, LZMA_OK },
+			{ { DL, X86, A64, PPC, L2, END }, LZMA_OPTIONS_ERROR },
+			{ { X86, END }, LZMA_OPTIONS_ERROR },
+			{ { END }, LZMA_OPTIONS_ERROR },
+			{ { L2, X86, END }, LZMA_OPTIONS_ERROR },
+			{ { L2, L2, END }, LZMA_OPTIONS_ERROR },
+			{ { XOFF, L2, END }, LZMA_OPTIONS_ERROR },
+			{ { X86, DNULL, L2, END }, LZMA_OPTIONS_ERROR },
+		};
+		mt.preset = 6;
+		for (size_t i = 0; i < sizeof(chains) / sizeof(chains[0]); ++i) {
+			lzma_stream c = LZMA_STREAM_INIT;
+			mt.filters = chains[i].f;
+			CHECK(lzma_stream_encoder_mt(&c, &mt) == chains[i].want);
+			lzma_end(&c);
+		}
+		mt.filters = NULL;
 	}
 
 	/* 5. one-shot buffer API, empty input */

@@ -609,6 +609,88 @@ def test_arm64_delta_chains_and_sha256_identical_to_reference(enc, kind):
     assert rr == 1 and dec == data, kind
 
 
+_CHAINS = {
+    "delta4_x86": [(0x03, 4), (0x04, 0)],
+    "x86_delta1": [(0x04, 0), (0x03, 1)],
+    "delta2_x86_arm64": [(0x03, 2), (0x04, 0), (0x0A, 0)],
+    "arm64_arm64_arm64": [(0x0A, 0), (0x0A, 0), (0x0A, 0)],
+    "riscv_delta256_powerpc": [(0x0B, 0), (0x03, 256), (0x05, 0)],
+}
+
+
+@pytest.mark.parametrize("name", sorted(_CHAINS))
+def test_filter_chains_of_up_to_four_identical_to_reference(enc, name, monkeypatch):
+    """Chains of two and three filters in front of LZMA2 (common/filter_common.c:250-334: at most four filters, LZMA2
+    last; each BCJ / delta filter runs over what the one before it made, simple_coder.c / delta_encoder.c): with one span
+    per Block the whole .xz Stream (Block Headers with every Filter Flags field incl.) equals the reference MT encoder's,
+    through xzamd_stream_encode and through lzma_stream_encoder_mt with the same lzma_filter array; the default
+    two-phase encode decodes bit-exactly through the real decoder."""
+    import torch, xz_amd
+    if not o.have_ref():
+        pytest.skip("oracle/_ref not built")
+    chain = _CHAINS[name]
+
+    def put(opts):
+        vals = [xz_amd.filter_delta(d) if fid == 3 else fid for fid, d in chain] + [0, 0]
+        opts.bcj, opts.bcj2, opts.bcj3 = vals[0], vals[1], vals[2]
+        return opts
+    cases = {"x86": o.corpus_x86(400000, 3), "arm": _arm64_like(300000, 3), "mixed": o.corpus_mixed(200000, 4), "tiny": bytes([0x94, 1, 2]), "odd": _arm64_like(4099, 2)}
+    for preset in (1, 3):
+        opts = put(xz_amd.preset_options(preset, span_size=xz_amd.SPAN_WHOLE_BLOCK))
+        for cname, data in cases.items():
+            for bs in (1 << 20, 200001, 65537):
+                t = torch.frombuffer(bytearray(data), dtype=torch.uint8).cuda()
+                out, _ = enc.encode(t, opts=opts, block_size=bs, check=4)
+                ref = o.ref_encode_mt_chain_n(data, preset, chain, threads=2, block_size=bs, check=4)
+                assert o.first_diff(out.cpu().numpy().tobytes(), ref) == -1, (name, cname, preset, bs)
+    data = cases["x86"] + cases["arm"] + cases["mixed"]
+    # the same chain as a lzma_filter array through the liblzma entry points (preset 1's lzma_options_lzma)
+    import ctypes as C
+    import sys
+    if os.path.join(o.ROOT, "tools") not in sys.path:
+        sys.path.insert(0, os.path.join(o.ROOT, "tools"))
+    from bench_lzma_code import Mt, Stream
+
+    class Filter(C.Structure):
+        _fields_ = [("id", C.c_uint64), ("options", C.c_void_p)]
+
+    class OptLzma(C.Structure):
+        _fields_ = [("dict_size", C.c_uint32), ("preset_dict", C.c_void_p), ("preset_dict_size", C.c_uint32),
+                    ("lc", C.c_uint32), ("lp", C.c_uint32), ("pb", C.c_uint32), ("mode", C.c_int),
+                    ("nice_len", C.c_uint32), ("mf", C.c_int), ("depth", C.c_uint32), ("pad", C.c_uint8 * 64)]
+    ol = OptLzma(dict_size=1 << 20, lc=3, lp=0, pb=2, mode=1, nice_len=128, mf=4, depth=8)
+    deltas = [(C.c_uint32 * 8)(0, d) for _, d in chain]          # lzma_options_delta: type BYTE, dist
+    fl = (Filter * (len(chain) + 2))()
+    for i, (fid, _) in enumerate(chain):
+        fl[i].id, fl[i].options = fid, (C.cast(deltas[i], C.c_void_p) if fid == 3 else None)
+    fl[len(chain)].id, fl[len(chain)].options = 0x21, C.cast(C.pointer(ol), C.c_void_p)
+    fl[len(chain) + 1].id = 2**64 - 1
+    L = xz_amd.lib()
+    ib = C.create_string_buffer(data, len(data))
+    ob = C.create_string_buffer(len(data) + (1 << 20))
+    st = Stream()
+    m = Mt(threads=1, check=4, block_size=200001, filters=C.cast(fl, C.c_void_p))
+    monkeypatch.setenv("XZAMD_SPAN_KIB", "1024")           # one span per Block: the reference's bytes
+    assert L.lzma_stream_encoder_mt(C.byref(st), C.byref(m)) == 0
+    monkeypatch.delenv("XZAMD_SPAN_KIB")
+    st.next_in, st.avail_in = C.cast(ib, C.c_void_p).value, len(data)
+    st.next_out, st.avail_out = C.cast(ob, C.c_void_p).value, len(ob)
+    r = L.lzma_code(C.byref(st), 3)
+    while r == 0:
+        r = L.lzma_code(C.byref(st), 3)
+    assert r == 1
+    got = ob.raw[: st.total_out]
+    L.lzma_end(C.byref(st))
+    ref = o.ref_encode_mt_chain_n(data, 1, chain, threads=2, block_size=200001, check=4)
+    assert o.first_diff(got, ref) == -1, (name, "lzma_code")
+
+    opts = put(xz_amd.preset_options(6))
+    t = torch.frombuffer(bytearray(data), dtype=torch.uint8).cuda()
+    out, _ = enc.encode(t, opts=opts, block_size=300000, check=4)
+    rr, dec = o.ref_decode(out.cpu().numpy().tobytes(), len(data) + 16)
+    assert rr == 1 and dec == data, name
+
+
 @pytest.mark.parametrize("preset", [1, 6, 9 | 0x80000000])
 def test_x86_bcj_default_spans_roundtrip(enc, preset):
     """Span-parallel mode with the BCJ pre-pass: decodes bit-exactly through the REAL reference decoder,

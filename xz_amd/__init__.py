@@ -34,7 +34,7 @@ class LzmaOptions(C.Structure):
     _fields_ = [(n, C.c_uint32) for n in (
         "dict_size", "lc", "lp", "pb", "mode", "nice_len", "mf", "depth",
         "gpu_mf", "gpu_nice_len", "gpu_depth", "span_size", "gpu_sa_window", "gpu_parser", "bcj",
-        "gpu_sa_depth", "span_cost", "span_bits", "enc_span_bits")]
+        "gpu_sa_depth", "span_cost", "span_bits", "enc_span_bits", "bcj2", "bcj3")]
 
 
 class Stats(C.Structure):

@@ -147,38 +147,61 @@ uint64_t xzamd_block_buffer_bound(uint64_t u)
 	return headers + ((lz2 + 3) & ~3ull);
 }
 
-/* `pre` = the filter in front of LZMA2 as xzamd_lzma_options.bcj carries it: 0 none, XZAMD_BCJ_X86,
- * XZAMD_BCJ_ARM64, XZAMD_FILTER_DELTA(dist). */
-static uint32_t prefilter_flags_size(uint32_t pre)
+/* The filters in front of LZMA2 as xzamd_lzma_options.bcj / bcj2 / bcj3 carry them (0 none, XZAMD_BCJ_*,
+ * XZAMD_FILTER_DELTA(dist)), in chain order; NULL = the chain {LZMA2}. */
+static uint32_t prefilter_list(const xzamd_lzma_options *opt, uint32_t pre[XZAMD_PREFILTERS_MAX])
 {
-	const uint32_t id = pre & 0xFF;
-	return id == 0 ? 0 : (id == 3 ? 3 : 2);
+	uint32_t n = 0;
+	if (opt != NULL) {
+		const uint32_t all[XZAMD_PREFILTERS_MAX] = { opt->bcj, opt->bcj2, opt->bcj3 };
+		while (n < XZAMD_PREFILTERS_MAX && all[n] != 0) { pre[n] = all[n]; ++n; }
+	}
+	return n;
 }
 
-static uint32_t block_header_size(uint64_t csize, uint64_t usize, uint32_t pre)
+static int prefilter_valid(uint32_t pre)
 {
-	/* block_header_encoder.c:17-70 for the chains {LZMA2} and {BCJ | delta, LZMA2} */
-	uint32_t s = 1 + 1 + 4 + vli_len(csize) + vli_len(usize) + 3 + prefilter_flags_size(pre);
+	return (pre >= XZAMD_BCJ_X86 && pre <= XZAMD_BCJ_RISCV) || ((pre & 0xFF) == 3 && (pre >> 8) <= 255);
+}
+
+static uint32_t prefilter_flags_size(const xzamd_lzma_options *opt)
+{
+	uint32_t pre[XZAMD_PREFILTERS_MAX], s = 0;
+	const uint32_t n = prefilter_list(opt, pre);
+	for (uint32_t i = 0; i < n; ++i)
+		s += (pre[i] & 0xFF) == 3 ? 3 : 2;
+	return s;
+}
+
+static uint32_t block_header_size(uint64_t csize, uint64_t usize, const xzamd_lzma_options *opt)
+{
+	/* block_header_encoder.c:17-70 for the chains {LZMA2} and {up to three of BCJ | delta, LZMA2} */
+	uint32_t s = 1 + 1 + 4 + vli_len(csize) + vli_len(usize) + 3 + prefilter_flags_size(opt);
 	return (s + 3) & ~3u;
 }
 
-static void block_header_put(uint8_t *out, uint32_t hs, uint64_t csize, uint64_t usize, uint8_t dict_byte, uint32_t pre)
+static void block_header_put(uint8_t *out, uint32_t hs, uint64_t csize, uint64_t usize, uint8_t dict_byte,
+		const xzamd_lzma_options *opt)
 {
 	/* block_header_encoder.c:73-131 */
 	const uint32_t body = hs - 4;
+	uint32_t pre[XZAMD_PREFILTERS_MAX];
+	const uint32_t npre = prefilter_list(opt, pre);
 	memset(out, 0, body);
 	out[0] = (uint8_t)(body / 4);
-	out[1] = (pre & 0xFF) ? 0xC1 : 0xC0;   /* both sizes present, number of filters - 1 */
+	out[1] = (uint8_t)(0xC0 | npre);   /* both sizes present, number of filters - 1 */
 	uint32_t p = 2;
 	p += vli_put(out + p, csize);
 	p += vli_put(out + p, usize);
-	if ((pre & 0xFF) == 3) {      /* delta: id 0x03, one property byte = distance - 1 (delta_encoder.c:99-111) */
-		out[p++] = 0x03;
-		out[p++] = 0x01;
-		out[p++] = (uint8_t)(pre >> 8);
-	} else if (pre & 0xFF) {      /* filter_flags_encoder.c:30-55: BCJ id, no properties (start offset 0) */
-		out[p++] = (uint8_t)(pre & 0xFF);
-		out[p++] = 0x00;
+	for (uint32_t i = 0; i < npre; ++i) {
+		if ((pre[i] & 0xFF) == 3) {      /* delta: id 0x03, one property byte = distance - 1 (delta_encoder.c:99-111) */
+			out[p++] = 0x03;
+			out[p++] = 0x01;
+			out[p++] = (uint8_t)(pre[i] >> 8);
+		} else {                         /* filter_flags_encoder.c:30-55: BCJ id, no properties (start offset 0) */
+			out[p++] = (uint8_t)(pre[i] & 0xFF);
+			out[p++] = 0x00;
+		}
 	}
 	out[p++] = 0x21;
 	out[p++] = 0x01;
@@ -232,12 +255,12 @@ int xzamd_stored_blocks_host_(const uint8_t *in, uint64_t n, uint64_t block_size
 	for (uint64_t bs = 0; bs < n; bs += block_size, ++nb) {
 		const uint64_t usize = n - bs < block_size ? n - bs : block_size;
 		const uint64_t csz = usize + ((usize + 65535) / 65536) * 3 + 1;
-		const uint32_t hs = block_header_size(csz, usize, 0);
+		const uint32_t hs = block_header_size(csz, usize, NULL);
 		const uint64_t pad = (4 - (csz & 3)) & 3;
 		if (opos + hs + csz + pad + cbytes > out_cap)
 			return XZAMD_BUF_ERROR;
 		const uint64_t bstart = opos;
-		block_header_put(out + opos, hs, csz, usize, 0x00, 0);
+		block_header_put(out + opos, hs, csz, usize, 0x00, NULL);
 		opos += hs;
 		uint8_t ctl = 0x01;
 		for (uint64_t ip = 0; ip < usize; ip += 65536) {
@@ -372,7 +395,7 @@ struct xzamd_ctx {
 	char err_msg_buf[200];
 	/* device buffers */
 	dbuf keys_a, keys_b, vals_a, vals_b, rank, sorted_pos, prev2, prev3, prev4, prev8, prev16, prev24, prev32, key64_a, key64_b, sa, sa_rank, sort_tmp;
-	dbuf scratch, span_bytes, strip_crc, block_crc, segs, lits, trace, errw, errw2, litp, mlen, mdist, bcj[2];
+	dbuf scratch, span_bytes, strip_crc, block_crc, segs, lits, trace, errw, errw2, litp, mlen, mdist, bcj[2], bcjt;
 	dbuf est, totals, span_tab, span_cnt, mtop, order;             /* span plan (kernels_api.h) */
 	dbuf sym_len[2], sym_dist[2], prior, enc_tab[2], enc_cnt[2];   /* two-phase mode ([2]: one set per pipeline parity) */
 	dbuf tok, chunks, h_chunks;                                    /* coder of the two-phase mode: tokens, chunk table */
@@ -467,7 +490,7 @@ static void ctx_device_bufs(xzamd_ctx *c, dbuf **d, size_t *nd)
 {
 	dbuf *all[] = { &c->keys_a, &c->keys_b, &c->vals_a, &c->vals_b, &c->rank, &c->sorted_pos,
 		&c->prev2, &c->prev3, &c->prev4, &c->prev8, &c->prev16, &c->prev24, &c->prev32, &c->key64_a, &c->key64_b, &c->sa, &c->sa_rank, &c->sort_tmp,
-		&c->scratch, &c->litp, &c->mlen, &c->mdist, &c->bcj[0], &c->bcj[1], &c->est, &c->mtop, &c->order,
+		&c->scratch, &c->litp, &c->mlen, &c->mdist, &c->bcj[0], &c->bcj[1], &c->bcjt, &c->est, &c->mtop, &c->order,
 		&c->sym_len[0], &c->sym_len[1], &c->sym_dist[0], &c->sym_dist[1], &c->tok,
 		/* small ones */
 		&c->chunks,
@@ -476,7 +499,7 @@ static void ctx_device_bufs(xzamd_ctx *c, dbuf **d, size_t *nd)
 	*nd = sizeof(all) / sizeof(all[0]);
 	memcpy(d, all, sizeof(all));
 }
-#define CTX_NBIG 32      /* the first CTX_NBIG entries of ctx_device_bufs scale with the batch */
+#define CTX_NBIG 33      /* the first CTX_NBIG entries of ctx_device_bufs scale with the batch */
 
 void xzamd_ctx_destroy(xzamd_ctx *c)
 {
@@ -535,9 +558,9 @@ const char *xzamd_options_check(const xzamd_lzma_options *opt)
 		return "unsupported match finder options for the device path";
 	if (opt->dict_size < 4096 || opt->dict_size > (1u << 30))
 		return "dict_size must be 4 KiB .. 1 GiB on the device path";
-	if (opt->bcj != 0 && !(opt->bcj >= XZAMD_BCJ_X86 && opt->bcj <= XZAMD_BCJ_RISCV)
-			&& ((opt->bcj & 0xFF) != 3 || (opt->bcj >> 8) > 255))
-		return "filters in front of LZMA2: x86 / PowerPC / IA-64 / ARM / ARM-Thumb / SPARC / ARM64 / RISC-V BCJ or delta";
+	if ((opt->bcj != 0 && !prefilter_valid(opt->bcj)) || (opt->bcj2 != 0 && (opt->bcj == 0 || !prefilter_valid(opt->bcj2)))
+			|| (opt->bcj3 != 0 && (opt->bcj2 == 0 || !prefilter_valid(opt->bcj3))))
+		return "filters in front of LZMA2: up to three of x86 / PowerPC / IA-64 / ARM / ARM-Thumb / SPARC / ARM64 / RISC-V BCJ or delta";
 	if (opt->gpu_parser && opt->pb > 2)
 		return "the optimal parser's price tables cover pb <= 2";
 	if (opt->gpu_sa_depth != 0 && opt->gpu_sa_depth != 32 && opt->gpu_sa_depth != 64 && opt->gpu_sa_depth != 128
@@ -806,9 +829,9 @@ static int back_finish(xzamd_ctx *c, job_env *J, batch_run *B)
 		if (J->hs_fixed + payload + pad + cbytes > J->bound) {
 			/* stream_encoder_mt.c:298,316-344 -> block_buffer_encoder.c:88-162 */
 			const uint64_t csz = usize + ((usize + 65535) / 65536) * 3 + 1;
-			const uint32_t hs = block_header_size(csz, usize, 0);      /* stored Blocks drop the BCJ filter */
+			const uint32_t hs = block_header_size(csz, usize, NULL);      /* stored Blocks drop the filters in front of LZMA2 */
 			if (opos + hs + csz + 3 + cbytes > J->out_cap) return fail(c, XZAMD_BUF_ERROR, "output buffer too small", 0);
-			block_header_put(small, hs, csz, usize, 0x00, 0);
+			block_header_put(small, hs, csz, usize, 0x00, NULL);
 			opos = plan_lit(&pl, small, hs, opos);
 			uint8_t ctl = 0x01;
 			for (uint64_t ip = 0; ip < usize; ip += 65536) {
@@ -824,7 +847,7 @@ static int back_finish(xzamd_ctx *c, job_env *J, batch_run *B)
 			++c->stats.blocks_stored;
 		} else {
 			if (opos + J->hs_fixed + payload + pad + cbytes > J->out_cap) return fail(c, XZAMD_BUF_ERROR, "output buffer too small", 0);
-			block_header_put(small, J->hs_fixed, payload, usize, J->dbyte, opt->bcj);
+			block_header_put(small, J->hs_fixed, payload, usize, J->dbyte, opt);
 			opos = plan_lit(&pl, small, J->hs_fixed, opos);
 			for (uint32_t s = 0; s < nsp; ++s) {
 				const uint64_t slot = b * opb + s, start = otab[2 * slot];
@@ -968,7 +991,7 @@ int xzamd_stream_encode_device(xzamd_ctx *c,
 		else per_byte += 8.0;                                            /* rank, sorted_pos */
 		if (opt->gpu_parser) per_byte += 32.0 + 2.0 + (list_packed ? 0.0 : 16.0);
 		if (two_) per_byte += 12.0 + 2.0 * XZAMD_TOK_PER_BYTE;
-		if (opt->bcj) per_byte += 2.0;
+		if (opt->bcj) per_byte += opt->bcj2 ? 3.0 : 2.0;
 		uint64_t free_b = 0, total_b = 0, held = 0;
 		if (xzk_mem_info(&free_b, &total_b) == 0 && total_b != 0) {
 			dbuf *d[64];
@@ -1008,7 +1031,7 @@ int xzamd_stream_encode_device(xzamd_ctx *c,
 	J.opt = opt; J.d_in = d_in; J.d_out = d_out; J.block_size = block_size; J.out_cap = out_cap;
 	J.bound = xzamd_block_buffer_bound(block_size);
 	J.binfo = binfo; J.binfo_cap = binfo_cap;
-	J.spb = spb; J.esb = esb; J.cbytes = cbytes; J.hs_fixed = block_header_size(J.bound, block_size, opt->bcj);
+	J.spb = spb; J.esb = esb; J.cbytes = cbytes; J.hs_fixed = block_header_size(J.bound, block_size, opt);
 	J.check = check; J.two = two; J.adaptive = adaptive;
 	J.dbyte = dict_size_byte(opt->dict_size);
 	J.st = st; J.stb = pipelined ? c->st2 : st;
@@ -1116,6 +1139,7 @@ int xzamd_stream_encode_device(xzamd_ctx *c,
 		GROW(h_segs, max_segs * sizeof(xzamd_copy_seg), 1);
 		GROW(h_lits, max_lits, 1);
 		if (x86) GROW(bcj[par], (uint64_t)n + 16, 0);
+		if (opt->bcj2) GROW(bcjt, (uint64_t)n + 16, 0);
 
 		batch_run cur;
 		memset(&cur, 0, sizeof(cur));
@@ -1138,12 +1162,21 @@ int xzamd_stream_encode_device(xzamd_ctx *c,
 			sha_early = 1;
 		}
 		if (x86) {
-			int e = opt->bcj == XZAMD_BCJ_X86
-					? xzk_x86_bcj(d_in + in_off, (uint8_t *)c->bcj[par].p, n, (uint32_t)block_size, (uint32_t)nb, st)
-					: xzk_prefilter(d_in + in_off, (uint8_t *)c->bcj[par].p, n, (uint32_t)block_size, (uint32_t)nb, opt->bcj & 0xFF,
-							(opt->bcj >> 8) + 1, st);
-			if (e) { rc = fail(c, XZAMD_DEVICE_ERROR, "filter in front of LZMA2", e); goto done; }
-			enc_in = (const uint8_t *)c->bcj[par].p;
+			/* the filters run one after another, each over the whole batch (they do not alias: in -> X for one,
+			 * in -> T -> X for two, in -> X -> T -> X for three; T is only live inside this sequence) */
+			uint32_t pre[XZAMD_PREFILTERS_MAX];
+			const uint32_t npre = prefilter_list(opt, pre);
+			uint8_t *const X = (uint8_t *)c->bcj[par].p, *const T = (uint8_t *)c->bcjt.p;
+			const uint8_t *src = d_in + in_off;
+			for (uint32_t i = 0; i < npre; ++i) {
+				uint8_t *dst = ((npre - 1 - i) & 1) ? T : X;
+				int e = pre[i] == XZAMD_BCJ_X86
+						? xzk_x86_bcj(src, dst, n, (uint32_t)block_size, (uint32_t)nb, st)
+						: xzk_prefilter(src, dst, n, (uint32_t)block_size, (uint32_t)nb, pre[i] & 0xFF, (pre[i] >> 8) + 1, st);
+				if (e) { rc = fail(c, XZAMD_DEVICE_ERROR, "filter in front of LZMA2", e); goto done; }
+				src = dst;
+			}
+			enc_in = X;
 		}
 		cur.enc_in = enc_in;
 		/* 1. match-finder structure */

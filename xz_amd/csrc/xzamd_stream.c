@@ -412,25 +412,32 @@ static lzma_ret parse_options(const lzma_mt *o, xzamd_lzma_options *opt, uint64_
 		return LZMA_OPTIONS_ERROR;
 	if (o->filters != NULL) {
 		const lzma_filter *f = o->filters;
-		uint32_t bcj = 0;
-		if (f[0].id >= LZMA_FILTER_X86 && f[0].id <= LZMA_FILTER_RISCV) {
-			/* {BCJ, LZMA2} for x86, PowerPC, IA-64, ARM, ARM-Thumb, SPARC, ARM64, RISC-V (the filter ids are the values
-			 * of xzamd_lzma_options.bcj): start offset must be 0 (bcj.h:81-98, NULL options = defaults) */
-			const lzma_options_bcj *b = (const lzma_options_bcj *)f[0].options;
-			if (b != NULL && b->start_offset != 0)
+		uint32_t pre[XZAMD_PREFILTERS_MAX] = { 0, 0, 0 }, npre = 0;
+		/* up to three filters in front of LZMA2 (a chain holds at most LZMA_FILTERS_MAX = 4, the last one must be
+		 * LZMA2 here; BCJ and delta filters may come in any order: common/filter_common.c:250-334) */
+		while (f[0].id != LZMA_FILTER_LZMA2) {
+			if (npre == XZAMD_PREFILTERS_MAX)
 				return LZMA_OPTIONS_ERROR;
-			bcj = (uint32_t)f[0].id;
-			++f;
-		} else if (f[0].id == LZMA_FILTER_DELTA) {
-			/* {delta, LZMA2}: delta/delta_common.c:38-60 */
-			const lzma_options_delta *dl = (const lzma_options_delta *)f[0].options;
-			if (dl == NULL || dl->type != LZMA_DELTA_TYPE_BYTE || dl->dist < 1 || dl->dist > 256)
-				return LZMA_OPTIONS_ERROR;
-			bcj = XZAMD_FILTER_DELTA(dl->dist);
+			if (f[0].id >= LZMA_FILTER_X86 && f[0].id <= LZMA_FILTER_RISCV) {
+				/* x86, PowerPC, IA-64, ARM, ARM-Thumb, SPARC, ARM64, RISC-V (the filter ids are the values of
+				 * xzamd_lzma_options.bcj): start offset must be 0 (bcj.h:81-98, NULL options = defaults) */
+				const lzma_options_bcj *b = (const lzma_options_bcj *)f[0].options;
+				if (b != NULL && b->start_offset != 0)
+					return LZMA_OPTIONS_ERROR;
+				pre[npre++] = (uint32_t)f[0].id;
+			} else if (f[0].id == LZMA_FILTER_DELTA) {
+				/* delta/delta_common.c:38-60 */
+				const lzma_options_delta *dl = (const lzma_options_delta *)f[0].options;
+				if (dl == NULL || dl->type != LZMA_DELTA_TYPE_BYTE || dl->dist < 1 || dl->dist > 256)
+					return LZMA_OPTIONS_ERROR;
+				pre[npre++] = XZAMD_FILTER_DELTA(dl->dist);
+			} else {
+				return LZMA_OPTIONS_ERROR;      /* incl. LZMA_VLI_UNKNOWN: a chain without LZMA2 */
+			}
 			++f;
 		}
-		if (f[0].id != LZMA_FILTER_LZMA2 || f[0].options == NULL || f[1].id != LZMA_VLI_UNKNOWN)
-			return LZMA_OPTIONS_ERROR;      /* device path: {LZMA2} and {BCJ | delta, LZMA2} */
+		if (f[0].options == NULL || f[1].id != LZMA_VLI_UNKNOWN)
+			return LZMA_OPTIONS_ERROR;      /* device path: {LZMA2} and {BCJ | delta ..., LZMA2} */
 		const lzma_options_lzma *l = (const lzma_options_lzma *)f[0].options;
 		if (l->preset_dict != NULL && l->preset_dict_size != 0)
 			return LZMA_OPTIONS_ERROR;
@@ -463,7 +470,7 @@ static lzma_ret parse_options(const lzma_mt *o, xzamd_lzma_options *opt, uint64_
 			return LZMA_OPTIONS_ERROR;
 		}
 		opt->span_size = XZAMD_SPAN_DEFAULT;
-		opt->bcj = bcj;
+		opt->bcj = pre[0]; opt->bcj2 = pre[1]; opt->bcj3 = pre[2];
 	} else if (xzamd_lzma_preset(opt, o->preset)) {
 		return LZMA_OPTIONS_ERROR;
 	}
