@@ -339,6 +339,8 @@ def main():
     else:
         host = xz_amd.corpus_text(max(n, 1), seed=1000 + rank)
     host = host[:n]
+    import hashlib
+    corpus_sha = hashlib.sha256(memoryview(host)).hexdigest() if rank == 0 and args.corpus != "text" else None   # text: a function of the seed
     data = torch.from_numpy(host).to(dev)
     enc = xz_amd.Encoder(dev_index)
     out_buf = torch.empty(xz_amd.lib().xzamd_stream_buffer_bound(n, block_size) + 64, dtype=torch.uint8, device=dev)
@@ -440,6 +442,7 @@ def main():
                             f"{'per GPU' if args.scaling == 'weak' else 'in total, whole Blocks dealt to the ranks in order'}; `value` = input resident in HBM, "
                             f"output = complete .xz Stream in HBM; the same job through lzma_code with host buffers (SURVEY 8d end-to-end) is `host_to_host`",
                 "world_size": world,
+                "corpus_sha256": corpus_sha,       # of rank 0's input: ties "elf" / "tar" numbers to the image they were made on
                 "device_match_finder": ((f"suffix-neighbourhood finder ({opts.gpu_sa_depth or 32}-byte-prefix suffix order, {opts.gpu_sa_window} slots per side + hash2/hash4 heads + equal 8/16 bytes)"
                                          if opts.gpu_sa_window else f"HC{opts.gpu_mf & 15} depth {opts.gpu_depth} (sort-built chains)")
                                         + f", nice {opts.gpu_nice_len}"),

@@ -222,34 +222,43 @@ typedef struct { char **v; size_t n, cap; } strlist;
 
 static int cmp_str(const void *a, const void *b) { return strcmp(*(char *const *)a, *(char *const *)b); }
 
-static void walk(const char *dir, strlist *files)
+/* Appends to `files`; an allocation failure ends the walk early (the corpus is then built from what was listed). */
+static int walk(const char *dir, strlist *files)
 {
 	DIR *d = opendir(dir);
-	if (!d) return;
+	if (!d) return 0;
 	strlist names = { NULL, 0, 0 };
 	struct dirent *de;
-	while ((de = readdir(d)) != NULL) {
+	int oom = 0;
+	while (!oom && (de = readdir(d)) != NULL) {
 		if (!strcmp(de->d_name, ".") || !strcmp(de->d_name, "..")) continue;
 		if (names.n == names.cap) {
-			names.cap = names.cap ? names.cap * 2 : 64;
-			names.v = (char **)realloc(names.v, names.cap * sizeof(char *));
+			const size_t cap = names.cap ? names.cap * 2 : 64;
+			char **v = (char **)realloc(names.v, cap * sizeof(char *));
+			if (!v) { oom = 1; break; }
+			names.v = v; names.cap = cap;
 		}
-		names.v[names.n++] = strdup(de->d_name);
+		char *nm = strdup(de->d_name);
+		if (!nm) { oom = 1; break; }
+		names.v[names.n++] = nm;
 	}
 	closedir(d);
-	qsort(names.v, names.n, sizeof(char *), cmp_str);
+	if (names.n) qsort(names.v, names.n, sizeof(char *), cmp_str);
 	for (size_t i = 0; i < names.n; ++i) {
 		const size_t len = strlen(dir) + strlen(names.v[i]) + 2;
-		char *path = (char *)malloc(len);
+		char *path = oom ? NULL : (char *)malloc(len);
+		if (!path) { oom = 1; free(names.v[i]); continue; }
 		snprintf(path, len, "%s/%s", dir, names.v[i]);
 		struct stat st;
 		if (lstat(path, &st) == 0 && S_ISDIR(st.st_mode)) {
-			walk(path, files);
+			oom |= walk(path, files);
 			free(path);
 		} else if (lstat(path, &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0) {
 			if (files->n == files->cap) {
-				files->cap = files->cap ? files->cap * 2 : 1024;
-				files->v = (char **)realloc(files->v, files->cap * sizeof(char *));
+				const size_t cap = files->cap ? files->cap * 2 : 1024;
+				char **v = (char **)realloc(files->v, cap * sizeof(char *));
+				if (!v) { oom = 1; free(path); free(names.v[i]); continue; }
+				files->v = v; files->cap = cap;
 			}
 			files->v[files->n++] = path;
 		} else {
@@ -258,6 +267,7 @@ static void walk(const char *dir, strlist *files)
 		free(names.v[i]);
 	}
 	free(names.v);
+	return oom;
 }
 
 static void tar_octal(uint8_t *dst, int width, uint64_t v)
@@ -304,12 +314,13 @@ uint64_t xzamd_corpus_tar(uint8_t *out, uint64_t n, const char *roots, uint64_t 
 {
 	strlist files = { NULL, 0, 0 };
 	char *r = strdup(roots ? roots : "");
+	if (!r) return 0;
 	for (char *tok = r, *next; tok && *tok; tok = next) {
 		next = strchr(tok, ':');
 		if (next) *next++ = 0;
 		size_t l = strlen(tok);
 		while (l > 1 && tok[l - 1] == '/') tok[--l] = 0;
-		walk(tok, &files);
+		if (walk(tok, &files)) break;
 	}
 	free(r);
 	const uint64_t nfiles = files.n;
