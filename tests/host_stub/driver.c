@@ -26,6 +26,7 @@ static size_t stream_encode(const lzma_mt *mt, const uint8_t *in, size_t n, size
 	lzma_stream s = LZMA_STREAM_INIT;
 	CHECK(lzma_stream_encoder_mt(&s, mt) == LZMA_OK);
 	size_t ipos = 0, opos = 0;
+	uint64_t last_pin = 0;
 	int flushed = flush_at == 0;
 	for (;;) {
 		lzma_action act = LZMA_RUN;
@@ -49,7 +50,9 @@ static size_t stream_encode(const lzma_mt *mt, const uint8_t *in, size_t n, size
 		lzma_ret r = lzma_code(&s, act);
 		uint64_t pin = 0, pout = 0;
 		lzma_get_progress(&s, &pin, &pout);
-		CHECK(pin <= n);
+		CHECK(pin <= n && pin <= s.total_in + s.avail_in);
+		CHECK(pin >= last_pin);              /* workers publish progress inside their jobs; it never goes back */
+		last_pin = pin;
 		if (r == LZMA_STREAM_END) {
 			if (act == LZMA_FINISH) break;
 			CHECK(act == flush_action && s.avail_in == 0);

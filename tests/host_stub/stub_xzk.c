@@ -35,6 +35,7 @@ int xzk_stream_destroy(void *st) { free(st); return 0; }
 int xzk_event_create(void **ev) { *ev = malloc(1); return *ev ? 0 : 2; }
 int xzk_event_destroy(void *ev) { free(ev); return 0; }
 int xzk_event_record(void *ev, void *st) { (void)ev; (void)st; return 0; }
+int xzk_event_query(void *ev) { (void)ev; return 0; }
 int xzk_event_elapsed_ms(void *a, void *b, float *ms) { (void)a; (void)b; *ms = 0.0f; return 0; }
 const char *xzk_error_string(int e) { (void)e; return "stub error"; }
 int xzk_mem_info(uint64_t *free_b, uint64_t *total_b) { *free_b = *total_b = 1ull << 34; return 0; }

@@ -1096,6 +1096,44 @@ def test_lzma_code_semantics(tmp_path):
     L.lzma_end(C.byref(s))      # idempotent
 
 
+def test_progress_moves_inside_a_job():
+    """lzma_get_progress (common/common.c:406, stream_encoder_mt.c:1004-1024; the reference's workers publish how far they
+    are inside their Block, :261-267): progress_in moves while a job is on the GPU -- by the shares of its finished stages
+    -- not only when a whole job is done, never goes back, never exceeds what was handed in, and ends at total_in."""
+    import ctypes as C
+    import sys
+    import xz_amd
+    if os.path.join(o.ROOT, "tools") not in sys.path:
+        sys.path.insert(0, os.path.join(o.ROOT, "tools"))
+    from bench_lzma_code import Mt, Stream
+    L = xz_amd.lib()
+    n = 192 << 20                                           # one job (< 1 GiB), 8 Blocks at preset 6
+    data = xz_amd.corpus_text(n, seed=5)
+    ob = C.create_string_buffer(n // 2)
+    s = Stream()
+    m = Mt(threads=1, preset=6, check=4, timeout=5)         # lzma_code returns every 5 ms while the worker is busy
+    assert L.lzma_stream_encoder_mt(C.byref(s), C.byref(m)) == 0
+    s.next_in, s.avail_in = data.ctypes.data, n
+    s.next_out, s.avail_out = C.cast(ob, C.c_void_p).value, len(ob)
+    seen, last = set(), 0
+    pin, pout = C.c_uint64(0), C.c_uint64(0)
+    r = 0
+    while r == 0:
+        r = L.lzma_code(C.byref(s), 3)
+        L.lzma_get_progress(C.byref(s), C.byref(pin), C.byref(pout))
+        assert last <= pin.value <= n, (last, pin.value)
+        last = pin.value
+        seen.add(pin.value)
+    assert r == 1 and s.total_in == n
+    L.lzma_get_progress(C.byref(s), C.byref(pin), C.byref(pout))
+    assert pin.value == n and pout.value == s.total_out
+    inside = sorted(v for v in seen if 0 < v < n)
+    assert len(inside) >= 2, sorted(seen)                   # e.g. 25 %, 40 %, 90 % of the job
+    L.lzma_end(C.byref(s))
+    rr, dec = o.ref_decode(ob.raw[: s.total_out], n + 16) if o.have_ref() else (1, data.tobytes())
+    assert rr == 1 and dec == data.tobytes()
+
+
 def test_lzma_code_worker_pipeline_timeout_barrier_and_filters_update(monkeypatch):
     """The front end deals batches of Blocks ("jobs") to one worker thread per GPU and drains them in order:
     many small jobs (XZAMD_BATCH_MIB=1) must give the same Stream as one big batch; lzma_mt.timeout makes a

@@ -199,6 +199,7 @@ int xzk_event_create(void **ev);
 int xzk_event_destroy(void *ev);
 int xzk_event_record(void *ev, void *stream);
 int xzk_event_elapsed_ms(void *a, void *b, float *ms);
+int xzk_event_query(void *ev);      /* 0 = everything recorded before the event has completed */
 const char *xzk_error_string(int e);
 int xzk_mem_info(uint64_t *free_b, uint64_t *total_b);
 

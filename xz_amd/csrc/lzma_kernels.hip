@@ -4496,6 +4496,7 @@ int xzk_event_create(void** ev) { return (int)hipEventCreate((hipEvent_t*)ev); }
 int xzk_event_destroy(void* ev) { return (int)hipEventDestroy((hipEvent_t)ev); }
 int xzk_event_record(void* ev, void* st) { return (int)hipEventRecord((hipEvent_t)ev, (hipStream_t)st); }
 int xzk_event_elapsed_ms(void* a, void* b, float* ms) { return (int)hipEventElapsedTime(ms, (hipEvent_t)a, (hipEvent_t)b); }
+int xzk_event_query(void* ev) { return (int)hipEventQuery((hipEvent_t)ev); }
 const char* xzk_error_string(int e) { return hipGetErrorString((hipError_t)e); }
 int xzk_mem_info(uint64_t* free_b, uint64_t* total_b)
 {

@@ -406,6 +406,12 @@ struct xzamd_ctx {
 	uint32_t trace_cap;
 	int trace_on;
 	int last_par;                /* pipeline parity of the last batch (debug fetches) */
+	/* progress of the running xzamd_stream_encode_device call, read by other threads (xzamd_ctx_progress_in_) */
+	pthread_mutex_t prog_mu;
+	int prog_mu_ok;
+	uint64_t prog_done;          /* input bytes of the batches that are through their back end */
+	uint64_t prog_cur;           /* input bytes of the batch whose launches are all in flight (0: none) */
+	int prog_par;                /* its event set */
 	xzamd_stats stats;
 };
 
@@ -451,6 +457,8 @@ int xzamd_ctx_create(xzamd_ctx **out, int device)
 	}
 	if (device >= ndev || xzk_set_device(device)) { free(c); return XZAMD_DEVICE_ERROR; }
 	c->device = device;
+	if (pthread_mutex_init(&c->prog_mu, NULL)) { free(c); return XZAMD_MEM_ERROR; }
+	c->prog_mu_ok = 1;
 	/* from here on every failure goes through xzamd_ctx_destroy (streams and events already made are released) */
 	if (xzk_stream_create(&c->own_stream)) { c->own_stream = NULL; xzamd_ctx_destroy(c); return XZAMD_DEVICE_ERROR; }
 	if (xzk_stream_create(&c->st2)) { c->st2 = NULL; xzamd_ctx_destroy(c); return XZAMD_DEVICE_ERROR; }
@@ -525,7 +533,55 @@ void xzamd_ctx_destroy(xzamd_ctx *c)
 	if (c->st3) xzk_stream_destroy(c->st3);
 	if (c->st2) xzk_stream_destroy(c->st2);
 	if (c->own_stream) xzk_stream_destroy(c->own_stream);
+	if (c->prog_mu_ok) pthread_mutex_destroy(&c->prog_mu);
 	free(c);
+}
+
+/* lzma_get_progress inside a job (stream_encoder_mt.c:261-267, 1004-1024: the reference's workers publish how far they
+ * are inside their Block).  A device batch has no byte position; what it has is stages whose ends are events on the
+ * batch's streams.  Input bytes this context has "consumed" of the call it is running = the batches that are complete +
+ * the share of the batch in flight that its finished stages stand for (structure build 25 %, finder 15 %, parse 50 %,
+ * model pass + range coder 10 %: their shares of a preset-6 job).  Monotonic within a call, 0
+ * outside of one; callable from any thread (the events are only queried). */
+uint64_t xzamd_ctx_progress_in_(xzamd_ctx *c)
+{
+	if (!c || !c->prog_mu_ok)
+		return 0;
+	pthread_mutex_lock(&c->prog_mu);
+	uint64_t v = c->prog_done;
+	if (c->prog_cur) {
+		void **ev = c->evp[c->prog_par];
+		uint32_t pct = 0;
+		if (xzk_event_query(ev[EV_CHAINS]) == 0) {
+			pct = 25;
+			if (xzk_event_query(ev[EV_FIND]) == 0) {
+				pct = 40;
+				if (xzk_event_query(ev[EV_PARSE]) == 0)
+					pct = xzk_event_query(ev[EV_CODE]) == 0 ? 100 : 90;
+			}
+		}
+		v += c->prog_cur / 100 * pct;
+	}
+	pthread_mutex_unlock(&c->prog_mu);
+	return v;
+}
+
+/* The call's figure stays up until the next call starts or the owner resets it (the lzma_* front end does so in the same
+ * critical section in which it books the finished job as a whole). */
+void xzamd_ctx_progress_reset_(xzamd_ctx *c)
+{
+	if (!c || !c->prog_mu_ok)
+		return;
+	pthread_mutex_lock(&c->prog_mu);
+	c->prog_done = c->prog_cur = 0;
+	pthread_mutex_unlock(&c->prog_mu);
+}
+
+static void progress_set(xzamd_ctx *c, uint64_t done, uint64_t cur, int par)
+{
+	pthread_mutex_lock(&c->prog_mu);
+	c->prog_done = done; c->prog_cur = cur; c->prog_par = par;
+	pthread_mutex_unlock(&c->prog_mu);
 }
 
 int xzamd_ctx_set_batch_bytes(xzamd_ctx *c, uint64_t bytes)
@@ -921,6 +977,7 @@ static int back_finish(xzamd_ctx *c, job_env *J, batch_run *B)
 	}
 	c->stats.batches += 1;
 	c->stats.encode_launches += 1;
+	progress_set(c, c->prog_done + n64, 0, 0);       /* (prog_done is written by this thread only) */
 	return XZAMD_OK;
 }
 
@@ -1058,6 +1115,7 @@ int xzamd_stream_encode_device(xzamd_ctx *c,
 	batch_run prev;
 	memset(&prev, 0, sizeof(prev));
 	uint64_t batch_index = 0;
+	progress_set(c, 0, 0, 0);
 	xzk_event_record(c->ev_total[0], st);
 	for (uint64_t b0 = 0; b0 < total_blocks && rc == XZAMD_OK; ) {
 		batch_geo g;
@@ -1346,6 +1404,7 @@ int xzamd_stream_encode_device(xzamd_ctx *c,
 			if (!e) e = xzk_d2h((uint8_t *)c->h_err[par].p + 512, c->errw2.p, 512, stb);
 			if (e) { rc = fail(c, XZAMD_DEVICE_ERROR, "d2h sizes", e); goto done; }
 		}
+		progress_set(c, c->prog_done, n64, par);     /* every stage event of this batch has been recorded */
 		if (pipelined) {
 			prev = cur;
 		} else {

@@ -9,6 +9,8 @@ uint32_t xzamd_crc32_host_(const uint8_t *p, size_t n);
 void *xzamd_ctx_stream_(xzamd_ctx *c);
 uint32_t xzamd_ctx_wave_slots_(const xzamd_ctx *c);
 int xzamd_ctx_fail_(xzamd_ctx *c, int code, const char *what);
+uint64_t xzamd_ctx_progress_in_(xzamd_ctx *c);
+void xzamd_ctx_progress_reset_(xzamd_ctx *c);
 int xzamd_stored_blocks_host_(const uint8_t *in, uint64_t n, uint64_t block_size, int check,
 		uint8_t *out, uint64_t out_cap, uint64_t *out_size, xzamd_block_info *binfo, uint64_t binfo_cap, uint64_t *nblocks);
 

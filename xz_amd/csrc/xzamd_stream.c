@@ -83,6 +83,7 @@ typedef struct {
 	void *d_out; uint64_t d_out_cap;
 	pthread_t thr;
 	int started;
+	const job *running;          /* the job this worker is on (written and read under owner->mu) */
 	struct lzma_internal_s *owner;
 } devslot;
 
@@ -355,9 +356,12 @@ static void *worker_main(void *arg)
 		}
 		job *j = &in->jobs[pick];
 		j->state = J_RUNNING;
+		d->running = j;
 		pthread_mutex_unlock(&in->mu);
 		const lzma_ret r = run_job(in, d, j);
 		pthread_mutex_lock(&in->mu);
+		d->running = NULL;
+		xzamd_ctx_progress_reset_(d->ctx);      /* the job counts as a whole from here on (progress_in below) */
 		j->err = r;
 		j->state = J_DONE;
 		__atomic_add_fetch(&in->ndone, 1, __ATOMIC_RELEASE);
@@ -1022,9 +1026,19 @@ void lzma_get_progress(lzma_stream *strm, uint64_t *progress_in, uint64_t *progr
 {
 	if (strm && strm->internal && strm->internal->magic == XZAMD_MAGIC) {
 		lzma_internal *in = strm->internal;
+		/* stream_encoder_mt.c:1004-1024: what is finished plus how far every worker is inside its job -- here the share of
+		 * the job's bytes that the finished stages of its device batches stand for (xzamd_ctx_progress_in_) */
 		pthread_mutex_lock(&in->mu);
-		*progress_in = in->progress_in;
+		uint64_t pin = in->progress_in;
+		for (int i = 0; i < in->ndev; ++i) {
+			const job *j = in->dev[i].running;
+			if (j != NULL) {
+				const uint64_t part = xzamd_ctx_progress_in_(in->dev[i].ctx);
+				pin += part < j->stage_len ? part : j->stage_len;
+			}
+		}
 		pthread_mutex_unlock(&in->mu);
+		*progress_in = pin;
 		*progress_out = in->progress_out;
 	} else if (strm) {
 		*progress_in = strm->total_in;
