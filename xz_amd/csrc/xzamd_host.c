@@ -13,6 +13,7 @@
  */
 #include "../../include/xz_amd.h"
 #include "kernels_api.h"
+#include "xzamd_internal.h"
 
 #include <stdio.h>
 #include <pthread.h>
@@ -378,6 +379,33 @@ typedef struct {
 /* stage events of one batch (one set per parity of the two-stream pipeline) */
 enum { EV_START, EV_CHAINS, EV_FIND, EV_PLAN0, EV_PLAN1, EV_SEED, EV_PARSE, EV_FRONT, EV_BACK0, EV_CODE, EV_CRC, EV_ASM, EV_COUNT };
 
+/* What the front end of a batch (match structures, plan, parse -- the caller's stream) hands to its back end (range
+ * coder of the two-phase mode, Block checks, sizes, layout, gather -- the second stream when the two are pipelined). */
+typedef struct {
+	int active;
+	uint64_t b0, nb, in_off, n64;
+	uint32_t n, nspans, nout, opb;
+	int par;                     /* which set of the double-buffered tables / events this batch uses */
+	const uint8_t *enc_in;       /* what LZMA2 reads (the filtered copy when a filter runs in front of it) */
+	int find_timed, seeds_early;
+	uint64_t max_segs, max_lits;
+} batch_run;
+
+/* constants of one xzamd_stream_encode_device call */
+typedef struct {
+	const xzamd_lzma_options *opt;
+	const uint8_t *d_in;
+	uint8_t *d_out;
+	uint64_t block_size, out_cap, bound, binfo_cap;
+	uint32_t spb, esb, cbytes, hs_fixed;
+	int check, two, adaptive, whole;
+	uint8_t dbyte;
+	void *st, *stb;
+	uint64_t *rec_unp, *rec_unc;
+	xzamd_block_info *binfo;
+	uint64_t opos;
+} job_env;
+
 struct xzamd_ctx {
 	int device;
 	void *own_stream;
@@ -406,6 +434,13 @@ struct xzamd_ctx {
 	uint32_t trace_cap;
 	int trace_on;
 	int last_par;                /* pipeline parity of the last batch (debug fetches) */
+	/* A call made with `defer` returns once the back end of its last batch has been LAUNCHED (second stream); the batch is
+	 * carried into the next call, which finishes it underneath the front end of its own first batch, or into
+	 * xzamd_encode_finish_.  pend = that batch and the constants of its call. */
+	struct { int active; job_env J; batch_run B; } pend;
+	int pend_has_result, pend_rc;
+	uint64_t pend_out_size;
+	uint64_t par_seq;            /* parity of the double-buffered tables: continues across calls while a batch is carried */
 	/* progress of the running xzamd_stream_encode_device call, read by other threads (xzamd_ctx_progress_in_) */
 	pthread_mutex_t prog_mu;
 	int prog_mu_ok;
@@ -424,10 +459,17 @@ static int fail(xzamd_ctx *c, int code, const char *what, int hip_err)
 	return code;
 }
 
+static int pend_complete(xzamd_ctx *c);
+
 static int dgrow(xzamd_ctx *c, dbuf *b, uint64_t bytes, int host)
 {
 	if (b->cap >= bytes)
 		return 0;
+	if (c->pend.active) {
+		/* a buffer is about to be replaced while the carried batch of the previous call may still be using it */
+		int r = pend_complete(c);
+		if (r) return r;
+	}
 	if (b->p) {
 		if (host) xzk_host_free(b->p); else xzk_free(b->p);
 		b->p = NULL;
@@ -770,32 +812,6 @@ static int launch_chains(xzamd_ctx *c, const xzamd_lzma_options *opt, const uint
 
 #define HIPCHK(call, what) do { int e_ = (call); if (e_) return fail(c, XZAMD_DEVICE_ERROR, what, e_); } while (0)
 
-/* What the front end of a batch (match structures, plan, parse -- the caller's stream) hands to its back end (range
- * coder of the two-phase mode, Block checks, sizes, layout, gather -- the second stream when the two are pipelined). */
-typedef struct {
-	int active;
-	uint64_t b0, nb, in_off, n64;
-	uint32_t n, nspans, nout, opb;
-	int par;                     /* which set of the double-buffered tables / events this batch uses */
-	const uint8_t *enc_in;       /* what LZMA2 reads (the filtered copy when a filter runs in front of it) */
-	int find_timed, seeds_early;
-	uint64_t max_segs, max_lits;
-} batch_run;
-
-/* constants of one xzamd_stream_encode_device call */
-typedef struct {
-	const xzamd_lzma_options *opt;
-	const uint8_t *d_in;
-	uint8_t *d_out;
-	uint64_t block_size, out_cap, bound, binfo_cap;
-	uint32_t spb, esb, cbytes, hs_fixed;
-	int check, two, adaptive, whole;
-	uint8_t dbyte;
-	void *st, *stb;
-	uint64_t *rec_unp, *rec_unc;
-	xzamd_block_info *binfo;
-	uint64_t opos;
-} job_env;
 
 /* Second half of a batch's back end: wait for the sizes, lay the Blocks out (the ordered output queue of the
  * reference, outqueue.c) and gather them into the Stream. */
@@ -977,8 +993,47 @@ static int back_finish(xzamd_ctx *c, job_env *J, batch_run *B)
 	}
 	c->stats.batches += 1;
 	c->stats.encode_launches += 1;
-	progress_set(c, c->prog_done + n64, 0, 0);       /* (prog_done is written by this thread only) */
 	return XZAMD_OK;
+}
+
+/* back_finish of a batch of the call that is running: its bytes count as done (prog_done is written by this thread only) */
+static int back_finish_own(xzamd_ctx *c, job_env *J, batch_run *B)
+{
+	const uint64_t n64 = B->n64;
+	int rc = back_finish(c, J, B);
+	if (rc == XZAMD_OK) progress_set(c, c->prog_done + n64, 0, 0);
+	return rc;
+}
+
+/* Finish the batch carried over from a deferred call and keep that call's result for xzamd_encode_finish_. */
+static int pend_complete(xzamd_ctx *c)
+{
+	if (!c->pend.active)
+		return XZAMD_OK;
+	c->pend.active = 0;
+	int rc = back_finish(c, &c->pend.J, &c->pend.B);
+	if (rc != XZAMD_OK) xzk_sync(c->st2);
+	c->pend_rc = rc;
+	c->pend_out_size = c->pend.J.opos;
+	c->pend_has_result = 1;
+	return rc;
+}
+
+int xzamd_encode_finish_(xzamd_ctx *c, uint64_t *out_size)
+{
+	if (!c || !out_size)
+		return XZAMD_PROG_ERROR;
+	/* the oldest deferred call first: its result is already there when a later call has finished it underneath itself
+	 * (and may have left a deferred batch of its own) */
+	if (!c->pend_has_result && c->pend.active) {
+		xzk_set_device(c->device);
+		pend_complete(c);
+	}
+	if (!c->pend_has_result)
+		return fail(c, XZAMD_PROG_ERROR, "no deferred call to finish", 0);
+	c->pend_has_result = 0;
+	*out_size = c->pend_out_size;
+	return c->pend_rc;
 }
 
 int xzamd_stream_encode_device(xzamd_ctx *c,
@@ -988,8 +1043,28 @@ int xzamd_stream_encode_device(xzamd_ctx *c,
 		xzamd_block_info *binfo, uint64_t binfo_cap, uint64_t *nblocks_out,
 		void *stream)
 {
+	return xzamd_encode_device_(c, d_in_, in_size, block_size, opt, check, flags, d_out_, out_cap, out_size, binfo, binfo_cap,
+			nblocks_out, stream, NULL);
+}
+
+/* xzamd_stream_encode_device, and -- with deferred != NULL, XZAMD_F_BLOCKS_ONLY and the two-phase encode -- its pipelined
+ * form for callers that run one call after another on the same context (the workers of the lzma_* front end): the call
+ * returns when the back end of its LAST batch has been launched (*deferred = 1; *out_size is not set), and that batch is
+ * finished by the next call underneath the front end of its own first batch -- the overlap the batches of ONE call have
+ * always had -- or by xzamd_encode_finish_, which also hands out the call's out_size and result.  The
+ * input, output and binfo buffers of a deferred call stay in use until then. */
+int xzamd_encode_device_(xzamd_ctx *c,
+		const void *d_in_, uint64_t in_size, uint64_t block_size,
+		const xzamd_lzma_options *opt, int check, uint32_t flags,
+		void *d_out_, uint64_t out_cap, uint64_t *out_size,
+		xzamd_block_info *binfo, uint64_t binfo_cap, uint64_t *nblocks_out,
+		void *stream, int *deferred)
+{
+	if (deferred) *deferred = 0;
 	if (!c || !opt || !out_size || (!d_in_ && in_size) || !d_out_)
 		return XZAMD_PROG_ERROR;
+	if (c->pend_has_result)
+		return fail(c, XZAMD_PROG_ERROR, "result of the previous deferred call not collected", 0);
 	c->err[0] = 0;
 	const uint32_t cbytes = check_bytes(check);
 	if ((unsigned)check > 15)
@@ -1081,7 +1156,15 @@ int xzamd_stream_encode_device(xzamd_ctx *c,
 	 * second stream while the front end of batch i + 1 -- match structures, plan, parse -- runs on the caller's: the coder
 	 * is a few thousand latency-bound wavefronts, the structure build is HBM-bound, they share the GPU well.  The
 	 * single-phase kernels read the match structures while they code, so their batches stay serial. */
-	const int pipelined = two && total_blocks > max_blocks && getenv("XZAMD_NO_OVERLAP") == NULL;
+	const int overlap_ok = two && getenv("XZAMD_NO_OVERLAP") == NULL;
+	const int defer = deferred != NULL && overlap_ok && (flags & XZAMD_F_BLOCKS_ONLY) && total_blocks > 0;
+	/* a batch carried over from the previous call: it can only be finished underneath this call's front end when this call
+	 * runs the same two-stream scheme on the same streams; else it is finished first */
+	if (c->pend.active && !(overlap_ok && c->pend.J.st == st)) {
+		int r = pend_complete(c);
+		if (r != XZAMD_OK) return r;
+	}
+	const int pipelined = overlap_ok && (total_blocks > max_blocks || defer || c->pend.active);
 
 	job_env J;
 	memset(&J, 0, sizeof(J));
@@ -1129,7 +1212,7 @@ int xzamd_stream_encode_device(xzamd_ctx *c,
 		const uint32_t nout = two ? nenc : nspans;            /* slots that write coded bytes */
 		const uint32_t opb = two ? esb : spb;
 		const uint32_t spb_crc = (uint32_t)((block_size + CRC_STRIP - 1) / CRC_STRIP);
-		const int par = pipelined ? (int)(batch_index & 1) : 0;
+		const int par = pipelined ? (int)(c->par_seq++ & 1) : 0;
 		void **ev = c->evp[par];
 
 		/* Out of device memory: retry this batch with half the Blocks (retry_smaller releases every per-batch
@@ -1367,8 +1450,11 @@ int xzamd_stream_encode_device(xzamd_ctx *c,
 
 		/* ================= back end ================= */
 		/* the previous batch's sizes, layout and gather: its coder has had the whole front end above to finish */
-		if (pipelined && prev.active) {
-			rc = back_finish(c, &J, &prev);
+		if (pipelined && c->pend.active) {
+			rc = pend_complete(c);              /* the last batch of the previous (deferred) call */
+			if (rc != XZAMD_OK) goto done;
+		} else if (pipelined && prev.active) {
+			rc = back_finish_own(c, &J, &prev);
 			if (rc != XZAMD_OK) goto done;
 		}
 		{
@@ -1408,7 +1494,7 @@ int xzamd_stream_encode_device(xzamd_ctx *c,
 		if (pipelined) {
 			prev = cur;
 		} else {
-			rc = back_finish(c, &J, &cur);
+			rc = back_finish_own(c, &J, &cur);
 			if (rc != XZAMD_OK) goto done;
 		}
 		b0 += nb;
@@ -1419,8 +1505,12 @@ retry_smaller:
 		/* The buffers grown so far have full-batch capacity: a retry that kept them would fight for what is left.
 		 * Nothing of this batch has been launched; an earlier batch may still be in its back end: finish it, then
 		 * release every per-batch device buffer and let the smaller geometry allocate afresh. */
+		if (c->pend.active) {
+			rc = pend_complete(c);
+			if (rc != XZAMD_OK) goto done;
+		}
 		if (prev.active) {
-			rc = back_finish(c, &J, &prev);
+			rc = back_finish_own(c, &J, &prev);
 			if (rc != XZAMD_OK) goto done;
 		}
 		xzk_sync(st);
@@ -1433,12 +1523,27 @@ retry_smaller:
 				if (d[i]->p) { xzk_free(d[i]->p); d[i]->p = NULL; d[i]->cap = 0; }
 		}
 	}
-	if (rc == XZAMD_OK && prev.active)
-		rc = back_finish(c, &J, &prev);
+	if (rc == XZAMD_OK && c->pend.active)
+		rc = pend_complete(c);       /* (a call without a batch of its own) */
+	if (rc == XZAMD_OK && prev.active) {
+		if (defer) {
+			/* the back end of the last batch is in flight on the second stream: whoever comes next finishes it */
+			c->pend.J = J;
+			c->pend.B = prev;
+			c->pend.active = 1;
+			prev.active = 0;
+			*deferred = 1;
+		} else {
+			rc = back_finish_own(c, &J, &prev);
+		}
+	}
 done:
+	if (rc != XZAMD_OK && c->pend.active)
+		pend_complete(c);            /* this call failed before it got there: the carried batch still gets finished */
 	xzk_sync(st);
 	xzk_sync(c->st3);
-	xzk_sync(c->st2);          /* a back end abandoned by an error path */
+	if (!(deferred && *deferred))
+		xzk_sync(c->st2);          /* a back end abandoned by an error path */
 	if (rc == XZAMD_OK && J.whole) {
 		const uint64_t isz_cap = 32 + total_blocks * 18 + 16;
 		uint8_t *ib = (uint8_t *)malloc(isz_cap);
@@ -1464,6 +1569,6 @@ done:
 	free(J.rec_unp);
 	c->stats.in_bytes = in_size;
 	c->stats.out_bytes = J.opos;
-	*out_size = J.opos;
+	*out_size = (deferred && *deferred) ? 0 : J.opos;
 	return rc;
 }

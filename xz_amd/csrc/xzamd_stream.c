@@ -41,7 +41,7 @@
 #define LZMA_THREADS_MAX 16384
 #define XZAMD_MAGIC 0x585A414D44474655ull
 #define MAX_DEVS 16
-#define MAX_JOBS (MAX_DEVS + 1)
+#define MAX_JOBS (2 * MAX_DEVS + 1)
 
 #include <errno.h>
 #include <time.h>
@@ -75,15 +75,22 @@ typedef struct {
 	lzma_ret err;
 } job;
 
-/* One GPU: context + device buffers, driven by one worker thread. */
+/* Device-side input and output of one job. */
+typedef struct { void *d_in, *d_out; uint64_t d_in_cap, d_out_cap; } devbufs;
+
+/* One GPU: context + device buffers, driven by one worker thread.  Two sets of job buffers: while the back end of one
+ * job (range coder, checks, gather) is still running on the context's second stream, the worker uploads and launches the
+ * next one (xzamd_encode_device_ with `deferred`). */
 typedef struct {
 	int device;
 	xzamd_ctx *ctx;
-	void *d_in; uint64_t d_in_cap;
-	void *d_out; uint64_t d_out_cap;
+	devbufs io[2];
+	int flip;                    /* which of io[] the next job takes */
 	pthread_t thr;
 	int started;
 	const job *running;          /* the job this worker is on (written and read under owner->mu) */
+	job *pending;                /* the job before it, launched with its back end still in flight (same lock) */
+	int pending_io;
 	struct lzma_internal_s *owner;
 } devslot;
 
@@ -149,7 +156,7 @@ static lzma_ret map_rc(int rc)
  * XZAMD_NO_PARK=1 disables parking. */
 static struct {
 	pthread_mutex_t mu;
-	struct { int full; xzamd_ctx *ctx; void *d_in, *d_out; uint64_t d_in_cap, d_out_cap; } dev[MAX_DEVS];
+	struct { int full; xzamd_ctx *ctx; devbufs io[2]; } dev[MAX_DEVS];
 	struct { uint8_t *p; uint64_t cap; } pinned[2 * MAX_JOBS];
 } g_park = { .mu = PTHREAD_MUTEX_INITIALIZER };
 
@@ -195,8 +202,10 @@ void xzamd_release_parked(void)
 	for (int i = 0; i < MAX_DEVS; ++i)
 		if (g_park.dev[i].full) {
 			xzk_set_device(xzamd_ctx_device(g_park.dev[i].ctx));
-			if (g_park.dev[i].d_in) xzk_free(g_park.dev[i].d_in);
-			if (g_park.dev[i].d_out) xzk_free(g_park.dev[i].d_out);
+			for (int k = 0; k < 2; ++k) {
+				if (g_park.dev[i].io[k].d_in) xzk_free(g_park.dev[i].io[k].d_in);
+				if (g_park.dev[i].io[k].d_out) xzk_free(g_park.dev[i].io[k].d_out);
+			}
 			xzamd_ctx_destroy(g_park.dev[i].ctx);
 			memset(&g_park.dev[i], 0, sizeof(g_park.dev[i]));
 		}
@@ -216,19 +225,20 @@ static void park_dev(devslot *d)
 		for (int i = 0; i < MAX_DEVS; ++i)
 			if (!g_park.dev[i].full) {
 				g_park.dev[i].full = 1; g_park.dev[i].ctx = d->ctx;
-				g_park.dev[i].d_in = d->d_in; g_park.dev[i].d_in_cap = d->d_in_cap;
-				g_park.dev[i].d_out = d->d_out; g_park.dev[i].d_out_cap = d->d_out_cap;
+				memcpy(g_park.dev[i].io, d->io, sizeof(d->io));
 				pthread_mutex_unlock(&g_park.mu);
-				d->ctx = NULL; d->d_in = d->d_out = NULL;
+				d->ctx = NULL; memset(d->io, 0, sizeof(d->io));
 				return;
 			}
 		pthread_mutex_unlock(&g_park.mu);
 	}
 	xzk_set_device(d->device);
-	if (d->d_in) xzk_free(d->d_in);
-	if (d->d_out) xzk_free(d->d_out);
+	for (int k = 0; k < 2; ++k) {
+		if (d->io[k].d_in) xzk_free(d->io[k].d_in);
+		if (d->io[k].d_out) xzk_free(d->io[k].d_out);
+	}
 	xzamd_ctx_destroy(d->ctx);
-	d->ctx = NULL; d->d_in = d->d_out = NULL;
+	d->ctx = NULL; memset(d->io, 0, sizeof(d->io));
 }
 
 static int unpark_dev(devslot *d, int device)
@@ -238,8 +248,7 @@ static int unpark_dev(devslot *d, int device)
 	for (int i = 0; i < MAX_DEVS; ++i)
 		if (g_park.dev[i].full && xzamd_ctx_device(g_park.dev[i].ctx) == device) {
 			d->ctx = g_park.dev[i].ctx;
-			d->d_in = g_park.dev[i].d_in; d->d_in_cap = g_park.dev[i].d_in_cap;
-			d->d_out = g_park.dev[i].d_out; d->d_out_cap = g_park.dev[i].d_out_cap;
+			memcpy(d->io, g_park.dev[i].io, sizeof(d->io));
 			memset(&g_park.dev[i], 0, sizeof(g_park.dev[i]));
 			got = 1;
 			break;
@@ -270,25 +279,34 @@ static lzma_ret grow_pinned(uint8_t **buf, uint64_t *cap, uint64_t keep, uint64_
 	return LZMA_OK;
 }
 
-/* worker_encode() x nblocks (stream_encoder_mt.c:219-361) for one job on one GPU. */
-static lzma_ret run_job(lzma_internal *in, devslot *d, job *j)
+static void vlog(const char *what, const job *j);
+
+/* worker_encode() x nblocks (stream_encoder_mt.c:219-361) for one job on one GPU, in two steps.  job_launch: buffers, upload,
+ * device encode -- which may come back DEFERRED: everything of the job is launched, the back end of its last batch still runs
+ * (the next job_launch on this context finishes it underneath its own front end).  job_collect: the result of
+ * the device encode (the deferred one is fetched with xzamd_encode_finish_), the stored-Block way out, the download. */
+static lzma_ret job_launch(lzma_internal *in, devslot *d, job *j, int io, int *rc_out, uint64_t *out_size, int *deferred)
 {
 	const uint64_t n = j->stage_len;
 	const uint64_t nb = (n + in->block_size - 1) / in->block_size;
 	const uint64_t bound = xzamd_stream_buffer_bound(n, in->block_size);
+	devbufs *b = &d->io[io];
+	*deferred = 0;
+	*out_size = 0;
+	*rc_out = XZAMD_DEVICE_ERROR;
 	if (xzk_set_device(d->device))
 		return LZMA_PROG_ERROR;
-	if (d->d_in_cap < n) {
-		if (d->d_in) xzk_free(d->d_in);
-		d->d_in = NULL; d->d_in_cap = 0;
-		if (xzk_malloc(&d->d_in, n)) return LZMA_MEM_ERROR;
-		d->d_in_cap = n;
+	if (b->d_in_cap < n) {
+		if (b->d_in) xzk_free(b->d_in);
+		b->d_in = NULL; b->d_in_cap = 0;
+		if (xzk_malloc(&b->d_in, n)) return LZMA_MEM_ERROR;
+		b->d_in_cap = n;
 	}
-	if (d->d_out_cap < bound) {
-		if (d->d_out) xzk_free(d->d_out);
-		d->d_out = NULL; d->d_out_cap = 0;
-		if (xzk_malloc(&d->d_out, bound)) return LZMA_MEM_ERROR;
-		d->d_out_cap = bound;
+	if (b->d_out_cap < bound) {
+		if (b->d_out) xzk_free(b->d_out);
+		b->d_out = NULL; b->d_out_cap = 0;
+		if (xzk_malloc(&b->d_out, bound)) return LZMA_MEM_ERROR;
+		b->d_out_cap = bound;
 	}
 	if (j->binfo_cap < nb) {
 		free(j->binfo);
@@ -298,20 +316,30 @@ static lzma_ret run_job(lzma_internal *in, devslot *d, job *j)
 	}
 	lzma_ret r = grow_pinned(&j->out, &j->out_cap, 0, bound);
 	if (r != LZMA_OK) return r;
-	uint64_t out_size = 0, nblocks = 0;
-	int rc = XZAMD_DEVICE_ERROR;
-	{
-		/* XZAMD_TEST_FAIL_JOB=k (tests): the k-th job behaves as if the device had failed */
-		const char *tf = getenv("XZAMD_TEST_FAIL_JOB");
-		const int injected = tf && *tf && (uint64_t)atoll(tf) == j->seq;
-		if (!injected && !(xzk_h2d(d->d_in, j->stage, n, NULL) || xzk_sync(NULL))) {
-			rc = xzamd_stream_encode_device(d->ctx, d->d_in, n, in->block_size, &j->opt, in->check,
-					XZAMD_F_BLOCKS_ONLY, d->d_out, d->d_out_cap, &out_size, j->binfo, j->binfo_cap,
-					&nblocks, NULL);
-			if (rc == XZAMD_OK && (xzk_d2h(j->out, d->d_out, out_size, NULL) || xzk_sync(NULL)))
-				rc = XZAMD_DEVICE_ERROR;
-		}
-	}
+	/* XZAMD_TEST_FAIL_JOB=k (tests): the k-th job behaves as if the device had failed */
+	const char *tf = getenv("XZAMD_TEST_FAIL_JOB");
+	const int injected = tf && *tf && (uint64_t)atoll(tf) == j->seq;
+	/* XZAMD_NO_DEFER=1 (measurement knob): every job is finished before the next one is launched */
+	const char *nd = getenv("XZAMD_NO_DEFER");
+	/* Copies go through the context's own (front-end) stream: it is idle between two jobs, and unlike the null stream it
+	 * is known not to share a hardware queue with the second stream, where the back end of the job before may be running
+	 * (measured: a null-stream copy waited ~250 ms for those kernels) */
+	void *cs = xzamd_ctx_stream_(d->ctx);
+	if (!injected && !(xzk_h2d(b->d_in, j->stage, n, cs) || xzk_sync(cs)) && (vlog("uploaded", j), 1))
+		*rc_out = xzamd_encode_device_(d->ctx, b->d_in, n, in->block_size, &j->opt, in->check,
+				XZAMD_F_BLOCKS_ONLY, b->d_out, b->d_out_cap, out_size, j->binfo, j->binfo_cap,
+				&j->nblocks, NULL, (nd && *nd == '1') ? NULL : deferred);
+	return LZMA_OK;
+}
+
+static lzma_ret job_collect(lzma_internal *in, devslot *d, job *j, int io, int rc, uint64_t out_size)
+{
+	const uint64_t n = j->stage_len;
+	if (rc == XZAMD_OK && out_size > j->out_cap)
+		rc = XZAMD_PROG_ERROR;
+	void *cs = xzamd_ctx_stream_(d->ctx);
+	if (rc == XZAMD_OK && (xzk_d2h(j->out, d->io[io].d_out, out_size, cs) || xzk_sync(cs)))
+		rc = XZAMD_DEVICE_ERROR;
 	if (rc == XZAMD_DEVICE_ERROR) {
 		/* A device (HIP runtime / kernel launch) failure in the middle of a Stream.  Default: the Stream fails
 		 * (LZMA_PROG_ERROR, latched).  With XZAMD_STORED_ON_DEVICE_ERROR=1 the job's Blocks are stored instead (the
@@ -319,21 +347,70 @@ static lzma_ret run_job(lzma_internal *in, devslot *d, job *j)
 		 * written so far stays a valid .xz Stream -- no encoding happens on the host.  The encoder's own consistency
 		 * failures (XZAMD_PROG_ERROR) are never papered over this way. */
 		const char *sf = getenv("XZAMD_STORED_ON_DEVICE_ERROR");
+		uint64_t nblocks = 0;
 		if (sf && *sf == '1'
 				&& xzamd_stored_blocks_host_(j->stage, n, in->block_size, in->check, j->out, j->out_cap, &out_size,
 						j->binfo, j->binfo_cap, &nblocks) == XZAMD_OK) {
 			if (getenv("XZAMD_VERBOSE"))
 				fprintf(stderr, "xz_amd: job of %llu bytes stored after a device error: %s\n", (unsigned long long)n,
 						xzamd_last_error(d->ctx));
+			j->nblocks = nblocks;
 			rc = XZAMD_OK;
 		}
 	}
-	if (rc != XZAMD_OK)
+	if (rc != XZAMD_OK) {
+		if (getenv("XZAMD_VERBOSE"))
+			fprintf(stderr, "xz_amd: job %llu failed (%d): %s\n", (unsigned long long)j->seq, rc, xzamd_last_error(d->ctx));
 		return map_rc(rc);
+	}
 	j->out_len = out_size;
 	j->out_pos = 0;
-	j->nblocks = nblocks;
 	return LZMA_OK;
+}
+
+/* XZAMD_VERBOSE=2: a line per step of a worker, with the time since the first one (how the jobs overlap) */
+static void vlog(const char *what, const job *j)
+{
+	static struct timespec t0;
+	static int on = -1;
+	if (on < 0) {
+		const char *e = getenv("XZAMD_VERBOSE");
+		on = e && atoi(e) >= 2;
+		clock_gettime(CLOCK_MONOTONIC, &t0);
+	}
+	if (!on) return;
+	struct timespec t;
+	clock_gettime(CLOCK_MONOTONIC, &t);
+	fprintf(stderr, "xz_amd: %8.1f ms  job %llu (%llu MiB) %s\n",
+			(double)(t.tv_sec - t0.tv_sec) * 1e3 + (double)(t.tv_nsec - t0.tv_nsec) * 1e-6,
+			(unsigned long long)j->seq, (unsigned long long)(j->stage_len >> 20), what);
+}
+
+/* the job is finished: hand it to the draining thread (in->mu held) */
+static void job_done_locked(lzma_internal *in, job *j, lzma_ret r)
+{
+	j->err = r;
+	j->state = J_DONE;
+	__atomic_add_fetch(&in->ndone, 1, __ATOMIC_RELEASE);
+	in->progress_in += j->stage_len;
+	pthread_cond_broadcast(&in->cv_done);
+}
+
+/* The deferred job of this worker: fetch its result (its device work ends here at the latest), download, report. */
+static void finish_pending(lzma_internal *in, devslot *d)
+{
+	job *p = d->pending;
+	uint64_t out_size = 0;
+	xzk_set_device(d->device);
+	vlog("finish: wait", p);
+	const int rc = xzamd_encode_finish_(d->ctx, &out_size);
+	vlog("finish: download", p);
+	const lzma_ret r = job_collect(in, d, p, d->pending_io, rc, out_size);
+	vlog("finish: done", p);
+	pthread_mutex_lock(&in->mu);
+	d->pending = NULL;
+	job_done_locked(in, p, r);
+	pthread_mutex_unlock(&in->mu);
 }
 
 /* Worker thread: takes the oldest queued job (jobs are dealt strictly in order, stream_encode_in
@@ -349,6 +426,13 @@ static void *worker_main(void *arg)
 			if (in->jobs[i].state == J_QUEUED && (pick < 0 || in->jobs[i].seq < in->jobs[pick].seq))
 				pick = i;
 		if (pick < 0) {
+			if (d->pending) {
+				/* nothing to launch on top of the deferred job: finish it now */
+				pthread_mutex_unlock(&in->mu);
+				finish_pending(in, d);
+				pthread_mutex_lock(&in->mu);
+				continue;
+			}
 			if (in->shutdown)
 				break;
 			pthread_cond_wait(&in->cv_work, &in->mu);
@@ -357,16 +441,28 @@ static void *worker_main(void *arg)
 		job *j = &in->jobs[pick];
 		j->state = J_RUNNING;
 		d->running = j;
+		const int io = d->flip;
+		d->flip ^= 1;
 		pthread_mutex_unlock(&in->mu);
-		const lzma_ret r = run_job(in, d, j);
+		int rc = XZAMD_DEVICE_ERROR, deferred = 0;
+		uint64_t out_size = 0;
+		vlog("launch", j);
+		lzma_ret r = job_launch(in, d, j, io, &rc, &out_size, &deferred);
+		vlog(deferred ? "launched, back end in flight" : "encoded", j);
+		/* whatever was deferred before has been finished underneath (or in front of) this launch */
+		if (d->pending)
+			finish_pending(in, d);
+		if (r == LZMA_OK && !deferred)
+			r = job_collect(in, d, j, io, rc, out_size);
 		pthread_mutex_lock(&in->mu);
 		d->running = NULL;
-		xzamd_ctx_progress_reset_(d->ctx);      /* the job counts as a whole from here on (progress_in below) */
-		j->err = r;
-		j->state = J_DONE;
-		__atomic_add_fetch(&in->ndone, 1, __ATOMIC_RELEASE);
-		in->progress_in += j->stage_len;
-		pthread_cond_broadcast(&in->cv_done);
+		xzamd_ctx_progress_reset_(d->ctx);      /* the job counts as a whole from here on (progress_in, or `pending`) */
+		if (r == LZMA_OK && deferred) {
+			d->pending = j;
+			d->pending_io = io;
+		} else {
+			job_done_locked(in, j, r);
+		}
 	}
 	pthread_mutex_unlock(&in->mu);
 	return NULL;
@@ -569,7 +665,7 @@ lzma_ret lzma_stream_encoder_mt(lzma_stream *strm, const lzma_mt *options)
 		in->ndev = i + 1;
 	}
 	xzk_set_device(cur);
-	in->njobs = in->ndev + 1;        /* one job is filled while every GPU works on one */
+	in->njobs = 2 * in->ndev + 1;    /* one job is filled while every GPU works on one and still has the back end of the one before in flight */
 	/* One job = one device batch of whole Blocks: 1 GiB, i.e. at least two full rounds of parse pieces at preset 6 on an
 	 * MI355X (4096 resident wavefronts x 128 KiB), whatever the number of workers -- a job that cannot fill its GPU
 	 * wastes it.  While the end of the input is unknown (LZMA_RUN) full jobs are dealt in order; once the caller has shown
@@ -1032,6 +1128,8 @@ void lzma_get_progress(lzma_stream *strm, uint64_t *progress_in, uint64_t *progr
 		uint64_t pin = in->progress_in;
 		for (int i = 0; i < in->ndev; ++i) {
 			const job *j = in->dev[i].running;
+			if (in->dev[i].pending != NULL)
+				pin += in->dev[i].pending->stage_len;     /* everything but the tail of its back end is done */
 			if (j != NULL) {
 				const uint64_t part = xzamd_ctx_progress_in_(in->dev[i].ctx);
 				pin += part < j->stage_len ? part : j->stage_len;
