@@ -42,6 +42,7 @@
 #define XZAMD_MAGIC 0x585A414D44474655ull
 #define MAX_DEVS 16
 #define MAX_JOBS (2 * MAX_DEVS + 1)
+#define JOB_BYTES (1280ull << 20)     /* a full job (see lzma_stream_encoder_mt) */
 
 #include <errno.h>
 #include <time.h>
@@ -666,12 +667,13 @@ lzma_ret lzma_stream_encoder_mt(lzma_stream *strm, const lzma_mt *options)
 	}
 	xzk_set_device(cur);
 	in->njobs = 2 * in->ndev + 1;    /* one job is filled while every GPU works on one and still has the back end of the one before in flight */
-	/* One job = one device batch of whole Blocks: 1 GiB, i.e. at least two full rounds of parse pieces at preset 6 on an
+	/* One job = one device batch of whole Blocks: 1.25 GiB, i.e. at least two full rounds of parse pieces at preset 6 on an
 	 * MI355X (4096 resident wavefronts x 128 KiB), whatever the number of workers -- a job that cannot fill its GPU
-	 * wastes it.  While the end of the input is unknown (LZMA_RUN) full jobs are dealt in order; once the caller has shown
+	 * wastes it, and every job costs ~100 ms of its own (4 GiB at 24 MiB Blocks: 4 jobs of 43 Blocks, 650 MB/s host to
+	 * host; the 5 jobs of 34 that a 1 GiB job size deals: 602 MB/s; 3 jobs of 57: 653 MB/s).  While the end of the input is unknown (LZMA_RUN) full jobs are dealt in order; once the caller has shown
 	 * the end (FINISH / FULL_FLUSH / FULL_BARRIER) the rest is dealt evenly over the workers (stream_code, below), as
 	 * stream_encoder_mt.c:599-665 deals Blocks to threads. */
-	uint64_t batch = 1ull << 30;
+	uint64_t batch = JOB_BYTES;
 	const char *env = getenv("XZAMD_BATCH_MIB");
 	if (env && atoll(env) > 0)
 		batch = (uint64_t)atoll(env) << 20;
@@ -716,7 +718,7 @@ uint64_t lzma_stream_encoder_mt_memusage(const lzma_mt *options)
 	int check = 0;
 	if (parse_options(options, &opt, &bs, &check) != LZMA_OK)
 		return UINT64_MAX;
-	uint64_t maxb = (1ull << 30) / bs;
+	uint64_t maxb = JOB_BYTES / bs;
 	if (maxb == 0) maxb = 1;
 	const uint64_t stage = maxb * bs;
 	/* host: staging + output queue; device: input + output, 32 B/byte of sort buffers and chain tables
