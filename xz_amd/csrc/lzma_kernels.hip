@@ -1172,8 +1172,25 @@ __device__ __forceinline__ void lists_load(const Env& e, uint32_t x, uint32_t& s
     }
 }
 
-__device__ __forceinline__ void round_lists(const Env& e, ListPre& LP, uint32_t x, uint32_t end,
-        uint32_t r0, uint32_t r1, uint32_t r2, uint32_t r3, RoundL& R)
+// The five byte rows of a round (lane = byte offset): the text at x and the four rep sources.  They can be issued as
+// soon as the node's rep distances are final -- for node j + 1 that is right after the literal / short-rep edge out of
+// node j, every other edge out of j is longer -- and are only waited for when the round is worked out.
+struct Rows { uint32_t cx, c0, c1, c2, c3; };
+
+__device__ __forceinline__ void rows_issue(const Env& e, uint32_t x, uint32_t end,
+        uint32_t r0, uint32_t r1, uint32_t r2, uint32_t r3, Rows& W)
+{
+    const uint32_t lane = threadIdx.x;
+    const uint32_t avail = end - x;
+    const uint32_t buf_avail = avail < MATCH_LEN_MAX ? avail : MATCH_LEN_MAX;
+    const uint32_t off = lane < buf_avail ? lane : 0u;      // lanes past the end re-read byte 0 (masked by the round)
+    W.cx = e.in[x + off];
+    W.c0 = e.in[x - r0 - 1 + off]; W.c1 = e.in[x - r1 - 1 + off];
+    W.c2 = e.in[x - r2 - 1 + off]; W.c3 = e.in[x - r3 - 1 + off];
+}
+
+__device__ __forceinline__ void round_lists_rows(const Env& e, ListPre& LP, uint32_t x, uint32_t end,
+        uint32_t r0, uint32_t r1, uint32_t r2, uint32_t r3, const Rows& W, RoundL& R)
 {
     const uint32_t lane = threadIdx.x;
     if (!(LP.valid && LP.pos == x)) lists_load(e, x, LP.sl, LP.sd, LP.tr);
@@ -1188,10 +1205,7 @@ __device__ __forceinline__ void round_lists(const Env& e, ListPre& LP, uint32_t 
     // length, "usable" length, the compound precheck -- is then worked out by lane i for rep i with vector
     // instructions (the scalar unit is what bounds this kernel), and only the results go back to scalars.
     {
-        const uint32_t off = lane < buf_avail ? lane : 0u;      // lanes past the end re-read byte 0 (masked below)
-        const uint32_t cx = e.in[x + off];
-        const uint32_t c0 = e.in[x - r0 - 1 + off], c1 = e.in[x - r1 - 1 + off];
-        const uint32_t c2 = e.in[x - r2 - 1 + off], c3 = e.in[x - r3 - 1 + off];
+        const uint32_t cx = W.cx, c0 = W.c0, c1 = W.c1, c2 = W.c2, c3 = W.c3;
         const uint64_t dead = buf_avail < 64 ? ~0ull << buf_avail : 0ull;
         const uint64_t m0 = __builtin_amdgcn_ballot_w64(c0 != cx) | dead, m1 = __builtin_amdgcn_ballot_w64(c1 != cx) | dead;
         const uint64_t m2 = __builtin_amdgcn_ballot_w64(c2 != cx) | dead, m3 = __builtin_amdgcn_ballot_w64(c3 != cx) | dead;
@@ -1236,6 +1250,14 @@ __device__ __forceinline__ void round_lists(const Env& e, ListPre& LP, uint32_t 
     R.l2a = l2a;
     R.l2b = l2b;
     R.longest = longest;
+}
+
+__device__ __forceinline__ void round_lists(const Env& e, ListPre& LP, uint32_t x, uint32_t end,
+        uint32_t r0, uint32_t r1, uint32_t r2, uint32_t r3, RoundL& R)
+{
+    Rows W;
+    rows_issue(e, x, end, r0, r1, r2, r3, W);
+    round_lists_rows(e, LP, x, end, r0, r1, r2, r3, W, R);
 }
 
 // ---- prices (rangecoder/price.h:28-92) ------------------------------------------------------
@@ -1687,6 +1709,16 @@ __device__ __forceinline__ bool optimum_window(const Env& e, const Work& w, List
             }
             wave_sync();
         }
+        // Node j + 1 is final now (every other edge out of j is longer): its rows go out here and are in flight
+        // while the length and compound edges of node j are priced.
+        Rows NW;
+        uint32_t n_mb = 0;
+        const bool rows_early = j + 1 != n_end;
+        if (rows_early) {
+            const uint4 nr = w.n_reps4[j + 1];
+            n_mb = in[x - nr.x];                         // in[(x + 1) - rep0 - 1]
+            rows_issue(e, x + 1, span_end, nr.x, nr.y, nr.z, nr.w, NW);
+        }
         TM_END(w, 3, t_lit);
         TM_BEGIN(t_relax);
         const uint32_t prep0 = Pj + (v23 & 0xFFFFu), prep1 = Pj + (v23 >> 16), prep2 = Pj + (v45 & 0xFFFFu), prep3 = Pj + (v45 >> 16);
@@ -1784,9 +1816,9 @@ __device__ __forceinline__ bool optimum_window(const Env& e, const Work& w, List
             TM_END(w, 0, t_derive);
             TM_BEGIN(t_round);
             const uint32_t xn = pos + j;
-            b_mb = in[xn - r0 - 1];
+            b_mb = n_mb;                                   // rows and rep0 byte of this node: issued by its predecessor
             if ((j & 63) == 0) lit_chunk(in, w.ptab, z, xn, block_start, span_end, lc);
-            round_lists(e, P, xn, span_end, r0, r1, r2, r3, RL);
+            round_lists_rows(e, P, xn, span_end, r0, r1, r2, r3, NW, RL);
             longest = RL.longest;
             TM_END(w, 1, t_round);
             if (longest >= e.nice) { next_cached = true; break; }
