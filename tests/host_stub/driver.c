@@ -215,6 +215,46 @@ int main(int argc, char **argv)
 		unsetenv("XZAMD_STORED_ON_DEVICE_ERROR");
 		unsetenv("XZAMD_TEST_FAIL_JOB");
 	}
+	/* 8. consecutive jobs of the two-phase encode are pipelined by the worker (the call of a job returns with the back end
+	 * of its last batch in flight, the next job finishes it): same bytes as with XZAMD_NO_DEFER=1, three workers on top
+	 * of each other, and a device failure of a job in the middle -- while the job before it is still deferred -- either
+	 * fails the Stream or, with the knob, stores that job's Blocks only */
+	{
+		setenv("XZAMD_BATCH_MIB", "1", 1);
+		memset(&mt, 0, sizeof(mt));
+		mt.threads = 1; mt.preset = 6; mt.check = LZMA_CHECK_CRC64; mt.block_size = 256u << 10;
+		const size_t cap = n1 + (n1 >> 2) + (1u << 20);
+		uint8_t *alt = (uint8_t *)malloc(cap);
+		CHECK(alt != NULL);
+		w = stream_encode(&mt, in, n1, 300000, 65536, 0, LZMA_RUN, out, cap);
+		save(dir, "case8.in", in, n1);
+		save(dir, "case8.xz", out, w);
+		setenv("XZAMD_NO_DEFER", "1", 1);
+		size_t w2 = stream_encode(&mt, in, n1, 300000, 65536, 0, LZMA_RUN, alt, cap);      /* (same job split: the stub's bytes depend on it) */
+		unsetenv("XZAMD_NO_DEFER");
+		CHECK(w2 == w && memcmp(out, alt, w) == 0);
+		setenv("XZAMD_TEST_WORKERS", "3", 1);
+		mt.threads = 3; mt.timeout = 1;
+		w2 = stream_encode(&mt, in, n1, 300000, 4096, 0, LZMA_RUN, alt, cap);
+		unsetenv("XZAMD_TEST_WORKERS");
+		CHECK(w2 == w && memcmp(out, alt, w) == 0);
+		mt.threads = 1; mt.timeout = 0;
+		setenv("XZAMD_TEST_FAIL_JOB", "2", 1);
+		lzma_stream s = LZMA_STREAM_INIT;
+		CHECK(lzma_stream_encoder_mt(&s, &mt) == LZMA_OK);
+		s.next_in = in; s.avail_in = n1; s.next_out = alt; s.avail_out = cap;
+		lzma_ret r;
+		do r = lzma_code(&s, LZMA_FINISH); while (r == LZMA_OK);
+		CHECK(r == LZMA_PROG_ERROR);
+		lzma_end(&s);
+		setenv("XZAMD_STORED_ON_DEVICE_ERROR", "1", 1);
+		w2 = stream_encode(&mt, in, n1, 1u << 20, 1u << 20, 0, LZMA_RUN, alt, cap);
+		save(dir, "case9.in", in, n1);
+		save(dir, "case9.xz", alt, w2);
+		unsetenv("XZAMD_STORED_ON_DEVICE_ERROR");
+		unsetenv("XZAMD_TEST_FAIL_JOB");
+		free(alt);
+	}
 	xzamd_release_parked();
 	free(in);
 	free(out);
