@@ -556,6 +556,11 @@ void xzamd_ctx_destroy(xzamd_ctx *c)
 	if (!c)
 		return;
 	xzk_set_device(c->device);
+	if (c->pend.active) {
+		/* a deferred call nobody finished (its owner is tearing down): let the kernels end before their buffers go */
+		if (c->st2) xzk_sync(c->st2);
+		c->pend.active = 0;
+	}
 	dbuf *d[64];
 	size_t nd = 0;
 	ctx_device_bufs(c, d, &nd);
