@@ -370,20 +370,24 @@ static lzma_ret job_collect(lzma_internal *in, devslot *d, job *j, int io, int r
 }
 
 /* XZAMD_VERBOSE=2: a line per step of a worker, with the time since the first one (how the jobs overlap) */
+static struct timespec vlog_t0;
+static int vlog_on;
+static pthread_once_t vlog_once = PTHREAD_ONCE_INIT;
+static void vlog_init(void)
+{
+	const char *e = getenv("XZAMD_VERBOSE");
+	vlog_on = e && atoi(e) >= 2;
+	clock_gettime(CLOCK_MONOTONIC, &vlog_t0);
+}
+
 static void vlog(const char *what, const job *j)
 {
-	static struct timespec t0;
-	static int on = -1;
-	if (on < 0) {
-		const char *e = getenv("XZAMD_VERBOSE");
-		on = e && atoi(e) >= 2;
-		clock_gettime(CLOCK_MONOTONIC, &t0);
-	}
-	if (!on) return;
+	pthread_once(&vlog_once, vlog_init);
+	if (!vlog_on) return;
 	struct timespec t;
 	clock_gettime(CLOCK_MONOTONIC, &t);
 	fprintf(stderr, "xz_amd: %8.1f ms  job %llu (%llu MiB) %s\n",
-			(double)(t.tv_sec - t0.tv_sec) * 1e3 + (double)(t.tv_nsec - t0.tv_nsec) * 1e-6,
+			(double)(t.tv_sec - vlog_t0.tv_sec) * 1e3 + (double)(t.tv_nsec - vlog_t0.tv_nsec) * 1e-6,
 			(unsigned long long)j->seq, (unsigned long long)(j->stage_len >> 20), what);
 }
 
