@@ -100,3 +100,132 @@ def dpkg_tar(n):
     if len(data) < (1 << 20):
         return None
     return data[:n]
+
+
+# ---- literal-heavy / numeric classes the round-4 review found outside the tolerance (numpy, seeded) -------------------
+def _np():
+    import numpy as np
+    return np
+
+
+def f32_sine(n, seed=101):
+    """float32 samples of sin(t * 7e-4) * 50 + N(0, 1e-3): slowly drifting mantissas, almost no matches."""
+    np = _np()
+    rng = np.random.default_rng(seed)
+    m = n // 4 + 1
+    t = np.arange(m, dtype=np.float64)
+    x = np.sin(t * 7e-4) * 50.0 + rng.normal(0.0, 1e-3, m)
+    return x.astype(np.float32).tobytes()[:n]
+
+
+def f32_two_sines(n, seed=102):
+    """float32 sin(t * 1e-3) * 100 + sin(t * 0.0137) * 3 + N(0, 0.01)."""
+    np = _np()
+    rng = np.random.default_rng(seed)
+    m = n // 4 + 1
+    t = np.arange(m, dtype=np.float64)
+    x = np.sin(t * 1e-3) * 100.0 + np.sin(t * 0.0137) * 3.0 + rng.normal(0.0, 0.01, m)
+    return x.astype(np.float32).tobytes()[:n]
+
+
+def f32_mesh(n, seed=103):
+    """float32 xyz vertices of a 512-wide grid, z = sin * cos, noise 1e-4."""
+    np = _np()
+    rng = np.random.default_rng(seed)
+    m = n // 12 + 1
+    i = np.arange(m, dtype=np.float64)
+    x, y = (i % 512) * 0.125, (i // 512) * 0.125
+    z = np.sin(x * 0.31) * np.cos(y * 0.17) * 4.0 + rng.normal(0.0, 1e-4, m)
+    v = np.stack([x, y, z], axis=1).astype(np.float32)
+    return v.tobytes()[:n]
+
+
+def fasta_repeats(n, seed=104):
+    """FASTA-like ACGT lines of 60 with repeated segments mutated at 1 %."""
+    np = _np()
+    rng = np.random.default_rng(seed)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    seq = np.empty(0, dtype=np.uint8)
+    parts, size = [], 0
+    pool = []
+    while size < n:
+        if pool and rng.random() < 0.35:
+            src = pool[int(rng.integers(len(pool)))]
+            a = int(rng.integers(0, max(1, len(src) - 2000)))
+            seg = src[a:a + int(rng.integers(500, 20000))].copy()
+            mut = rng.random(len(seg)) < 0.01
+            seg[mut] = acgt[rng.integers(0, 4, int(mut.sum()))]
+        else:
+            seg = acgt[rng.integers(0, 4, int(rng.integers(2000, 40000)))]
+            pool.append(seg)
+            if len(pool) > 64:
+                pool.pop(0)
+        parts.append(seg)
+        size += len(seg)
+    seq = np.concatenate(parts)[: n]
+    rows = len(seq) // 60
+    body = np.concatenate([seq[: rows * 60].reshape(rows, 60), np.full((rows, 1), 10, dtype=np.uint8)], axis=1).reshape(-1)
+    return (b">chr_synthetic\n" + body.tobytes())[:n]
+
+
+def sparse_text(n, seed=105):
+    """Zero pages with islands of lorem-like text."""
+    rnd = random.Random(seed)
+    words = ("lorem ipsum dolor sit amet consectetur adipiscing elit sed do eiusmod tempor incididunt ut labore et dolore "
+             "magna aliqua ut enim ad minim veniam quis nostrud exercitation ullamco laboris nisi aliquip ex ea commodo").split()
+    out, size = [], 0
+    while size < n:
+        z = bytes(rnd.randint(512, 16384))
+        txt = " ".join(rnd.choice(words) for _ in range(rnd.randint(20, 600))).encode()
+        out.append(z)
+        out.append(txt)
+        size += len(z) + len(txt)
+    return b"".join(out)[:n]
+
+
+def html_rows(n, seed=106):
+    """An HTML table: one <tr> per record with ids, names, prices, dates."""
+    rnd = random.Random(seed)
+    names = ["widget", "gadget", "sprocket", "flange", "gasket", "bearing", "bracket", "coupling", "valve", "manifold"]
+    out, size = ["<html><body><table class=\"inventory\">\n"], 0
+    while size < n:
+        line = (f"<tr class=\"{'odd' if rnd.random() < 0.5 else 'even'}\"><td>{rnd.randint(1, 10 ** 7)}</td>"
+                f"<td><a href=\"/item/{rnd.randint(1, 99999)}\">{rnd.choice(names)}-{rnd.randint(1, 999)}</a></td>"
+                f"<td class=\"num\">{rnd.uniform(0.5, 9999):.2f}</td><td>{rnd.randint(2001, 2024)}-{rnd.randint(1, 12):02d}-{rnd.randint(1, 28):02d}</td>"
+                f"<td>{rnd.choice(['in stock', 'backorder', 'discontinued'])}</td></tr>\n")
+        out.append(line)
+        size += len(line)
+    return "".join(out).encode()[:n]
+
+
+def csv_sensors(n, seed=107):
+    """CSV rows: timestamp, sensor id, three slowly varying readings, a status word."""
+    rnd = random.Random(seed)
+    out, size, t = ["ts,sensor,temp_c,rh_pct,press_hpa,status\n"], 0, 1700000000.0
+    temp, rh, pr = 21.0, 45.0, 1013.0
+    while size < n:
+        t += rnd.uniform(0.5, 1.5)
+        temp += rnd.gauss(0, 0.02); rh += rnd.gauss(0, 0.05); pr += rnd.gauss(0, 0.03)
+        line = f"{t:.3f},S{rnd.randint(1, 32):02d},{temp:.3f},{rh:.2f},{pr:.2f},{rnd.choice(['OK', 'OK', 'OK', 'WARN', 'CAL'])}\n"
+        out.append(line)
+        size += len(line)
+    return "".join(out).encode()[:n]
+
+
+def pcm16_stereo(n, seed=108):
+    """16-bit little-endian stereo PCM: a few drifting partials + noise, the right channel a delayed copy."""
+    np = _np()
+    rng = np.random.default_rng(seed)
+    m = n // 4 + 1
+    t = np.arange(m, dtype=np.float64) / 44100.0
+    sig = (np.sin(2 * np.pi * 220.0 * t) * 6000 + np.sin(2 * np.pi * 331.7 * t + np.sin(t * 0.9)) * 3500
+           + np.sin(2 * np.pi * 1200.5 * t) * 900 * (1 + np.sin(t * 0.31)) + rng.normal(0, 40, m))
+    left = sig.astype(np.int16)
+    right = (np.roll(sig, 37) * 0.8 + rng.normal(0, 40, m)).astype(np.int16)
+    return np.stack([left, right], axis=1).tobytes()[:n]
+
+
+NUMERIC_CLASSES = {
+    "f32sine": f32_sine, "f32two": f32_two_sines, "f32mesh": f32_mesh, "fasta": fasta_repeats, "sparse": sparse_text,
+    "html": html_rows, "csv": csv_sensors, "pcm16": pcm16_stereo,
+}

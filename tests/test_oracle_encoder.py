@@ -156,7 +156,10 @@ def _elf_mix(n):
 
 @pytest.mark.parametrize("corpus,n", [("lorem", 4 << 20), ("text", 4 << 20), ("elf", 4 << 20), ("tar", 6 << 20),
                                       ("rocm_headers", 6 << 20), ("logs", 4 << 20), ("json", 4 << 20),
-                                      ("sqlite", 4 << 20), ("dpkg_tar", 6 << 20)])
+                                      ("sqlite", 4 << 20), ("dpkg_tar", 6 << 20),
+                                      # round 5: the literal-heavy / numeric classes of the round-4 review
+                                      ("f32sine", 4 << 20), ("f32two", 4 << 20), ("f32mesh", 4 << 20), ("fasta", 4 << 20),
+                                      ("sparse", 4 << 20), ("html", 4 << 20), ("csv", 4 << 20), ("pcm16", 4 << 20)])
 def test_size_within_tolerance_of_reference_preset6(corpus, n):
     """Oracle restatement of what the device runs for preset 6 (64-byte suffix order, cost-balanced spans) against
     the REAL liblzma at preset 6 on the same Block: compressed size within the stated tolerance.  (The GPU test
@@ -179,10 +182,13 @@ def test_size_within_tolerance_of_reference_preset6(corpus, n):
                 "dpkg_tar": _corpora.dpkg_tar}[corpus](n)
         if data is None:
             pytest.skip("no /var/lib/dpkg on this box")
-    else:
+    elif corpus == "elf":
         data = _elf_mix(n)
         if len(data) < n:
             pytest.skip("not enough ELF files on this box")
+    else:
+        import _corpora
+        data = _corpora.NUMERIC_CLASSES[corpus](n)
     prm = o.params_for_gpu_options(xz_amd.preset_options(6))
     assert prm.span_cost and prm.sa_depth == 64 and prm.enc_bits        # two-phase: parse pieces + encode spans
     ours_raw = o.orc_encode_block(data, prm)

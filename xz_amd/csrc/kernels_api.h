@@ -90,6 +90,7 @@ typedef struct xzamd_chunk {
 #define XZAMD_PRIOR_WORDS 928u      /* 1856 x u16 >= the 1846 non-literal probabilities */
 #define XZAMD_SEED_LEN 65536u       /* two-phase: the first piece of every Block (oracle: ORC_SEED_LEN) */
 #define XZAMD_ENC_MIN_LEN (512u << 10)  /* shortest encode span (but the last of a Block) */
+#define XZAMD_WARM 16384u          /* two-phase: bytes in front of the pre-roll walked greedily to train the price model (oracle: ORC_WARM) */
 #define XZAMD_PREROLL 2048u         /* two-phase: bytes in front of a piece that are parsed twice (oracle: ORC_PREROLL) */
 #define XZAMD_SPAN_SLACK 4112u      /* 4096 + 16 bytes of scratch per span slot on top of 9/8 of the input */
 #define XZAMD_EST_CHUNK 4096u       /* positions per work estimate of the span plan */

@@ -2415,6 +2415,49 @@ __device__ __forceinline__ void parse_piece_one(const xzamd_span_args& a, const 
         lim = span_start;
         rec = false;
     }
+    // Warm-up (oracle: parse_piece, ORC_WARM): the prior is what the Block's first 64 KiB teach; data that has drifted since
+    // (float arrays, PCM, ...) needs more than the pre-roll to re-train the model, so the XZAMD_WARM bytes in front of the
+    // pre-roll -- never the seed piece's -- are walked greedily first: at every symbol boundary the longest entry of the
+    // position's list record when it is cheap by a fixed rule, else a literal; each symbol adapts the model, nothing is
+    // recorded, no prices, no DP.  64 positions per trip: lane = position (its longest entry, its byte, the byte before it,
+    // the byte at rep0), the walk itself runs on readlanes.
+    if (k != 0 && span_start - block_start > XZAMD_PREROLL + XZAMD_SEED_LEN) {
+        const uint32_t w1 = span_start - XZAMD_PREROLL;
+        uint32_t x0 = w1 - block_start - XZAMD_SEED_LEN > XZAMD_WARM ? w1 - XZAMD_WARM : block_start + XZAMD_SEED_LEN;
+        while (x0 < w1) {
+            const uint32_t px = min(x0 + lane, w1 - 1);
+            const uint64_t rb = (uint64_t)px * LIST_W;
+            const uint32_t tr = e.mdist[rb + LIST_K];
+            const uint32_t cnt = tr & 0xFFu;
+            const uint32_t ev = cnt ? e.mdist[rb + cnt - 1] : 0u;
+            uint32_t L = 0, D = 0;
+            if (cnt) {
+                if (e.packed) { L = ev >> 23; D = ev & 0x7FFFFFu; }
+                else { D = ev; L = e.mlen[rb + cnt - 1]; }
+            }
+            const uint32_t tc = in[px], tp = in[px - 1];
+            uint32_t tm = in[px - z.rep0 - 1];
+            uint32_t i = 0;
+            const uint32_t rowlen = min(64u, w1 - x0);
+            while (i < rowlen) {
+                const uint32_t x = x0 + i;
+                uint32_t len = min(lane_of(L, i), w1 - x);
+                const uint32_t dist = lane_of(D, i);
+                const uint32_t bl = dist ? 32u - (uint32_t)__builtin_clz(dist) : 0u;         // bit length of the distance
+                if (len >= 2 && (14 + bl < 6 * len || dist == z.rep0)) {
+                    const bool rep = dist == z.rep0;
+                    encode_symbol_t<false, true>(rc, probs, z, x - block_start, rep ? 0u : dist + 4, len, 0u);
+                    i += len;
+                    if (!rep && i < rowlen) tm = in[px - z.rep0 - 1];      // rep0 changed: the match bytes of the rest of the row
+                } else {
+                    const uint32_t l3 = lane_of(tc, i) | (lane_of(tp, i) << 8) | (lane_of(tm, i) << 16);
+                    encode_symbol_t<false, true>(rc, probs, z, x - block_start, LITERAL, 1, l3);
+                    i += 1;
+                }
+            }
+            x0 += i;
+        }
+    }
     bool cached = false;
     RoundL RL;
     RL.L = 0; RL.SL = 0; RL.SD = 0; RL.cnt = 0; RL.longest = 0; RL.l2a = RL.l2b = 0;
