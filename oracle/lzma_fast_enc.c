@@ -172,6 +172,7 @@ typedef struct {
 	uint32_t lit_rec;           /* phase 2: != 0: the record of the literal being coded | 1 << 31 */
 	int est_on;                 /* phase 2: sum the prices of the coded decisions (chunk rule of the two-phase coder) */
 	uint64_t est;               /* in 1/16 bit, from the probabilities before their update */
+	uint64_t ntok;              /* phase 2: binary decisions (tokens of the device's model pass) of the encode span so far */
 #ifdef ORC_XPREV
 	uint32_t *xprev[8];
 	int xprev_n;
@@ -647,8 +648,10 @@ static inline void rc_bit(enc *e, uint16_t *prob, uint32_t bit)
 		e->range <<= 8;
 	}
 	uint32_t p = *prob;
-	if (e->est_on)
+	if (e->est_on) {
 		e->est += e->price_tab[(p ^ ((0u - bit) & 0x7FFu)) >> 4];
+		++e->ntok;
+	}
 	const uint32_t bound = (e->range >> 11) * p;
 	if (!bit) {
 		e->range = bound;
@@ -685,7 +688,7 @@ static void rc_tree_rev(enc *e, uint16_t *probs, uint32_t nbits, uint32_t sym)
 static void rc_direct(enc *e, uint32_t value, uint32_t nbits)
 {
 	if (e->rc_off) return;
-	if (e->est_on) e->est += 16u * nbits;
+	if (e->est_on) { e->est += 16u * nbits; e->ntok += nbits; }
 	do {
 		if (e->range < (1u << 24)) {
 			rc_shift_low(e);
@@ -1377,6 +1380,9 @@ static int optimum_window(enc *e, uint32_t pos, int cached)
 #define ORC_CHUNK_EST (56000u * 128u)   /* two-phase coder: a chunk ends when the summed prices reach this (1/16 bit) */
 #ifndef ORC_PREROLL
 #define ORC_PREROLL 2048u         /* two-phase: bytes in front of a piece that are parsed twice (the device: XZAMD_PREROLL) */
+#define ORC_TOK_PER_BYTE 10u      /* two-phase coder: token budget per input byte of an encode span (XZAMD_TOK_PER_BYTE) */
+static uint32_t orc_tok_per_byte; /* tests: a smaller budget (orc_set_tok_per_byte; the device: XZAMD_TEST_TOK_PER_BYTE) */
+void orc_set_tok_per_byte(uint32_t v) { orc_tok_per_byte = v >= 1 && v < ORC_TOK_PER_BYTE ? v : 0; }
 #define ORC_WARM 16384u           /* two-phase: bytes in front of the pre-roll that train the price model by a greedy walk (XZAMD_WARM) */
 #endif
 
@@ -1741,13 +1747,35 @@ static int encode_syms(enc *e, uint32_t start, uint32_t end, int first_in_block,
 	 * ORC_CHUNK_EST (56,000 bytes: the coded size stays far below the format's 65,536) or 2 MiB - 273 bytes of input;
 	 * it is stored raw when the estimate says it would not shrink (est / 128 + 5 >= bytes of input). */
 	e->est_on = 1;
+	/* Token budget (the device's token buffer: ORC_TOK_PER_BYTE per input byte of the span + 4096, 64 spare): when it
+	 * runs out -- data made of far three-byte matches needs 32 ... 41 decisions per 3 bytes -- the chunk is closed where
+	 * it stands and the REST of the span is stored as raw chunks of 64 KiB (lzma2_encoder.c:110-131). */
+	const uint64_t tok_cap = (uint64_t)(end - start) * (orc_tok_per_byte ? orc_tok_per_byte : ORC_TOK_PER_BYTE) + 4096u - 64u;
+	int tok_full = 0;
+	e->ntok = 0;
 	int initialized = !first_in_block;
 	while (cur < end) {
 		if (need_state_reset)
 			lzma_state_reset(e);
 		const uint32_t chunk_start = cur;
+		const uint64_t chunk_tok = e->ntok;
 		e->cpos = 0;
 		e->est = 0;
+		if (tok_full) {
+			const uint32_t usize = end - cur < 65536u ? end - cur : 65536u;
+			uint8_t hdr[3];
+			hdr[0] = need_dict_reset ? 1 : 2;
+			need_dict_reset = 0;
+			hdr[1] = (uint8_t)((usize - 1) >> 8);
+			hdr[2] = (uint8_t)(usize - 1);
+			if (put(out, cap, opos, hdr, 3) || put(out, cap, opos, e->in + chunk_start, usize)) {
+				e->est_on = 0;
+				return -1;
+			}
+			if (e->trace) ++e->trace->chunks_uncompressed;
+			cur += usize;
+			continue;
+		}
 		if (!initialized) {
 			rc_bit(e, &e->probs[P_IS_MATCH], 0);
 			rc_tree(e, e->probs + P_LITERAL, 8, e->in[0]);
@@ -1760,6 +1788,7 @@ static int encode_syms(enc *e, uint32_t start, uint32_t end, int first_in_block,
 				break;
 			if (cur >= end)
 				break;
+			if (e->ntok + 64u > tok_cap) { tok_full = 1; break; }
 			uint32_t len = e->sy_len[cur];
 			const uint32_t d = e->sy_dist[cur];
 			uint32_t back;
@@ -1778,8 +1807,10 @@ static int encode_syms(enc *e, uint32_t start, uint32_t end, int first_in_block,
 		rc_flush(e);
 		const uint32_t usize = cur - chunk_start, csize = e->cpos;
 		uint8_t hdr[6];
+		if (usize == 0) continue;                              /* the budget ran out right at a chunk start */
 		if (csize > 65536) { e->est_on = 0; return -4; }      /* cannot happen: see ORC_CHUNK_EST */
 		if (e->est / 128 + 5 >= usize) {
+			e->ntok = chunk_tok;                               /* a raw chunk's tokens are dropped */
 			hdr[0] = need_dict_reset ? 1 : 2;
 			need_dict_reset = 0;
 			hdr[1] = (uint8_t)((usize - 1) >> 8);

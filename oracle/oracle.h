@@ -166,6 +166,8 @@ int orc_parse_dump(const uint8_t *in, uint32_t n, const orc_enc_params *p, uint1
 int orc_lzma2_encode_block_syms(const uint8_t *in, uint32_t n, const orc_enc_params *p,
 		uint8_t *out, uint64_t out_cap, uint64_t *out_size, uint16_t *sym_len, uint32_t *sym_dist);
 
+/* tests only: a smaller token budget per input byte for the two-phase coder (0 / >= 10: the default) */
+void orc_set_tok_per_byte(uint32_t v);
 int orc_preset(uint32_t preset, orc_enc_params *p, uint32_t *mode_normal);
 
 /* Encode one Block's raw LZMA2 payload (incl. 0x00 end marker).

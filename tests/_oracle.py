@@ -566,3 +566,11 @@ def first_diff(a, b):
     if len(d):
         return int(d[0])
     return -1 if len(a) == len(b) else n
+
+
+def orc_set_tok_per_byte(v):
+    """Tests only: token budget per input byte of the two-phase coder (0 = default); the device: XZAMD_TEST_TOK_PER_BYTE."""
+    f = orc().orc_set_tok_per_byte
+    f.restype = None
+    f.argtypes = [C.c_uint32]
+    f(v)

@@ -305,6 +305,35 @@ def test_two_phase_stages_identical_to_oracle(enc, preset, single_phase):
     assert st.spans == pieces and st.enc_spans == spans and spans > nb
 
 
+def test_two_phase_token_budget_overflow_identical_to_oracle(enc, monkeypatch):
+    """Out of tokens (round-4 advisor, medium: far three-byte matches need more than the 10 tokens per byte the buffer
+    holds) the model pass closes the chunk where it stands and stores the rest of the encode span raw.  Reached on
+    ordinary data by turning the budget down on both sides; bytes identical to the oracle, decodable by liblzma."""
+    import xz_amd
+    rng = np.random.default_rng(5)
+    data = (xz_amd.corpus_text(5 << 20, seed=9).tobytes() + bytes(rng.integers(0, 256, size=200000, dtype=np.uint8))
+            + o.corpus_lorem(3 << 20))
+    bs = 3 << 20
+    opts = xz_amd.preset_options(6)
+    opts.enc_span_bits = 400000
+    prm = o.params_for_gpu_options(opts)
+    full, _ = gpu_encode(enc, data, opts, bs)
+    try:
+        for budget in (1, 3):
+            monkeypatch.setenv("XZAMD_TEST_TOK_PER_BYTE", str(budget))
+            o.orc_set_tok_per_byte(budget)
+            got, _ = gpu_encode(enc, data, opts, bs)
+            assert o.first_diff(got, o.orc_xz_stream(data, prm, bs)) == -1, budget
+            rr, rdec = o.ref_decode(got, len(data) + 16)
+            assert rr == 1 and rdec == data
+            assert len(got) > len(full)
+    finally:
+        o.orc_set_tok_per_byte(0)
+        monkeypatch.delenv("XZAMD_TEST_TOK_PER_BYTE", raising=False)
+    again, _ = gpu_encode(enc, data, opts, bs)
+    assert again == full
+
+
 def test_output_independent_of_batching_and_feeding(enc):
     """The compressed bytes of presets 4-9 are a function of (input, options, block size) only: the same Stream whatever
     the device batch size (one batch, many small batches, the pipelined two-stream path) and however the client feeds

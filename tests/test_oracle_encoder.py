@@ -268,3 +268,33 @@ def test_two_phase_round_trip_many_small_pieces():
     raw = o.orc_encode_block(data, prm)
     r, dec = o.ref_raw_decode(raw, prm.dict_size, len(data) + 16)
     assert r == 1 and dec == data
+
+
+def test_two_phase_token_budget_overflow_goes_raw():
+    """Round-4 advisor (medium): the model pass of the two-phase coder has a fixed token budget per encode span (10 per input
+    byte); data made of far three-byte matches needs more.  Out of tokens, the chunk is closed where it stands and the rest
+    of the span is stored as raw chunks -- a valid Stream, never an error.  Reached here on ordinary data with the budget
+    turned down (the device: XZAMD_TEST_TOK_PER_BYTE, same rule, byte-identical: test_gpu_parity)."""
+    if not o.have_ref():
+        pytest.skip("oracle/_ref not built")
+    import xz_amd
+    rng = np.random.default_rng(5)
+    data = (xz_amd.corpus_text(2 << 20, seed=9).tobytes() + bytes(rng.integers(0, 256, size=200000, dtype=np.uint8))
+            + o.corpus_lorem(1 << 20))
+    prm = o.params_for_gpu_options(xz_amd.preset_options(6))
+    prm.enc_bits = 400000
+    full = o.orc_encode_block(data, prm)
+    try:
+        sizes = {}
+        for budget in (1, 2, 3):
+            o.orc_set_tok_per_byte(budget)
+            raw = o.orc_encode_block(data, prm)
+            r, dec = o.ref_raw_decode(raw, prm.dict_size, len(data) + 16)
+            assert r == 1 and dec == data, budget
+            sizes[budget] = len(raw)
+            r2, dec2, _, tr = o.orc_decode_raw(raw, prm.dict_size, len(data) + 16, want_trace=True)
+            assert r2 == 0 and dec2 == data and tr.chunks_uncompressed > 3, budget       # the raw tails of the encode spans
+    finally:
+        o.orc_set_tok_per_byte(0)
+    assert len(full) < sizes[3] < sizes[2] < sizes[1] < len(data) + len(data) // 1000
+    assert o.orc_encode_block(data, prm) == full                 # the knob is off again

@@ -65,6 +65,8 @@ typedef struct {
 	 * per LZMA2 chunk; the range coder then runs one LANE per chunk. */
 	uint16_t *tok;               /* tokens of encode-span slot s (first byte st): from XZAMD_TOK_BASE(st, s) on */
 	struct xzamd_chunk *chunks;  /* chunk slots of encode-span slot s: from XZAMD_CHUNK_BASE(st, s) on; usize 0 = unused */
+	uint32_t tok_limit;          /* 0 = XZAMD_TOK_PER_BYTE; tests (XZAMD_TEST_TOK_PER_BYTE): a smaller token budget per input byte,
+	                                to reach the "out of tokens: the rest of the span goes out raw" path on ordinary data */
 } xzamd_span_args;
 /* One LZMA2 chunk of the two-phase coder.  Its bytes (chunk header included) are written at
  * scratch + XZAMD_CHUNK_OUT(in_start, its slot index). */

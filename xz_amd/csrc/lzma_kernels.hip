@@ -2661,7 +2661,12 @@ __global__ __launch_bounds__(64) void k_model_syms(xzamd_span_args a, uint32_t n
     RC rc;
     rc.cpos = 0; rc.out = nullptr; rc.reset();
     uint16_t* const tok0 = a.tok + XZAMD_TOK_BASE(span_start, slot);
-    const uint64_t tok_cap = (uint64_t)(span_end - span_start) * XZAMD_TOK_PER_BYTE + 4096u - 64u;
+    // Token budget of the span.  The buffer holds XZAMD_TOK_PER_BYTE tokens per input byte (+ 4096); a.tok_limit (tests only,
+    // <= XZAMD_TOK_PER_BYTE) lowers the budget without changing the layout.  Data made of far three-byte matches needs more
+    // (32 ... 41 tokens per 3 bytes): when the budget runs out the chunk is closed where it stands and the REST of the span
+    // is stored as raw LZMA2 chunks (lzma2_encoder.c:110-131) -- valid output instead of a failed Stream (oracle: encode_syms).
+    const uint64_t tok_cap = (uint64_t)(span_end - span_start) * (a.tok_limit ? a.tok_limit : XZAMD_TOK_PER_BYTE) + 4096u - 64u;
+    bool tok_full = false;
     rc.tok = tok0; rc.est = 0; rc.ptab = ptab;
     const uint32_t cbase = XZAMD_CHUNK_BASE(span_start, slot);
     const uint32_t ccap = ((span_end - span_start) >> 15) + 2u;
@@ -2691,6 +2696,27 @@ __global__ __launch_bounds__(64) void k_model_syms(xzamd_span_args a, uint32_t n
         const uint32_t chunk_start = cur;
         uint16_t* const chunk_tok = rc.tok;
         rc.est = 0;
+        if (tok_full) {
+            // out of tokens: the rest of the span goes out raw, 64 KiB at a time
+            const uint32_t usize = min(span_end - cur, 65536u);
+            const uint32_t cidx = cbase + nchunks;
+            if (nchunks + 1 >= ccap) { f_pos = cur - block_start; failed = true; break; }
+            uint8_t* const hdr = a.scratch + XZAMD_CHUNK_OUT(chunk_start, cidx);
+            for (uint32_t i = lane; i < usize; i += 64) hdr[3 + i] = in[chunk_start + i];
+            if (lane == 0) {
+                hdr[0] = need_dict_reset ? 1 : 2;
+                hdr[1] = (uint8_t)((usize - 1) >> 8);
+                hdr[2] = (uint8_t)(usize - 1);
+                xzamd_chunk c;
+                c.in_start = chunk_start; c.usize = usize; c.tok_lo = 0; c.tok_hi = 0;
+                c.ntok = 0; c.csize = 3u + usize; c.flags = XZAMD_CH_RAW; c.pad_ = 0;
+                a.chunks[cidx] = c;
+            }
+            need_dict_reset = false;
+            ++nchunks;
+            cur += usize;
+            continue;
+        }
         for (;;) {
             // the chunk rule of the two-phase coder (oracle: encode_syms): input limit of lzma2_encoder.c:167-181, and
             // the summed prices in place of the coded size
@@ -2698,6 +2724,7 @@ __global__ __launch_bounds__(64) void k_model_syms(xzamd_span_args a, uint32_t n
                 break;
             if (cur >= span_end)
                 break;
+            if ((uint64_t)(rc.tok - tok0) + 64u > tok_cap) { tok_full = true; break; }
             uint32_t off = cur - R.base;
             if (off >= 64) {
                 if (off < 128) {
@@ -2725,7 +2752,7 @@ __global__ __launch_bounds__(64) void k_model_syms(xzamd_span_args a, uint32_t n
             else back = d + 4;
             if (len > MATCH_LEN_MAX || cur + len > span_end
                     || (back != LITERAL && back >= 4 && back - 4 >= cur - block_start)
-                    || (uint64_t)(rc.tok - tok0) + 64u > tok_cap || nchunks + 1 >= ccap) {
+                    || nchunks + 1 >= ccap) {
                 // internal consistency failure: report it and leave through the loop conditions (an early return from
                 // inside the loops costs the compiler its proof that the coder state is wave-uniform)
                 f_pos = cur - block_start; f_back = back; f_len = len; f_d = d;
@@ -2745,6 +2772,7 @@ __global__ __launch_bounds__(64) void k_model_syms(xzamd_span_args a, uint32_t n
         }
         if (failed) break;
         const uint32_t usize = cur - chunk_start;
+        if (usize == 0) continue;                          // the budget ran out right at a chunk start
         const uint32_t ntok = (uint32_t)(rc.tok - chunk_tok);
         const bool raw = rc.est / 128u + 5u >= usize;
         const uint32_t cidx = cbase + nchunks;

@@ -1367,6 +1367,12 @@ int xzamd_encode_device_(xzamd_ctx *c,
 			a.enc_cnt = (const uint32_t *)c->enc_cnt[par].p;
 			a.max_esb = esb;
 			a.enc_bits = opt->enc_span_bits;
+			{
+				/* test knob: a smaller token budget per input byte (never a larger one: the buffer is what it is) */
+				const char *tl = getenv("XZAMD_TEST_TOK_PER_BYTE");
+				const unsigned long v = tl ? strtoul(tl, NULL, 10) : 0;
+				a.tok_limit = v >= 1 && v < XZAMD_TOK_PER_BYTE ? (uint32_t)v : 0;
+			}
 			a.tok = (uint16_t *)c->tok.p;
 			a.chunks = (xzamd_chunk *)c->chunks.p;
 		}
