@@ -178,7 +178,7 @@ def reference_ratio(sample, preset, bcj, block_size):
     """Compressed size of the reference MT encoder on a few Blocks of the input (the ratio baseline)."""
     import _oracle as o
     nb = max(1, (len(sample) + block_size - 1) // block_size)
-    enc = (o.ref_encode_mt_x86 if bcj else o.ref_encode_mt)(sample, preset, threads=min(nb, 8), block_size=block_size)
+    enc = (o.ref_encode_mt_x86 if bcj else o.ref_encode_mt)(sample, preset, threads=min(nb, 16), block_size=block_size)
     return len(enc)
 
 
@@ -250,6 +250,45 @@ def host_to_host(host, preset, block_size, reps=2, bcj=False):
     return res
 
 
+def extra_configs():
+    """BASELINE.json's other single-GPU configurations, each as a child `bench.py` (its own process, its own device
+    context), summarised: C2 = configs[1] (preset 1, 1 GiB synthetic text, 64 Blocks of 16 MiB), C5_1gpu = one GPU's
+    run of configs[4] (preset 9e + x86 BCJ, 8 GiB of the box's ELF objects, 192 MiB Blocks)."""
+    import subprocess
+    runs = {
+        "C2": ["--preset", "1", "--size-mib", "1024", "--block-mib", "16", "--steps", "3", "--warmup", "1", "--ratio-blocks", "16"],
+        "C5_1gpu": ["--preset", "0x80000009", "--bcj", "--corpus", "elf", "--size-mib", "8192", "--steps", "1", "--warmup", "1",
+                    "--ratio-blocks", "2"],
+    }
+    out = {}
+    for name, extra in runs.items():
+        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--no-extra-configs", "--no-cpu-baseline"] + extra
+        t0 = time.perf_counter()
+        try:
+            p = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+            line = [l for l in p.stdout.splitlines() if l.startswith("{")]
+            if p.returncode != 0 or not line:
+                out[name] = {"value": None, "error": (p.stderr or "")[-400:], "rc": p.returncode}
+                continue
+            d = json.loads(line[-1])
+            h2h = d.get("host_to_host") or {}
+            out[name] = {
+                "value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "steps": d["steps"],
+                "workload": d["config"]["workload"], "data": d["data"], "corpus_sha256": d["config"].get("corpus_sha256"),
+                "ratio": d["ratio"].get("ours"), "size_vs_reference_pct": d["ratio"].get("size_vs_reference_pct"),
+                "ratio_sample_mib": d["ratio"].get("sample_mib"),
+                "roundtrip_reference_decoder": d.get("roundtrip_reference_decoder"),
+                "host_to_host": h2h.get("value"),
+                "host_to_host_roundtrip_whole_output": (h2h.get("roundtrip_reference_decoder_whole_output") or {}).get("ok"),
+                "roofline": d.get("roofline"), "stage_ms_last_step": d.get("stage_ms_last_step"),
+                "wall_s": round(time.perf_counter() - t0, 1),
+                "cmd": "python bench.py " + " ".join(extra),
+            }
+        except Exception as e:  # noqa: BLE001
+            out[name] = {"value": None, "error": str(e)}
+    return out
+
+
 def relaunch_under_torchrun(args_list, n):
     """`python bench.py --gpus N` with N > 1: spawn the N ranks ourselves (one process per GPU, RCCL)."""
     import socket
@@ -284,6 +323,13 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-to-host", action="store_true")
     ap.add_argument("--bcj", action="store_true", help="chain {x86 BCJ, LZMA2} (SURVEY.md 8d config C5)")
+    ap.add_argument("--no-extra-configs", action="store_true",
+                    help="the default 1-GPU run also runs BASELINE's other single-GPU configurations (C2: preset 1, 1 GiB text, "
+                         "16 MiB Blocks; C5_1gpu: 9e + x86 BCJ, 8 GiB ELF) as child processes and embeds their results as `configs`; "
+                         "this switch leaves them out")
+    ap.add_argument("--ratio-blocks", type=int, default=0,
+                    help="Blocks of the input the ratio is measured on against the reference encoder (0 = about 1 GiB for the "
+                         "headline workload, 4 Blocks otherwise)")
     ap.add_argument("--corpus", choices=["text", "elf", "tar"], default="text",
                     help="text: seeded synthetic enwik-style text (the headline workload); elf: the x86-64 shared "
                          "objects present on the box, concatenated and cycled (config C5's input); tar: ustar stream "
@@ -483,7 +529,11 @@ def main():
                 if args.no_ratio:
                     pass
                 elif o.have_ref():
-                    sample_n = min(n, 4 * block_size)
+                    # the headline workload: >= 1 GiB of it (43 Blocks of 24 MiB; the reference needs ~40 s of the box's
+                    # 16 CPUs for that); other workloads: 4 Blocks unless asked
+                    headline = args.preset == 6 and args.corpus == "text" and not args.bcj and not args.block_mib
+                    rb = args.ratio_blocks if args.ratio_blocks else (43 if headline else 4)
+                    sample_n = min(n, rb * block_size)
                     ref_size = reference_ratio(host[:sample_n], args.preset, args.bcj, block_size)
                     # (the span plan of a Block depends on the Block and the options only: the sample's Blocks are coded
                     # exactly as in the timed run)
@@ -523,6 +573,17 @@ def main():
                 cb = cpu_baseline(host, args.preset, args.bcj, block_size)
                 if cb is not None:
                     res["cpu_baseline"] = cb
+            default_workload = (args.preset == 6 and args.corpus == "text" and not args.bcj and not args.block_mib
+                                and args.size_mib == 4096 and args.parser == "default" and not args.span_kib)
+            if default_workload and not args.no_extra_configs and not args.no_ratio:
+                try:
+                    del host
+                    enc.close()
+                    torch.cuda.empty_cache()
+                    xz_amd.lib().xzamd_release_parked()
+                except Exception:  # noqa: BLE001
+                    pass
+                res["configs"] = extra_configs()
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()

@@ -2448,7 +2448,8 @@ __device__ __forceinline__ void parse_piece_one(const xzamd_span_args& a, const 
                     const bool rep = dist == z.rep0;
                     encode_symbol_t<false, true>(rc, probs, z, x - block_start, rep ? 0u : dist + 4, len, 0u);
                     i += len;
-                    if (!rep && i < rowlen) tm = in[px - z.rep0 - 1];      // rep0 changed: the match bytes of the rest of the row
+                    if (!rep && i < rowlen) tm = in[max(px, x0 + i) - z.rep0 - 1];   // rep0 changed: the match bytes of the rest of the row
+                                                                                     // (lanes behind the walk would reach in front of the Block)
                 } else {
                     const uint32_t l3 = lane_of(tc, i) | (lane_of(tp, i) << 8) | (lane_of(tm, i) << 16);
                     encode_symbol_t<false, true>(rc, probs, z, x - block_start, LITERAL, 1, l3);
