@@ -54,7 +54,7 @@ def two_phase(opts):
 
 def span_kernel_name(opts, pmc=False):
     """Name of the dominant kernel for these options (template args: finder source, parser, parser window)."""
-    wm = 360 if (opts.gpu_parser and opts.gpu_nice_len > 128) else 232
+    wm = 384            # one parser window for every option set since round 5 (lzma_kernels.hip: WMAX_STD == WMAX_LONG)
     if two_phase(opts):
         return "k_parse_pieces<%du>" % wm if pmc else "k_parse_pieces<%d>" % wm
     finder = 2 if opts.gpu_parser else 0
@@ -258,7 +258,7 @@ def extra_configs():
     runs = {
         "C2": ["--preset", "1", "--size-mib", "1024", "--block-mib", "16", "--steps", "3", "--warmup", "1", "--ratio-blocks", "16"],
         "C5_1gpu": ["--preset", "0x80000009", "--bcj", "--corpus", "elf", "--size-mib", "8192", "--steps", "1", "--warmup", "1",
-                    "--ratio-blocks", "2"],
+                    "--ratio-blocks", "1", "--ratio-async", "--no-host-to-host"],
     }
     out = {}
     for name, extra in runs.items():
@@ -327,6 +327,10 @@ def main():
                     help="the default 1-GPU run also runs BASELINE's other single-GPU configurations (C2: preset 1, 1 GiB text, "
                          "16 MiB Blocks; C5_1gpu: 9e + x86 BCJ, 8 GiB ELF) as child processes and embeds their results as `configs`; "
                          "this switch leaves them out")
+    ap.add_argument("--ratio-async", action="store_true",
+                    help="start the reference encoder of the ratio sample on the host cores BEFORE the warm-up and collect it after "
+                         "the timed steps (the child runs of `configs`: a 192 MiB Block at 9e costs liblzma two minutes on one "
+                         "core; the device-resident path needs no CPU meanwhile)")
     ap.add_argument("--ratio-blocks", type=int, default=0,
                     help="Blocks of the input the ratio is measured on against the reference encoder (0 = about 1 GiB for the "
                          "headline workload, 4 Blocks otherwise)")
@@ -390,6 +394,20 @@ def main():
     data = torch.from_numpy(host).to(dev)
     enc = xz_amd.Encoder(dev_index)
     out_buf = torch.empty(xz_amd.lib().xzamd_stream_buffer_bound(n, block_size) + 64, dtype=torch.uint8, device=dev)
+
+    def ratio_sample_bytes():
+        # the headline workload: >= 1 GiB of it (43 Blocks of 24 MiB; the reference needs ~40 s of the box's 16 CPUs for
+        # that); other workloads: 4 Blocks unless asked
+        headline = args.preset == 6 and args.corpus == "text" and not args.bcj and not args.block_mib
+        rb = args.ratio_blocks if args.ratio_blocks else (43 if headline else 4)
+        return min(n, rb * block_size)
+
+    ref_future = None
+    if args.ratio_async and world == 1 and n and not args.no_ratio:
+        import concurrent.futures as cf
+        import _oracle as o_
+        if o_.have_ref():
+            ref_future = cf.ThreadPoolExecutor(1).submit(reference_ratio, host[:ratio_sample_bytes()], args.preset, args.bcj, block_size)
 
     def step():
         if world == 1:
@@ -492,7 +510,7 @@ def main():
                 "device_match_finder": ((f"suffix-neighbourhood finder ({opts.gpu_sa_depth or 32}-byte-prefix suffix order, {opts.gpu_sa_window} slots per side + hash2/hash4 heads + equal 8/16 bytes)"
                                          if opts.gpu_sa_window else f"HC{opts.gpu_mf & 15} depth {opts.gpu_depth} (sort-built chains)")
                                         + f", nice {opts.gpu_nice_len}"),
-                "device_parser": (f"windowed optimal parser ({360 if opts.gpu_nice_len > 128 else 232}-node DP, exact prices, compound edges) over per-position match lists" if opts.gpu_parser
+                "device_parser": ("windowed optimal parser (384-node DP, exact prices, compound edges) over per-position match lists" if opts.gpu_parser
                                   else "lzma_lzma_optimum_fast semantics (greedy + 1-byte lazy)"),
                 "span_bytes": int(st.span_size) if st.span_size else f"cost-balanced (work target {int(st.span_cost_used)} per span, >= 64 KiB)",
                 "parallelism": (f"{world} x (two-phase: one wavefront per parse piece, {int(st.spans)} pieces on rank 0 incl. one 64 KiB seed piece per Block; "
@@ -529,12 +547,8 @@ def main():
                 if args.no_ratio:
                     pass
                 elif o.have_ref():
-                    # the headline workload: >= 1 GiB of it (43 Blocks of 24 MiB; the reference needs ~40 s of the box's
-                    # 16 CPUs for that); other workloads: 4 Blocks unless asked
-                    headline = args.preset == 6 and args.corpus == "text" and not args.bcj and not args.block_mib
-                    rb = args.ratio_blocks if args.ratio_blocks else (43 if headline else 4)
-                    sample_n = min(n, rb * block_size)
-                    ref_size = reference_ratio(host[:sample_n], args.preset, args.bcj, block_size)
+                    sample_n = ratio_sample_bytes()
+                    ref_size = ref_future.result() if ref_future is not None else reference_ratio(host[:sample_n], args.preset, args.bcj, block_size)
                     # (the span plan of a Block depends on the Block and the options only: the sample's Blocks are coded
                     # exactly as in the timed run)
                     s_out, _ = enc.encode(data[:sample_n], opts=opts, block_size=block_size)

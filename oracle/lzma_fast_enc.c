@@ -68,13 +68,13 @@
 #define LIT 0xFFFFFFFFu
 #define NO_DELTA 0xFFFFFFFFu
 #ifndef WMAX_STD
-#define WMAX_STD 232u             /* optimal-parser window (nodes 0..WMAX); sized so the GPU's node arrays +
-                                   * model + price tables fit 10 KiB of LDS per wavefront */
+#define WMAX_STD 384u             /* optimal-parser window (nodes 0..WMAX); sized so the GPU's node arrays +
+                                   * price tables fit 10 KiB of LDS per wavefront (round 5: the model moved to L2) */
 #endif
 #ifndef WTAIL
-#define WTAIL 16u
+#define WTAIL 32u
 #endif
-#define WMAX_LONG 360u            /* nice_len > 128 (the extreme presets): 13 KiB per wavefront = 12 per CU */
+#define WMAX_LONG 384u            /* nice_len > 128 (the extreme presets): the same window since round 5 */
 #define WMAX_CAP WMAX_LONG
 #define WTAIL_                 /* symbols ending less than WTAIL nodes before a forced window cut are re-parsed */
 #ifndef LIST_K

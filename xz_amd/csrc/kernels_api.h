@@ -54,8 +54,9 @@ typedef struct {
 	 * and leaves the prior of the others), the recorded symbols are range-coded per ENCODE SPAN (xzk_encode_syms). */
 	uint16_t *sym_len;           /* per position, valid at symbol starts: 0 = literal, else the match / rep length (1 = short rep) */
 	uint32_t *sym_dist;          /* zero-based distance; literal: byte | previous byte << 8 | match byte << 16 | (parser state >= 7) << 24 */
-	uint32_t *prior;             /* XZAMD_PRIOR_WORDS x u32 per Block: the LDS part of the model its seed piece leaves
-	                                (the literal part stays in the seed's `lit` slice) */
+	uint32_t *prior;             /* XZAMD_PRIOR_WORDS x u32 per PIECE slot (b * max_spb + k): the non-literal probabilities of the
+	                                piece's price model (the literal coders: `lit`, same slots); slot 0 of a Block = its seed
+	                                piece, whose model is the prior the other pieces of the Block copy */
 	const uint32_t *enc_tab;     /* encode spans: (first byte, end) per slot b * max_esb + j, offsets into the batch */
 	const uint32_t *enc_cnt;     /* encode spans per Block */
 	uint32_t max_esb;            /* encode span slots per Block */
@@ -89,7 +90,7 @@ typedef struct xzamd_chunk {
 #define XZAMD_CHUNK_BASE(st, slot) (((st) >> 15) + 2u * (slot))     /* a chunk but the last of its span holds > 32 KiB of input */
 #define XZAMD_CHUNK_SLOTS(n, nslots) (((n) >> 15) + 2u * (nslots) + 2u)
 #define XZAMD_CHUNK_OUT(in_start, cidx) (((((uint64_t)(in_start) + ((in_start) >> 3)) + 15) & ~15ull) + (uint64_t)(cidx) * 32u)
-#define XZAMD_PRIOR_WORDS 928u      /* 1856 x u16 >= the 1846 non-literal probabilities */
+#define XZAMD_PRIOR_WORDS 1856u     /* u32 each, >= the 1846 non-literal probabilities (a multiple of 64) */
 #define XZAMD_SEED_LEN 65536u       /* two-phase: the first piece of every Block (oracle: ORC_SEED_LEN) */
 #define XZAMD_ENC_MIN_LEN (512u << 10)  /* shortest encode span (but the last of a Block) */
 #define XZAMD_WARM 16384u          /* two-phase: bytes in front of the pre-roll walked greedily to train the price model (oracle: ORC_WARM) */

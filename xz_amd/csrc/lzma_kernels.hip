@@ -816,6 +816,7 @@ struct Lz {
     uint32_t lc, lp, pb;
     uint32_t cnt_len, cnt_match, cnt_align;   // coded lengths / matches / align-coded matches since refresh
     uint32_t* lit;                            // literal coder probabilities of this span (global memory, L2-resident)
+    uint32_t* gp;                             // parse pieces (PG): every other probability of the piece's model, u32 each, global
 };
 
 __device__ __forceinline__ uint32_t dist_slot_of(uint32_t d)
@@ -907,8 +908,9 @@ __device__ __forceinline__ void rc_run(RC& rc, uint32_t packed, uint32_t n, uint
 // LITG: literal-coder probabilities live in global memory (u32 each, `lit`), else in LDS behind P_LITERAL (u16);
 // TOK: the model pass of the two-phase coder: one 16-bit token per decision goes to rc.tok and the price of the
 // decisions (the parser's table, probability before its update) is added to rc.est.
-template <bool CODE, bool LITG, bool TOK = false>
-__device__ __forceinline__ void rc_emit(RC& rc, uint16_t* probs, uint32_t* lit, const SegSel& s, uint32_t total,
+// PG: the whole model lives in global memory (the parse pieces: `gp` holds what LDS holds elsewhere).
+template <bool CODE, bool LITG, bool TOK = false, bool PG = false>
+__device__ __forceinline__ void rc_emit(RC& rc, uint16_t* probs, uint32_t* lit, uint32_t* gp, const SegSel& s, uint32_t total,
         uint32_t d0, uint32_t d1)
 {
     uint32_t idx = 0, bit = 0;
@@ -937,8 +939,8 @@ __device__ __forceinline__ void rc_emit(RC& rc, uint16_t* probs, uint32_t* lit, 
     }
     uint32_t p = 0;
     if (s.hit && !direct) {
-        if (LITG && idx >= P_LITERAL) {
-            uint32_t* g = lit + (idx - P_LITERAL);
+        if ((LITG && idx >= P_LITERAL) || PG) {
+            uint32_t* g = (!PG || idx >= P_LITERAL) ? lit + (idx - P_LITERAL) : gp + idx;
             p = lit_load(g);
             lit_store(g, bit ? p - (p >> 5) : p + ((2048 - p) >> 5));
         } else {
@@ -963,10 +965,11 @@ __device__ __forceinline__ void rc_emit(RC& rc, uint16_t* probs, uint32_t* lit, 
 
 // upos = offset of the symbol inside the Block; lit3 (literals only) = byte | previous byte << 8 | match byte << 16
 // (the match byte is read only in states >= 7)
-template <bool CODE, bool LITG, bool TOK = false>
+template <bool CODE, bool LITG, bool TOK = false, bool PG = false>
 __device__ __forceinline__ void encode_symbol_t(RC& rc, uint16_t* probs, Lz& z, uint32_t upos, uint32_t back, uint32_t len,
         uint32_t lit3)
 {
+    if (PG) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the previous symbol's probability scatter
     const uint32_t ps = upos & ((1u << z.pb) - 1);
     SegSel s;
     s.type = 0; s.base = 0; s.sym = 0; s.i = 0; s.n = 0; s.hit = false;
@@ -986,7 +989,7 @@ __device__ __forceinline__ void encode_symbol_t(RC& rc, uint16_t* probs, Lz& z, 
             const uint32_t mb = (lit3 >> 16) & 0xFFu;
             seg_add(s, off, 8, SEG_MATCHED, sub, cur | (mb << 8));
         }
-        rc_emit<CODE, LITG, TOK>(rc, probs, z.lit, s, off, off, off);
+        rc_emit<CODE, LITG, TOK, PG>(rc, probs, z.lit, z.gp, s, off, off, off);
         return;
     }
     seg_add(s, off, 1, SEG_BIT, P_IS_MATCH + z.state * 16 + ps, 1);
@@ -1014,7 +1017,7 @@ __device__ __forceinline__ void encode_symbol_t(RC& rc, uint16_t* probs, Lz& z, 
         }
         if (len == 1) {
             z.state = z.state < 7 ? 9 : 11;
-            rc_emit<CODE, LITG, TOK>(rc, probs, z.lit, s, off, off, off);
+            rc_emit<CODE, LITG, TOK, PG>(rc, probs, z.lit, z.gp, s, off, off, off);
             return;
         }
         len_base = P_REP_LEN;
@@ -1066,7 +1069,7 @@ __device__ __forceinline__ void encode_symbol_t(RC& rc, uint16_t* probs, Lz& z, 
         z.rep3 = z.rep2; z.rep2 = z.rep1; z.rep1 = z.rep0; z.rep0 = dist;
     }
     if (dir0 == ~0u) dir0 = dir1 = off;
-    rc_emit<CODE, LITG, TOK>(rc, probs, z.lit, s, off, dir0, dir1);
+    rc_emit<CODE, LITG, TOK, PG>(rc, probs, z.lit, z.gp, s, off, dir0, dir1);
 }
 
 // the bytes a literal at global offset g needs, for encode_symbol_t
@@ -1099,8 +1102,8 @@ __device__ __forceinline__ bool change_pair(uint32_t small_dist, uint32_t big_di
 // per CU, what every option set with nice_len <= 128 runs.  WMAX_LONG (nice_len > 128: the extreme presets): matches
 // of 233..273 bytes fit a window and the tail re-parse weighs less -- 13 KiB per wave = 12 waves per CU, which is also
 // what 168 VGPRs per wave (3 per SIMD, a fifth of the scratch spills) allow.
-constexpr uint32_t WMAX_STD = 232;
-constexpr uint32_t WMAX_LONG = 360;
+constexpr uint32_t WMAX_STD = 384;
+constexpr uint32_t WMAX_LONG = 384;
 constexpr uint32_t PRICE_INF = 1u << 30;
 
 #ifdef XZAMD_TIMING
@@ -1261,11 +1264,20 @@ __device__ __forceinline__ void round_lists(const Env& e, ListPre& LP, uint32_t 
 }
 
 // ---- prices (rangecoder/price.h:28-92) ------------------------------------------------------
-__device__ __forceinline__ uint32_t pr_bit(const uint16_t* probs, const uint8_t* ptab, uint32_t idx, uint32_t bit)
+// The non-literal probabilities of a model behind one accessor: `const uint16_t*` (LDS: the single-phase kernels) or GProbs
+// (global memory, u32 each, read past L1 like the literal coders: the parse pieces, whose LDS goes to the DP nodes).
+struct GProbs {
+    uint32_t* p;
+    __device__ __forceinline__ uint32_t operator[](uint32_t i) const { return lit_load(p + i); }
+};
+
+template <class PR>
+__device__ __forceinline__ uint32_t pr_bit(PR probs, const uint8_t* ptab, uint32_t idx, uint32_t bit)
 {
     return ptab[(probs[idx] ^ ((0u - bit) & 0x7FFu)) >> 4];
 }
-__device__ __forceinline__ uint32_t pr_tree(const uint16_t* probs, const uint8_t* ptab, uint32_t base,
+template <class PR>
+__device__ __forceinline__ uint32_t pr_tree(PR probs, const uint8_t* ptab, uint32_t base,
         uint32_t nbits, uint32_t sym)
 {
     uint32_t price = 0;
@@ -1277,7 +1289,8 @@ __device__ __forceinline__ uint32_t pr_tree(const uint16_t* probs, const uint8_t
     } while (sym != 1);
     return price;
 }
-__device__ __forceinline__ uint32_t pr_tree_rev(const uint16_t* probs, const uint8_t* ptab, uint32_t base,
+template <class PR>
+__device__ __forceinline__ uint32_t pr_tree_rev(PR probs, const uint8_t* ptab, uint32_t base,
         uint32_t nbits, uint32_t sym)
 {
     uint32_t price = 0, m = 1;
@@ -1295,7 +1308,8 @@ __device__ __forceinline__ uint32_t pr_tree_rev(const uint16_t* probs, const uin
 struct LenTab { uint32_t lo[4]; uint32_t hi[5]; };
 
 // tmp: 256 words of LDS that are dead while the tables are rebuilt (the parser's node array)
-__device__ __forceinline__ void refresh_len_tables(const uint16_t* probs, const uint8_t* ptab, LenTab& t, uint32_t nps,
+template <class PR>
+__device__ __forceinline__ void refresh_len_tables(PR probs, const uint8_t* ptab, LenTab& t, uint32_t nps,
         uint32_t* tmp)
 {
     const uint32_t lane = threadIdx.x;
@@ -1334,7 +1348,8 @@ __device__ __forceinline__ void refresh_len_tables(const uint16_t* probs, const 
     }
 }
 
-__device__ __forceinline__ void refresh_dist_tables(const uint16_t* probs, const Work& w)
+template <class PR>
+__device__ __forceinline__ void refresh_dist_tables(PR probs, const Work& w)
 {
     const uint32_t lane = threadIdx.x;
 #pragma unroll 1
@@ -1361,7 +1376,8 @@ __device__ __forceinline__ void refresh_dist_tables(const uint16_t* probs, const
     wave_sync();
 }
 
-__device__ __forceinline__ void refresh_align_table(const uint16_t* probs, const Work& w)
+template <class PR>
+__device__ __forceinline__ void refresh_align_table(PR probs, const Work& w)
 {
     const uint32_t lane = threadIdx.x;
     if (lane < 16) w.ap[lane] = (uint16_t)pr_tree_rev(probs, w.ptab, P_DIST_ALIGN, 4, lane);
@@ -1560,9 +1576,9 @@ __device__ __forceinline__ void compound_setup(const RoundL& RL, uint32_t j, uin
 // One window of the optimal parser (oracle: optimum_window).  Returns with the chosen symbol path
 // stored as out-edges: node t -> (n_price[t] = back, out-len in n_info[t]); q_end = last node to code
 // (a window cut by the node limit only commits the symbols that end WTAIL nodes before the cut).
-constexpr uint32_t WTAIL = 16;
-template <uint32_t WMAX>
-__device__ __forceinline__ bool optimum_window(const Env& e, const Work& w, ListPre& P, uint16_t* probs, const Lz& z, LenTab& lt,
+constexpr uint32_t WTAIL = 32;
+template <uint32_t WMAX, class PR>
+__device__ __forceinline__ bool optimum_window(const Env& e, const Work& w, ListPre& P, PR probs, const Lz& z, LenTab& lt,
         const uint8_t* __restrict__ in, uint32_t pos, uint32_t block_start, uint32_t span_end, bool cached,
         RoundL& RL, uint32_t& q_end)
 {
@@ -1957,6 +1973,7 @@ __device__ __forceinline__ void span_encode_one(const xzamd_span_args& a, const 
     z.cnt_len = z.cnt_match = z.cnt_align = 0;
     const uint32_t lit_size = 0x300u << (a.lc + a.lp);       // literal coders of this span (lc + lp <= 4)
     z.lit = a.lit + (uint64_t)span * lit_size;
+    z.gp = nullptr;
     RC rc;
     rc.cpos = 0; rc.out = outp; rc.reset();
 
@@ -2281,7 +2298,7 @@ __device__ __forceinline__ void span_encode_one(const xzamd_span_args& a, const 
 // of equally long spans and fewer resident wavefronts can be asked for (leaving room for other streams).
 template <int FINDER, bool OPT, uint32_t WMAX = WMAX_STD>
 __global__ __launch_bounds__(64)
-__attribute__((amdgpu_waves_per_eu(OPT ? (WMAX > WMAX_STD ? 3 : XZAMD_WAVES_OPT) : XZAMD_WAVES_FAST, OPT ? (WMAX > WMAX_STD ? 3 : XZAMD_WAVES_OPT) : XZAMD_WAVES_FAST)))
+__attribute__((amdgpu_waves_per_eu(OPT ? 2 : XZAMD_WAVES_FAST, OPT ? 2 : XZAMD_WAVES_FAST)))      // OPT: the single-phase optimal kernel keeps its model in LDS (14 KiB per wave); a test mode
 void k_span_encode_t(xzamd_span_args a, uint32_t nspans, uint32_t* __restrict__ counter)
 {
     for (;;) {
@@ -2314,16 +2331,18 @@ void k_span_encode_t(xzamd_span_args a, uint32_t nspans, uint32_t* __restrict__ 
 template <uint32_t WMAX>
 __device__ __forceinline__ void parse_piece_one(const xzamd_span_args& a, const uint32_t span)
 {
-    constexpr uint32_t W_PROBS = XZAMD_PRIOR_WORDS;                      // 1856 x u16 >= P_LITERAL (1846): all but the literal coders
+    // LDS per wavefront: the DP nodes and the price tables -- 10,176 bytes at WMAX = 384 -> 16 wavefronts per CU.  The
+    // probabilities of the piece's price model live in global memory (a.prior / a.lit, one slot per piece, L2-resident
+    // while the piece runs): a parser window reads them once (bit-price table, length / distance tables on refresh), a
+    // recorded symbol gathers and scatters <= 48 of them -- the 3.7 KiB they took in LDS buy 152 more nodes per window.
     constexpr uint32_t W_NODES = 6 * (WMAX + 1) + 2;                     // reps[4], price, info (16-byte multiple)
     constexpr uint32_t W_TABS = 128 + 72 + 32;                           // dsp, xt + ap (u16), ptab (u8)
-    __shared__ __attribute__((aligned(16))) uint32_t pool[W_PROBS + W_NODES + W_TABS];
+    __shared__ __attribute__((aligned(16))) uint32_t pool[W_NODES + W_TABS];
 #ifdef XZAMD_TIMING
     __shared__ unsigned long long tm_lds[16];
     if (threadIdx.x < 16) tm_lds[threadIdx.x] = 0;
     const uint64_t tm_start = __builtin_amdgcn_s_memtime();
 #endif
-    uint16_t* const probs = reinterpret_cast<uint16_t*>(pool);
     const uint32_t lane = threadIdx.x;
     const uint32_t blk = span / a.max_spb;
     const uint32_t k = span - blk * a.max_spb;
@@ -2353,7 +2372,7 @@ __device__ __forceinline__ void parse_piece_one(const xzamd_span_args& a, const 
     w.tm = tm_lds;
 #endif
     {
-        uint32_t* nb = pool + W_PROBS;
+        uint32_t* nb = pool;
         w.n_reps4 = reinterpret_cast<uint4*>(nb);
         w.n_price = nb + 4 * (WMAX + 1);
         w.n_info = nb + 5 * (WMAX + 1);
@@ -2381,21 +2400,24 @@ __device__ __forceinline__ void parse_piece_one(const xzamd_span_args& a, const 
     z.cnt_len = z.cnt_match = z.cnt_align = 0;
     const uint32_t lit_size = 0x300u << (a.lc + a.lp);
     z.lit = a.lit + (uint64_t)span * lit_size;
+    z.gp = a.prior + (uint64_t)span * XZAMD_PRIOR_WORDS;
     z.state = 0; z.rep0 = z.rep1 = z.rep2 = z.rep3 = 0;
     RC rc;                                              // never codes: encode_symbol_t<false, .> only adapts the model
     rc.cpos = 0; rc.out = nullptr; rc.reset();
+    const GProbs probs{z.gp};
+    uint16_t* const no_lds = nullptr;                   // encode_symbol_t<.., PG = true> never touches its LDS argument
 
-    // price model: flat for the seed piece (slot 0 of the Block), else the model the seed left
+    // price model: flat for the seed piece (slot 0 of the Block), else the model the seed left in ITS slot
     {
-        uint32_t* p32 = reinterpret_cast<uint32_t*>(probs);
+        uint4* g4 = reinterpret_cast<uint4*>(z.gp);
         uint4* l4 = reinterpret_cast<uint4*>(z.lit);
         if (k == 0) {
-            for (uint32_t i = lane; i < W_PROBS; i += 64) p32[i] = 0x04000400u;
             const uint4 v = make_uint4(1024u, 1024u, 1024u, 1024u);
+            for (uint32_t i = lane; i < XZAMD_PRIOR_WORDS / 4; i += 64) g4[i] = v;
             for (uint32_t i = lane; i < lit_size / 4; i += 64) l4[i] = v;
         } else {
-            const uint32_t* pr = a.prior + (uint64_t)blk * XZAMD_PRIOR_WORDS;
-            for (uint32_t i = lane; i < W_PROBS; i += 64) p32[i] = pr[i];
+            const uint4* p4 = reinterpret_cast<const uint4*>(a.prior + (uint64_t)blk * a.max_spb * XZAMD_PRIOR_WORDS);
+            for (uint32_t i = lane; i < XZAMD_PRIOR_WORDS / 4; i += 64) g4[i] = p4[i];
             const uint4* s4 = reinterpret_cast<const uint4*>(a.lit + (uint64_t)blk * a.max_spb * lit_size);
             for (uint32_t i = lane; i < lit_size / 4; i += 64) l4[i] = s4[i];
         }
@@ -2446,13 +2468,13 @@ __device__ __forceinline__ void parse_piece_one(const xzamd_span_args& a, const 
                 const uint32_t bl = dist ? 32u - (uint32_t)__builtin_clz(dist) : 0u;         // bit length of the distance
                 if (len >= 2 && (14 + bl < 6 * len || dist == z.rep0)) {
                     const bool rep = dist == z.rep0;
-                    encode_symbol_t<false, true>(rc, probs, z, x - block_start, rep ? 0u : dist + 4, len, 0u);
+                    encode_symbol_t<false, true, false, true>(rc, no_lds, z, x - block_start, rep ? 0u : dist + 4, len, 0u);
                     i += len;
                     if (!rep && i < rowlen) tm = in[max(px, x0 + i) - z.rep0 - 1];   // rep0 changed: the match bytes of the rest of the row
                                                                                      // (lanes behind the walk would reach in front of the Block)
                 } else {
                     const uint32_t l3 = lane_of(tc, i) | (lane_of(tp, i) << 8) | (lane_of(tm, i) << 16);
-                    encode_symbol_t<false, true>(rc, probs, z, x - block_start, LITERAL, 1, l3);
+                    encode_symbol_t<false, true, false, true>(rc, no_lds, z, x - block_start, LITERAL, 1, l3);
                     i += 1;
                 }
             }
@@ -2474,7 +2496,7 @@ __device__ __forceinline__ void parse_piece_one(const xzamd_span_args& a, const 
         // encode_init (lzma_encoder.c:267-293): the first byte of a Block is a literal in the initial contexts
         const uint32_t l3 = literal_bytes(in, block_start, 0, z);
         if (lane == 0) { a.sym_len[block_start] = 0; a.sym_dist[block_start] = l3; }
-        encode_symbol_t<false, true>(rc, probs, z, 0, LITERAL, 1, l3);
+        encode_symbol_t<false, true, false, true>(rc, no_lds, z, 0, LITERAL, 1, l3);
         cur = block_start + 1;
     }
     for (;;) {
@@ -2488,6 +2510,7 @@ __device__ __forceinline__ void parse_piece_one(const xzamd_span_args& a, const 
         }
         uint32_t back = LITERAL, len = 1;
         if (q_pos == q_end) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the model updates of the symbols so far: the prices read them
             TM_BEGIN(t_refresh);
             if (!tables_valid || z.cnt_len >= 64) { refresh_len_tables(probs, w.ptab, lt, 1u << z.pb, reinterpret_cast<uint32_t*>(w.n_reps4)); z.cnt_len = 0; }
             if (!tables_valid || z.cnt_match >= 128) { refresh_dist_tables(probs, w); z.cnt_match = 0; }
@@ -2550,7 +2573,7 @@ __device__ __forceinline__ void parse_piece_one(const xzamd_span_args& a, const 
         }
         {
             TM_BEGIN(t_sym);
-            encode_symbol_t<false, true>(rc, probs, z, cur - block_start, back, len, l3);
+            encode_symbol_t<false, true, false, true>(rc, no_lds, z, cur - block_start, back, len, l3);
             TM_END(w, 6, t_sym);
             TM_COUNT(w, 10);
         }
@@ -2565,14 +2588,8 @@ __device__ __forceinline__ void parse_piece_one(const xzamd_span_args& a, const 
         }
         cur += len;
     }
-    if (k == 0) {
-        // the seed piece leaves the prior of the Block: the LDS part here, the literal part is this slot's `lit`
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        wave_sync();
-        uint32_t* pr = a.prior + (uint64_t)blk * XZAMD_PRIOR_WORDS;
-        const uint32_t* p32 = reinterpret_cast<const uint32_t*>(probs);
-        for (uint32_t i = lane; i < W_PROBS; i += 64) pr[i] = p32[i];
-    }
+    // (the seed piece leaves the prior of the Block where it is: its own slot of a.prior / a.lit)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #ifdef XZAMD_TIMING
     if (lane == 0 && a.err) {
         tm_lds[8] = __builtin_amdgcn_s_memtime() - tm_start;
@@ -2658,6 +2675,7 @@ __global__ __launch_bounds__(64) void k_model_syms(xzamd_span_args a, uint32_t n
     z.lc = a.lc; z.lp = a.lp; z.pb = a.pb;
     z.cnt_len = z.cnt_match = z.cnt_align = 0;
     z.lit = nullptr;
+    z.gp = nullptr;
     z.state = 0; z.rep0 = z.rep1 = z.rep2 = z.rep3 = 0;
     RC rc;
     rc.cpos = 0; rc.out = nullptr; rc.reset();

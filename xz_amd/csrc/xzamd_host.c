@@ -1247,7 +1247,7 @@ int xzamd_encode_device_(xzamd_ctx *c,
 		if (two) {
 			GROW(sym_len[par], 2ull * n + 64, 0);
 			GROW(sym_dist[par], 4ull * n + 64, 0);
-			GROW(prior, 4ull * XZAMD_PRIOR_WORDS * nb, 0);
+			GROW(prior, 4ull * XZAMD_PRIOR_WORDS * nspans, 0);
 			GROW(enc_tab[par], 8ull * nenc, 0);
 			GROW(enc_cnt[par], 4ull * nb, 0);
 			GROW(h_enc_tab[par], 8ull * nenc, 1);
