@@ -492,7 +492,7 @@ def params_for_gpu_options(opts, span_size=None, span_cost_used=None):
         p.enc_bits = opts.enc_span_bits                # != 0: two-phase (parse pieces + encode spans)
         return p
     if sp in (0, 1):
-        sp = 131072 if opts.gpu_parser else 65536    # xzamd_host.c DEFAULT_SPAN_OPT / DEFAULT_SPAN
+        sp = 131072 if opts.gpu_parser else 262144 if opts.dict_size >= (1 << 20) else 65536    # xzamd_host.c DEFAULT_SPAN_OPT / _FAST_BIG / DEFAULT_SPAN
     p.span_size = 0 if sp == 0xFFFFFFFF else sp
     return p
 

@@ -405,7 +405,9 @@ def test_full_size_blocks_identical_to_oracle(enc):
             assert rr == 1 and rdec == data, name
 
 
-SIZE_TOLERANCE = 0.025
+SIZE_TOLERANCE = 0.0225     # presets 4-9, full Blocks: measured max +2.10 % (zero pages with islands of random words, preset 6);
+                            # every other class <= +1.46 % at preset 6 and <= +1.31 % at 9e (round 5)
+SIZE_TOLERANCE_FAST = 0.01  # presets 1-3, default spans (256 KiB state-reset spans): measured max +0.72 % (HTML rows)
 
 
 def _tolerance_cases(preset):
@@ -453,7 +455,7 @@ def _tolerance_cases(preset):
 
 @pytest.mark.parametrize("preset", [6, 9 | 0x80000000])
 def test_size_within_tolerance_of_reference(enc, preset):
-    """Stated tolerance (README/DESIGN): at the same preset and Block size the device output is at most 3 %
+    """Stated tolerance (README/DESIGN): at the same preset and Block size the device output is at most SIZE_TOLERANCE
     larger than the REAL liblzma's (oracle/_ref), on FULL Blocks (24 MiB at -6) of every corpus class."""
     import concurrent.futures as cf
     import xz_amd
@@ -474,6 +476,38 @@ def test_size_within_tolerance_of_reference(enc, preset):
     print("size vs liblzma, preset", hex(preset), report)
     over = {k: v for k, v in report.items() if v > 100.0 * SIZE_TOLERANCE}
     assert not over, (hex(preset), report)
+
+
+@pytest.mark.parametrize("preset", [1, 3])
+def test_size_within_tolerance_of_reference_fast_presets(enc, preset):
+    """Presets 1-3 in PRODUCT mode (default spans: 256 KiB state-reset spans; one span per Block is byte-identical to
+    liblzma and pinned elsewhere): output within 1 % of liblzma's on full Blocks of the text-like classes where a reset
+    costs the most (round-4 review: HTML rows +2.82 % with 64 KiB spans) and on binary / numeric data."""
+    import concurrent.futures as cf
+    import xz_amd
+    import _corpora
+    from test_oracle_encoder import _elf_mix
+    if not o.have_ref():
+        pytest.skip("oracle/_ref not built")
+    opts = xz_amd.preset_options(preset)
+    bs = xz_amd.mt_block_size(opts)
+    n = 2 * bs
+    cases = {"bench_text": xz_amd.corpus_text(n, seed=1000).tobytes(), "lorem": o.corpus_lorem(n), "html": _corpora.html_rows(n),
+             "logs": _corpora.logs(n), "f32sine": _corpora.f32_sine(n), "csv": _corpora.csv_sensors(n)}
+    elf = _elf_mix(n)
+    if len(elf) == n:
+        cases["elf"] = elf
+    report = {}
+    with cf.ThreadPoolExecutor(max_workers=len(cases)) as pool:
+        refs = {name: pool.submit(o.ref_encode_mt, data, preset, 2, bs) for name, data in cases.items()}
+        for name, data in cases.items():
+            got, _ = gpu_encode(enc, data, opts, bs)
+            rr, dec = o.ref_decode(got, len(data) + 16)
+            assert rr == 1 and dec == data, ("liblzma decoder", name)
+            report[name] = round(100.0 * (len(got) / len(refs[name].result()) - 1), 2)
+    print("size vs liblzma, preset", preset, report)
+    over = {k: v for k, v in report.items() if v > 100.0 * SIZE_TOLERANCE_FAST}
+    assert not over, (preset, report)
 
 
 @pytest.mark.parametrize("preset", [0, 1, 3])
