@@ -179,6 +179,10 @@ typedef struct {
 	float ms_parse;              /* two-phase: every other piece */
 	float ms_code;               /* two-phase: k_encode_syms */
 } xzamd_stats;
+/* Stats of the last xzamd_stream_encode_device call of the context.  Under the lzma_* front end consecutive jobs of a
+ * worker are pipelined (the back end of a job's last batch finishes underneath the next job's front end): there the stage
+ * times, blocks, spans and batches of that carried batch are booked to the call that finishes it, i.e. the figures are
+ * running per-context totals shifted by one batch, not per-job figures. */
 void xzamd_get_stats(const xzamd_ctx *ctx, xzamd_stats *out);
 
 /* Encode in_size bytes resident in device memory (d_in) into a complete,

@@ -1044,6 +1044,22 @@ int xzamd_encode_finish_(xzamd_ctx *c, uint64_t *out_size)
 	return c->pend_rc;
 }
 
+/* Device work buffers per input byte of a batch: what the batch planner budgets with and what
+ * lzma_stream_encoder_mt_memusage reports -- one expression for both (round-4 advisor: the two had drifted apart). */
+double xzamd_work_bytes_per_byte_(const xzamd_lzma_options *opt)
+{
+	const int list_packed = opt->gpu_parser && opt->dict_size <= (1u << 23);
+	const int two_ = opt->gpu_parser && opt->gpu_sa_window && opt->span_cost != 0 && opt->enc_span_bits != 0
+			&& (opt->span_size == XZAMD_SPAN_DEFAULT || opt->span_size == XZAMD_SPAN_AUTO);
+	double per_byte = 16.0 + 8.0 + 1.2 + 0.5;                        /* sort buffers, two link arrays, scratch, tables */
+	if (opt->gpu_sa_window) per_byte += 4.0 + 16.0 + 8.0 + 16.0 + 8.0;   /* prev4, rp8/16, prev24/32, key64, sa + rank */
+	else per_byte += 8.0;                                            /* rank, sorted_pos */
+	if (opt->gpu_parser) per_byte += 32.0 + 2.0 + (list_packed ? 0.0 : 16.0);
+	if (two_) per_byte += 12.0 + 2.0 * XZAMD_TOK_PER_BYTE + 0.3;     /* recorded parse x 2, tokens, piece models in L2 */
+	if (opt->bcj) per_byte += opt->bcj2 ? 3.0 : 2.0;
+	return per_byte;
+}
+
 int xzamd_stream_encode_device(xzamd_ctx *c,
 		const void *d_in_, uint64_t in_size, uint64_t block_size,
 		const xzamd_lzma_options *opt, int check, uint32_t flags,
@@ -1126,12 +1142,8 @@ int xzamd_encode_device_(xzamd_ctx *c,
 	{
 		const int two_ = opt->gpu_parser && opt->gpu_sa_window && opt->span_cost != 0 && opt->enc_span_bits != 0
 				&& (opt->span_size == XZAMD_SPAN_DEFAULT || opt->span_size == XZAMD_SPAN_AUTO);
-		double per_byte = 16.0 + 8.0 + 1.2 + 0.5;                        /* sort buffers, two link arrays, scratch, tables */
-		if (opt->gpu_sa_window) per_byte += 4.0 + 16.0 + 8.0 + 16.0 + 8.0;   /* prev4, rp8/16, prev24/32, key64, sa + rank */
-		else per_byte += 8.0;                                            /* rank, sorted_pos */
-		if (opt->gpu_parser) per_byte += 32.0 + 2.0 + (list_packed ? 0.0 : 16.0);
-		if (two_) per_byte += 12.0 + 2.0 * XZAMD_TOK_PER_BYTE;
-		if (opt->bcj) per_byte += opt->bcj2 ? 3.0 : 2.0;
+		const double per_byte = xzamd_work_bytes_per_byte_(opt);
+		(void)two_;
 		uint64_t free_b = 0, total_b = 0, held = 0;
 		if (xzk_mem_info(&free_b, &total_b) == 0 && total_b != 0) {
 			dbuf *d[64];
@@ -1168,10 +1180,9 @@ int xzamd_encode_device_(xzamd_ctx *c,
 	const int defer = deferred != NULL && overlap_ok && (flags & XZAMD_F_BLOCKS_ONLY) && total_blocks > 0;
 	/* a batch carried over from the previous call: it can only be finished underneath this call's front end when this call
 	 * runs the same two-stream scheme on the same streams; else it is finished first */
-	if (c->pend.active && !(overlap_ok && c->pend.J.st == st)) {
-		int r = pend_complete(c);
-		if (r != XZAMD_OK) return r;
-	}
+	if (c->pend.active && !(overlap_ok && c->pend.J.st == st))
+		(void)pend_complete(c);      /* its result (good or bad) belongs to the deferred call: xzamd_encode_finish_ hands it out;
+		                              * nothing of THIS call has failed (round-4 advisor) */
 	const int pipelined = overlap_ok && (total_blocks > max_blocks || defer || c->pend.active);
 
 	job_env J;
@@ -1455,6 +1466,9 @@ int xzamd_encode_device_(xzamd_ctx *c,
 				xzk_event_record(ev[EV_PARSE], st);
 			} else {
 				e = xzk_span_encode(&a, nspans, c->span_waves, (uint32_t *)c->errw.p + 60, st);
+				/* single phase: the span kernel parses AND codes; its end is this batch's EV_PARSE for lzma_get_progress (a stage
+				 * event that is not recorded for a batch would query as complete: the figure jumped to 90 % at the finder's end) */
+				xzk_event_record(ev[EV_PARSE], st);
 			}
 			if (e) { rc = fail(c, XZAMD_DEVICE_ERROR, "span_encode launch", e); goto done; }
 			e = xzk_d2h(c->h_err[par].p, c->errw.p, 512, st);
@@ -1465,8 +1479,9 @@ int xzamd_encode_device_(xzamd_ctx *c,
 		/* ================= back end ================= */
 		/* the previous batch's sizes, layout and gather: its coder has had the whole front end above to finish */
 		if (pipelined && c->pend.active) {
-			rc = pend_complete(c);              /* the last batch of the previous (deferred) call */
-			if (rc != XZAMD_OK) goto done;
+			/* the last batch of the previous (deferred) call; a failure there is that call's (pend_rc, handed out by
+			 * xzamd_encode_finish_), pend_complete has drained the second stream, this call goes on */
+			(void)pend_complete(c);
 		} else if (pipelined && prev.active) {
 			rc = back_finish_own(c, &J, &prev);
 			if (rc != XZAMD_OK) goto done;
@@ -1519,10 +1534,8 @@ retry_smaller:
 		/* The buffers grown so far have full-batch capacity: a retry that kept them would fight for what is left.
 		 * Nothing of this batch has been launched; an earlier batch may still be in its back end: finish it, then
 		 * release every per-batch device buffer and let the smaller geometry allocate afresh. */
-		if (c->pend.active) {
-			rc = pend_complete(c);
-			if (rc != XZAMD_OK) goto done;
-		}
+		if (c->pend.active)
+			(void)pend_complete(c);          /* (its result is the deferred call's) */
 		if (prev.active) {
 			rc = back_finish_own(c, &J, &prev);
 			if (rc != XZAMD_OK) goto done;
@@ -1538,7 +1551,7 @@ retry_smaller:
 		}
 	}
 	if (rc == XZAMD_OK && c->pend.active)
-		rc = pend_complete(c);       /* (a call without a batch of its own) */
+		(void)pend_complete(c);      /* (a call without a batch of its own) */
 	if (rc == XZAMD_OK && prev.active) {
 		if (defer) {
 			/* the back end of the last batch is in flight on the second stream: whoever comes next finishes it */

@@ -18,4 +18,5 @@ int xzamd_encode_finish_(xzamd_ctx *c, uint64_t *out_size);
 int xzamd_stored_blocks_host_(const uint8_t *in, uint64_t n, uint64_t block_size, int check,
 		uint8_t *out, uint64_t out_cap, uint64_t *out_size, xzamd_block_info *binfo, uint64_t binfo_cap, uint64_t *nblocks);
 
+double xzamd_work_bytes_per_byte_(const xzamd_lzma_options *opt);   /* device work buffers per input byte of a batch */
 #endif

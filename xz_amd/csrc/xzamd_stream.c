@@ -725,13 +725,18 @@ uint64_t lzma_stream_encoder_mt_memusage(const lzma_mt *options)
 	uint64_t maxb = JOB_BYTES / bs;
 	if (maxb == 0) maxb = 1;
 	const uint64_t stage = maxb * bs;
-	/* host: staging + output queue; device: input + output, 32 B/byte of sort buffers and chain tables
-	 * (64 with the suffix-order build), span scratch, and for the optimal parser the match lists
-	 * (2 x 32 B/byte packed, 2 x 48 B/byte for dictionaries above 8 MiB) */
-	uint64_t per_byte = 2 + 2 + (opt.gpu_sa_window ? 64 : 32) + 2;
-	if (opt.gpu_parser)
-		per_byte += opt.dict_size <= (1u << 23) ? 64 : 96;
-	return stage * per_byte;
+	/* Per GPU (= per worker; the reference: per thread): the device work buffers of a batch -- the same expression the batch
+	 * planner budgets with -- plus the two device in / out sets of consecutive jobs; on the host `2 x GPUs + 1` pinned job
+	 * slots of (staging + output bound) each.  GPUs = min(options->threads, visible devices), 1 when none can be counted. */
+	int ndev = 1;
+	if (xzk_device_count(&ndev) || ndev <= 0) ndev = 1;
+	if ((uint32_t)ndev > options->threads) ndev = (int)options->threads;
+	if (ndev > MAX_DEVS) ndev = MAX_DEVS;
+	const uint64_t bound = stage + stage / 64 + 65536;               /* ~ maxb x lzma_block_buffer_bound */
+	const double dev = (double)stage * xzamd_work_bytes_per_byte_(&opt) + 2.0 * (double)(stage + bound);
+	const double host = (double)(2 * ndev + 1) * (double)(stage + bound);
+	const double total = dev * ndev + host;
+	return total >= 1.8e19 ? UINT64_MAX - 1 : (uint64_t)total;
 }
 
 uint64_t lzma_mt_block_size(const lzma_filter *filters)
