@@ -65,3 +65,22 @@ def test_encode_blocks_only_and_gather_world2(preset, nbytes):
     if o.have_ref():
         rr, rdec = o.ref_decode(got, len(data) + 16)
         assert rr == 1 and rdec == data
+
+
+def test_bench_two_ranks_oversubscribed():
+    """`bench.py --gpus 2` end to end on this 1-GPU box (XZAMD_BENCH_OVERSUBSCRIBE=1: both ranks on GPU 0, gather over gloo):
+    the launch path the driver uses for its N-GPU runs -- torch.distributed.run, one process per rank, Blocks sharded, the
+    gather inside the timed region, max over ranks, ONE JSON line from rank 0."""
+    import json
+    import subprocess
+    env = dict(os.environ, XZAMD_BENCH_OVERSUBSCRIBE="1")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--size-mib", "256", "--steps", "1",
+                        "--warmup", "1", "--no-ratio", "--no-cpu-baseline", "--no-host-to-host"],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 1 and d["value"] > 0 and d["scaling"] == "strong"
+    assert d["other_scaling"]["scaling"] == "weak" and d["other_scaling"]["value"] > 0
+    assert "roofline" in d and d["config"]["world_size"] == 2

@@ -1261,6 +1261,15 @@ def test_lzma_code_worker_pipeline_timeout_barrier_and_filters_update(monkeypatc
     L.xzamd_release_parked()
     assert two == small and three == small
     monkeypatch.delenv("XZAMD_BATCH_MIB")
+    # several GPUs under LZMA_RUN (how `xz` feeds): jobs no larger than (input seen so far) / GPUs, so that every worker gets
+    # work before the end of the input is known -- here with the 256 MiB floor turned down to 1 MiB: jobs of 1, 1, 1, 2, ... MiB
+    monkeypatch.setenv("XZAMD_TEST_WORKERS", "2")
+    monkeypatch.setenv("XZAMD_TEST_JOB_MIN_MIB", "1")
+    grow, _ = run(0, 300000)
+    monkeypatch.delenv("XZAMD_TEST_WORKERS")
+    monkeypatch.delenv("XZAMD_TEST_JOB_MIN_MIB")
+    L.xzamd_release_parked()
+    assert grow == small
     big, _ = run(0, len(data))
     assert small == big and timed == big
     r, dec, nb = o.orc_xz_decode(big, len(data) + 16)

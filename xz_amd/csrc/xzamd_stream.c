@@ -109,6 +109,7 @@ struct lzma_internal_s {
 	uint64_t stage_max;
 	/* workers */
 	devslot dev[MAX_DEVS]; int ndev;
+	uint64_t seen_in;             /* input bytes staged since the stream was initialised (sizes the jobs of several GPUs) */
 	job jobs[MAX_JOBS]; int njobs;
 	int fill;                    /* job being filled by the calling thread, -1 = none */
 	int ndone;                   /* jobs in J_DONE (written under mu, read without it by the calling thread: a stale 0 only
@@ -639,6 +640,7 @@ lzma_ret lzma_stream_encoder_mt(lzma_stream *strm, const lzma_mt *options)
 	in->sequence = ISEQ_RUN;
 	in->sseq = SEQ_HEADER;
 	in->fill = -1;
+	in->seen_in = 0;
 	/* one worker per visible GPU, the current device first; never more workers than lzma_mt.threads
 	 * (XZAMD_DEVICES=n caps it further) */
 	int ndev = ndev_all;
@@ -913,6 +915,22 @@ static lzma_ret stream_code(lzma_internal *in, const uint8_t *inb, size_t *in_po
 				 * is done, common.c:253-281): the rest is dealt in EVEN jobs, so that the last one is not a sliver that
 				 * cannot fill the GPU (4 GiB at 24 MiB Blocks: 35+34+34+34+34 Blocks instead of 42+42+42+42+3). */
 				uint64_t job_max = in->stage_max;
+				if (action == LZMA_RUN && in->ndev > 1) {
+					/* Several GPUs and the end of the input unknown (how `xz` feeds: 8 KiB at a time, LZMA_RUN until EOF): full
+					 * 1.25 GiB jobs dealt in order would keep 4 of 8 workers busy on a 4 GiB file.  A job is therefore no larger
+					 * than the input seen so far divided by the GPUs, at least 256 MiB, in whole Blocks -- the jobs grow with the
+					 * input (the reference hands a Block to every thread as soon as it is full, stream_encoder_mt.c:599-665). */
+					uint64_t cap = in->seen_in / (uint64_t)in->ndev;
+					uint64_t floor_b = 256ull << 20;
+					{
+						const char *e = getenv("XZAMD_TEST_JOB_MIN_MIB");      /* test knob: reach the growing-jobs path on small inputs */
+						if (e && atoi(e) > 0) floor_b = (uint64_t)atoi(e) << 20;
+					}
+					if (cap < floor_b) cap = floor_b;
+					cap = (cap / in->block_size) * in->block_size;
+					if (cap < in->block_size) cap = in->block_size;
+					if (cap < job_max) job_max = cap;
+				}
 				if (action != LZMA_RUN) {
 					const uint64_t rem = (in_size - *in_pos) + j->stage_len;
 					const uint64_t nbr = (rem + in->block_size - 1) / in->block_size;
@@ -950,6 +968,7 @@ static lzma_ret stream_code(lzma_internal *in, const uint8_t *inb, size_t *in_po
 				memcpy(j->stage + j->stage_len, inb + *in_pos, take);
 				j->stage_len += take;
 				*in_pos += take;
+				in->seen_in += take;
 				if (j->stage_len == job_max)
 					queue_fill_job(in);
 			}

@@ -70,8 +70,10 @@ def gather_stream(blocks, binfo, check, dst=0, group=None):
     total = 12 + sum(sizes) + len(tail)
     out = torch.empty(total, dtype=torch.uint8, device=dev)
     out[:12] = torch.from_numpy(frame_header(check)).to(dev)
-    # every peer's Blocks land straight in their place of the Stream: all receives are posted up front (one per peer
-    # link of the xGMI mesh), then waited for together
+    # all receives are posted up front (one per peer link of the xGMI mesh), then waited for together.  Each lands in a
+    # staging tensor of its own -- allocator-aligned, whereas a peer's place in the Stream starts at an arbitrary multiple of
+    # four bytes, which RCCL's send/recv kernels handle with narrow accesses at best -- and is copied into place on the device
+    # (a device-to-device copy at HBM rate: nothing next to the link rate)
     off = 12
     pending = []
     for r in range(world):
@@ -80,9 +82,11 @@ def gather_stream(blocks, binfo, check, dst=0, group=None):
         if r == rank:
             out[off:off + sizes[r]] = blocks
         else:
-            pending.append(dist.irecv(out[off:off + sizes[r]], src=r, group=group))
+            stage = torch.empty(sizes[r], dtype=torch.uint8, device=dev)
+            pending.append((dist.irecv(stage, src=r, group=group), stage, off))
         off += sizes[r]
     out[off:] = torch.from_numpy(tail.copy()).to(dev)
-    for req in pending:
+    for req, stage, at in pending:
         req.wait()
+        out[at:at + stage.numel()].copy_(stage)
     return out
