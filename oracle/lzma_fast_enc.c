@@ -1646,7 +1646,7 @@ static void parse_piece(enc *e, uint32_t start, uint32_t end, int first_in_block
 		 * seen -- are walked greedily first: at every symbol boundary the LONGEST entry of the position's match-list
 		 * record is taken when it is cheap by a fixed rule (14 + bit length of the distance < 6 bits per byte covered, or
 		 * it repeats rep0), else a literal; every symbol adapts the model exactly as a coded one would, nothing is
-		 * recorded.  No dynamic program, no prices: ~1 % of a piece's parser steps on literal-heavy data, less elsewhere. */
+		 * recorded.  No dynamic program: ~1 % of a piece's parser steps on literal-heavy data, less elsewhere. */
 		orc_trace *const tr = e->trace;
 		e->trace = NULL;
 		const uint32_t w1 = start - ORC_PREROLL;
@@ -1659,7 +1659,32 @@ static void parse_piece(enc *e, uint32_t start, uint32_t end, int first_in_block
 			uint32_t bl = 0;
 			while (dist >> bl) ++bl;
 			if (len >= 2 && (14 + bl < 6 * len || dist == e->reps[0])) {
-				enc_symbol(e, x, dist == e->reps[0] ? 0 : dist + 4, len);
+				/* HOW the taken symbol is coded -- as a rep when its distance is one of the four rep distances, or as a
+				 * match all the same -- is decided by the current prices, as the optimal parser decides it: data made of
+				 * fixed-size records (relocation tables: "distance 24" thousands of times in a row) has two
+				 * self-reinforcing ways to code the same copy, and a walk that always said "rep0" trained the piece's
+				 * model into the other equilibrium than the one the parser (and so the coder's continuous model) lives
+				 * in: +6.2 % vs liblzma on an ELF .rela.dyn section, +2.1 % with this rule (round 5). */
+				uint32_t back = dist + 4;
+				int ri = -1;
+				for (int i = 0; i < 4; ++i)
+					if (dist == e->reps[i]) { ri = i; break; }
+				if (ri >= 0) {
+					const uint32_t ps = x & ((1u << e->prm.pb) - 1), st = e->state;
+					uint32_t prep = pr_bit(e, P_IS_REP + st, 1);
+					if (ri == 0)
+						prep += pr_bit(e, P_IS_REP0 + st, 0) + pr_bit(e, P_IS_REP0_LONG + st * 16 + ps, 1);
+					else {
+						prep += pr_bit(e, P_IS_REP0 + st, 1);
+						if (ri == 1) prep += pr_bit(e, P_IS_REP1 + st, 0);
+						else prep += pr_bit(e, P_IS_REP1 + st, 1) + pr_bit(e, P_IS_REP2 + st, (uint32_t)ri - 2);
+					}
+					prep += pr_len(e, P_REP_LEN, ps, len);
+					const uint32_t pm = pr_bit(e, P_IS_REP + st, 0) + pr_len(e, P_MATCH_LEN, ps, len)
+							+ pr_dist(e, dist, len < 6 ? len - 2 : 3);
+					if (prep <= pm) back = (uint32_t)ri;
+				}
+				enc_symbol(e, x, back, len);
 				x += len;
 			} else {
 				enc_symbol(e, x, LIT, 1);
@@ -1706,7 +1731,12 @@ static void parse_piece(enc *e, uint32_t start, uint32_t end, int first_in_block
 		++e->q_head;
 		if (back == LIT) record_literal(e, cur, cur == start);
 		else {
-			e->sy_len[cur] = (uint16_t)len;
+			/* bit 15: the parser chose a MATCH (not a rep).  The coder then codes a match even when the distance is one of
+			 * its rep distances -- legal LZMA, and what the single-phase encoder and liblzma do when the match path is the
+			 * cheaper one under the adapted model (relocation tables: "match, distance 24" thousands of times in a row).
+			 * Round 4's coder turned every such match into a rep: other probabilities than the parser had priced and a rep
+			 * stack that drifted away from the parser's -- +8.5 % vs liblzma on an ELF .rela.dyn section (round 5). */
+			e->sy_len[cur] = (uint16_t)(len | (back >= 4 ? 0x8000u : 0u));
 			e->sy_dist[cur] = back < 4 ? e->reps[back] : back - 4;
 		}
 		enc_symbol(e, cur, back, len);
@@ -1791,9 +1821,12 @@ static int encode_syms(enc *e, uint32_t start, uint32_t end, int first_in_block,
 			if (e->ntok + 64u > tok_cap) { tok_full = 1; break; }
 			uint32_t len = e->sy_len[cur];
 			const uint32_t d = e->sy_dist[cur];
+			const uint32_t as_match = len >> 15;            /* the parser's choice: a match, whatever the coder's reps are */
+			len &= 0x7FFFu;
 			uint32_t back;
 			e->lit_rec = 0;
 			if (len == 0) { back = LIT; len = 1; e->lit_rec = d | (1u << 31); }
+			else if (as_match) back = d + 4;
 			else if (len == 1) back = d == e->reps[0] ? 0 : LIT;
 			else if (d == e->reps[0]) back = 0;
 			else if (d == e->reps[1]) back = 1;

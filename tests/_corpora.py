@@ -225,7 +225,33 @@ def pcm16_stereo(n, seed=108):
     return np.stack([left, right], axis=1).tobytes()[:n]
 
 
+def reloc_table(n, seed=109):
+    """An ELF .rela.dyn-like table: 24-byte records {r_offset, r_info, r_addend} (little-endian u64 each): offsets that grow by 8
+    with occasional jumps, R_X86_64_RELATIVE almost always (a few GLOB_DAT / 64 with a symbol index), addends that wander
+    through a text segment.  Fixed-size records = "distance 24" thousands of times in a row: the class where a model that
+    has learnt "rep0" and one that has learnt "match, distance 24" are both stable (round 5: +8.5 % vs liblzma on the real
+    section of libMIOpen.so before the coder kept the parser's rep / match choice)."""
+    np = _np()
+    rng = np.random.default_rng(seed)
+    m = n // 24 + 1
+    step = np.where(rng.random(m) < 0.97, 8, rng.integers(16, 4096, m) & ~7)
+    off = 0x3E4E3A50 + np.cumsum(step)
+    kind = rng.random(m)
+    info = np.where(kind < 0.96, 8, np.where(kind < 0.98, 6 | (rng.integers(1, 20000, m) << 32), 1 | (rng.integers(1, 20000, m) << 32)))
+    add = 0x31E29540 + np.cumsum(rng.integers(-200, 1400, m)) * 16
+    add = np.where(info == 8, add, 0)
+    rec = np.stack([off, info, add], axis=1).astype("<u8")
+    return rec.tobytes()[:n]
+
+
 NUMERIC_CLASSES = {
     "f32sine": f32_sine, "f32two": f32_two_sines, "f32mesh": f32_mesh, "fasta": fasta_repeats, "sparse": sparse_text,
     "html": html_rows, "csv": csv_sensors, "pcm16": pcm16_stereo,
 }
+# Classes known to lie OUTSIDE the stated tolerance, kept in the tests so that the number is measured and pinned, not hidden:
+# relocs (preset 6, 24 MiB: +4.9 %): liblzma settles into coding every record as an 11-byte match (the constant r_info + two
+# addend bytes) with the NEAREST earlier record that shares them -- BT4 returns the nearest match of every length; the
+# suffix-neighbourhood finder has "nearest" heads at 8 and 16 bytes only, its 11-byte candidates are the most recent of ten
+# suffix neighbours (about 3 bits farther), so the parser stays with rep0 + two literals.  The real .rela.dyn section of
+# libMIOpen.so (24-byte records with more regular addends) is inside: +2.1 %.
+KNOWN_OUTSIDE = {"relocs": (reloc_table, 0.06)}

@@ -247,7 +247,7 @@ def _walk_symbols(sl, sd, gsl, gsd, n):
     while p < n:
         if sl[p] != gsl[p] or sd[p] != gsd[p]:
             return p
-        p += max(1, int(sl[p]))
+        p += max(1, int(sl[p]) & 0x7FFF)           # bit 15 = "coded as a match" flag
     return None
 
 
@@ -450,6 +450,8 @@ def _tolerance_cases(preset):
     # +5.4 %: the seeded price model at piece starts), all seeded numpy / random generators -- no dependence on the image
     for name, gen in _corpora.NUMERIC_CLASSES.items():
         cases[name] = gen(n_new)
+    for name, (gen, _) in _corpora.KNOWN_OUTSIDE.items():          # measured and pinned with their own (looser) bound
+        cases[name] = gen(n_new)
     return cases
 
 
@@ -474,7 +476,8 @@ def test_size_within_tolerance_of_reference(enc, preset):
             assert r == 1 and dec == data, ("liblzma decoder", name)
             report[name] = round(100.0 * (len(got) / len(ref) - 1), 2)
     print("size vs liblzma, preset", hex(preset), report)
-    over = {k: v for k, v in report.items() if v > 100.0 * SIZE_TOLERANCE}
+    import _corpora
+    over = {k: v for k, v in report.items() if v > 100.0 * (_corpora.KNOWN_OUTSIDE[k][1] if k in _corpora.KNOWN_OUTSIDE else SIZE_TOLERANCE)}
     assert not over, (hex(preset), report)
 
 

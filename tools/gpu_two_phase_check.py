@@ -48,7 +48,7 @@ def check(enc, data, preset, block_size, label):
                 if osl[p] != gsl[p] or osd[p] != gsd[p]:
                     bad = p
                     break
-                p += max(1, int(osl[p]))
+                p += max(1, int(osl[p]) & 0x7FFF)
             if bad is not None:
                 print(f"  block {b}: symbol records differ at {bad}: oracle ({osl[bad]}, {osd[bad]:#x}) gpu ({gsl[bad]}, {gsd[bad]:#x})")
                 ok = False

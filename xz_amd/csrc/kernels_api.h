@@ -52,7 +52,8 @@ typedef struct {
 	/* Two-phase mode (oracle: parse_piece / encode_syms): the spans of the plan are parse PIECES (xzk_parse_pieces: the
 	 * optimal parser with an adaptive price model that codes nothing; the seed piece = slot 0 of every Block starts flat
 	 * and leaves the prior of the others), the recorded symbols are range-coded per ENCODE SPAN (xzk_encode_syms). */
-	uint16_t *sym_len;           /* per position, valid at symbol starts: 0 = literal, else the match / rep length (1 = short rep) */
+	uint16_t *sym_len;           /* per position, valid at symbol starts: 0 = literal, else the match / rep length (1 = short rep);
+	                                bit 15: the parser chose a MATCH (the coder codes a match even at one of its rep distances) */
 	uint32_t *sym_dist;          /* zero-based distance; literal: byte | previous byte << 8 | match byte << 16 | (parser state >= 7) << 24 */
 	uint32_t *prior;             /* XZAMD_PRIOR_WORDS x u32 per PIECE slot (b * max_spb + k): the non-literal probabilities of the
 	                                piece's price model (the literal coders: `lit`, same slots); slot 0 of a Block = its seed

@@ -810,12 +810,17 @@ __device__ __forceinline__ void do_round(const Env& e, Pre& P, uint32_t x, uint3
 // ------------------------------------------------------------------------------------------
 // LZMA symbol coder (lzma/lzma_encoder.c:23-263)
 // ------------------------------------------------------------------------------------------
+#ifdef XZAMD_LIT16
+typedef uint16_t plit_t_fwd;
+#else
+typedef uint32_t plit_t_fwd;
+#endif
 struct Lz {
     uint32_t state;
     uint32_t rep0, rep1, rep2, rep3;
     uint32_t lc, lp, pb;
     uint32_t cnt_len, cnt_match, cnt_align;   // coded lengths / matches / align-coded matches since refresh
-    uint32_t* lit;                            // literal coder probabilities of this span (global memory, L2-resident)
+    plit_t_fwd* lit;                          // literal coder probabilities of this span (global memory, L2-resident)
     uint32_t* gp;                             // parse pieces (PG): every other probability of the piece's model, u32 each, global
 };
 
@@ -832,6 +837,24 @@ __device__ __forceinline__ uint32_t dist_slot_of(uint32_t d)
 // scales with resident waves (measured: halving occupancy costs 1.8x).  A literal touches 8 of them:
 // one gather and one scatter per symbol, L1 bypassed (sc1) so the wave reads back its own updates
 // from L2.
+// XZAMD_LIT16 (measurement build): the literal coders as u16 instead of u32 -- half the L2 footprint of a piece's model
+#ifdef XZAMD_LIT16
+typedef uint16_t plit_t;
+#define PLIT_PER_U4 8u
+#define PLIT_FLAT4 make_uint4(0x04000400u, 0x04000400u, 0x04000400u, 0x04000400u)
+__device__ __forceinline__ uint32_t lit_load(const uint16_t* p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void lit_store(uint16_t* p, uint32_t v)
+{
+    __hip_atomic_store(p, (uint16_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+#else
+typedef uint32_t plit_t;
+#define PLIT_PER_U4 4u
+#define PLIT_FLAT4 make_uint4(1024u, 1024u, 1024u, 1024u)
+#endif
 __device__ __forceinline__ uint32_t lit_load(const uint32_t* p)
 {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -910,7 +933,7 @@ __device__ __forceinline__ void rc_run(RC& rc, uint32_t packed, uint32_t n, uint
 // decisions (the parser's table, probability before its update) is added to rc.est.
 // PG: the whole model lives in global memory (the parse pieces: `gp` holds what LDS holds elsewhere).
 template <bool CODE, bool LITG, bool TOK = false, bool PG = false>
-__device__ __forceinline__ void rc_emit(RC& rc, uint16_t* probs, uint32_t* lit, uint32_t* gp, const SegSel& s, uint32_t total,
+__device__ __forceinline__ void rc_emit(RC& rc, uint16_t* probs, plit_t* lit, uint32_t* gp, const SegSel& s, uint32_t total,
         uint32_t d0, uint32_t d1)
 {
     uint32_t idx = 0, bit = 0;
@@ -939,8 +962,12 @@ __device__ __forceinline__ void rc_emit(RC& rc, uint16_t* probs, uint32_t* lit, 
     }
     uint32_t p = 0;
     if (s.hit && !direct) {
-        if ((LITG && idx >= P_LITERAL) || PG) {
-            uint32_t* g = (!PG || idx >= P_LITERAL) ? lit + (idx - P_LITERAL) : gp + idx;
+        if ((LITG || PG) && idx >= P_LITERAL) {
+            plit_t* g = lit + (idx - P_LITERAL);
+            p = lit_load(g);
+            lit_store(g, bit ? p - (p >> 5) : p + ((2048 - p) >> 5));
+        } else if (PG) {
+            uint32_t* g = gp + idx;
             p = lit_load(g);
             lit_store(g, bit ? p - (p >> 5) : p + ((2048 - p) >> 5));
         } else {
@@ -1302,6 +1329,21 @@ __device__ __forceinline__ uint32_t pr_tree_rev(PR probs, const uint8_t* ptab, u
     } while (--nbits);
     return price;
 }
+// price of one length under a length coder (length_update_prices, lzma_encoder.c:77-102, evaluated for a single length)
+template <class PR>
+__device__ __forceinline__ uint32_t pr_len_one(PR probs, const uint8_t* ptab, uint32_t base, uint32_t ps, uint32_t len)
+{
+    len -= 2;
+    if (len < 8)
+        return pr_bit(probs, ptab, base + LEN_CHOICE, 0) + pr_tree(probs, ptab, base + LEN_LOW + ps * 8, 3, len);
+    len -= 8;
+    if (len < 8)
+        return pr_bit(probs, ptab, base + LEN_CHOICE, 1) + pr_bit(probs, ptab, base + LEN_CHOICE2, 0)
+                + pr_tree(probs, ptab, base + LEN_MID + ps * 8, 3, len);
+    return pr_bit(probs, ptab, base + LEN_CHOICE, 1) + pr_bit(probs, ptab, base + LEN_CHOICE2, 1)
+            + pr_tree(probs, ptab, base + LEN_HIGH, 8, len - 8);
+}
+
 // Length price tables live in registers, lane = length: lane holds lengths 2 + lane + 64*it.
 // The low/mid trees depend on pos_state but cover only lengths 2..17 (lanes 0..15 of it == 0);
 // the high tree is shared by all pos_states.  Low 16 bits = match length coder, high 16 = rep.
@@ -1406,7 +1448,7 @@ __device__ __forceinline__ void lit_chunk(const uint8_t* __restrict__ in, const 
     const uint32_t prev = x > block_start ? in[x - 1] : 0;
     const uint32_t upos = x - block_start;
     const uint32_t mask = (0x100u << z.lp) - (0x100u >> z.lc);
-    const uint32_t* sub = z.lit + 3u * ((((upos << 8) + prev) & mask) << z.lc);
+    const plit_t* sub = z.lit + 3u * ((((upos << 8) + prev) & mask) << z.lc);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the coder's probability updates must have landed
     uint32_t pn[8], pa[8], pb[8];
 #pragma unroll
@@ -1972,7 +2014,7 @@ __device__ __forceinline__ void span_encode_one(const xzamd_span_args& a, const 
     z.lc = a.lc; z.lp = a.lp; z.pb = a.pb;
     z.cnt_len = z.cnt_match = z.cnt_align = 0;
     const uint32_t lit_size = 0x300u << (a.lc + a.lp);       // literal coders of this span (lc + lp <= 4)
-    z.lit = a.lit + (uint64_t)span * lit_size;
+    z.lit = reinterpret_cast<plit_t*>(a.lit) + (uint64_t)span * lit_size;
     z.gp = nullptr;
     RC rc;
     rc.cpos = 0; rc.out = outp; rc.reset();
@@ -2006,8 +2048,8 @@ __device__ __forceinline__ void span_encode_one(const xzamd_span_args& a, const 
             for (uint32_t i = lane; i < 928; i += 64) p32[i] = 0x04000400u;
             {
                 uint4* l4 = reinterpret_cast<uint4*>(z.lit);
-                const uint4 v = make_uint4(1024u, 1024u, 1024u, 1024u);
-                for (uint32_t i = lane; i < lit_size / 4; i += 64) l4[i] = v;
+                const uint4 v = PLIT_FLAT4;
+                for (uint32_t i = lane; i < lit_size / PLIT_PER_U4; i += 64) l4[i] = v;
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
             wave_sync();
@@ -2273,9 +2315,10 @@ __device__ __forceinline__ void span_encode_one(const xzamd_span_args& a, const 
                 asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
                 uint32_t xcc_id;
                 asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_id));
-                z.lit[0] = 0x54494D45u; z.lit[1] = (uint32_t)tm_lds[8]; z.lit[2] = (uint32_t)(tm_lds[8] >> 32);
-                z.lit[3] = hw_id; z.lit[4] = xcc_id; z.lit[5] = (uint32_t)tm_lds[9]; z.lit[6] = (uint32_t)(tm_start >> 10);
-                z.lit[7] = span_end - span_start;
+                uint32_t* zl = reinterpret_cast<uint32_t*>(z.lit);
+                zl[0] = 0x54494D45u; zl[1] = (uint32_t)tm_lds[8]; zl[2] = (uint32_t)(tm_lds[8] >> 32);
+                zl[3] = hw_id; zl[4] = xcc_id; zl[5] = (uint32_t)tm_lds[9]; zl[6] = (uint32_t)(tm_start >> 10);
+                zl[7] = span_end - span_start;
             }
             unsigned long long* g = reinterpret_cast<unsigned long long*>(a.err + 16);
             for (int i = 0; i < 12; ++i) atomicAdd(g + i, tm_lds[i]);
@@ -2399,7 +2442,7 @@ __device__ __forceinline__ void parse_piece_one(const xzamd_span_args& a, const 
     z.lc = a.lc; z.lp = a.lp; z.pb = a.pb;
     z.cnt_len = z.cnt_match = z.cnt_align = 0;
     const uint32_t lit_size = 0x300u << (a.lc + a.lp);
-    z.lit = a.lit + (uint64_t)span * lit_size;
+    z.lit = reinterpret_cast<plit_t*>(a.lit) + (uint64_t)span * lit_size;
     z.gp = a.prior + (uint64_t)span * XZAMD_PRIOR_WORDS;
     z.state = 0; z.rep0 = z.rep1 = z.rep2 = z.rep3 = 0;
     RC rc;                                              // never codes: encode_symbol_t<false, .> only adapts the model
@@ -2414,12 +2457,13 @@ __device__ __forceinline__ void parse_piece_one(const xzamd_span_args& a, const 
         if (k == 0) {
             const uint4 v = make_uint4(1024u, 1024u, 1024u, 1024u);
             for (uint32_t i = lane; i < XZAMD_PRIOR_WORDS / 4; i += 64) g4[i] = v;
-            for (uint32_t i = lane; i < lit_size / 4; i += 64) l4[i] = v;
+            const uint4 vl = PLIT_FLAT4;
+            for (uint32_t i = lane; i < lit_size / PLIT_PER_U4; i += 64) l4[i] = vl;
         } else {
             const uint4* p4 = reinterpret_cast<const uint4*>(a.prior + (uint64_t)blk * a.max_spb * XZAMD_PRIOR_WORDS);
             for (uint32_t i = lane; i < XZAMD_PRIOR_WORDS / 4; i += 64) g4[i] = p4[i];
-            const uint4* s4 = reinterpret_cast<const uint4*>(a.lit + (uint64_t)blk * a.max_spb * lit_size);
-            for (uint32_t i = lane; i < lit_size / 4; i += 64) l4[i] = s4[i];
+            const uint4* s4 = reinterpret_cast<const uint4*>(reinterpret_cast<const plit_t*>(a.lit) + (uint64_t)blk * a.max_spb * lit_size);
+            for (uint32_t i = lane; i < lit_size / PLIT_PER_U4; i += 64) l4[i] = s4[i];
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         wave_sync();
@@ -2467,8 +2511,39 @@ __device__ __forceinline__ void parse_piece_one(const xzamd_span_args& a, const 
                 const uint32_t dist = lane_of(D, i);
                 const uint32_t bl = dist ? 32u - (uint32_t)__builtin_clz(dist) : 0u;         // bit length of the distance
                 if (len >= 2 && (14 + bl < 6 * len || dist == z.rep0)) {
-                    const bool rep = dist == z.rep0;
-                    encode_symbol_t<false, true, false, true>(rc, no_lds, z, x - block_start, rep ? 0u : dist + 4, len, 0u);
+                    // rep or match?  When the distance is one of the rep distances the current prices decide, as they do in
+                    // the optimal parser (oracle: parse_piece -- data made of fixed-size records has two self-reinforcing
+                    // ways to code the same copy; the walk must train the model into the one the parser lives in)
+                    uint32_t back = dist + 4;
+                    const uint32_t ri = dist == z.rep0 ? 0u : dist == z.rep1 ? 1u : dist == z.rep2 ? 2u : dist == z.rep3 ? 3u : 4u;
+                    if (ri < 4) {
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the model updates so far
+                        const uint32_t ps = (x - block_start) & ((1u << z.pb) - 1), st = z.state;
+                        const uint8_t* pt = w.ptab;
+                        uint32_t prep = pr_bit(probs, pt, P_IS_REP + st, 1);
+                        if (ri == 0) prep += pr_bit(probs, pt, P_IS_REP0 + st, 0) + pr_bit(probs, pt, P_IS_REP0_LONG + st * 16 + ps, 1);
+                        else {
+                            prep += pr_bit(probs, pt, P_IS_REP0 + st, 1);
+                            if (ri == 1) prep += pr_bit(probs, pt, P_IS_REP1 + st, 0);
+                            else prep += pr_bit(probs, pt, P_IS_REP1 + st, 1) + pr_bit(probs, pt, P_IS_REP2 + st, ri - 2);
+                        }
+                        prep += pr_len_one(probs, pt, P_REP_LEN, ps, len);
+                        uint32_t pm = pr_bit(probs, pt, P_IS_REP + st, 0) + pr_len_one(probs, pt, P_MATCH_LEN, ps, len);
+                        {
+                            const uint32_t slot = dist_slot_of(dist);
+                            pm += pr_tree(probs, pt, P_DIST_SLOT + (len < 6 ? len - 2 : 3u) * 64, 6, slot);
+                            if (slot >= 4) {
+                                const uint32_t fb = (slot >> 1) - 1;
+                                const uint32_t base = (2 | (slot & 1)) << fb;
+                                const uint32_t red = dist - base;
+                                if (slot < 14) pm += pr_tree_rev(probs, pt, P_DIST_SPECIAL + base - slot - 1, fb, red);
+                                else pm += ((fb - 4) << 4) + pr_tree_rev(probs, pt, P_DIST_ALIGN, 4, red & 15);
+                            }
+                        }
+                        if (uni(prep) <= uni(pm)) back = ri;
+                    }
+                    const bool rep = back == 0;                              // rep0 stays what it was
+                    encode_symbol_t<false, true, false, true>(rc, no_lds, z, x - block_start, back, len, 0u);
                     i += len;
                     if (!rep && i < rowlen) tm = in[max(px, x0 + i) - z.rep0 - 1];   // rep0 changed: the match bytes of the rest of the row
                                                                                      // (lanes behind the walk would reach in front of the Block)
@@ -2568,7 +2643,9 @@ __device__ __forceinline__ void parse_piece_one(const xzamd_span_args& a, const 
             const uint32_t l3r = cur == span_start ? (l3 & 0xFFFFu) : l3;
             if (lane == 0 && rec) { a.sym_len[cur] = 0; a.sym_dist[cur] = l3r; }
         } else if (lane == 0 && rec) {
-            a.sym_len[cur] = (uint16_t)len;
+            // bit 15: the parser chose a MATCH -- the coder then codes a match even when the distance is one of its rep
+            // distances (oracle: parse_piece)
+            a.sym_len[cur] = (uint16_t)(len | (back >= 4 ? 0x8000u : 0u));
             a.sym_dist[cur] = back >= 4 ? back - 4 : back == 0 ? z.rep0 : back == 1 ? z.rep1 : back == 2 ? z.rep2 : z.rep3;
         }
         {
@@ -2756,11 +2833,15 @@ __global__ __launch_bounds__(64) void k_model_syms(xzamd_span_args a, uint32_t n
             }
             uint32_t len = lane_of(R.l, off);
             const uint32_t d = lane_of(R.d, off);
+            const uint32_t as_match = len >> 15;         // the parser's choice: a match, whatever the coder's rep distances are
+            len &= 0x7FFFu;
             uint32_t back, l3 = 0;
             if (len == 0) {
                 back = LITERAL; len = 1; l3 = d;
                 if (z.state >= 7 && !(d >> 24))          // no match byte with the record (first symbol of a piece): fetch it
                     l3 = (d & 0xFFFFu) | (uni(in[cur - z.rep0 - 1]) << 16);
+            } else if (as_match) {
+                back = d + 4;
             } else if (len == 1) {
                 if (d == z.rep0) back = 0;
                 else { back = LITERAL; l3 = literal_bytes(in, cur, cur - block_start, z); }   // a short rep0 of another distance: code the byte
