@@ -255,3 +255,14 @@ NUMERIC_CLASSES = {
 # suffix neighbours (about 3 bits farther), so the parser stays with rep0 + two literals.  The real .rela.dyn section of
 # libMIOpen.so (24-byte records with more regular addends) is inside: +2.1 %.
 KNOWN_OUTSIDE = {"relocs": (reloc_table, 0.06)}
+
+
+def elf_metadata(n):
+    """The first n bytes of the largest ELF shared object of the ROCm install (libMIOpen.so: .dynsym, .dynstr, 12 MiB of
+    .rela.dyn, .gcc_except_table, the start of .rodata): tables of fixed-size records.  Image-dependent: None when absent."""
+    import glob
+    files = [f for f in glob.glob("/opt/rocm/lib/libMIOpen.so.*") if os.path.isfile(f) and not os.path.islink(f)]
+    if not files or os.path.getsize(sorted(files)[0]) < n:
+        return None
+    with open(sorted(files)[0], "rb") as fh:
+        return fh.read(n)
