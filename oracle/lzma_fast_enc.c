@@ -1651,6 +1651,14 @@ static void parse_piece(enc *e, uint32_t start, uint32_t end, int first_in_block
 		e->trace = NULL;
 		const uint32_t w1 = start - ORC_PREROLL;
 		uint32_t x = w1 - ORC_SEED_LEN > ORC_WARM ? w1 - ORC_WARM : ORC_SEED_LEN;
+		/* Rep distances that a continuous parse would be carrying.  Periodic numeric data (a float64 sine: +5.4 % vs liblzma
+		 * before this) lives on a far distance D -- the same phase one period earlier -- that is only affordable as a REP
+		 * (three or four bytes per use): the continuous parse finds it once and keeps it in its rep stack for the rest of
+		 * the Block; a piece that starts with the rep stack of a 2 KiB pre-roll never gets it back.  So the walk remembers
+		 * the distances of the last four candidates it REJECTED as too expensive (length >= 3); one that comes up again is
+		 * put into the oldest rep slot -- nothing is coded, no probability moves -- and from then on counts as a rep
+		 * distance: taken when it matches, coded as the prices say. */
+		uint32_t rej[4] = { 0, 0, 0, 0 }, nrej = 0;
 		while (x < w1) {
 			find_sn(e, x);
 			uint32_t len = e->m_longest;
@@ -1658,7 +1666,21 @@ static void parse_piece(enc *e, uint32_t start, uint32_t end, int first_in_block
 			if (len > w1 - x) len = w1 - x;
 			uint32_t bl = 0;
 			while (dist >> bl) ++bl;
-			if (len >= 2 && (14 + bl < 6 * len || dist == e->reps[0])) {
+			const int in_reps = dist == e->reps[0] || dist == e->reps[1] || dist == e->reps[2] || dist == e->reps[3];
+			const int take = len >= 2 && (14 + bl < 6 * len || in_reps);
+			if (!take && len >= 3) {
+				int seen = 0;
+				for (uint32_t i = 0; i < nrej; ++i)
+					if (rej[i] == dist) seen = 1;
+				if (seen)
+					e->reps[3] = dist;
+				else if (nrej < 4)
+					rej[nrej++] = dist;
+				else {
+					rej[0] = rej[1]; rej[1] = rej[2]; rej[2] = rej[3]; rej[3] = dist;
+				}
+			}
+			if (take) {
 				/* HOW the taken symbol is coded -- as a rep when its distance is one of the four rep distances, or as a
 				 * match all the same -- is decided by the current prices, as the optimal parser decides it: data made of
 				 * fixed-size records (relocation tables: "distance 24" thousands of times in a row) has two

@@ -2490,6 +2490,10 @@ __device__ __forceinline__ void parse_piece_one(const xzamd_span_args& a, const 
     if (k != 0 && span_start - block_start > XZAMD_PREROLL + XZAMD_SEED_LEN) {
         const uint32_t w1 = span_start - XZAMD_PREROLL;
         uint32_t x0 = w1 - block_start - XZAMD_SEED_LEN > XZAMD_WARM ? w1 - XZAMD_WARM : block_start + XZAMD_SEED_LEN;
+        // the distances of the last four candidates the walk rejected as too expensive: one that comes up again is a distance a
+        // continuous parse would be carrying in its rep stack (periodic numeric data) and goes into the oldest rep slot -- nothing
+        // is coded (oracle: parse_piece)
+        uint32_t rj0 = 0, rj1 = 0, rj2 = 0, rj3 = 0, nrej = 0;
         while (x0 < w1) {
             const uint32_t px = min(x0 + lane, w1 - 1);
             const uint64_t rb = (uint64_t)px * LIST_W;
@@ -2510,7 +2514,15 @@ __device__ __forceinline__ void parse_piece_one(const xzamd_span_args& a, const 
                 uint32_t len = min(lane_of(L, i), w1 - x);
                 const uint32_t dist = lane_of(D, i);
                 const uint32_t bl = dist ? 32u - (uint32_t)__builtin_clz(dist) : 0u;         // bit length of the distance
-                if (len >= 2 && (14 + bl < 6 * len || dist == z.rep0)) {
+                const bool in_reps = dist == z.rep0 || dist == z.rep1 || dist == z.rep2 || dist == z.rep3;
+                const bool take = len >= 2 && (14 + bl < 6 * len || in_reps);
+                if (!take && len >= 3) {
+                    const bool seen = (nrej > 0 && rj0 == dist) || (nrej > 1 && rj1 == dist) || (nrej > 2 && rj2 == dist) || (nrej > 3 && rj3 == dist);
+                    if (seen) z.rep3 = dist;
+                    else if (nrej < 4) { rj0 = nrej == 0 ? dist : rj0; rj1 = nrej == 1 ? dist : rj1; rj2 = nrej == 2 ? dist : rj2; rj3 = nrej == 3 ? dist : rj3; ++nrej; }
+                    else { rj0 = rj1; rj1 = rj2; rj2 = rj3; rj3 = dist; }
+                }
+                if (take) {
                     // rep or match?  When the distance is one of the rep distances the current prices decide, as they do in
                     // the optimal parser (oracle: parse_piece -- data made of fixed-size records has two self-reinforcing
                     // ways to code the same copy; the walk must train the model into the one the parser lives in)
