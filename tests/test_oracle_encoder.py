@@ -161,7 +161,7 @@ def _elf_mix(n):
                                       # round 5: the literal-heavy / numeric classes of the round-4 review
                                       ("f32sine", 4 << 20), ("f32two", 4 << 20), ("f32mesh", 4 << 20), ("fasta", 4 << 20),
                                       ("sparse", 4 << 20), ("html", 4 << 20), ("csv", 4 << 20), ("pcm16", 4 << 20),
-                                      ("f64sine", 4 << 20), ("int32walk", 4 << 20), ("structs24", 4 << 20)])
+                                      ("f64sine", 4 << 20), ("int32walk", 4 << 20), ("structs24", 4 << 20), ("hexids", 4 << 20)])
 def test_size_within_tolerance_of_reference_preset6(corpus, n):
     """Oracle restatement of what the device runs for preset 6 (64-byte suffix order, cost-balanced spans) against
     the REAL liblzma at preset 6 on the same Block: compressed size within the stated tolerance.  (The GPU test

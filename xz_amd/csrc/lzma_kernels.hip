@@ -2494,6 +2494,11 @@ __device__ __forceinline__ void parse_piece_one(const xzamd_span_args& a, const 
         // continuous parse would be carrying in its rep stack (periodic numeric data) and goes into the oldest rep slot -- nothing
         // is coded (oracle: parse_piece)
         uint32_t rj0 = 0, rj1 = 0, rj2 = 0, rj3 = 0, nrej = 0;
+        // what the walk may not teach: is_rep / is_rep0 / is_rep1 / is_rep2 (48 probabilities) keep the seed piece's values -- its
+        // rep decisions are the least like the optimal parser's (oracle: parse_piece)
+        static_assert(P_IS_REP0_LONG - P_IS_REP == 48, "the rep-choice probabilities");
+        const uint32_t keep_rep = lane < 48 ? lit_load(z.gp + P_IS_REP + lane) : 0u;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // in hand before the walk's first scatter
         while (x0 < w1) {
             const uint32_t px = min(x0 + lane, w1 - 1);
             const uint64_t rb = (uint64_t)px * LIST_W;
@@ -2567,6 +2572,8 @@ __device__ __forceinline__ void parse_piece_one(const xzamd_span_args& a, const 
             }
             x0 += i;
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane < 48) lit_store(z.gp + P_IS_REP + lane, keep_rep);
     }
     bool cached = false;
     RoundL RL;
