@@ -1785,10 +1785,16 @@ static int parse_block(enc *e, const uint32_t *piece_start, uint32_t np)
 	uint16_t *prior = (uint16_t *)malloc(sizeof(e->probs));
 	if (!e->sy_len || !e->sy_dist || !prior) { free(prior); return -3; }
 	orc_trace *const tr = e->trace;
+	/* pb = 3, 4 (lzma/lzma_common.h:32-37): the price model of the parse pieces is the parser's alone -- the coder runs
+	 * its own continuous model with the real pb (encode_syms) -- and takes a pb = 2 view of the positions: the device
+	 * parser's per-window price tables hold four position states.  The recorded symbols are valid under any pb. */
+	const uint32_t pb_coder = e->prm.pb;
+	if (e->prm.pb > 2) e->prm.pb = 2;
 	for (uint32_t k = 0; k < np; ++k) {
 		parse_piece(e, piece_start[k], k + 1 < np ? piece_start[k + 1] : n, k == 0, k == 0 ? NULL : prior);
 		if (k == 0) memcpy(prior, e->probs, sizeof(e->probs));
 	}
+	e->prm.pb = pb_coder;
 	e->trace = tr;
 	free(prior);
 	return 0;

@@ -305,6 +305,52 @@ def test_two_phase_stages_identical_to_oracle(enc, preset, single_phase):
     assert st.spans == pieces and st.enc_spans == spans and spans > nb
 
 
+@pytest.mark.parametrize("pb,lc,lp", [(3, 3, 0), (4, 3, 0), (4, 0, 2)])
+def test_two_phase_pb_above_two_identical_to_oracle(enc, pb, lc, lp):
+    """pb = 3, 4 with the optimal parser (lzma/lzma_common.h:32-37; refused until round 5): the parse pieces price with
+    a pb = 2 view of the positions, the coder's continuous model runs the real pb (oracle: parse_block / encode_syms).
+    Recorded symbols and bytes equal the oracle's, the Stream decodes through the reference decoder; the single-phase
+    span kernel (one model for parser and coder) still refuses the option set."""
+    import xz_amd
+    import _corpora
+    rng = np.random.default_rng(21)
+    k = 60000
+    rec = np.zeros((k, 16), dtype=np.uint8)                       # 16-byte records: what pb = 4 is for
+    rec[:, 0:4] = np.arange(k, dtype=np.uint32).view(np.uint8).reshape(k, 4)
+    rec[:, 4:8] = (np.sin(np.arange(k) * 7e-4) * 50).astype(np.float32).view(np.uint8).reshape(k, 4)
+    rec[:, 8:16] = rng.integers(0, 4, size=(k, 8), dtype=np.uint8)
+    mix = rec.tobytes() + xz_amd.corpus_text(900000, seed=4).tobytes() + _corpora.f64_sine(700000) + o.corpus_lorem(300000)
+    bs = 1 << 21
+    opts = xz_amd.preset_options(6)
+    opts.pb, opts.lc, opts.lp = pb, lc, lp
+    opts.span_cost = 50000
+    opts.span_bits = 0
+    opts.enc_span_bits = 300000
+    got, _ = gpu_encode(enc, mix, opts, bs)
+    prm = o.params_for_gpu_options(opts)
+    assert prm.pb == pb and prm.enc_bits
+    assert o.first_diff(got, o.orc_xz_stream(mix, prm, bs)) == -1
+    rr, rdec = o.ref_decode(got, len(mix) + 16)
+    assert rr == 1 and rdec == mix
+    gsl = enc.debug_fetch(9, len(mix), "uint16")
+    gsd = enc.debug_fetch(10, len(mix), "uint32")
+    for b in range((len(mix) + bs - 1) // bs):
+        blk = mix[b * bs:(b + 1) * bs]
+        sl, sd = o.orc_parse_dump(blk, prm)
+        bad = _walk_symbols(sl, sd, gsl[b * bs:b * bs + len(blk)], gsd[b * bs:b * bs + len(blk)], len(blk))
+        assert bad is None, ("symbol records", b, bad)
+    # default spans of the product (work target 131072, 1.6 Mbit encode spans)
+    opts = xz_amd.preset_options(6)
+    opts.pb, opts.lc, opts.lp = pb, lc, lp
+    got, _ = gpu_encode(enc, mix, opts, bs)
+    assert o.first_diff(got, o.orc_xz_stream(mix, o.params_for_gpu_options(opts, span_cost_used=enc.stats().span_cost_used), bs)) == -1
+    rr, rdec = o.ref_decode(got, len(mix) + 16)
+    assert rr == 1 and rdec == mix
+    opts.enc_span_bits = 0                                          # single phase: one model for parser and coder
+    with pytest.raises(Exception):
+        gpu_encode(enc, mix[:200000], opts, bs)
+
+
 def test_two_phase_token_budget_overflow_identical_to_oracle(enc, monkeypatch):
     """Out of tokens (round-4 advisor, medium: far three-byte matches need more than the 10 tokens per byte the buffer
     holds) the model pass closes the chunk where it stands and stores the rest of the encode span raw.  Reached on
@@ -1327,10 +1373,27 @@ def test_lzma_code_worker_pipeline_timeout_barrier_and_filters_update(monkeypatc
     assert L.lzma_mt_block_size(fl) == 24 << 20
     assert L.lzma_cputhreads() >= 1
     # an option set outside the device path is refused at init (a preload client then stays on the CPU library)
-    ol.dict_size = 1 << 20; ol.pb = 4; ol.mode = 2; ol.mf = 0x14
+    ol.dict_size = (1 << 30) + (1 << 28); ol.mode = 2; ol.mf = 0x14                 # dictionary > 1 GiB
     mm = Mt(threads=1, check=4, filters=C.cast(fl, C.c_void_p))
     assert L.lzma_stream_encoder_mt(C.byref(s), C.byref(mm)) == 8
-    ol.pb = 2; ol.lc = 4; ol.lp = 0; ol.mode = 1; ol.mf = 4; ol.depth = 8
+    # pb = 4 with LZMA_MODE_NORMAL runs on the device (two-phase mode), with a BT and with an HC finder
+    for mf in (0x14, 0x04):
+        ol.dict_size = 1 << 20; ol.pb = 4; ol.lc = 3; ol.lp = 0; ol.mode = 2; ol.mf = mf; ol.depth = 0
+        assert L.lzma_stream_encoder_mt(C.byref(s), C.byref(mm)) == 0
+        s.next_in = C.cast(ib, C.c_void_p).value; s.avail_in = 700000
+        s.next_out = C.cast(ob, C.c_void_p).value; s.avail_out = len(ob)
+        r = L.lzma_code(C.byref(s), FINISH)
+        while r == OK:
+            r = L.lzma_code(C.byref(s), FINISH)
+        assert r == STREAM_END
+        got = ob.raw[: s.total_out]
+        L.lzma_end(C.byref(s))
+        if o.have_ref():
+            rr, rdec = o.ref_decode(got, 700016)
+            assert rr == 1 and rdec == data[:700000]
+        r, dec, nb = o.orc_xz_decode(got, 700016)
+        assert r == 0 and dec == data[:700000]
+    ol.pb = 2; ol.lc = 4; ol.lp = 0; ol.mode = 1; ol.mf = 4; ol.depth = 8; ol.dict_size = 1 << 20
     assert L.lzma_stream_encoder_mt(C.byref(s), C.byref(mm)) == 0       # lc + lp = 4 runs on the device
     s.next_in = C.cast(ib, C.c_void_p).value; s.avail_in = 500000
     s.next_out = C.cast(ob, C.c_void_p).value; s.avail_out = len(ob)

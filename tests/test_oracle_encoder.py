@@ -272,6 +272,40 @@ def test_two_phase_round_trip_many_small_pieces():
     assert r == 1 and dec == data
 
 
+@pytest.mark.parametrize("pb", [3, 4])
+def test_two_phase_pb_above_two(pb):
+    """pb = 3, 4 with the optimal parser (lzma/lzma_common.h:32-37): the parse pieces price with a pb = 2 view of the
+    positions (their model is the parser's alone; the device parser's per-window tables hold four position states), the
+    coder's continuous model runs the real pb.  The stream carries the real pb in its props byte, decodes through the
+    reference decoder, and stays inside the stated size tolerance of liblzma at the SAME pb (BT4, normal mode) on 16-byte
+    records -- the data pb = 4 is for (measured: pb 3 +1.4 %, pb 4 +1.8 %; pb 2 +1.9 %)."""
+    if not o.have_ref():
+        pytest.skip("oracle/_ref not built")
+    import xz_amd
+    rng = np.random.default_rng(3)
+    k = (4 << 20) // 16
+    rec = np.zeros((k, 16), dtype=np.uint8)
+    rec[:, 0:4] = np.arange(k, dtype=np.uint32).view(np.uint8).reshape(k, 4)
+    rec[:, 4:8] = (np.sin(np.arange(k) * 7e-4) * 50).astype(np.float32).view(np.uint8).reshape(k, 4)
+    rec[:, 8:10] = rng.integers(0, 4, size=(k, 2), dtype=np.uint8)
+    rec[:, 10:16] = rng.integers(0, 256, size=(k, 6), dtype=np.uint8) // 64
+    data = rec.tobytes()
+    opts = xz_amd.preset_options(6)
+    opts.pb = pb
+    prm = o.params_for_gpu_options(opts)
+    assert prm.pb == pb and prm.enc_bits and prm.parser == 1
+    raw = o.orc_encode_block(data, prm)
+    assert raw[0] >> 5 == 7 and raw[5] == (pb * 5 + 0) * 9 + 3          # first chunk: dict reset + props (lzma2_encoder.c:54-107)
+    r, dec = o.ref_raw_decode(raw, prm.dict_size, len(data) + 16)
+    assert r == 1 and dec == data
+    p2 = o.OrcParams()
+    p2.dict_size, p2.lc, p2.lp, p2.pb, p2.nice_len, p2.mf, p2.depth = prm.dict_size, 3, 0, pb, 64, 0x14, 0
+    ref = o.ref_raw_encode(data, p2, mode=2)
+    assert len(raw) <= len(ref) * (1 + SIZE_TOLERANCE), (pb, len(raw), len(ref))
+    prm2 = o.params_for_gpu_options(xz_amd.preset_options(6))
+    assert len(raw) < len(o.orc_encode_block(data, prm2))              # the finer position contexts pay on such data
+
+
 def test_two_phase_token_budget_overflow_goes_raw():
     """Round-4 advisor (medium): the model pass of the two-phase coder has a fixed token budget per encode span (10 per input
     byte); data made of far three-byte matches needs more.  Out of tokens, the chunk is closed where it stands and the rest

@@ -2439,7 +2439,10 @@ __device__ __forceinline__ void parse_piece_one(const xzamd_span_args& a, const 
     }
 
     Lz z;
-    z.lc = a.lc; z.lp = a.lp; z.pb = a.pb;
+    // pb = 3, 4: the piece's price model -- which is the parser's alone, the coder keeps its own (k_model_syms, the real
+    // pb) -- takes a pb = 2 view of the positions; the bit-price and length tables of the window cover four position
+    // states (oracle: parse_block).  The recorded symbols are valid under any pb.
+    z.lc = a.lc; z.lp = a.lp; z.pb = a.pb < 2u ? a.pb : 2u;
     z.cnt_len = z.cnt_match = z.cnt_align = 0;
     const uint32_t lit_size = 0x300u << (a.lc + a.lp);
     z.lit = reinterpret_cast<plit_t*>(a.lit) + (uint64_t)span * lit_size;

@@ -667,8 +667,13 @@ const char *xzamd_options_check(const xzamd_lzma_options *opt)
 	if ((opt->bcj != 0 && !prefilter_valid(opt->bcj)) || (opt->bcj2 != 0 && (opt->bcj == 0 || !prefilter_valid(opt->bcj2)))
 			|| (opt->bcj3 != 0 && (opt->bcj2 == 0 || !prefilter_valid(opt->bcj3))))
 		return "filters in front of LZMA2: up to three of x86 / PowerPC / IA-64 / ARM / ARM-Thumb / SPARC / ARM64 / RISC-V BCJ or delta";
-	if (opt->gpu_parser && opt->pb > 2)
-		return "the optimal parser's price tables cover pb <= 2";
+	/* pb = 3, 4 (lzma/lzma_common.h:32-37) with the optimal parser: in two-phase mode the parse pieces price with a
+	 * pb = 2 view of the positions (their model is the parser's alone) and the coder's continuous model runs the real pb
+	 * (k_parse_pieces / k_model_syms).  The single-phase span kernel has ONE model for both: pb <= 2. */
+	if (opt->gpu_parser && opt->pb > 2
+			&& !(opt->gpu_sa_window && opt->span_cost != 0 && opt->enc_span_bits != 0
+				&& (opt->span_size == XZAMD_SPAN_DEFAULT || opt->span_size == XZAMD_SPAN_AUTO)))
+		return "pb > 2 with the optimal parser needs the two-phase mode (default spans); the single-phase parser's price tables cover pb <= 2";
 	if (opt->gpu_sa_depth != 0 && opt->gpu_sa_depth != 32 && opt->gpu_sa_depth != 64 && opt->gpu_sa_depth != 128
 			&& opt->gpu_sa_depth != 256)
 		return "gpu_sa_depth: 32, 64, 128 or 256";

@@ -559,13 +559,17 @@ static lzma_ret parse_options(const lzma_mt *o, xzamd_lzma_options *opt, uint64_
 		opt->nice_len = l->nice_len;
 		opt->mf = (uint32_t)l->mf;
 		opt->depth = l->depth;
-		if (l->mf == LZMA_MF_HC3 || l->mf == LZMA_MF_HC4) {
+		/* pb = 3, 4 with LZMA_MODE_NORMAL needs the two-phase mode (xzamd_options_check), which comes with the
+		 * suffix-neighbourhood finder: a hash-chain finder is mapped like a binary-tree one then */
+		const int hc = (l->mf == LZMA_MF_HC3 || l->mf == LZMA_MF_HC4) && !(l->mode == LZMA_MODE_NORMAL && l->pb > 2);
+		if (hc) {
 			opt->gpu_mf = (uint32_t)l->mf;
 			opt->gpu_nice_len = l->nice_len < (opt->gpu_mf & 15) ? (opt->gpu_mf & 15) : l->nice_len;
 			uint32_t d = l->depth ? l->depth : 4 + opt->gpu_nice_len / 4;
 			opt->gpu_depth = d > 56 ? 56 : d;
 			opt->gpu_parser = l->mode == LZMA_MODE_NORMAL ? 1 : 0;
-		} else if (l->mf == LZMA_MF_BT2 || l->mf == LZMA_MF_BT3 || l->mf == LZMA_MF_BT4) {
+		} else if (l->mf == LZMA_MF_HC3 || l->mf == LZMA_MF_HC4
+				|| l->mf == LZMA_MF_BT2 || l->mf == LZMA_MF_BT3 || l->mf == LZMA_MF_BT4) {
 			/* binary-tree finders -> suffix-neighbourhood finder + windowed optimal parser (the device has
 			 * no fast parser for it: LZMA_MODE_FAST with a BT finder gets the optimal parser too) */
 			opt->gpu_mf = XZAMD_MF_HC4;
@@ -590,6 +594,8 @@ static lzma_ret parse_options(const lzma_mt *o, xzamd_lzma_options *opt, uint64_
 	const char *env = getenv("XZAMD_SPAN_KIB");
 	if (env && atoi(env) > 0)
 		opt->span_size = (uint32_t)atoi(env) << 10;
+	if (xzamd_options_check(opt) != NULL)
+		return LZMA_OPTIONS_ERROR;      /* the span overrides can leave the two-phase mode (pb > 2 needs it) */
 	*block_size = o->block_size ? o->block_size : xzamd_mt_block_size(opt);
 	if (*block_size >= (1ull << 31))
 		return LZMA_OPTIONS_ERROR;
