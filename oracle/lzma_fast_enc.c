@@ -1445,7 +1445,18 @@ static uint32_t plan_spans_ex(enc *e, uint32_t *chunk_cost, uint32_t *span_start
 	/* k spans of equal estimated work: k = floor(total / T), but no more than the Block's estimated coded size
 	 * allows at span_bits per span, at least one; threshold = ceil(total / k) */
 	uint64_t k = total / T;
-	if (e->prm.span_bits && total_bits / e->prm.span_bits < k) k = total_bits / e->prm.span_bits;
+	if (e->prm.span_bits) {
+		/* A piece start costs 150 ... 280 bytes of output whatever the data (its price model starts from the seed's), so
+		 * on highly compressible Blocks -- whose parse is cheap: the GPU is not short of wavefronts there -- a piece must
+		 * produce more: below one estimated bit per planned byte span_bits grows with the bytes per bit, up to 4x
+		 * (zero pages with islands of words: 24 -> 9 pieces per 24 MiB Block, +2.10 -> +1.82 % vs liblzma; a tar of headers
+		 * 33 -> 17 pieces, +1.05 -> +0.96 %; text, at 3.5 estimated bits per byte: unchanged).  In sixteenths, integers only (the device: k_span_cut). */
+		const uint64_t planned = (uint64_t)(m - seed_chunks) * ORC_EST_CHUNK;
+		uint64_t f16 = total_bits ? 16u * planned / total_bits : 64u;
+		f16 = f16 < 16 ? 16 : f16 > 64 ? 64 : f16;
+		const uint64_t kb = total_bits * 16u / ((uint64_t)e->prm.span_bits * f16);
+		if (kb < k) k = kb;
+	}
 	if (k == 0) k = 1;
 	const uint64_t Tb = (total + k - 1) / k;
 	/* encode spans (two-phase): ke of about equal estimated coded size, closed at piece ends */

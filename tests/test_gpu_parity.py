@@ -176,7 +176,11 @@ def test_span_plan_identical_to_oracle(enc):
     lorem = o.corpus_lorem(600000)
     mix = (lorem[:300000] + b"\0" * 400000 + bytes(rng.integers(0, 256, size=200000, dtype=np.uint8))
            + (lorem[:4000] * 200) + xz_amd.corpus_text(500000, seed=9).tobytes())
-    for bs, cost, bits in ((1 << 20, 0, None), (700000, 40000, 50000), (1 << 21, 20000, 0)):
+    import _corpora
+    sparse = _corpora.sparse_text(5 << 20)        # < 0.5 estimated bits per byte: the bit bound of a piece scales up (plan_spans_ex)
+    for bs, cost, bits in ((1 << 20, 0, None), (700000, 40000, 50000), (1 << 21, 20000, 0), (3 << 20, 0, None), (3 << 20, 0, 30000)):
+        if bs == 3 << 20:
+            mix = sparse
         opts = xz_amd.preset_options(6)
         if cost:
             opts.span_cost = cost

@@ -222,6 +222,18 @@ def test_span_plan_properties():
     _, _, starts2 = o.orc_span_plan(data, prm2)
     assert len(starts2) < len(starts)
     assert int(work.sum()) >= (len(data) - (3 << 20)) // 2
+    # highly compressible Blocks: below one estimated bit per planned byte a piece must produce more than span_bits (up
+    # to 4x): a piece start costs 150 ... 280 bytes whatever the data
+    import _corpora
+    sp = _corpora.sparse_text(8 << 20)
+    prm3 = o.params_for_gpu_options(xz_amd.preset_options(6))
+    bits3, starts3 = o.orc_span_plan(sp, prm3)[1], o.orc_piece_plan(sp, prm3)[0]
+    planned_bits = int(bits3[16:].sum())                      # without the seed piece's 16 chunks
+    assert planned_bits * 2 < len(sp) - 65536                    # < 0.5 estimated bits per byte
+    assert 1 + 1 <= len(starts3) - 1 <= planned_bits // prm3.span_bits // 2      # the bound is at least twice as tight as span_bits alone
+    txt = xz_amd.corpus_text(4 << 20, seed=2).tobytes()
+    _, bits4, _ = o.orc_span_plan(txt, prm3)
+    assert int(bits4.sum()) > len(txt)                           # text: > 1 estimated bit per byte, the plain span_bits bound
 
 
 def test_tar_corpus_is_a_deterministic_ustar_stream(tmp_path):

@@ -3472,7 +3472,16 @@ __global__ __launch_bounds__(64) void k_span_cut(xzamd_span_args a, uint32_t nbl
         total += lane_of(wave_incl_sum(planned ? vw : 0u), 63);
     }
     unsigned long long k = total / T;
-    if (bits_min && total_bits / bits_min < k) k = total_bits / bits_min;
+    if (bits_min) {
+        // below one estimated bit per planned byte bits_min grows with the bytes per bit, up to 4x (in sixteenths): a piece
+        // start costs 150 ... 280 bytes of output whatever the data, and a highly compressible Block is cheap to parse
+        // (oracle: plan_spans_ex)
+        const unsigned long long planned = (unsigned long long)(m - seed_chunks) * XZAMD_EST_CHUNK;
+        unsigned long long f16 = total_bits ? 16ull * planned / total_bits : 64ull;
+        f16 = f16 < 16 ? 16 : f16 > 64 ? 64 : f16;
+        const unsigned long long kb = total_bits * 16ull / ((unsigned long long)bits_min * f16);
+        if (kb < k) k = kb;
+    }
     if (k == 0) k = 1;
     const unsigned long long Tb = (total + k - 1) / k;
     // encode spans (two-phase): ke of about equal estimated coded size, each closed at a piece end
