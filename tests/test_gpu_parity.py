@@ -455,8 +455,8 @@ def test_full_size_blocks_identical_to_oracle(enc):
             assert rr == 1 and rdec == data, name
 
 
-SIZE_TOLERANCE = 0.0225     # presets 4-9, full Blocks of 23 classes: measured max +2.09 % (zero pages with islands of random words,
-                            # preset 6); every other class <= +1.46 % at preset 6 and <= +1.70 % at 9e (round 5, final tree)
+SIZE_TOLERANCE = 0.02       # presets 4-9, full Blocks of 23 classes: measured max +1.82 % at preset 6 (zero pages with islands of random
+                            # words; every other class <= +1.46 %) and +1.70 % at 9e (ELF metadata) (round 5, final tree)
 SIZE_TOLERANCE_FAST = 0.01  # presets 1-3, default spans (256 KiB state-reset spans): measured max +0.72 % (HTML rows)
 
 

@@ -137,7 +137,7 @@ def test_optimal_parser_beats_fast_parser():
         assert opt <= ref6 * (1 + SIZE_TOLERANCE), (opt, ref6)
 
 
-SIZE_TOLERANCE = 0.0225    # stated tolerance (presets 4-9): device output <= 1.0225 x liblzma at the same preset and block size
+SIZE_TOLERANCE = 0.02      # stated tolerance (presets 4-9): device output <= 1.02 x liblzma at the same preset and block size
 SIZE_TOLERANCE_FAST = 0.01 # presets 1-3 with the default 256 KiB spans
 
 
