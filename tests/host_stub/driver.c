@@ -176,6 +176,37 @@ int main(int argc, char **argv)
 			CHECK(lzma_stream_encoder_mt(&c, &mt) == chains[i].want);
 			lzma_end(&c);
 		}
+		/* LZMA2 option sets (xzamd_options_check, lzma/lzma_common.h:32-37): pb = 3, 4 runs -- with LZMA_MODE_NORMAL in
+		 * two-phase mode, a hash-chain finder mapped like a binary-tree one; a span override that leaves the two-phase mode
+		 * (XZAMD_SPAN_KIB) is refused with pb > 2; a preset dictionary and a dictionary above 1 GiB are refused */
+		{
+			lzma_options_lzma q = lz;
+			const lzma_filter chain[2] = { { LZMA_FILTER_LZMA2, &q }, { LZMA_VLI_UNKNOWN, NULL } };
+			mt.filters = chain;
+			const struct { uint32_t pb; lzma_mode mode; lzma_match_finder mf; lzma_ret want; } sets[] = {
+				{ 4, LZMA_MODE_FAST, LZMA_MF_HC4, LZMA_OK }, { 3, LZMA_MODE_NORMAL, LZMA_MF_BT4, LZMA_OK },
+				{ 4, LZMA_MODE_NORMAL, LZMA_MF_HC4, LZMA_OK }, { 4, LZMA_MODE_NORMAL, LZMA_MF_BT2, LZMA_OK },
+				{ 5, LZMA_MODE_NORMAL, LZMA_MF_BT4, LZMA_OPTIONS_ERROR }, { 2, LZMA_MODE_NORMAL, LZMA_MF_HC3, LZMA_OK },
+			};
+			for (size_t i = 0; i < sizeof(sets) / sizeof(sets[0]); ++i) {
+				lzma_stream c = LZMA_STREAM_INIT;
+				q.pb = sets[i].pb; q.mode = sets[i].mode; q.mf = sets[i].mf;
+				CHECK(lzma_stream_encoder_mt(&c, &mt) == sets[i].want);
+				lzma_end(&c);
+			}
+			q.pb = 4; q.mode = LZMA_MODE_NORMAL; q.mf = LZMA_MF_BT4;
+			setenv("XZAMD_SPAN_KIB", "128", 1);
+			{ lzma_stream c = LZMA_STREAM_INIT; CHECK(lzma_stream_encoder_mt(&c, &mt) == LZMA_OPTIONS_ERROR); lzma_end(&c); }
+			q.pb = 2;
+			{ lzma_stream c = LZMA_STREAM_INIT; CHECK(lzma_stream_encoder_mt(&c, &mt) == LZMA_OK); lzma_end(&c); }
+			unsetenv("XZAMD_SPAN_KIB");
+			static const uint8_t pd[16] = { 1, 2, 3 };
+			q.preset_dict = pd; q.preset_dict_size = sizeof(pd);
+			{ lzma_stream c = LZMA_STREAM_INIT; CHECK(lzma_stream_encoder_mt(&c, &mt) == LZMA_OPTIONS_ERROR); lzma_end(&c); }
+			q.preset_dict = NULL; q.preset_dict_size = 0;
+			q.dict_size = (1u << 30) + (1u << 28);
+			{ lzma_stream c = LZMA_STREAM_INIT; CHECK(lzma_stream_encoder_mt(&c, &mt) == LZMA_OPTIONS_ERROR); lzma_end(&c); }
+		}
 		mt.filters = NULL;
 	}
 
