@@ -173,6 +173,10 @@ typedef struct {
 	int est_on;                 /* phase 2: sum the prices of the coded decisions (chunk rule of the two-phase coder) */
 	uint64_t est;               /* in 1/16 bit, from the probabilities before their update */
 	uint64_t ntok;              /* phase 2: binary decisions (tokens of the device's model pass) of the encode span so far */
+	/* carried encode spans (round 6): the bounds every probability of a span's walk stays between whatever the span's
+	 * start model is -- what the device's k_model_bounds computes per span in parallel (see carry_* below) */
+	int bnd_on;
+	uint16_t blo[P_TOTAL_MAX], bhi[P_TOTAL_MAX], bcnt[P_TOTAL_MAX];
 #ifdef ORC_XPREV
 	uint32_t *xprev[8];
 	int xprev_n;
@@ -636,10 +640,27 @@ static void rc_shift_low(enc *e)
 	e->low = (e->low & 0x00FFFFFF) << 8;
 }
 
+/* Bounds of a probability over one encode span, whatever value it has at the span start: lo starts at 31, hi at 2017 (the
+ * extremes an adapted probability can reach), both take every update of the walk; the update rule is monotone, so the true
+ * value stays between them, and once they meet the value is KNOWN without knowing the start.  Until then the bits of the
+ * slot are counted (the device logs them: the chain kernel replays them on the true start value), at most ORC_LOG_CAP. */
+#define ORC_LOG_CAP 1023u
+static inline void bnd_update(enc *e, uint32_t idx, uint32_t bit)
+{
+	uint32_t lo = e->blo[idx], hi = e->bhi[idx];
+	if (lo != hi && e->bcnt[idx] < ORC_LOG_CAP) ++e->bcnt[idx];
+	e->blo[idx] = (uint16_t)(bit ? lo - (lo >> 5) : lo + ((2048 - lo) >> 5));
+	e->bhi[idx] = (uint16_t)(bit ? hi - (hi >> 5) : hi + ((2048 - hi) >> 5));
+}
+
 static inline void rc_bit(enc *e, uint16_t *prob, uint32_t bit)
 {
-	if (e->rc_off) {            /* phase 1 of the two-phase mode: the price model adapts, nothing is coded */
+	if (e->bnd_on)
+		bnd_update(e, (uint32_t)(prob - e->probs), bit);
+	if (e->rc_off) {            /* phase 1 of the two-phase mode: the price model adapts, nothing is coded; the prices of the
+		                         * decisions (probabilities before their update) are summed: the price of a parse piece */
 		uint32_t p = *prob;
+		e->est += e->price_tab[(p ^ ((0u - bit) & 0x7FFu)) >> 4];
 		*prob = (uint16_t)(bit ? p - (p >> 5) : p + ((2048 - p) >> 5));
 		return;
 	}
@@ -687,7 +708,7 @@ static void rc_tree_rev(enc *e, uint16_t *probs, uint32_t nbits, uint32_t sym)
 
 static void rc_direct(enc *e, uint32_t value, uint32_t nbits)
 {
-	if (e->rc_off) return;
+	if (e->rc_off) { e->est += 16u * nbits; return; }
 	if (e->est_on) { e->est += 16u * nbits; e->ntok += nbits; }
 	do {
 		if (e->range < (1u << 24)) {
@@ -1639,7 +1660,24 @@ static void record_literal(enc *e, uint32_t pos, int first_of_piece)
 	e->sy_dist[pos] = cur | (prev << 8) | (mb << 16) | (matched << 24);
 }
 
-static void parse_piece(enc *e, uint32_t start, uint32_t end, int first_in_block, const uint16_t *prior)
+/* Price model, coder state and rep distances at a piece start (round 6: what the carried model walk over the first
+ * iteration's records hands to the second iteration -- the device: k_model_syms in snapshot mode writes the piece's slot of
+ * a.prior / a.lit and a.snap_sr) */
+typedef struct { uint16_t probs[P_TOTAL_MAX]; uint32_t state, reps[4]; } snap;
+
+/* First iteration: only the first part of a piece is parsed (ORC_PART_MIN bytes or an eighth of it, whichever is more) */
+#define ORC_PART_MIN 16384u
+static uint32_t part_len(uint32_t len)
+{
+	if (len <= ORC_PART_MIN) return len;
+	return (len >> 3) < ORC_PART_MIN ? ORC_PART_MIN : len >> 3;
+}
+
+/* Parses [start, end) of the piece that starts at `start` (end = the piece end, or the end of its first part in the first
+ * iteration; symbols never cross `end`).  prior != NULL: the price model starts from the Block's prior + warm-up walk +
+ * pre-roll (first iteration); sn != NULL: from the snapshot (second iteration; no walk, no pre-roll); both NULL: flat (the
+ * seed piece).  Returns the summed prices of the recorded symbols (1/16 bit, probabilities before their update). */
+static uint64_t parse_piece(enc *e, uint32_t start, uint32_t end, int first_in_block, const uint16_t *prior, const snap *sn)
 {
 	uint32_t cur = start;
 	int cached = 0;
@@ -1648,6 +1686,12 @@ static void parse_piece(enc *e, uint32_t start, uint32_t end, int first_in_block
 	lzma_state_reset(e);
 	if (prior)
 		memcpy(e->probs, prior, sizeof(e->probs));
+	if (sn) {
+		memcpy(e->probs, sn->probs, sizeof(e->probs));
+		e->state = sn->state;
+		memcpy(e->reps, sn->reps, sizeof(e->reps));
+		prior = NULL;
+	}
 	e->rc_off = 1;
 #if ORC_WARM
 	if (prior && start > ORC_PREROLL + ORC_SEED_LEN) {
@@ -1758,6 +1802,7 @@ static void parse_piece(enc *e, uint32_t start, uint32_t end, int first_in_block
 		e->trace = tr;
 	}
 #endif
+	e->est = 0;
 	if (first_in_block && cur < end) {
 		record_literal(e, 0, 1);
 		rc_bit(e, &e->probs[P_IS_MATCH], 0);
@@ -1785,145 +1830,338 @@ static void parse_piece(enc *e, uint32_t start, uint32_t end, int first_in_block
 		cur += len;
 	}
 	e->rc_off = 0;
+	return e->est;
 }
 
-/* phase 1 of a whole Block: the seed piece, then every other piece from the seed's model */
-static int parse_block(enc *e, const uint32_t *piece_start, uint32_t np)
+/* ---- carried encode spans (round 6; OUR definition) -------------------------------------------------------------------
+ * The reference codes a Block with ONE continuous model (lzma/lzma_encoder.c:313-436; reset only per lzma2_encoder.c:63-77).
+ * Rounds 4-5 reset the coder's model at every encode span (>= 512 KiB) so that the spans could be walked in parallel; on
+ * data whose model learns slowly (image pixels: thousands of literal contexts in use) each reset costs 7 ... 20 KB.  Now the
+ * model is CARRIED from span to span -- exactly, and the spans are still walked in parallel on the device:
+ *   1. k_model_bounds walks every span with two values per probability, lo (from 31) and hi (from 2017): the update rule is
+ *      monotone, so the true value stays between them whatever the span's start model is; once lo == hi the value is known.
+ *      Until then the slot's bits are logged (<= ORC_LOG_CAP per span and slot).
+ *   2. k_model_chain, per Block and slot, span after span: start value of span k + 1 = lo if the slot merged in span k, else
+ *      the logged bits replayed on its start value in span k.
+ *   3. k_model_syms walks every span from its TRUE start model (tokens, chunks).
+ * The coder state and the rep distances at a span start come from a LOOK-BACK over the piece in front of it (lookback()):
+ * the state depends on the last few symbols only; rep distances the look-back has not seen stay UNKNOWN (ORC_REP_UNKNOWN:
+ * never equal to a recorded distance, so such a symbol is coded as a match -- legal LZMA, the decoder does not care).
+ * What cannot be carried falls back to round 5's reset: a slot that has not merged after ORC_LOG_CAP logged bits, a span that
+ * ran out of token budget, a look-back that does not name the state -- from there on every span of the Block starts with a
+ * state reset.  The oracle walks the spans one after another with the true model and the same bounds beside it, so that it
+ * fails exactly where the device does.
+ *
+ * Two iterations of the parse.  The price model a piece starts from decides which of several self-consistent codings its
+ * parser settles into; a model trained on other data than the piece's own neighbourhood costs up to 10 % on image pixels
+ * (round-5 review).  So: iteration 1 parses only the first part of every piece (part_len(): an eighth, >= 16 KiB) from the
+ * seed's prior + warm-up walk + pre-roll as round 5 did; the carried model walk over THOSE records (a continuous model over a
+ * sample of the Block) leaves a snapshot at every piece start; iteration 2 parses every piece in full from its snapshot. */
+#define ORC_REP_UNKNOWN 0xFFFFFFFFu
+
+static uint32_t state_type(uint32_t s, int type)   /* type 0 literal, 1 match, 2 rep, 3 short rep (lzma_common.h:118-141) */
+{
+	switch (type) {
+	case 0: return s <= 3 ? 0 : s <= 9 ? s - 3 : s - 6;
+	case 1: return s < 7 ? 7 : 10;
+	case 2: return s < 7 ? 8 : 11;
+	default: return s < 7 ? 9 : 11;
+	}
+}
+
+/* Coder state and rep distances behind the recorded symbols of [a, b) (a = a piece start, b = the end of its parsed
+ * part), without knowing either at a: twelve candidate states run side by side (they agree after a few symbols), unknown
+ * rep distances stay ORC_REP_UNKNOWN.  Returns 0, or -1 when the candidates still differ at b. */
+static int lookback(const enc *e, uint32_t a, uint32_t b, uint32_t *state, uint32_t reps[4])
+{
+	uint32_t st[12], r[4] = { ORC_REP_UNKNOWN, ORC_REP_UNKNOWN, ORC_REP_UNKNOWN, ORC_REP_UNKNOWN };
+	for (uint32_t i = 0; i < 12; ++i) st[i] = i;
+	uint32_t cur = a;
+	while (cur < b) {
+		uint32_t len = e->sy_len[cur];
+		const uint32_t d = e->sy_dist[cur];
+		const uint32_t as_match = len >> 15;
+		len &= 0x7FFFu;
+		int type, ri = -1;
+		if (len == 0) { type = 0; len = 1; }
+		else if (as_match) type = 1;
+		else if (len == 1) type = d == r[0] ? 3 : 0;
+		else {
+			for (int i = 0; i < 4; ++i)
+				if (d == r[i]) { ri = i; break; }
+			type = ri >= 0 ? 2 : 1;
+		}
+		if (type == 1) { r[3] = r[2]; r[2] = r[1]; r[1] = r[0]; r[0] = d; }
+		else if (type == 2 && ri > 0) {
+			for (int i = ri; i > 0; --i) r[i] = r[i - 1];
+			r[0] = d;
+		}
+		for (uint32_t i = 0; i < 12; ++i) st[i] = state_type(st[i], type);
+		cur += len;
+	}
+	for (uint32_t i = 1; i < 12; ++i)
+		if (st[i] != st[0]) return -1;
+	*state = st[0];
+	memcpy(reps, r, 16);
+	return 0;
+}
+
+static void bnd_reset(enc *e, int known)
+{
+	for (uint32_t i = 0; i < P_TOTAL_MAX; ++i) {
+		e->blo[i] = known ? 1024 : 31;
+		e->bhi[i] = known ? 1024 : 2017;
+		e->bcnt[i] = 0;
+	}
+}
+
+static int bnd_failed(const enc *e)
+{
+	const uint32_t total = P_LITERAL + (0x300u << (e->prm.lc + e->prm.lp));
+	for (uint32_t i = 0; i < total; ++i)
+		if (e->blo[i] != e->bhi[i] && e->bcnt[i] >= ORC_LOG_CAP) return 1;
+	return 0;
+}
+
+/* the coder's reading of the record at cur (the device: k_model_syms): back = LIT / rep index / distance + 4 */
+static uint32_t record_back(enc *e, uint32_t cur, uint32_t *len_out)
+{
+	uint32_t len = e->sy_len[cur];
+	const uint32_t d = e->sy_dist[cur];
+	const uint32_t as_match = len >> 15;            /* the parser's choice: a match, whatever the coder's reps are */
+	len &= 0x7FFFu;
+	uint32_t back;
+	e->lit_rec = 0;
+	if (len == 0) { back = LIT; len = 1; e->lit_rec = d | (1u << 31); }
+	else if (as_match) back = d + 4;
+	else if (len == 1) { back = d == e->reps[0] ? 0 : LIT; if (back == LIT) e->lit_rec = 0; }
+	else if (d == e->reps[0]) back = 0;
+	else if (d == e->reps[1]) back = 1;
+	else if (d == e->reps[2]) back = 2;
+	else if (d == e->reps[3]) back = 3;
+	else back = d + 4;
+	*len_out = len;
+	return back;
+}
+
+/* The carried model walk over the FIRST iteration's records (only the first part of every piece has them): one continuous
+ * model per Block, carried across the encode spans as the coder's is, nothing coded; snaps[j] = model, state and rep
+ * distances when the walk reaches piece j (j >= 1).  The price model is the parser's: it runs with the parser's pb. */
+static void snapshot_walk(enc *e, const uint32_t *ps, uint32_t np, const uint32_t *es, uint32_t ne, snap *snaps)
+{
+	const uint32_t n = e->n;
+	uint32_t ke = 0;
+	int failed = 0;
+	lzma_state_reset(e);
+	e->rc_off = 1;
+	e->bnd_on = 1;
+	bnd_reset(e, 1);
+	for (uint32_t j = 0; j < np; ++j) {
+		const uint32_t a = ps[j], pe = j + 1 < np ? ps[j + 1] : n, b = a + part_len(pe - a);
+		if (ke + 1 < ne && a == es[ke + 1]) {
+			/* a span boundary: can the model be carried into this span? */
+			if (!failed && bnd_failed(e)) failed = 1;
+			++ke;
+			uint32_t st = 0, rp[4] = { 0, 0, 0, 0 };
+			if (!failed && lookback(e, ps[j - 1], ps[j - 1] + part_len(a - ps[j - 1]), &st, rp)) failed = 1;
+			if (failed) lzma_state_reset(e);
+			else { e->state = st; memcpy(e->reps, rp, 16); }
+			e->rc_off = 1;
+			bnd_reset(e, failed);
+		}
+		if (j >= 1) {
+			memcpy(snaps[j].probs, e->probs, sizeof(e->probs));
+			snaps[j].state = e->state;
+			for (int i = 0; i < 4; ++i)      /* a parser's rep distances must be real ones: unknown -> 0, as after a reset */
+				snaps[j].reps[i] = e->reps[i] == ORC_REP_UNKNOWN ? 0 : e->reps[i];
+		}
+		uint32_t cur = a;
+		if (j == 0 && cur < b) {
+			rc_bit(e, &e->probs[P_IS_MATCH], 0);
+			rc_tree(e, e->probs + P_LITERAL, 8, e->in[0]);
+			cur = 1;
+		}
+		while (cur < b) {
+			uint32_t len;
+			const uint32_t back = record_back(e, cur, &len);
+			enc_symbol(e, cur, back, len);
+			e->lit_rec = 0;
+			cur += len;
+		}
+	}
+	e->bnd_on = 0;
+	e->rc_off = 0;
+}
+
+/* phase 1 of a whole Block: the seed piece; iteration 1 (the first part of every other piece, from the seed's model);
+ * the carried model walk over its records; iteration 2 (every piece in full, from its snapshot).  raw[k] = 1: the parser's
+ * own price of piece k says it does not shrink -- the coder stores it (encode_block_syms). */
+static int parse_block(enc *e, const uint32_t *piece_start, uint32_t np, const uint32_t *enc_start, uint32_t ne, uint8_t *raw)
 {
 	const uint32_t n = e->n;
 	e->sy_len = (uint16_t *)calloc((size_t)n + 1, 2);
 	e->sy_dist = (uint32_t *)calloc((size_t)n + 1, 4);
 	uint16_t *prior = (uint16_t *)malloc(sizeof(e->probs));
-	if (!e->sy_len || !e->sy_dist || !prior) { free(prior); return -3; }
+	snap *snaps = (snap *)malloc(sizeof(snap) * (np ? np : 1));
+	if (!e->sy_len || !e->sy_dist || !prior || !snaps) { free(prior); free(snaps); return -3; }
 	orc_trace *const tr = e->trace;
 	/* pb = 3, 4 (lzma/lzma_common.h:32-37): the price model of the parse pieces is the parser's alone -- the coder runs
-	 * its own continuous model with the real pb (encode_syms) -- and takes a pb = 2 view of the positions: the device
+	 * its own continuous model with the real pb (encode_block_syms) -- and takes a pb = 2 view of the positions: the device
 	 * parser's per-window price tables hold four position states.  The recorded symbols are valid under any pb. */
 	const uint32_t pb_coder = e->prm.pb;
 	if (e->prm.pb > 2) e->prm.pb = 2;
+	uint64_t price0 = 0;
+	e->trace = NULL;                /* the trace is the second iteration's (and the seed piece's) */
 	for (uint32_t k = 0; k < np; ++k) {
-		parse_piece(e, piece_start[k], k + 1 < np ? piece_start[k + 1] : n, k == 0, k == 0 ? NULL : prior);
-		if (k == 0) memcpy(prior, e->probs, sizeof(e->probs));
+		const uint32_t a = piece_start[k], pe = k + 1 < np ? piece_start[k + 1] : n;
+		if (k == 0) e->trace = tr;
+		const uint64_t pr = parse_piece(e, a, k == 0 ? pe : a + part_len(pe - a), k == 0, k == 0 ? NULL : prior, NULL);
+		if (k == 0) { memcpy(prior, e->probs, sizeof(e->probs)); price0 = pr; e->trace = NULL; }
+	}
+	snapshot_walk(e, piece_start, np, enc_start, ne, snaps);
+	e->trace = tr;
+	for (uint32_t k = 0; k < np; ++k) {
+		const uint32_t a = piece_start[k], pe = k + 1 < np ? piece_start[k + 1] : n;
+		const uint64_t pr = k == 0 ? price0 : parse_piece(e, a, pe, 0, NULL, &snaps[k]);
+		if (raw) raw[k] = pr / 128u >= pe - a;
 	}
 	e->prm.pb = pb_coder;
 	e->trace = tr;
 	free(prior);
+	free(snaps);
 	return 0;
 }
 
-static int encode_syms(enc *e, uint32_t start, uint32_t end, int first_in_block,
+static int put_raw(enc *e, uint32_t a, uint32_t b, int *need_dict_reset, uint8_t *out, uint64_t cap, uint64_t *opos)
+{
+	/* lzma2_encoder.c:110-131: uncompressed chunks of at most 64 KiB */
+	while (a < b) {
+		const uint32_t usize = b - a < 65536u ? b - a : 65536u;
+		uint8_t hdr[3];
+		hdr[0] = *need_dict_reset ? 1 : 2;
+		*need_dict_reset = 0;
+		hdr[1] = (uint8_t)((usize - 1) >> 8);
+		hdr[2] = (uint8_t)(usize - 1);
+		if (put(out, cap, opos, hdr, 3) || put(out, cap, opos, e->in + a, usize))
+			return -1;
+		if (e->trace) ++e->trace->chunks_uncompressed;
+		a += usize;
+	}
+	return 0;
+}
+
+/* phase 2 of a whole Block: the recorded symbols through the coder, encode span after encode span (the device walks them in
+ * parallel: k_model_bounds / k_model_chain / k_model_syms / k_rc_chunks). */
+static int encode_block_syms(enc *e, const uint32_t *ps, uint32_t np, const uint32_t *es, uint32_t ne, const uint8_t *raw,
 		uint8_t *out, uint64_t cap, uint64_t *opos)
 {
-	int need_props = 1, need_dict_reset = first_in_block, need_state_reset = 0;
-	uint32_t cur = start;
+	const uint32_t n = e->n;
+	int need_dict_reset = 1, failed = 0, r = 0;
+	uint32_t j = 0;                                       /* piece that holds `cur` */
 	lzma_state_reset(e);
+	e->bnd_on = 1;
 	/* Chunk rule of the two-phase coder (OUR definition; the device: k_model_syms / k_rc_chunks).  The range coder of a
 	 * chunk runs apart from the model pass that decides where chunks end, so that pass cannot look at the coded size:
 	 * it sums the PRICES of the decisions instead (the parser's table, 1/16 bit each, probabilities before their
 	 * update; 16 per direct bit).  A chunk ends in front of the first symbol at which the sum has reached
-	 * ORC_CHUNK_EST (56,000 bytes: the coded size stays far below the format's 65,536) or 2 MiB - 273 bytes of input;
-	 * it is stored raw when the estimate says it would not shrink (est / 128 + 5 >= bytes of input). */
+	 * ORC_CHUNK_EST (56,000 bytes: the coded size stays far below the format's 65,536) or 2 MiB - 273 bytes of input.
+	 * Round 6: what is stored raw is decided per PIECE, by the parser's price of it (raw[]: the walk that finds the
+	 * bounds has no exact prices to decide by); a state reset follows a stored piece as it follows a stored chunk in the
+	 * reference (lzma2_encoder.c:205-214). */
 	e->est_on = 1;
-	/* Token budget (the device's token buffer: ORC_TOK_PER_BYTE per input byte of the span + 4096, 64 spare): when it
-	 * runs out -- data made of far three-byte matches needs 32 ... 41 decisions per 3 bytes -- the chunk is closed where
-	 * it stands and the REST of the span is stored as raw chunks of 64 KiB (lzma2_encoder.c:110-131). */
-	const uint64_t tok_cap = (uint64_t)(end - start) * (orc_tok_per_byte ? orc_tok_per_byte : ORC_TOK_PER_BYTE) + 4096u - 64u;
-	int tok_full = 0;
-	e->ntok = 0;
-	int initialized = !first_in_block;
-	while (cur < end) {
-		if (need_state_reset)
-			lzma_state_reset(e);
-		const uint32_t chunk_start = cur;
-		const uint64_t chunk_tok = e->ntok;
-		e->cpos = 0;
-		e->est = 0;
-		if (tok_full) {
-			const uint32_t usize = end - cur < 65536u ? end - cur : 65536u;
-			uint8_t hdr[3];
-			hdr[0] = need_dict_reset ? 1 : 2;
-			need_dict_reset = 0;
-			hdr[1] = (uint8_t)((usize - 1) >> 8);
-			hdr[2] = (uint8_t)(usize - 1);
-			if (put(out, cap, opos, hdr, 3) || put(out, cap, opos, e->in + chunk_start, usize)) {
-				e->est_on = 0;
-				return -1;
+	for (uint32_t k = 0; k < ne && !r; ++k) {
+		const uint32_t start = es[k], end = k + 1 < ne ? es[k + 1] : n;
+		int need_props = k == 0, need_state_reset = 0;
+		while (j + 1 < np && ps[j + 1] <= start) ++j;     /* ps[j] == start */
+		if (k > 0) {
+			/* carried, or round 5's reset (control 0xC0: state reset + properties, as every span start had) */
+			uint32_t st = 0, rp[4] = { 0, 0, 0, 0 };
+			if (!failed && bnd_failed(e)) failed = 1;
+			const int prev_raw = raw[j - 1];
+			if (!failed && !prev_raw && lookback(e, ps[j - 1], ps[j], &st, rp)) failed = 1;
+			if (failed) { lzma_state_reset(e); need_props = 1; }
+			else if (prev_raw) need_state_reset = 1;       /* the model was reset behind the stored piece: nothing to carry */
+			else { e->state = st; memcpy(e->reps, rp, 16); }
+			bnd_reset(e, failed || prev_raw);
+		} else
+			bnd_reset(e, 1);
+		/* Token budget (the device's token buffer: ORC_TOK_PER_BYTE per input byte of the span + 4096, 64 spare): when it
+		 * runs out -- data made of far three-byte matches needs 32 ... 41 decisions per 3 bytes -- the chunk is closed where
+		 * it stands and the REST of the span is stored as raw chunks of 64 KiB (lzma2_encoder.c:110-131); no later span of
+		 * the Block is carried. */
+		const uint64_t tok_cap = (uint64_t)(end - start) * (orc_tok_per_byte ? orc_tok_per_byte : ORC_TOK_PER_BYTE) + 4096u - 64u;
+		e->ntok = 0;
+		uint32_t cur = start;
+		while (cur < end && !r) {
+			if (cur == ps[j] && raw[j]) {
+				/* a stored piece */
+				const uint32_t pe = j + 1 < np ? ps[j + 1] : n;
+				r = put_raw(e, cur, pe, &need_dict_reset, out, cap, opos);
+				need_state_reset = 1;
+				cur = pe;
+				if (j + 1 < np) ++j;
+				continue;
 			}
-			if (e->trace) ++e->trace->chunks_uncompressed;
-			cur += usize;
-			continue;
-		}
-		if (!initialized) {
-			rc_bit(e, &e->probs[P_IS_MATCH], 0);
-			rc_tree(e, e->probs + P_LITERAL, 8, e->in[0]);
-			trace_sym(e, 0, LIT, 1);
-			cur = 1;
-			initialized = 1;
-		}
-		for (;;) {
-			if (cur - chunk_start >= (1u << 21) - MATCH_LEN_MAX || e->est >= ORC_CHUNK_EST)
-				break;
-			if (cur >= end)
-				break;
-			if (e->ntok + 64u > tok_cap) { tok_full = 1; break; }
-			uint32_t len = e->sy_len[cur];
-			const uint32_t d = e->sy_dist[cur];
-			const uint32_t as_match = len >> 15;            /* the parser's choice: a match, whatever the coder's reps are */
-			len &= 0x7FFFu;
-			uint32_t back;
-			e->lit_rec = 0;
-			if (len == 0) { back = LIT; len = 1; e->lit_rec = d | (1u << 31); }
-			else if (as_match) back = d + 4;
-			else if (len == 1) back = d == e->reps[0] ? 0 : LIT;
-			else if (d == e->reps[0]) back = 0;
-			else if (d == e->reps[1]) back = 1;
-			else if (d == e->reps[2]) back = 2;
-			else if (d == e->reps[3]) back = 3;
-			else back = d + 4;
-			enc_symbol(e, cur, back, len);
-			e->lit_rec = 0;
-			cur += len;
-		}
-		rc_flush(e);
-		const uint32_t usize = cur - chunk_start, csize = e->cpos;
-		uint8_t hdr[6];
-		if (usize == 0) continue;                              /* the budget ran out right at a chunk start */
-		if (csize > 65536) { e->est_on = 0; return -4; }      /* cannot happen: see ORC_CHUNK_EST */
-		if (e->est / 128 + 5 >= usize) {
-			e->ntok = chunk_tok;                               /* a raw chunk's tokens are dropped */
-			hdr[0] = need_dict_reset ? 1 : 2;
-			need_dict_reset = 0;
-			hdr[1] = (uint8_t)((usize - 1) >> 8);
-			hdr[2] = (uint8_t)(usize - 1);
-			need_state_reset = 1;
-			if (put(out, cap, opos, hdr, 3) || put(out, cap, opos, e->in + chunk_start, usize)) {
-				e->est_on = 0;
-				return -1;
+			if (need_state_reset) {
+				lzma_state_reset(e);
+				bnd_reset(e, 1);
 			}
-			if (e->trace) ++e->trace->chunks_uncompressed;
-			continue;
+			const uint32_t chunk_start = cur;
+			e->cpos = 0;
+			e->est = 0;
+			if (k == 0 && cur == 0) {
+				rc_bit(e, &e->probs[P_IS_MATCH], 0);
+				rc_tree(e, e->probs + P_LITERAL, 8, e->in[0]);
+				cur = 1;
+			}
+			int tok_full = 0;
+			for (;;) {
+				if (cur - chunk_start >= (1u << 21) - MATCH_LEN_MAX || e->est >= ORC_CHUNK_EST)
+					break;
+				if (cur >= end)
+					break;
+				if (j + 1 < np && cur == ps[j + 1]) {
+					++j;
+					if (raw[j]) break;
+				}
+				if (e->ntok + 64u > tok_cap) { tok_full = 1; break; }
+				uint32_t len;
+				const uint32_t back = record_back(e, cur, &len);
+				enc_symbol(e, cur, back, len);
+				e->lit_rec = 0;
+				cur += len;
+			}
+			rc_flush(e);
+			const uint32_t usize = cur - chunk_start, csize = e->cpos;
+			if (usize) {
+				uint8_t hdr[6];
+				if (csize > 65536) { r = -4; break; }              /* cannot happen: see ORC_CHUNK_EST */
+				uint32_t hl = 0;
+				if (need_props)
+					hdr[hl] = need_dict_reset ? 0x80 + (3 << 5) : 0x80 + (2 << 5);
+				else
+					hdr[hl] = need_state_reset ? 0x80 + (1 << 5) : 0x80;
+				hdr[hl++] += (uint8_t)((usize - 1) >> 16);
+				hdr[hl++] = (uint8_t)((usize - 1) >> 8);
+				hdr[hl++] = (uint8_t)(usize - 1);
+				hdr[hl++] = (uint8_t)((csize - 1) >> 8);
+				hdr[hl++] = (uint8_t)(csize - 1);
+				if (need_props)
+					hdr[hl++] = (uint8_t)((e->prm.pb * 5 + e->prm.lp) * 9 + e->prm.lc);
+				need_props = need_state_reset = need_dict_reset = 0;
+				if (put(out, cap, opos, hdr, hl) || put(out, cap, opos, e->cbuf, csize)) { r = -1; break; }
+				if (e->trace) ++e->trace->chunks_lzma;
+			}
+			if (tok_full) {
+				r = put_raw(e, cur, end, &need_dict_reset, out, cap, opos);
+				cur = end;
+				failed = 1;
+			}
 		}
-		uint32_t hl = 0;
-		if (need_props)
-			hdr[hl] = need_dict_reset ? 0x80 + (3 << 5) : 0x80 + (2 << 5);
-		else
-			hdr[hl] = need_state_reset ? 0x80 + (1 << 5) : 0x80;
-		hdr[hl++] += (uint8_t)((usize - 1) >> 16);
-		hdr[hl++] = (uint8_t)((usize - 1) >> 8);
-		hdr[hl++] = (uint8_t)(usize - 1);
-		hdr[hl++] = (uint8_t)((csize - 1) >> 8);
-		hdr[hl++] = (uint8_t)(csize - 1);
-		if (need_props)
-			hdr[hl++] = (uint8_t)((e->prm.pb * 5 + e->prm.lp) * 9 + e->prm.lc);
-		need_props = need_state_reset = need_dict_reset = 0;
-		if (put(out, cap, opos, hdr, hl) || put(out, cap, opos, e->cbuf, csize)) {
-			e->est_on = 0;
-			return -1;
-		}
-		if (e->trace) ++e->trace->chunks_lzma;
 	}
 	e->est_on = 0;
-	return 0;
+	e->bnd_on = 0;
+	return r;
 }
 
 static uint32_t hash_mask_for(uint32_t dict_size, uint32_t hash_bytes)
@@ -2040,14 +2278,15 @@ static int encode_block_impl(const uint8_t *in, uint32_t n, const orc_enc_params
 		const uint32_t scap = n / 4096 + 2;
 		uint32_t *ss = (uint32_t *)malloc((size_t)scap * 8), *es = ss + scap, ne = 0;
 		const uint32_t np = plan_spans_ex(e, NULL, ss, scap, es, scap, &ne);
-		r = parse_block(e, ss, np);
+		uint8_t *raw = (uint8_t *)calloc(np + 1, 1);
+		r = raw ? parse_block(e, ss, np, es, ne, raw) : -3;
 		if (!r && sym_len && sym_dist) {
 			memcpy(sym_len, e->sy_len, (size_t)n * 2);
 			memcpy(sym_dist, e->sy_dist, (size_t)n * 4);
 		}
 		e->trace = NULL;            /* the trace is the parser's */
-		for (uint32_t k = 0; k < ne && !r; ++k)
-			r = encode_syms(e, es[k], k + 1 < ne ? es[k + 1] : n, k == 0, out, cap, &opos);
+		if (!r && n) r = encode_block_syms(e, ss, np, es, ne, raw, out, cap, &opos);
+		free(raw);
 		e->trace = trace;
 		free(ss);
 	} else if (p->span_cost && p->sa_window) {
@@ -2127,9 +2366,9 @@ int orc_parse_dump(const uint8_t *in, uint32_t n, const orc_enc_params *p, uint1
 	enc *e = enc_new(in, n, p);
 	if (!e) return -3;
 	const uint32_t scap = n / 4096 + 2;
-	uint32_t *ss = (uint32_t *)malloc((size_t)scap * 4);
-	const uint32_t np = plan_spans_ex(e, NULL, ss, scap, NULL, 0, NULL);
-	const int r = parse_block(e, ss, np);
+	uint32_t *ss = (uint32_t *)malloc((size_t)scap * 8), *es = ss + scap, ne = 0;
+	const uint32_t np = plan_spans_ex(e, NULL, ss, scap, es, scap, &ne);
+	const int r = parse_block(e, ss, np, es, ne, NULL);
 	if (!r) {
 		memcpy(sym_len, e->sy_len, (size_t)n * 2);
 		memcpy(sym_dist, e->sy_dist, (size_t)n * 4);

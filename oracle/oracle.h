@@ -145,7 +145,7 @@ typedef struct {
 	                       first piece end where the estimate reaches ceil(bits / ke) and the span is >= ORC_ENC_MIN_LEN long */
 } orc_enc_params;
 #define ORC_EST_CHUNK 4096u
-#define ORC_SPAN_MAX (16u << 20)
+#define ORC_SPAN_MAX (1u << 20)    /* longest piece (round 6: 16 MiB let one wavefront walk 16 MiB of a highly compressible Block) */
 #define ORC_SEED_LEN 65536u
 #define ORC_ENC_MIN_LEN (512u << 10)
 

@@ -39,6 +39,7 @@ def main():
             "tar": lambda k: xz_amd.corpus_tar(k).tobytes(), "logs": _corpora.logs, "json": _corpora.json_records,
             "sqlite": _corpora.sqlite_file, "dpkg_tar": _corpora.dpkg_tar, "elf_metadata": _corpora.elf_metadata}
     gens.update(_corpora.NUMERIC_CLASSES)
+    gens.update(_corpora.REVIEW_CLASSES)
     gens.update({k: v[0] for k, v in _corpora.KNOWN_OUTSIDE.items()})
     data = gens[which](n)
     if data is None:

@@ -98,7 +98,7 @@ typedef struct xzamd_chunk {
 #define XZAMD_PREROLL 2048u         /* two-phase: bytes in front of a piece that are parsed twice (oracle: ORC_PREROLL) */
 #define XZAMD_SPAN_SLACK 4112u      /* 4096 + 16 bytes of scratch per span slot on top of 9/8 of the input */
 #define XZAMD_EST_CHUNK 4096u       /* positions per work estimate of the span plan */
-#define XZAMD_SPAN_MAX (16u << 20)  /* longest cost-balanced span */
+#define XZAMD_SPAN_MAX (1u << 20)   /* longest cost-balanced span (oracle: ORC_SPAN_MAX) */
 
 /* One gather segment of the final assembly. kind 0: src is an offset into the span scratch,
  * 1: into the literal-bytes buffer prepared by the host, 2: into the batch input (raw). */
