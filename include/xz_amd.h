@@ -250,6 +250,12 @@ int xzamd_trace_read(xzamd_ctx *ctx, uint32_t *out, uint32_t cap, uint32_t *coun
 #define XZAMD_DEBUG_SYM_DIST 10     /* two-phase: u32 per position (distance / literal bytes) */
 #define XZAMD_DEBUG_ENC_TAB 11      /* two-phase: (first byte, end) per encode-span slot, slots = Block * (block_size / 512 KiB + 1) + j */
 #define XZAMD_DEBUG_ENC_CNT 12      /* encode spans per Block */
+#define XZAMD_DEBUG_PINFO 13        /* two-phase: 16 x u32 per piece slot ([0..7] iteration 1, [8..15] iteration 2: state | ok << 31, rep distances, raw) */
+#define XZAMD_DEBUG_SNAP_SR 14      /* 8 x u32 per piece slot: state and rep distances a piece starts iteration 2 with */
+#define XZAMD_DEBUG_PRIOR 15        /* 1856 x u32 per piece slot: the non-literal probabilities of the piece's price model (after the run: as adapted) */
+#define XZAMD_DEBUG_CARRY 16        /* the coder's walk, per encode-span slot: 0 = reset + properties, 1 = carried, 2 = flat start */
+#define XZAMD_DEBUG_CB_HDR 17       /* the coder's bounds walk, per encode-span slot: XZAMD_CB_* flags */
+#define XZAMD_DEBUG_CB_START 18     /* the coder's walk: the model at the span start, u16 per probability (padded to 64) */
 int xzamd_debug_fetch(xzamd_ctx *ctx, int what, void *host_out, uint64_t bytes);
 
 /* Seeded synthetic corpora used by bench.py and the tests (host memory). */

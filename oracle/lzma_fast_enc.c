@@ -1858,6 +1858,7 @@ static uint64_t parse_piece(enc *e, uint32_t start, uint32_t end, int first_in_b
  * seed's prior + warm-up walk + pre-roll as round 5 did; the carried model walk over THOSE records (a continuous model over a
  * sample of the Block) leaves a snapshot at every piece start; iteration 2 parses every piece in full from its snapshot. */
 #define ORC_REP_UNKNOWN 0xFFFFFFFFu
+#define ORC_RAW_MIN_LEN 32768u     /* shortest piece that is stored raw (the device's chunk table: XZAMD_RAW_MIN_LEN) */
 
 static uint32_t state_type(uint32_t s, int type)   /* type 0 literal, 1 match, 2 rep, 3 short rep (lzma_common.h:118-141) */
 {
@@ -1957,13 +1958,13 @@ static void snapshot_walk(enc *e, const uint32_t *ps, uint32_t np, const uint32_
 	e->bnd_on = 1;
 	bnd_reset(e, 1);
 	for (uint32_t j = 0; j < np; ++j) {
-		const uint32_t a = ps[j], pe = j + 1 < np ? ps[j + 1] : n, b = a + part_len(pe - a);
+		const uint32_t a = ps[j], pe = j + 1 < np ? ps[j + 1] : n, b = j == 0 ? pe : a + part_len(pe - a);   /* (the seed piece has all its records) */
 		if (ke + 1 < ne && a == es[ke + 1]) {
 			/* a span boundary: can the model be carried into this span? */
 			if (!failed && bnd_failed(e)) failed = 1;
 			++ke;
 			uint32_t st = 0, rp[4] = { 0, 0, 0, 0 };
-			if (!failed && lookback(e, ps[j - 1], ps[j - 1] + part_len(a - ps[j - 1]), &st, rp)) failed = 1;
+			if (!failed && lookback(e, ps[j - 1], j == 1 ? a : ps[j - 1] + part_len(a - ps[j - 1]), &st, rp)) failed = 1;
 			if (failed) lzma_state_reset(e);
 			else { e->state = st; memcpy(e->reps, rp, 16); }
 			e->rc_off = 1;
@@ -1993,6 +1994,9 @@ static void snapshot_walk(enc *e, const uint32_t *ps, uint32_t np, const uint32_
 	e->rc_off = 0;
 }
 
+/* test hook (orc_two_phase_debug): what the stages leave */
+static orc_two_phase_dbg *tp_dbg;
+
 /* phase 1 of a whole Block: the seed piece; iteration 1 (the first part of every other piece, from the seed's model);
  * the carried model walk over its records; iteration 2 (every piece in full, from its snapshot).  raw[k] = 1: the parser's
  * own price of piece k says it does not shrink -- the coder stores it (encode_block_syms). */
@@ -2019,11 +2023,18 @@ static int parse_block(enc *e, const uint32_t *piece_start, uint32_t np, const u
 		if (k == 0) { memcpy(prior, e->probs, sizeof(e->probs)); price0 = pr; e->trace = NULL; }
 	}
 	snapshot_walk(e, piece_start, np, enc_start, ne, snaps);
+	if (tp_dbg && tp_dbg->snap_sr)
+		for (uint32_t k = 1; k < np; ++k) {
+			tp_dbg->snap_sr[5 * k] = snaps[k].state;
+			memcpy(tp_dbg->snap_sr + 5 * k + 1, snaps[k].reps, 16);
+			if (tp_dbg->snap_probs) memcpy(tp_dbg->snap_probs + (size_t)k * P_LITERAL, snaps[k].probs, 2 * P_LITERAL);
+		}
 	e->trace = tr;
 	for (uint32_t k = 0; k < np; ++k) {
 		const uint32_t a = piece_start[k], pe = k + 1 < np ? piece_start[k + 1] : n;
 		const uint64_t pr = k == 0 ? price0 : parse_piece(e, a, pe, 0, NULL, &snaps[k]);
-		if (raw) raw[k] = pr / 128u >= pe - a;
+		if (raw) raw[k] = pe - a >= ORC_RAW_MIN_LEN && pr / 128u >= pe - a;
+		if (tp_dbg && tp_dbg->price) tp_dbg->price[k] = pr;
 	}
 	e->prm.pb = pb_coder;
 	e->trace = tr;
@@ -2083,6 +2094,7 @@ static int encode_block_syms(enc *e, const uint32_t *ps, uint32_t np, const uint
 			else if (prev_raw) need_state_reset = 1;       /* the model was reset behind the stored piece: nothing to carry */
 			else { e->state = st; memcpy(e->reps, rp, 16); }
 			bnd_reset(e, failed || prev_raw);
+			if (tp_dbg && tp_dbg->carry) tp_dbg->carry[k] = failed ? 0 : prev_raw ? 2 : 1;
 		} else
 			bnd_reset(e, 1);
 		/* Token budget (the device's token buffer: ORC_TOK_PER_BYTE per input byte of the span + 4096, 64 spare): when it
@@ -2357,6 +2369,18 @@ uint32_t orc_piece_plan(const uint8_t *in, uint32_t n, const orc_enc_params *p, 
 	const uint32_t ns = plan_spans_ex(e, chunk_cost, span_start, span_cap, enc_start, enc_cap, n_enc);
 	enc_free(e);
 	return ns;
+}
+
+int orc_two_phase_debug(const uint8_t *in, uint32_t n, const orc_enc_params *p, orc_two_phase_dbg *d)
+{
+	uint64_t osz = 0;
+	uint8_t *out = (uint8_t *)malloc((size_t)n + n / 8 + 4096);
+	if (!out) return -3;
+	tp_dbg = d;
+	const int r = encode_block_impl(in, n, p, out, (uint64_t)n + n / 8 + 4096, &osz, NULL, NULL, NULL);
+	tp_dbg = NULL;
+	free(out);
+	return r;
 }
 
 int orc_parse_dump(const uint8_t *in, uint32_t n, const orc_enc_params *p, uint16_t *sym_len, uint32_t *sym_dist)

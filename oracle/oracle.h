@@ -162,6 +162,17 @@ uint32_t orc_piece_plan(const uint8_t *in, uint32_t n, const orc_enc_params *p, 
  * sym_len (0 = literal, else the match length) and sym_dist (zero-based distance; literal: byte | previous byte << 8 |
  * match byte << 16 | (parser state >= 7) << 24). */
 int orc_parse_dump(const uint8_t *in, uint32_t n, const orc_enc_params *p, uint16_t *sym_len, uint32_t *sym_dist);
+/* Two-phase mode, stage by stage (device parity tests): every pointer optional.  snap_sr: 5 x u32 per piece (state, rep
+ * distances a piece starts iteration 2 with; piece 0 unused), snap_probs: the 1846 non-literal probabilities of that model per
+ * piece, price: the parser's price of every piece (1/16 bit), carry: per encode span 0 = reset + properties, 1 = carried,
+ * 2 = flat start behind a stored piece (span 0 unused). */
+typedef struct {
+	uint32_t *snap_sr;
+	uint16_t *snap_probs;
+	uint64_t *price;
+	uint32_t *carry;
+} orc_two_phase_dbg;
+int orc_two_phase_debug(const uint8_t *in, uint32_t n, const orc_enc_params *p, orc_two_phase_dbg *d);
 /* Two-phase mode: orc_lzma2_encode_block and orc_parse_dump in one pass (full-size parity tests). */
 int orc_lzma2_encode_block_syms(const uint8_t *in, uint32_t n, const orc_enc_params *p,
 		uint8_t *out, uint64_t out_cap, uint64_t *out_size, uint16_t *sym_len, uint32_t *sym_dist);

@@ -541,6 +541,27 @@ def orc_parse_dump(data, prm):
     return sl, sd
 
 
+class OrcTwoPhaseDbg(C.Structure):
+    _fields_ = [("snap_sr", u32p), ("snap_probs", C.POINTER(C.c_uint16)), ("price", C.POINTER(C.c_uint64)), ("carry", u32p)]
+
+
+def orc_two_phase_debug(data, prm, npieces, nspans):
+    """Two-phase, stage by stage (oracle.h: orc_two_phase_debug): per piece the state / rep distances (npieces x 5) and the 1846
+    non-literal probabilities iteration 2 starts from, the parser's price of every piece; per encode span the carry decision."""
+    data = as_u8(data)
+    sr = np.zeros((npieces, 5), dtype=np.uint32)
+    probs = np.zeros((npieces, 1846), dtype=np.uint16)
+    price = np.zeros(npieces, dtype=np.uint64)
+    carry = np.zeros(nspans, dtype=np.uint32)
+    d = OrcTwoPhaseDbg(_ptr(sr, u32p), _ptr(probs, C.POINTER(C.c_uint16)), _ptr(price, C.POINTER(C.c_uint64)), _ptr(carry, u32p))
+    f = orc().orc_two_phase_debug
+    f.restype = C.c_int
+    f.argtypes = [u8p, C.c_uint32, C.POINTER(OrcParams), C.POINTER(OrcTwoPhaseDbg)]
+    r = f(_ptr(data), len(data), C.byref(prm), C.byref(d))
+    assert r == 0, r
+    return sr, probs, price, carry
+
+
 def orc_encode_block_syms(data, prm):
     """Two-phase: (raw LZMA2 payload, sym_len, sym_dist) of one Block in one pass of the oracle."""
     data = as_u8(data)

@@ -69,7 +69,35 @@ typedef struct {
 	struct xzamd_chunk *chunks;  /* chunk slots of encode-span slot s: from XZAMD_CHUNK_BASE(st, s) on; usize 0 = unused */
 	uint32_t tok_limit;          /* 0 = XZAMD_TOK_PER_BYTE; tests (XZAMD_TEST_TOK_PER_BYTE): a smaller token budget per input byte,
 	                                to reach the "out of tokens: the rest of the span goes out raw" path on ordinary data */
+	/* Round 6 (oracle: "carried encode spans"): two parse iterations and a coder model that is carried from encode span to
+	 * encode span.  iter 1: every piece but the seed parses only its first part (XZAMD_PART_LEN) from the prior + walk +
+	 * pre-roll; iter 2: every piece but the seed parses in full from the snapshot the carried model walk over iteration 1's
+	 * records left in ITS slot of prior / lit (state and rep distances: snap_sr). */
+	uint32_t iter;
+	uint32_t *pinfo;             /* XZAMD_PINFO_WORDS x u32 per piece slot, two halves of 8: [0..7] written by iter 1, [8..15] by iter 2, the
+	                                seed piece (parsed once) writes both: [0] coder state behind the piece's recorded symbols |
+	                                XZAMD_PI_STATE_OK (the twelve candidate states agree), [1..4] the coder's rep distances there
+	                                (XZAMD_REP_UNKNOWN: not named by the piece), [5] 1 = the parser's price of the piece says it does not
+	                                shrink: stored raw (full parses only) */
+	uint32_t *snap_sr;           /* 8 x u32 per piece slot: [0] state, [1..4] rep distances a piece of iter 2 starts with */
+	/* the carried model walk (k_model_bounds / k_model_chain / k_model_syms), per encode-span slot */
+	uint32_t *cb_bnd;            /* model_slots_pad x u32: lo | hi << 11 | logged bits << 22 of every probability over the span */
+	uint32_t *cb_log;            /* model_slots_pad x XZAMD_LOG_WORDS x u32: the bits of a probability until lo == hi */
+	uint32_t *cb_hdr;            /* 1 x u32: XZAMD_CB_* flags of the span */
+	uint16_t *cb_start;          /* model_slots_pad x u16: the model at the span start (k_model_chain) */
+	uint32_t *cb_carry;          /* 1 = the span continues the model of the span in front of it (k_model_chain) */
+	uint32_t model_slots_pad;    /* probabilities of the model, rounded up to 64 */
 } xzamd_span_args;
+#define XZAMD_PINFO_WORDS 16u
+#define XZAMD_PI_STATE_OK 0x80000000u
+#define XZAMD_REP_UNKNOWN 0xFFFFFFFFu
+#define XZAMD_PART_MIN 16384u       /* iter 1 parses the first max(XZAMD_PART_MIN, length / 8) bytes of a piece (oracle: part_len) */
+#define XZAMD_PART_LEN(len) ((len) <= XZAMD_PART_MIN ? (len) : ((len) >> 3) < XZAMD_PART_MIN ? XZAMD_PART_MIN : (len) >> 3)
+#define XZAMD_LOG_WORDS 32u         /* 1023 logged bits per span and probability (oracle: ORC_LOG_CAP) */
+#define XZAMD_LOG_CAP 1023u
+#define XZAMD_CB_BAD_END 1u         /* a probability has not merged within XZAMD_LOG_CAP logged bits, or the span ran out of tokens */
+#define XZAMD_CB_KNOWN_START 2u     /* first span of its Block, or behind a stored piece: the model is flat there */
+#define XZAMD_CB_BAD_START 4u       /* the piece in front does not name the coder state */
 /* One LZMA2 chunk of the two-phase coder.  Its bytes (chunk header included) are written at
  * scratch + XZAMD_CHUNK_OUT(in_start, its slot index). */
 typedef struct xzamd_chunk {
@@ -88,8 +116,12 @@ typedef struct xzamd_chunk {
 #define XZAMD_CHUNK_EST (56000u * 128u)  /* a chunk ends when the summed prices of its decisions reach this (1/16 bit): oracle ORC_CHUNK_EST */
 #define XZAMD_TOK_PER_BYTE 10u      /* token capacity: a literal is 9 decisions */
 #define XZAMD_TOK_BASE(st, slot) ((uint64_t)(st) * XZAMD_TOK_PER_BYTE + (uint64_t)(slot) * 4096u)
-#define XZAMD_CHUNK_BASE(st, slot) (((st) >> 15) + 2u * (slot))     /* a chunk but the last of its span holds > 32 KiB of input */
-#define XZAMD_CHUNK_SLOTS(n, nslots) (((n) >> 15) + 2u * (nslots) + 2u)
+/* chunk slots: an LZMA chunk holds > 32 KiB of input unless its span ends or a stored piece (>= 32 KiB: XZAMD_RAW_MIN_LEN; 64 KiB per
+ * raw chunk) cuts it short -- two slots per 32 KiB of input cover every mix of the two */
+#define XZAMD_CHUNK_BASE(st, slot) (((st) >> 14) + 2u * (slot))
+#define XZAMD_CHUNK_CAP(len) (((len) >> 14) + 2u)                      /* chunk slots of a span of len bytes */
+#define XZAMD_CHUNK_SLOTS(n, nslots) (((n) >> 14) + 2u * (nslots) + 2u)
+#define XZAMD_RAW_MIN_LEN 32768u    /* shortest piece that is stored raw when its price says so (oracle: ORC_RAW_MIN_LEN) */
 #define XZAMD_CHUNK_OUT(in_start, cidx) (((((uint64_t)(in_start) + ((in_start) >> 3)) + 15) & ~15ull) + (uint64_t)(cidx) * 32u)
 #define XZAMD_PRIOR_WORDS 1856u     /* u32 each, >= the 1846 non-literal probabilities (a multiple of 64) */
 #define XZAMD_SEED_LEN 65536u       /* two-phase: the first piece of every Block (oracle: ORC_SEED_LEN) */
@@ -143,6 +175,10 @@ int xzk_span_encode(const xzamd_span_args *a, uint32_t nslots, uint32_t waves, u
  * range coder (one lane per chunk slot); the chunk table must be zero on entry (the call clears it). */
 int xzk_parse_pieces(const xzamd_span_args *a, uint32_t nblocks, int phase, uint32_t waves, uint32_t *counter, void *stream);
 int xzk_encode_syms(const xzamd_span_args *a, uint32_t nblocks, void *stream);
+/* The carried model walk over the records of parse iteration 1 (sub-sampled: the first part of every piece): k_model_bounds,
+ * k_model_chain, then k_model_syms in snapshot mode -- every piece but the seed finds the price model it starts iteration 2
+ * from in its slot of a->prior / a->lit, state and rep distances in a->snap_sr. */
+int xzk_model_snapshots(const xzamd_span_args *a, uint32_t nblocks, void *stream);
 /* wavefronts of the span kernel variant for (parser, nice_len) one CU holds at once */
 int xzk_span_occupancy(int parser, uint32_t nice_len, int *waves_per_cu);
 /* x86 BCJ encoder: d_out = filtered copy of d_in, every Block filtered independently (simple/x86.c). */

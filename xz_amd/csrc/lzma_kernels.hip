@@ -514,6 +514,7 @@ struct RC {
     uint16_t* tok;      // next free token of the encode span
     uint32_t est;       // summed prices of the current chunk's decisions, 1/16 bit
     const uint8_t* ptab;
+    uint32_t* log;      // k_model_bounds (rc_emit<.., BND>): the logged bits of the span, XZAMD_LOG_WORDS per probability
 #ifdef XZAMD_TIMING
     uint64_t tm_run;    // cycles inside rc_run (profiling builds only)
     uint64_t tm_bits;
@@ -932,7 +933,10 @@ __device__ __forceinline__ void rc_run(RC& rc, uint32_t packed, uint32_t n, uint
 // TOK: the model pass of the two-phase coder: one 16-bit token per decision goes to rc.tok and the price of the
 // decisions (the parser's table, probability before its update) is added to rc.est.
 // PG: the whole model lives in global memory (the parse pieces: `gp` holds what LDS holds elsewhere).
-template <bool CODE, bool LITG, bool TOK = false, bool PG = false>
+// BND: the bounds walk of the carried model (k_model_walk<1, 2>): `probs` is a u32 array, lo | hi << 11 | logged << 22 per
+// probability; both bounds take the update, and while they differ the bit is logged for k_model_chain (the log is zero on entry:
+// only 1 bits are written).  Tokens are only counted.
+template <bool CODE, bool LITG, bool TOK = false, bool PG = false, bool BND = false>
 __device__ __forceinline__ void rc_emit(RC& rc, uint16_t* probs, plit_t* lit, uint32_t* gp, const SegSel& s, uint32_t total,
         uint32_t d0, uint32_t d1)
 {
@@ -960,6 +964,22 @@ __device__ __forceinline__ void rc_emit(RC& rc, uint16_t* probs, plit_t* lit, ui
             idx = s.base + (same ? 0x100u + (((mb >> (7 - i)) & 1) << 8) + pre : pre);
         }
     }
+    if constexpr (BND) {
+        uint32_t* const M = reinterpret_cast<uint32_t*>(probs);
+        if (s.hit && !direct) {
+            const uint32_t v = M[idx];
+            uint32_t lo = v & 0x7FFu, hi = (v >> 11) & 0x7FFu, nb = v >> 22;
+            if (lo != hi && nb < XZAMD_LOG_CAP) {
+                if (bit) atomicOr(rc.log + (uint64_t)idx * XZAMD_LOG_WORDS + (nb >> 5), 1u << (nb & 31u));
+                ++nb;
+            }
+            lo = bit ? lo - (lo >> 5) : lo + ((2048u - lo) >> 5);
+            hi = bit ? hi - (hi >> 5) : hi + ((2048u - hi) >> 5);
+            M[idx] = lo | (hi << 11) | (nb << 22);
+        }
+        rc.tok += total;
+        return;
+    }
     uint32_t p = 0;
     if (s.hit && !direct) {
         if ((LITG || PG) && idx >= P_LITERAL) {
@@ -984,6 +1004,12 @@ __device__ __forceinline__ void rc_emit(RC& rc, uint16_t* probs, plit_t* lit, ui
         }
         rc.est += wave_sum_dpp(price);
         rc.tok += total;
+    } else if constexpr (PG) {
+        // the parser's price of its own parse (rc.ptab set: the recorded symbols of a piece; oracle: parse_piece's return value)
+        if (rc.ptab != nullptr) {
+            const uint32_t price = threadIdx.x < total ? (direct ? 16u : (uint32_t)rc.ptab[(p ^ ((0u - bit) & 0x7FFu)) >> 4]) : 0u;
+            rc.est += wave_sum_dpp(price);
+        }
     } else if constexpr (CODE) {
         const uint32_t packed = p | (bit << 12) | (direct ? 0x2000u : 0u);
         rc_run<!LITG>(rc, packed, total, d0, d1);
@@ -992,7 +1018,7 @@ __device__ __forceinline__ void rc_emit(RC& rc, uint16_t* probs, plit_t* lit, ui
 
 // upos = offset of the symbol inside the Block; lit3 (literals only) = byte | previous byte << 8 | match byte << 16
 // (the match byte is read only in states >= 7)
-template <bool CODE, bool LITG, bool TOK = false, bool PG = false>
+template <bool CODE, bool LITG, bool TOK = false, bool PG = false, bool BND = false>
 __device__ __forceinline__ void encode_symbol_t(RC& rc, uint16_t* probs, Lz& z, uint32_t upos, uint32_t back, uint32_t len,
         uint32_t lit3)
 {
@@ -1016,7 +1042,7 @@ __device__ __forceinline__ void encode_symbol_t(RC& rc, uint16_t* probs, Lz& z, 
             const uint32_t mb = (lit3 >> 16) & 0xFFu;
             seg_add(s, off, 8, SEG_MATCHED, sub, cur | (mb << 8));
         }
-        rc_emit<CODE, LITG, TOK, PG>(rc, probs, z.lit, z.gp, s, off, off, off);
+        rc_emit<CODE, LITG, TOK, PG, BND>(rc, probs, z.lit, z.gp, s, off, off, off);
         return;
     }
     seg_add(s, off, 1, SEG_BIT, P_IS_MATCH + z.state * 16 + ps, 1);
@@ -1044,7 +1070,7 @@ __device__ __forceinline__ void encode_symbol_t(RC& rc, uint16_t* probs, Lz& z, 
         }
         if (len == 1) {
             z.state = z.state < 7 ? 9 : 11;
-            rc_emit<CODE, LITG, TOK, PG>(rc, probs, z.lit, z.gp, s, off, off, off);
+            rc_emit<CODE, LITG, TOK, PG, BND>(rc, probs, z.lit, z.gp, s, off, off, off);
             return;
         }
         len_base = P_REP_LEN;
@@ -1096,7 +1122,7 @@ __device__ __forceinline__ void encode_symbol_t(RC& rc, uint16_t* probs, Lz& z, 
         z.rep3 = z.rep2; z.rep2 = z.rep1; z.rep1 = z.rep0; z.rep0 = dist;
     }
     if (dir0 == ~0u) dir0 = dir1 = off;
-    rc_emit<CODE, LITG, TOK, PG>(rc, probs, z.lit, z.gp, s, off, dir0, dir1);
+    rc_emit<CODE, LITG, TOK, PG, BND>(rc, probs, z.lit, z.gp, s, off, dir0, dir1);
 }
 
 // the bytes a literal at global offset g needs, for encode_symbol_t
@@ -2392,14 +2418,22 @@ __device__ __forceinline__ void parse_piece_one(const xzamd_span_args& a, const 
     const uint32_t block_start = blk * a.block_size;
     const uint32_t block_end = min(a.n, block_start + a.block_size);
     uint32_t span_start, span_end;
+    uint32_t piece_end;
     if (k == 0) {
         // the seed piece is the same whatever the plan says (k_span_cut: seed_chunks), so it can run before the plan exists
         span_start = block_start;
         span_end = block_end - block_start > XZAMD_SEED_LEN ? block_start + XZAMD_SEED_LEN : block_end;
+        piece_end = span_end;
     } else {
         if (k >= a.span_cnt[blk]) return;              // an unused slot of the span plan
         span_start = uni(a.span_tab[2 * span]); span_end = uni(a.span_tab[2 * span + 1]);
+        piece_end = span_end;
+        // iteration 1 parses only the first part of the piece (oracle: part_len); symbols never cross its end
+        if (a.iter == 1) span_end = span_start + XZAMD_PART_LEN(span_end - span_start);
     }
+    // iteration 2: the price model, coder state and rep distances come from the carried model walk over iteration 1's
+    // records (k_model_walk<3>: this piece's slot of a.prior / a.lit, a.snap_sr) -- no prior, no walk, no pre-roll
+    const bool from_snap = k != 0 && a.iter == 2;
     const uint8_t* __restrict__ in = a.in;
 
     Env e;
@@ -2450,6 +2484,7 @@ __device__ __forceinline__ void parse_piece_one(const xzamd_span_args& a, const 
     z.state = 0; z.rep0 = z.rep1 = z.rep2 = z.rep3 = 0;
     RC rc;                                              // never codes: encode_symbol_t<false, .> only adapts the model
     rc.cpos = 0; rc.out = nullptr; rc.reset();
+    rc.ptab = nullptr; rc.est = 0; rc.tok = nullptr; rc.log = nullptr;
     const GProbs probs{z.gp};
     uint16_t* const no_lds = nullptr;                   // encode_symbol_t<.., PG = true> never touches its LDS argument
 
@@ -2462,6 +2497,9 @@ __device__ __forceinline__ void parse_piece_one(const xzamd_span_args& a, const 
             for (uint32_t i = lane; i < XZAMD_PRIOR_WORDS / 4; i += 64) g4[i] = v;
             const uint4 vl = PLIT_FLAT4;
             for (uint32_t i = lane; i < lit_size / PLIT_PER_U4; i += 64) l4[i] = vl;
+        } else if (from_snap) {
+            const uint32_t* sr = a.snap_sr + (uint64_t)span * 8u;
+            z.state = uni(sr[0]); z.rep0 = uni(sr[1]); z.rep1 = uni(sr[2]); z.rep2 = uni(sr[3]); z.rep3 = uni(sr[4]);
         } else {
             const uint4* p4 = reinterpret_cast<const uint4*>(a.prior + (uint64_t)blk * a.max_spb * XZAMD_PRIOR_WORDS);
             for (uint32_t i = lane; i < XZAMD_PRIOR_WORDS / 4; i += 64) g4[i] = p4[i];
@@ -2479,7 +2517,7 @@ __device__ __forceinline__ void parse_piece_one(const xzamd_span_args& a, const 
     // parser may not cross: the piece start while pre-rolling, then the piece end.
     uint32_t lim = span_end;
     bool rec = true;
-    if (k != 0 && span_start - block_start > XZAMD_PREROLL) {
+    if (k != 0 && !from_snap && span_start - block_start > XZAMD_PREROLL) {
         cur = span_start - XZAMD_PREROLL;
         lim = span_start;
         rec = false;
@@ -2490,7 +2528,7 @@ __device__ __forceinline__ void parse_piece_one(const xzamd_span_args& a, const 
     // position's list record when it is cheap by a fixed rule, else a literal; each symbol adapts the model, nothing is
     // recorded, no prices, no DP.  64 positions per trip: lane = position (its longest entry, its byte, the byte before it,
     // the byte at rep0), the walk itself runs on readlanes.
-    if (k != 0 && span_start - block_start > XZAMD_PREROLL + XZAMD_SEED_LEN) {
+    if (k != 0 && !from_snap && span_start - block_start > XZAMD_PREROLL + XZAMD_SEED_LEN) {
         const uint32_t w1 = span_start - XZAMD_PREROLL;
         uint32_t x0 = w1 - block_start - XZAMD_SEED_LEN > XZAMD_WARM ? w1 - XZAMD_WARM : block_start + XZAMD_SEED_LEN;
         // the distances of the last four candidates the walk rejected as too expensive: one that comes up again is a distance a
@@ -2589,17 +2627,26 @@ __device__ __forceinline__ void parse_piece_one(const xzamd_span_args& a, const 
     uint32_t q_pos = 0, q_end = 0;
     bool tables_valid = false;
 
+    // What the coder will read out of this piece's records WITHOUT knowing its state and rep distances at the piece start
+    // (oracle: lookback): twelve candidate states side by side (lane = candidate; they agree after a few symbols), rep
+    // distances the piece does not name stay XZAMD_REP_UNKNOWN.  The walk of the encode span that starts behind this piece
+    // begins with them (k_model_walk).
+    uint32_t tl_st = lane < 12 ? lane : 0u;
+    uint32_t tl_r0 = XZAMD_REP_UNKNOWN, tl_r1 = XZAMD_REP_UNKNOWN, tl_r2 = XZAMD_REP_UNKNOWN, tl_r3 = XZAMD_REP_UNKNOWN;
+    if (rec) rc.ptab = w.ptab;                           // the price of the piece: its recorded symbols only
     if (span_start == block_start) {
         // encode_init (lzma_encoder.c:267-293): the first byte of a Block is a literal in the initial contexts
         const uint32_t l3 = literal_bytes(in, block_start, 0, z);
         if (lane == 0) { a.sym_len[block_start] = 0; a.sym_dist[block_start] = l3; }
         encode_symbol_t<false, true, false, true>(rc, no_lds, z, 0, LITERAL, 1, l3);
+        tl_st = tl_st <= 3 ? 0u : tl_st <= 9 ? tl_st - 3 : tl_st - 6;
         cur = block_start + 1;
     }
     for (;;) {
         if (cur >= lim) {
             if (rec) break;
             rec = true;                                  // the pre-roll is over: the piece proper
+            rc.ptab = w.ptab; rc.est = 0;
             lim = span_end;
             cached = false;
             q_pos = q_end = 0;
@@ -2670,6 +2717,25 @@ __device__ __forceinline__ void parse_piece_one(const xzamd_span_args& a, const 
             a.sym_len[cur] = (uint16_t)(len | (back >= 4 ? 0x8000u : 0u));
             a.sym_dist[cur] = back >= 4 ? back - 4 : back == 0 ? z.rep0 : back == 1 ? z.rep1 : back == 2 ? z.rep2 : z.rep3;
         }
+        if (rec) {
+            // the coder's reading of the record (k_model_walk) with unknown rep distances: 0 literal, 1 match, 2 rep, 3 short rep
+            uint32_t type = 0;
+            if (back != LITERAL) {
+                const uint32_t dd = back >= 4 ? back - 4 : back == 0 ? z.rep0 : back == 1 ? z.rep1 : back == 2 ? z.rep2 : z.rep3;
+                if (back >= 4) type = 1;
+                else if (len == 1) type = dd == tl_r0 ? 3u : 0u;
+                else {
+                    const uint32_t ri = dd == tl_r0 ? 0u : dd == tl_r1 ? 1u : dd == tl_r2 ? 2u : dd == tl_r3 ? 3u : 4u;
+                    type = ri < 4 ? 2u : 1u;
+                    if (ri == 1) { tl_r1 = tl_r0; tl_r0 = dd; }
+                    else if (ri == 2) { tl_r2 = tl_r1; tl_r1 = tl_r0; tl_r0 = dd; }
+                    else if (ri == 3) { tl_r3 = tl_r2; tl_r2 = tl_r1; tl_r1 = tl_r0; tl_r0 = dd; }
+                }
+                if (type == 1) { tl_r3 = tl_r2; tl_r2 = tl_r1; tl_r1 = tl_r0; tl_r0 = dd; }
+            }
+            tl_st = type == 0 ? (tl_st <= 3 ? 0u : tl_st <= 9 ? tl_st - 3 : tl_st - 6)
+                    : tl_st < 7 ? (type == 1 ? 7u : type == 2 ? 8u : 9u) : (type == 1 ? 10u : 11u);
+        }
         {
             TM_BEGIN(t_sym);
             encode_symbol_t<false, true, false, true>(rc, no_lds, z, cur - block_start, back, len, l3);
@@ -2689,6 +2755,24 @@ __device__ __forceinline__ void parse_piece_one(const xzamd_span_args& a, const 
     }
     // (the seed piece leaves the prior of the Block where it is: its own slot of a.prior / a.lit)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    {
+        // what the walk of the encode span behind this piece starts from, and whether the coder stores the piece raw: its
+        // parser's own price says it does not shrink (oracle: parse_block)
+        const uint32_t s0 = lane_of(tl_st, 0);
+        const bool agree = __builtin_amdgcn_ballot_w64(lane < 12 && tl_st != s0) == 0;
+        if (lane < 2 && a.pinfo) {
+            // lane 0: the half the walk over iteration 1's records reads, lane 1: the half the coder's walk reads (the seed
+            // piece is parsed once and serves both)
+            const bool mine = k == 0 || (lane == 0) == (a.iter == 1);
+            if (mine) {
+                uint32_t* pi = a.pinfo + (uint64_t)span * XZAMD_PINFO_WORDS + lane * (XZAMD_PINFO_WORDS / 2);
+                pi[0] = s0 | (agree ? XZAMD_PI_STATE_OK : 0u);
+                pi[1] = tl_r0; pi[2] = tl_r1; pi[3] = tl_r2; pi[4] = tl_r3;
+                const uint32_t plen = piece_end - span_start;
+                pi[5] = (span_end == piece_end && plen >= XZAMD_RAW_MIN_LEN && rc.est / 128u >= plen) ? 1u : 0u;
+            }
+        }
+    }
 #ifdef XZAMD_TIMING
     if (lane == 0 && a.err) {
         tm_lds[8] = __builtin_amdgcn_s_memtime() - tm_start;
@@ -2726,7 +2810,7 @@ void k_parse_pieces(xzamd_span_args a, uint32_t nslots, int phase, uint32_t* __r
     }
 }
 
-// ---- phase 2: range-code the recorded symbols of one encode span ----
+// ---- phase 2: the recorded symbols of one encode span through the coder's model ----
 struct SymRow {
     uint32_t base;          // position of lane 0 of `l` / `d`
     uint32_t l, d;          // records of positions base + lane
@@ -2741,11 +2825,20 @@ __device__ __forceinline__ void symrow_load(const xzamd_span_args& a, uint32_t p
     d = a.sym_dist[x];
 }
 
-__global__ __launch_bounds__(64) void k_model_syms(xzamd_span_args a, uint32_t nslots)
+// The walk of one encode span over its recorded symbols (oracle: encode_block_syms / snapshot_walk), in four forms:
+//   MODE 0  k_model_syms      the coder's model pass: from the span's TRUE start model (k_model_chain) every binary decision
+//                             leaves a token, chunks are cut by the summed prices of their decisions (the range coder runs
+//                             later, one lane per chunk: k_rc_chunks), stored pieces are copied
+//   MODE 1  k_model_bounds    the same walk with two values per probability, lo (from 31) and hi (from 2017): whatever the
+//                             start model is, the true value stays between them (the update is monotone); until they meet the
+//                             slot's bits are logged for k_model_chain
+//   MODE 2  bounds, and MODE 3 snapshots, over the records of parse iteration 1 (only the first XZAMD_PART_LEN bytes of a
+//                             piece have them): the model every piece starts iteration 2 from goes into ITS slot of
+//                             a.prior / a.lit (u32 each), coder state and rep distances into a.snap_sr
+template <int MODE>
+__global__ __launch_bounds__(64) void k_model_walk(xzamd_span_args a, uint32_t nslots)
 {
-    // Model pass of one encode span (oracle: encode_syms): the recorded symbols go through ONE continuous probability
-    // model (all of it in LDS); every binary decision leaves a token, the chunks are cut by the summed prices of their
-    // decisions (the range coder runs later, one lane per chunk: k_rc_chunks), raw chunks are copied here.
+    constexpr bool BND = MODE == 1 || MODE == 2, SUB = MODE >= 2, TOKM = MODE == 0;
     extern __shared__ __attribute__((aligned(16))) uint32_t enc_pool[];
     uint16_t* const probs = reinterpret_cast<uint16_t*>(enc_pool);
     const uint32_t lane = threadIdx.x;
@@ -2757,92 +2850,171 @@ __global__ __launch_bounds__(64) void k_model_syms(xzamd_span_args a, uint32_t n
     const uint32_t block_start = blk * a.block_size;
     const uint32_t span_start = uni(a.enc_tab[2 * slot]), span_end = uni(a.enc_tab[2 * slot + 1]);
     const uint8_t* __restrict__ in = a.in;
-    const uint32_t model_words = (P_LITERAL + (0x300u << (a.lc + a.lp)) + 1) / 2;
+    const uint32_t nprob = P_LITERAL + (0x300u << (a.lc + a.lp));
+    const uint32_t model_words = BND ? nprob : (nprob + 1) / 2;
     uint8_t* const ptab = reinterpret_cast<uint8_t*>(enc_pool + model_words);
-    for (uint32_t t = lane; t < 128; t += 64) {         // bit price table (price_tablegen.c:31-58)
-        uint32_t wv = t * 16 + 8, bit_count = 0;
-        for (int jj = 0; jj < 4; ++jj) {
-            wv *= wv;
-            bit_count <<= 1;
-            while (wv >= (1u << 16)) { wv >>= 1; ++bit_count; }
+    if (!BND) {
+        for (uint32_t t = lane; t < 128; t += 64) {         // bit price table (price_tablegen.c:31-58)
+            uint32_t wv = t * 16 + 8, bit_count = 0;
+            for (int jj = 0; jj < 4; ++jj) {
+                wv *= wv;
+                bit_count <<= 1;
+                while (wv >= (1u << 16)) { wv >>= 1; ++bit_count; }
+            }
+            ptab[t] = (uint8_t)((11 << 4) - 15 - bit_count);
         }
-        ptab[t] = (uint8_t)((11 << 4) - 15 - bit_count);
     }
-    wave_sync();
+    // the piece that starts at the span start (encode spans are closed at piece ends)
+    const uint32_t pcnt = uni(a.span_cnt[blk]);
+    const uint32_t* __restrict__ ptb = a.span_tab + 2ull * blk * a.max_spb;
+    uint32_t pj = 0;
+    for (uint32_t j0 = 0; j0 < pcnt; j0 += 64) {
+        const uint32_t jj = j0 + lane;
+        const uint64_t m = __builtin_amdgcn_ballot_w64(jj < pcnt && ptb[2 * jj] == span_start);
+        if (m) { pj = j0 + (uint32_t)__builtin_ctzll(m); break; }
+    }
+    // (the half of a piece's info written by the parse iteration whose records this walk reads)
+    const uint32_t* __restrict__ pinfo = a.pinfo + (uint64_t)blk * a.max_spb * XZAMD_PINFO_WORDS + (SUB ? 0u : XZAMD_PINFO_WORDS / 2);
 
     Lz z;
-    z.lc = a.lc; z.lp = a.lp; z.pb = a.pb;
+    z.lc = a.lc; z.lp = a.lp; z.pb = SUB ? min(a.pb, 2u) : a.pb;     // (the snapshots are the PARSER's price model: its pb view)
     z.cnt_len = z.cnt_match = z.cnt_align = 0;
     z.lit = nullptr;
     z.gp = nullptr;
     z.state = 0; z.rep0 = z.rep1 = z.rep2 = z.rep3 = 0;
     RC rc;
     rc.cpos = 0; rc.out = nullptr; rc.reset();
-    uint16_t* const tok0 = a.tok + XZAMD_TOK_BASE(span_start, slot);
+    rc.log = BND ? a.cb_log + (uint64_t)slot * a.model_slots_pad * XZAMD_LOG_WORDS : nullptr;
+
+    // how the span starts
+    uint32_t hflags = 0;
+    bool known = k == 0;                    // the model at the span start does not depend on the spans in front
+    if (k != 0) {
+        const uint32_t* pi = pinfo + (uint64_t)(pj - 1) * XZAMD_PINFO_WORDS;
+        if (!SUB && uni(pi[5])) known = true;          // behind a stored piece: state reset
+        else {
+            const uint32_t w0 = uni(pi[0]);
+            if (!(w0 & XZAMD_PI_STATE_OK)) hflags |= XZAMD_CB_BAD_START;
+            z.state = w0 & 15u;
+            z.rep0 = uni(pi[1]); z.rep1 = uni(pi[2]); z.rep2 = uni(pi[3]); z.rep3 = uni(pi[4]);
+        }
+    }
+    if (known) hflags |= XZAMD_CB_KNOWN_START;
+    uint32_t carry = 1;                     // MODE 0 / 3: 0 = round 5's reset (+ properties), 1 = carried, 2 = flat start, no properties
+    if (!BND && k != 0) carry = uni(a.cb_carry[slot]);
+    if (BND) {
+        const uint32_t v0 = known ? (1024u | 1024u << 11) : (31u | 2017u << 11);
+        for (uint32_t i = lane; i < nprob; i += 64) enc_pool[i] = v0;
+    } else if (k != 0 && carry == 1) {
+        const uint32_t* s32 = reinterpret_cast<const uint32_t*>(a.cb_start + (uint64_t)slot * a.model_slots_pad);
+        for (uint32_t i = lane; i < model_words; i += 64) enc_pool[i] = s32[i];
+    } else {
+        for (uint32_t i = lane; i < model_words; i += 64) enc_pool[i] = 0x04000400u;
+        z.state = 0; z.rep0 = z.rep1 = z.rep2 = z.rep3 = 0;
+    }
+    wave_sync();
+
+    uint16_t* const tok0 = TOKM ? a.tok + XZAMD_TOK_BASE(span_start, slot) : nullptr;
     // Token budget of the span.  The buffer holds XZAMD_TOK_PER_BYTE tokens per input byte (+ 4096); a.tok_limit (tests only,
     // <= XZAMD_TOK_PER_BYTE) lowers the budget without changing the layout.  Data made of far three-byte matches needs more
     // (32 ... 41 tokens per 3 bytes): when the budget runs out the chunk is closed where it stands and the REST of the span
-    // is stored as raw LZMA2 chunks (lzma2_encoder.c:110-131) -- valid output instead of a failed Stream (oracle: encode_syms).
+    // is stored as raw LZMA2 chunks (lzma2_encoder.c:110-131) -- valid output instead of a failed Stream -- and no later span
+    // of the Block is carried (oracle: encode_block_syms).  The walks over iteration 1's records write no tokens: no budget.
     const uint64_t tok_cap = (uint64_t)(span_end - span_start) * (a.tok_limit ? a.tok_limit : XZAMD_TOK_PER_BYTE) + 4096u - 64u;
-    bool tok_full = false;
     rc.tok = tok0; rc.est = 0; rc.ptab = ptab;
     const uint32_t cbase = XZAMD_CHUNK_BASE(span_start, slot);
-    const uint32_t ccap = ((span_end - span_start) >> 15) + 2u;
+    const uint32_t ccap = XZAMD_CHUNK_CAP(span_end - span_start);
     uint32_t nchunks = 0;
-#ifdef XZAMD_TIMING
-    rc.tm_run = 0; rc.tm_bits = 0;
-    uint64_t tm_sym = 0, tm_nsym = 0;
-    const uint64_t tm_start = __builtin_amdgcn_s_memtime();
-#endif
 
-    bool need_props = true, need_dict_reset = (span_start == block_start), need_state_reset = true;
-    bool failed = false;
+    bool need_props = k == 0 || carry == 0, need_dict_reset = (span_start == block_start), need_state_reset = k == 0 || carry != 1;
+    bool failed = false, tok_full = false;
     uint32_t f_pos = 0, f_back = 0, f_len = 0, f_d = 0;
     uint32_t cur = span_start;
+    uint32_t p_end = uni(ptb[2 * pj + 1]);                           // end of the piece that holds cur
+    uint32_t seg_end = SUB && pj != 0 ? span_start + XZAMD_PART_LEN(p_end - span_start) : p_end;   // end of what is walked of it (the seed piece has all its records)
+    uint32_t raw_until = (!SUB && uni(pinfo[(uint64_t)pj * XZAMD_PINFO_WORDS + 5])) ? p_end : span_start;
+    bool fresh_piece = true;                                          // cur is a piece start that has not been looked at
     SymRow R;
     R.base = span_start;
     symrow_load(a, span_start, R.l, R.d);
     symrow_load(a, span_start + 64, R.nl, R.nd);
 
     while (cur < span_end) {
-        if (need_state_reset) {
+        if (cur < raw_until) {
+            // a stored piece, or the rest of a span that ran out of tokens: raw chunks of 64 KiB (lzma2_encoder.c:110-131)
+            if (TOKM) {
+                const uint32_t usize = min(raw_until - cur, 65536u);
+                const uint32_t cidx = cbase + nchunks;
+                if (nchunks + 1 >= ccap) { f_pos = cur - block_start; f_back = 0xFFFFFFF0u; failed = true; break; }
+                uint8_t* const hdr = a.scratch + XZAMD_CHUNK_OUT(cur, cidx);
+                for (uint32_t i = lane; i < usize; i += 64) hdr[3 + i] = in[cur + i];
+                if (lane == 0) {
+                    hdr[0] = need_dict_reset ? 1 : 2;
+                    hdr[1] = (uint8_t)((usize - 1) >> 8);
+                    hdr[2] = (uint8_t)(usize - 1);
+                    xzamd_chunk c;
+                    c.in_start = cur; c.usize = usize; c.tok_lo = 0; c.tok_hi = 0;
+                    c.ntok = 0; c.csize = 3u + usize; c.flags = XZAMD_CH_RAW; c.pad_ = 0;
+                    a.chunks[cidx] = c;
+                }
+                need_dict_reset = false;
+                ++nchunks;
+                cur += usize;
+            } else
+                cur = raw_until;
+            need_state_reset = true;
+            if (cur == p_end && cur < span_end) {                    // (a stored piece ends where the next piece starts)
+                ++pj;
+                p_end = uni(ptb[2 * pj + 1]);
+                seg_end = p_end;
+                if (uni(pinfo[(uint64_t)pj * XZAMD_PINFO_WORDS + 5])) raw_until = p_end;
+            }
+            continue;
+        }
+        if (need_state_reset && !(k != 0 && carry == 1 && cur == span_start)) {
             // lzma_lzma_encoder_reset (lzma_encoder.c:529-598); the flag stays set until a chunk header has announced it
-            for (uint32_t i = lane; i < model_words; i += 64) enc_pool[i] = 0x04000400u;
+            if (BND) { for (uint32_t i = lane; i < nprob; i += 64) enc_pool[i] = 1024u | 1024u << 11; }
+            else { for (uint32_t i = lane; i < model_words; i += 64) enc_pool[i] = 0x04000400u; }
             wave_sync();
             z.state = 0; z.rep0 = z.rep1 = z.rep2 = z.rep3 = 0;
         }
         const uint32_t chunk_start = cur;
         uint16_t* const chunk_tok = rc.tok;
         rc.est = 0;
-        if (tok_full) {
-            // out of tokens: the rest of the span goes out raw, 64 KiB at a time
-            const uint32_t usize = min(span_end - cur, 65536u);
-            const uint32_t cidx = cbase + nchunks;
-            if (nchunks + 1 >= ccap) { f_pos = cur - block_start; failed = true; break; }
-            uint8_t* const hdr = a.scratch + XZAMD_CHUNK_OUT(chunk_start, cidx);
-            for (uint32_t i = lane; i < usize; i += 64) hdr[3 + i] = in[chunk_start + i];
-            if (lane == 0) {
-                hdr[0] = need_dict_reset ? 1 : 2;
-                hdr[1] = (uint8_t)((usize - 1) >> 8);
-                hdr[2] = (uint8_t)(usize - 1);
-                xzamd_chunk c;
-                c.in_start = chunk_start; c.usize = usize; c.tok_lo = 0; c.tok_hi = 0;
-                c.ntok = 0; c.csize = 3u + usize; c.flags = XZAMD_CH_RAW; c.pad_ = 0;
-                a.chunks[cidx] = c;
-            }
-            need_dict_reset = false;
-            ++nchunks;
-            cur += usize;
-            continue;
-        }
+        bool piece_break = false;
         for (;;) {
-            // the chunk rule of the two-phase coder (oracle: encode_syms): input limit of lzma2_encoder.c:167-181, and
+            // the chunk rule of the two-phase coder (oracle: encode_block_syms): input limit of lzma2_encoder.c:167-181, and
             // the summed prices in place of the coded size
-            if (cur - chunk_start >= (1u << 21) - MATCH_LEN_MAX || rc.est >= XZAMD_CHUNK_EST)
+            if (TOKM && (cur - chunk_start >= (1u << 21) - MATCH_LEN_MAX || rc.est >= XZAMD_CHUNK_EST))
                 break;
             if (cur >= span_end)
                 break;
-            if ((uint64_t)(rc.tok - tok0) + 64u > tok_cap) { tok_full = true; break; }
+            if (cur >= seg_end) {
+                // the next piece (SUB: behind the part of this one that iteration 1 parsed)
+                cur = p_end;
+                if (cur >= span_end) break;
+                ++pj;
+                p_end = uni(ptb[2 * pj + 1]);
+                seg_end = SUB ? cur + XZAMD_PART_LEN(p_end - cur) : p_end;
+                fresh_piece = true;
+                if (!SUB && uni(pinfo[(uint64_t)pj * XZAMD_PINFO_WORDS + 5])) { raw_until = p_end; piece_break = true; break; }
+            }
+            if (MODE == 3 && fresh_piece && cur != block_start) {
+                // snapshot: the price model piece pj starts iteration 2 from (its slot of a.prior / a.lit), state, rep distances
+                const uint64_t ps_ = (uint64_t)blk * a.max_spb + pj;
+                uint32_t* gp = a.prior + ps_ * XZAMD_PRIOR_WORDS;
+                plit_t* gl = reinterpret_cast<plit_t*>(a.lit) + ps_ * (0x300ull << (a.lc + a.lp));
+                for (uint32_t i = lane; i < P_LITERAL; i += 64) gp[i] = probs[i];
+                for (uint32_t i = lane; i < nprob - P_LITERAL; i += 64) gl[i] = (plit_t)probs[P_LITERAL + i];
+                if (lane == 0) {
+                    uint32_t* sr = a.snap_sr + ps_ * 8u;
+                    sr[0] = z.state;                  // a parser's rep distances must be real ones: unknown -> 0, as after a reset
+                    sr[1] = z.rep0 == XZAMD_REP_UNKNOWN ? 0u : z.rep0; sr[2] = z.rep1 == XZAMD_REP_UNKNOWN ? 0u : z.rep1;
+                    sr[3] = z.rep2 == XZAMD_REP_UNKNOWN ? 0u : z.rep2; sr[4] = z.rep3 == XZAMD_REP_UNKNOWN ? 0u : z.rep3;
+                }
+            }
+            fresh_piece = false;
+            if (!SUB && (uint64_t)(rc.tok - tok0) + 64u > tok_cap) { tok_full = true; break; }
             uint32_t off = cur - R.base;
             if (off >= 64) {
                 if (off < 128) {
@@ -2872,9 +3044,9 @@ __global__ __launch_bounds__(64) void k_model_syms(xzamd_span_args a, uint32_t n
             else if (d == z.rep2) back = 2;
             else if (d == z.rep3) back = 3;
             else back = d + 4;
-            if (len > MATCH_LEN_MAX || cur + len > span_end
+            if (len > MATCH_LEN_MAX || cur + len > seg_end
                     || (back != LITERAL && back >= 4 && back - 4 >= cur - block_start)
-                    || nchunks + 1 >= ccap) {
+                    || (TOKM && nchunks + 1 >= ccap)) {
                 // internal consistency failure: report it and leave through the loop conditions (an early return from
                 // inside the loops costs the compiler its proof that the coder state is wave-uniform)
                 f_pos = cur - block_start; f_back = back; f_len = len; f_d = d;
@@ -2882,64 +3054,95 @@ __global__ __launch_bounds__(64) void k_model_syms(xzamd_span_args a, uint32_t n
                 cur = span_end;
                 break;
             }
-#ifdef XZAMD_TIMING
-            const uint64_t ts0 = __builtin_amdgcn_s_memtime();
-#endif
-            encode_symbol_t<false, false, true>(rc, probs, z, cur - block_start, back, len, l3);
-#ifdef XZAMD_TIMING
-            tm_sym += __builtin_amdgcn_s_memtime() - ts0;
-            ++tm_nsym;
-#endif
+            encode_symbol_t<false, false, TOKM, false, BND>(rc, probs, z, cur - block_start, back, len, l3);
             cur += len;
         }
         if (failed) break;
-        const uint32_t usize = cur - chunk_start;
-        if (usize == 0) continue;                          // the budget ran out right at a chunk start
-        const uint32_t ntok = (uint32_t)(rc.tok - chunk_tok);
-        const bool raw = rc.est / 128u + 5u >= usize;
-        const uint32_t cidx = cbase + nchunks;
-        uint32_t flags = raw ? XZAMD_CH_RAW : 0u;
-        if (raw) {
-            // lzma2_encoder.c:205-214: the chunk is stored, the next LZMA chunk resets the state; its tokens are dropped
-            uint8_t* const hdr = a.scratch + XZAMD_CHUNK_OUT(chunk_start, cidx);
-            for (uint32_t i = lane; i < usize; i += 64) hdr[3 + i] = in[chunk_start + i];
-            if (lane == 0) {
-                hdr[0] = need_dict_reset ? 1 : 2;
-                hdr[1] = (uint8_t)((usize - 1) >> 8);
-                hdr[2] = (uint8_t)(usize - 1);
+        if (TOKM) {
+            const uint32_t usize = cur - chunk_start;
+            if (usize != 0) {
+                const uint32_t ntok = (uint32_t)(rc.tok - chunk_tok);
+                const uint32_t cidx = cbase + nchunks;
+                uint32_t flags = 0u;
+                if (need_props) flags |= XZAMD_CH_PROPS;
+                if (need_dict_reset) flags |= XZAMD_CH_DICT_RESET;
+                if (need_state_reset) flags |= XZAMD_CH_STATE_RESET;
+                need_props = false; need_dict_reset = false; need_state_reset = false;
+                if (lane == 0) {
+                    const uint64_t tix = (uint64_t)(chunk_tok - a.tok);
+                    xzamd_chunk c;
+                    c.in_start = chunk_start; c.usize = usize; c.tok_lo = (uint32_t)tix; c.tok_hi = (uint32_t)(tix >> 32);
+                    c.ntok = ntok; c.csize = 0u; c.flags = flags; c.pad_ = 0;
+                    a.chunks[cidx] = c;
+                }
+                ++nchunks;
             }
-            rc.tok = chunk_tok;
-            need_dict_reset = false;
-            need_state_reset = true;
-        } else {
-            if (need_props) flags |= XZAMD_CH_PROPS;
-            if (need_dict_reset) flags |= XZAMD_CH_DICT_RESET;
-            if (need_state_reset) flags |= XZAMD_CH_STATE_RESET;
-            need_props = false; need_dict_reset = false; need_state_reset = false;
+        } else if (cur != chunk_start)
+            need_state_reset = false;
+        (void)piece_break;
+        if (tok_full) raw_until = span_end;                // the rest of the span goes out raw
+    }
+    if (BND) {
+        // what k_model_chain needs of the span: the bounds, and whether the span can hand its model on at all
+        uint32_t* gb = a.cb_bnd + (uint64_t)slot * a.model_slots_pad;
+        bool bad = false;
+        for (uint32_t i = lane; i < nprob; i += 64) {
+            const uint32_t v = enc_pool[i];
+            gb[i] = v;
+            bad = bad || ((v & 0x7FFu) != ((v >> 11) & 0x7FFu) && (v >> 22) >= XZAMD_LOG_CAP);
         }
-        if (lane == 0) {
-            const uint64_t tix = (uint64_t)(chunk_tok - a.tok);
-            xzamd_chunk c;
-            c.in_start = chunk_start; c.usize = usize; c.tok_lo = (uint32_t)tix; c.tok_hi = (uint32_t)(tix >> 32);
-            c.ntok = raw ? 0u : ntok; c.csize = raw ? 3u + usize : 0u; c.flags = flags; c.pad_ = 0;
-            a.chunks[cidx] = c;
-        }
-        ++nchunks;
+        if (__builtin_amdgcn_ballot_w64(bad) != 0 || tok_full) hflags |= XZAMD_CB_BAD_END;
+        if (lane == 0) a.cb_hdr[slot] = hflags;
     }
     if (failed && lane == 0 && a.err) {
-        if (atomicCAS(a.err, 0u, 3u) == 0u) {
+        if (atomicCAS(a.err, 0u, 3u + (uint32_t)MODE * 16u) == 0u) {
             a.err[1] = slot; a.err[2] = f_pos; a.err[3] = f_back; a.err[4] = f_len;
             a.err[5] = f_d; a.err[6] = nchunks; a.err[7] = (uint32_t)(rc.tok - tok0);
         }
     }
-#ifdef XZAMD_TIMING
-    if (lane == 0 && a.err) {
-        unsigned long long* g = reinterpret_cast<unsigned long long*>(a.err + 48);      // [0] total [1] in encode_symbol [3] symbols [4] tokens [5] max span
-        const uint64_t tot = __builtin_amdgcn_s_memtime() - tm_start;
-        atomicAdd(g + 0, tot); atomicAdd(g + 1, tm_sym); atomicAdd(g + 3, tm_nsym); atomicAdd(g + 4, (unsigned long long)(rc.tok - tok0));
-        atomicMax(g + 5, tot);
+}
+
+// The model of every encode span at its start (oracle: the `failed` / lookback logic of encode_block_syms): one thread
+// per probability and Block walks the Block's spans in order -- start value of span k + 1 = lo where the slot's bounds met
+// in span k, else the slot's logged bits replayed on its start value in span k.  A span that cannot hand its model on
+// (XZAMD_CB_BAD_END), or whose start state the piece in front does not name (XZAMD_CB_BAD_START), ends the carrying: every
+// later span of the Block starts with round 5's reset.  cb_carry: 0 = reset + properties, 1 = carried, 2 = flat, no properties
+// (behind a stored piece).
+__global__ __launch_bounds__(256) void k_model_chain(xzamd_span_args a, uint32_t nblocks)
+{
+    const uint32_t blk = blockIdx.y;
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (blk >= nblocks) return;
+    const uint32_t nprob = P_LITERAL + (0x300u << (a.lc + a.lp));
+    const uint32_t cnt = a.enc_cnt[blk];
+    uint32_t p = 1024;
+    bool ok = true;
+    for (uint32_t k = 0; k < cnt; ++k) {
+        const uint32_t slot = blk * a.max_esb + k;
+        const uint32_t hf = a.cb_hdr[slot];
+        if (k != 0 && (hf & XZAMD_CB_BAD_START)) ok = false;
+        const bool known = (hf & XZAMD_CB_KNOWN_START) != 0;
+        if (!ok || known) p = 1024;
+        if (k != 0) {
+            if (i == 0) a.cb_carry[slot] = !ok ? 0u : known ? 2u : 1u;
+            if (i < a.model_slots_pad) a.cb_start[(uint64_t)slot * a.model_slots_pad + i] = (uint16_t)(i < nprob ? p : 1024u);
+        }
+        if (hf & XZAMD_CB_BAD_END) ok = false;
+        if (i < nprob && ok) {
+            const uint32_t v = a.cb_bnd[(uint64_t)slot * a.model_slots_pad + i];
+            const uint32_t lo = v & 0x7FFu, hi = (v >> 11) & 0x7FFu, nb = v >> 22;
+            if (lo == hi) p = lo;
+            else {
+                const uint32_t* lg = a.cb_log + ((uint64_t)slot * a.model_slots_pad + i) * XZAMD_LOG_WORDS;
+                uint32_t w = 0;
+                for (uint32_t t = 0; t < nb; ++t) {
+                    if ((t & 31u) == 0) w = lg[t >> 5];
+                    const uint32_t bit = (w >> (t & 31u)) & 1u;
+                    p = bit ? p - (p >> 5) : p + ((2048u - p) >> 5);
+                }
+            }
+        }
     }
-#endif
 }
 
 // Range coder of the two-phase mode: one LANE per LZMA2 chunk (rangecoder/range_encoder.h:136-263 per lane).  A chunk's
@@ -4594,6 +4797,23 @@ int xzk_parse_pieces(const xzamd_span_args* a, uint32_t nblocks, int phase, uint
 
 // Two-phase mode, phase 2: the model pass (one wavefront per encode-span slot, the whole model in LDS) and the range
 // coder (one lane per chunk slot).
+// the bounds walk and the chain: what every encode span starts from (sub: over the records of parse iteration 1)
+static int carried_starts(const xzamd_span_args* a, uint32_t nblocks, bool sub, hipStream_t st)
+{
+    if (!a->cb_bnd || !a->cb_log || !a->cb_hdr || !a->cb_start || !a->cb_carry || !a->pinfo || !a->span_tab || !a->span_cnt
+            || a->model_slots_pad == 0)
+        return (int)hipErrorInvalidValue;
+    const uint32_t nslots = nblocks * a->max_esb;
+    const uint32_t nprob = P_LITERAL + (0x300u << (a->lc + a->lp));
+    hipError_t e = hipMemsetAsync(a->cb_log, 0, (size_t)nslots * a->model_slots_pad * XZAMD_LOG_WORDS * 4, st);
+    if (e != hipSuccess) return (int)e;
+    const uint32_t lds = (nprob * 4 + 15) & ~15u;
+    if (sub) hipLaunchKernelGGL(k_model_walk<2>, dim3(nslots), dim3(64), lds, st, *a, nslots);
+    else hipLaunchKernelGGL(k_model_walk<1>, dim3(nslots), dim3(64), lds, st, *a, nslots);
+    hipLaunchKernelGGL(k_model_chain, dim3((a->model_slots_pad + 255) / 256, nblocks), dim3(256), 0, st, *a, nblocks);
+    return (int)hipGetLastError();
+}
+
 int xzk_encode_syms(const xzamd_span_args* a, uint32_t nblocks, void* stream_)
 {
     hipStream_t st = (hipStream_t)stream_;
@@ -4602,11 +4822,27 @@ int xzk_encode_syms(const xzamd_span_args* a, uint32_t nblocks, void* stream_)
         return (int)hipErrorInvalidValue;
     const uint32_t nslots = nblocks * a->max_esb;
     const uint32_t nch = XZAMD_CHUNK_SLOTS(a->n, nslots);
+    int r = carried_starts(a, nblocks, false, st);
+    if (r) return r;
     hipError_t e = hipMemsetAsync(a->chunks, 0, (size_t)nch * sizeof(xzamd_chunk), st);
     if (e != hipSuccess) return (int)e;
     const uint32_t lds = ((((P_LITERAL + (0x300u << (a->lc + a->lp)) + 1) / 2) * 4 + 128) + 15) & ~15u;
-    hipLaunchKernelGGL(k_model_syms, dim3(nslots), dim3(64), lds, st, *a, nslots);
+    hipLaunchKernelGGL(k_model_walk<0>, dim3(nslots), dim3(64), lds, st, *a, nslots);
     hipLaunchKernelGGL(k_rc_chunks, dim3((nch + 63) / 64), dim3(64), 0, st, *a, nch);
+    return (int)hipGetLastError();
+}
+
+int xzk_model_snapshots(const xzamd_span_args* a, uint32_t nblocks, void* stream_)
+{
+    hipStream_t st = (hipStream_t)stream_;
+    if (nblocks == 0) return 0;
+    if (!a->enc_tab || !a->enc_cnt || a->max_esb == 0 || !a->sym_len || !a->sym_dist || !a->prior || !a->lit || !a->snap_sr)
+        return (int)hipErrorInvalidValue;
+    const uint32_t nslots = nblocks * a->max_esb;
+    int r = carried_starts(a, nblocks, true, st);
+    if (r) return r;
+    const uint32_t lds = ((((P_LITERAL + (0x300u << (a->lc + a->lp)) + 1) / 2) * 4 + 128) + 15) & ~15u;
+    hipLaunchKernelGGL(k_model_walk<3>, dim3(nslots), dim3(64), lds, st, *a, nslots);
     return (int)hipGetLastError();
 }
 

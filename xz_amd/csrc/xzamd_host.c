@@ -380,7 +380,7 @@ typedef struct {
 } dbuf;
 
 /* stage events of one batch (one set per parity of the two-stream pipeline) */
-enum { EV_START, EV_CHAINS, EV_FIND, EV_PLAN0, EV_PLAN1, EV_SEED, EV_PARSE, EV_FRONT, EV_BACK0, EV_CODE, EV_CRC, EV_ASM, EV_COUNT };
+enum { EV_START, EV_CHAINS, EV_FIND, EV_PLAN0, EV_PLAN1, EV_SEED, EV_ITER1, EV_PARSE, EV_FRONT, EV_BACK0, EV_CODE, EV_CRC, EV_ASM, EV_COUNT };
 
 /* What the front end of a batch (match structures, plan, parse -- the caller's stream) hands to its back end (range
  * coder of the two-phase mode, Block checks, sizes, layout, gather -- the second stream when the two are pipelined). */
@@ -427,7 +427,9 @@ struct xzamd_ctx {
 	/* device buffers */
 	dbuf keys_a, keys_b, vals_a, vals_b, rank, sorted_pos, prev2, prev3, prev4, prev8, prev16, prev24, prev32, key64_a, key64_b, sa, sa_rank, sort_tmp;
 	dbuf scratch, span_bytes, strip_crc, block_crc, segs, lits, trace, errw, errw2, litp, mlen, mdist, bcj[2], bcjt;
-	dbuf est, totals, span_tab, span_cnt, mtop, order;             /* span plan (kernels_api.h) */
+	dbuf est, totals, span_tab[2], span_cnt[2], mtop, order;       /* span plan (kernels_api.h); the piece table per pipeline parity: the coder's walk reads it */
+	dbuf pinfo[2], snap_sr;                                        /* per piece: what its parser leaves for the coder's walk; what a piece of iteration 2 starts with */
+	dbuf cb_bnd[2], cb_log[2], cb_hdr[2], cb_start[2], cb_carry[2]; /* carried model walk: [0] over iteration 1's records (front end), [1] the coder's (back end) */
 	dbuf sym_len[2], sym_dist[2], prior, enc_tab[2], enc_cnt[2];   /* two-phase mode ([2]: one set per pipeline parity) */
 	dbuf tok, chunks, h_chunks;                                    /* coder of the two-phase mode: tokens, chunk table */
 	/* pinned host buffers */
@@ -544,15 +546,17 @@ static void ctx_device_bufs(xzamd_ctx *c, dbuf **d, size_t *nd)
 	dbuf *all[] = { &c->keys_a, &c->keys_b, &c->vals_a, &c->vals_b, &c->rank, &c->sorted_pos,
 		&c->prev2, &c->prev3, &c->prev4, &c->prev8, &c->prev16, &c->prev24, &c->prev32, &c->key64_a, &c->key64_b, &c->sa, &c->sa_rank, &c->sort_tmp,
 		&c->scratch, &c->litp, &c->mlen, &c->mdist, &c->bcj[0], &c->bcj[1], &c->bcjt, &c->est, &c->mtop, &c->order,
-		&c->sym_len[0], &c->sym_len[1], &c->sym_dist[0], &c->sym_dist[1], &c->tok,
+		&c->sym_len[0], &c->sym_len[1], &c->sym_dist[0], &c->sym_dist[1], &c->tok, &c->cb_log[0], &c->cb_log[1],
 		/* small ones */
 		&c->chunks,
 		&c->span_bytes, &c->strip_crc, &c->block_crc, &c->segs, &c->lits, &c->trace, &c->errw, &c->errw2,
-		&c->totals, &c->span_tab, &c->span_cnt, &c->prior, &c->enc_tab[0], &c->enc_tab[1], &c->enc_cnt[0], &c->enc_cnt[1] };
+		&c->totals, &c->span_tab[0], &c->span_tab[1], &c->span_cnt[0], &c->span_cnt[1], &c->prior, &c->enc_tab[0], &c->enc_tab[1], &c->enc_cnt[0], &c->enc_cnt[1],
+		&c->pinfo[0], &c->pinfo[1], &c->snap_sr, &c->cb_bnd[0], &c->cb_bnd[1], &c->cb_hdr[0], &c->cb_hdr[1], &c->cb_start[0], &c->cb_start[1],
+		&c->cb_carry[0], &c->cb_carry[1] };
 	*nd = sizeof(all) / sizeof(all[0]);
 	memcpy(d, all, sizeof(all));
 }
-#define CTX_NBIG 33      /* the first CTX_NBIG entries of ctx_device_bufs scale with the batch */
+#define CTX_NBIG 35      /* the first CTX_NBIG entries of ctx_device_bufs scale with the batch */
 
 void xzamd_ctx_destroy(xzamd_ctx *c)
 {
@@ -698,10 +702,13 @@ int xzamd_debug_fetch(xzamd_ctx *c, int what, void *out, uint64_t bytes)
 		return XZAMD_PROG_ERROR;
 	const dbuf *b = what == XZAMD_DEBUG_SA ? &c->sa : what == XZAMD_DEBUG_SA_RANK ? &c->sa_rank
 			: what == XZAMD_DEBUG_LISTS ? &c->mdist : what == XZAMD_DEBUG_LIST_LENS ? &c->mlen
-			: what == XZAMD_DEBUG_SPAN_TAB ? &c->span_tab : what == XZAMD_DEBUG_SPAN_CNT ? &c->span_cnt
+			: what == XZAMD_DEBUG_SPAN_TAB ? &c->span_tab[c->last_par] : what == XZAMD_DEBUG_SPAN_CNT ? &c->span_cnt[c->last_par]
 			: what == XZAMD_DEBUG_SPAN_EST ? &c->est : what == XZAMD_DEBUG_LITP ? &c->litp
 			: what == XZAMD_DEBUG_SYM_LEN ? &c->sym_len[c->last_par] : what == XZAMD_DEBUG_SYM_DIST ? &c->sym_dist[c->last_par]
-			: what == XZAMD_DEBUG_ENC_TAB ? &c->enc_tab[c->last_par] : what == XZAMD_DEBUG_ENC_CNT ? &c->enc_cnt[c->last_par] : NULL;
+			: what == XZAMD_DEBUG_ENC_TAB ? &c->enc_tab[c->last_par] : what == XZAMD_DEBUG_ENC_CNT ? &c->enc_cnt[c->last_par]
+			: what == XZAMD_DEBUG_PINFO ? &c->pinfo[c->last_par] : what == XZAMD_DEBUG_SNAP_SR ? &c->snap_sr
+			: what == XZAMD_DEBUG_PRIOR ? &c->prior : what == XZAMD_DEBUG_CARRY ? &c->cb_carry[1]
+			: what == XZAMD_DEBUG_CB_HDR ? &c->cb_hdr[1] : what == XZAMD_DEBUG_CB_START ? &c->cb_start[1] : NULL;
 	if (!b || !b->p || b->cap < bytes)
 		return XZAMD_PROG_ERROR;
 	xzk_set_device(c->device);
@@ -891,7 +898,7 @@ static int back_finish(xzamd_ctx *c, job_env *J, batch_run *B)
 			/* the chunks of the Block's encode spans, in order (k_model_syms / k_rc_chunks) */
 			for (uint32_t s = 0; s < nsp; ++s) {
 				const uint32_t slot = (uint32_t)(b * opb + s), st0 = otab[2 * slot], en0 = otab[2 * slot + 1];
-				const uint32_t cb = XZAMD_CHUNK_BASE(st0, slot), cc = ((en0 - st0) >> 15) + 2u;
+				const uint32_t cb = XZAMD_CHUNK_BASE(st0, slot), cc = XZAMD_CHUNK_CAP(en0 - st0);
 				uint64_t covered = 0;
 				for (uint32_t k = 0; k < cc && hch[cb + k].usize != 0; ++k) {
 					if (hch[cb + k].csize == 0 || hch[cb + k].in_start != st0 + covered)
@@ -937,7 +944,7 @@ static int back_finish(xzamd_ctx *c, job_env *J, batch_run *B)
 			for (uint32_t s = 0; s < nsp; ++s) {
 				const uint64_t slot = b * opb + s, start = otab[2 * slot];
 				if (two) {
-					const uint32_t cb = XZAMD_CHUNK_BASE((uint32_t)start, (uint32_t)slot), cc = ((otab[2 * slot + 1] - (uint32_t)start) >> 15) + 2u;
+					const uint32_t cb = XZAMD_CHUNK_BASE((uint32_t)start, (uint32_t)slot), cc = XZAMD_CHUNK_CAP(otab[2 * slot + 1] - (uint32_t)start);
 					for (uint32_t k = 0; k < cc && hch[cb + k].usize != 0; ++k)
 						opos = plan_seg(&pl, 0, XZAMD_CHUNK_OUT(hch[cb + k].in_start, cb + k), hch[cb + k].csize, opos);
 				} else
@@ -1061,6 +1068,11 @@ double xzamd_work_bytes_per_byte_(const xzamd_lzma_options *opt)
 	else per_byte += 8.0;                                            /* rank, sorted_pos */
 	if (opt->gpu_parser) per_byte += 32.0 + 2.0 + (list_packed ? 0.0 : 16.0);
 	if (two_) per_byte += 12.0 + 2.0 * XZAMD_TOK_PER_BYTE + 0.3;     /* recorded parse x 2, tokens, piece models in L2 */
+	if (two_) {
+		/* the carried model walk: bounds, logged bits and start model per encode-span slot (>= 512 KiB of input), two sets */
+		const double mslots = (double)((1846u + (0x300u << (opt->lc + opt->lp)) + 63u) & ~63u);
+		per_byte += 2.0 * (4.0 * XZAMD_LOG_WORDS + 6.0) * mslots / (double)XZAMD_ENC_MIN_LEN;
+	}
 	if (opt->bcj) per_byte += opt->bcj2 ? 3.0 : 2.0;
 	return per_byte;
 }
@@ -1257,10 +1269,11 @@ int xzamd_encode_device_(xzamd_ctx *c,
 		}
 		GROW(sort_tmp, sort_bytes + 256, 0);
 		const uint32_t nch = two ? XZAMD_CHUNK_SLOTS(n, nenc) : 0;      /* chunk slots of the two-phase coder */
+		const uint32_t mslots = (1846u + (0x300u << (opt->lc + opt->lp)) + 63u) & ~63u;   /* probabilities of the model, padded */
 		GROW(scratch, two ? (uint64_t)n + (n >> 3) + 64 + 32ull * nch : (uint64_t)n + (n >> 3) + 32 + (uint64_t)XZAMD_SPAN_SLACK * nout, 0);
 		GROW(span_bytes, 4ull * nout, 0);
-		GROW(span_tab, 8ull * nspans, 0);
-		GROW(span_cnt, 4ull * nb, 0);
+		GROW(span_tab[par], 8ull * nspans, 0);
+		GROW(span_cnt[par], 4ull * nb, 0);
 		GROW(h_span_tab, 8ull * nspans, 1);
 		GROW(h_span_cnt[par], 4ull * nb + 16, 1);
 		if (two) {
@@ -1272,6 +1285,15 @@ int xzamd_encode_device_(xzamd_ctx *c,
 			GROW(h_enc_tab[par], 8ull * nenc, 1);
 			GROW(h_enc_cnt[par], 4ull * nb + 16, 1);
 			GROW(tok, 2ull * ((uint64_t)n * XZAMD_TOK_PER_BYTE + 4096ull * nenc + 64), 0);
+			GROW(pinfo[par], 4ull * XZAMD_PINFO_WORDS * nspans, 0);
+			GROW(snap_sr, 32ull * nspans, 0);
+			for (int f = 0; f < 2; ++f) {
+				GROW(cb_bnd[f], 4ull * mslots * nenc, 0);
+				GROW(cb_log[f], 4ull * XZAMD_LOG_WORDS * mslots * nenc, 0);
+				GROW(cb_hdr[f], 4ull * nenc + 16, 0);
+				GROW(cb_start[f], 2ull * mslots * nenc + 16, 0);
+				GROW(cb_carry[f], 4ull * nenc + 16, 0);
+			}
 			GROW(chunks, (uint64_t)nch * sizeof(xzamd_chunk), 0);
 			GROW(h_chunks, (uint64_t)nch * sizeof(xzamd_chunk), 1);
 		}
@@ -1358,8 +1380,8 @@ int xzamd_encode_device_(xzamd_ctx *c,
 		a.sa_window = opt->gpu_sa_window;
 		a.parser = opt->gpu_parser;
 		a.scratch = (uint8_t *)c->scratch.p;
-		a.span_tab = (const uint32_t *)c->span_tab.p;
-		a.span_cnt = (const uint32_t *)c->span_cnt.p;
+		a.span_tab = (const uint32_t *)c->span_tab[par].p;
+		a.span_cnt = (const uint32_t *)c->span_cnt[par].p;
 		a.max_spb = spb;
 		a.span_bytes = (uint32_t *)c->span_bytes.p;
 		a.err = (uint32_t *)c->errw.p;
@@ -1394,6 +1416,12 @@ int xzamd_encode_device_(xzamd_ctx *c,
 			}
 			a.tok = (uint16_t *)c->tok.p;
 			a.chunks = (xzamd_chunk *)c->chunks.p;
+			a.pinfo = (uint32_t *)c->pinfo[par].p;
+			a.snap_sr = (uint32_t *)c->snap_sr.p;
+			a.model_slots_pad = mslots;
+			/* (the front end's set of the carried-walk buffers; the back end switches to its own below) */
+			a.cb_bnd = (uint32_t *)c->cb_bnd[0].p; a.cb_log = (uint32_t *)c->cb_log[0].p; a.cb_hdr = (uint32_t *)c->cb_hdr[0].p;
+			a.cb_start = (uint16_t *)c->cb_start[0].p; a.cb_carry = (uint32_t *)c->cb_carry[0].p;
 		}
 		{
 			int e = 0, seeds_early = 0;
@@ -1434,14 +1462,14 @@ int xzamd_encode_device_(xzamd_ctx *c,
 							? c->wave_slots : c->cus * (uint32_t)occ;
 				}
 				e = xzk_span_plan(&a, (uint32_t)nb, (uint32_t *)c->est.p, (unsigned long long *)c->totals.p,
-						(uint32_t *)c->span_tab.p, (uint32_t *)c->span_cnt.p, opt->span_cost, opt->span_bits,
+						(uint32_t *)c->span_tab[par].p, (uint32_t *)c->span_cnt[par].p, opt->span_cost, opt->span_bits,
 						XZAMD_SPAN_MIN_LEN, two ? (uint32_t *)c->enc_tab[par].p : NULL, two ? (uint32_t *)c->enc_cnt[par].p : NULL,
 						(uint32_t *)c->order.p, c->sort_tmp.p, c->sort_tmp.cap, &launch_order, st);
 				if (e) { rc = fail(c, XZAMD_DEVICE_ERROR, "span plan launch", e); goto done; }
 				a.order = launch_order;
 				/* the host lays the Blocks out from the plan: fetched with the span sizes below */
-				if (!two) e = xzk_d2h(htab, c->span_tab.p, 8ull * nspans, st);
-				if (!e) e = xzk_d2h(hcnt, c->span_cnt.p, 4ull * nb, st);
+				if (!two) e = xzk_d2h(htab, c->span_tab[par].p, 8ull * nspans, st);
+				if (!e) e = xzk_d2h(hcnt, c->span_cnt[par].p, 4ull * nb, st);
 				if (!e) e = xzk_d2h(hcnt + 2 * ((nb + 1) / 2), (uint8_t *)c->totals.p + 8ull * (nb + 1), 8, st);   /* target used, behind the counts */
 				if (!e && two) e = xzk_d2h(c->h_enc_tab[par].p, c->enc_tab[par].p, 8ull * nenc, st);
 				if (!e && two) e = xzk_d2h(c->h_enc_cnt[par].p, c->enc_cnt[par].p, 4ull * nb, st);
@@ -1456,8 +1484,8 @@ int xzamd_encode_device_(xzamd_ctx *c,
 					}
 					hcnt[b] = k;
 				}
-				e = xzk_h2d(c->span_tab.p, htab, 8ull * nspans, st);
-				if (!e) e = xzk_h2d(c->span_cnt.p, hcnt, 4ull * nb, st);
+				e = xzk_h2d(c->span_tab[par].p, htab, 8ull * nspans, st);
+				if (!e) e = xzk_h2d(c->span_cnt[par].p, hcnt, 4ull * nb, st);
 				if (e) { rc = fail(c, XZAMD_DEVICE_ERROR, "h2d span plan", e); goto done; }
 			}
 			xzk_event_record(ev[EV_PLAN1], st);
@@ -1467,6 +1495,14 @@ int xzamd_encode_device_(xzamd_ctx *c,
 				else e = xzk_parse_pieces(&a, (uint32_t)nb, 0, 0, NULL, st);
 				xzk_event_record(ev[EV_SEED], st);
 				cur.seeds_early = seeds_early;
+				/* iteration 1: the first part of every piece from the seed's prior; the carried model walk over its records leaves
+				 * every piece the price model it starts iteration 2 from (oracle: parse_block) */
+				a.iter = 1;
+				if (!e) e = xzk_parse_pieces(&a, (uint32_t)nb, 1, c->span_waves, (uint32_t *)c->errw.p + 60, st);
+				if (!e) e = xzk_model_snapshots(&a, (uint32_t)nb, st);
+				xzk_event_record(ev[EV_ITER1], st);
+				a.iter = 2;
+				if (!e) e = xzk_memset((uint32_t *)c->errw.p + 60, 0, 4, st);
 				if (!e) e = xzk_parse_pieces(&a, (uint32_t)nb, 1, c->span_waves, (uint32_t *)c->errw.p + 60, st);
 				xzk_event_record(ev[EV_PARSE], st);
 			} else {
@@ -1500,6 +1536,8 @@ int xzamd_encode_device_(xzamd_ctx *c,
 			if (!e && two) {
 				xzamd_span_args a2 = a;
 				a2.err = (uint32_t *)c->errw2.p;
+				a2.cb_bnd = (uint32_t *)c->cb_bnd[1].p; a2.cb_log = (uint32_t *)c->cb_log[1].p; a2.cb_hdr = (uint32_t *)c->cb_hdr[1].p;
+				a2.cb_start = (uint16_t *)c->cb_start[1].p; a2.cb_carry = (uint32_t *)c->cb_carry[1].p;
 				e = xzk_encode_syms(&a2, (uint32_t)nb, stb);
 			}
 			xzk_event_record(ev[EV_CODE], stb);
