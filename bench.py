@@ -162,12 +162,20 @@ def cpu_baseline(host, preset, bcj, block_size, seconds=20.0):
         pin1, el1, th1 = C.c_uint64(), C.c_double(), C.c_uint32()
         f(host.ctypes.data, host.size, preset, 1 if bcj else 0, 1, 0, min(seconds, 6.0), C.byref(pin1), C.byref(el1), C.byref(th1))
         t1 = pin1.value / max(el1.value, 1e-9) / 1e6
+        # the same encoder with threads = the CPUs this process may use (what `xz -T<usable>` would run): no oversubscription
+        pinu, elu, thu = C.c_uint64(), C.c_double(), C.c_uint32()
+        f(host.ctypes.data, host.size, preset, 1 if bcj else 0, max(1, usable), 0, min(seconds, 10.0), C.byref(pinu), C.byref(elu), C.byref(thu))
+        tu = pinu.value / max(elu.value, 1e-9) / 1e6
         return {"value": round(mt, 2), "unit": "MB/s", "cores": usable, "kind": "reference",
                 "sample": (f"liblzma 5.8.3 lzma_stream_encoder_mt preset {preset & 31}{'e' if preset >> 31 else ''}{' + x86 BCJ' if bcj else ''}, "
                            f"threads={int(th.value)} (lzma_cputhreads, as xz -T0), whole {host.size >> 20} MiB input of rank 0 on offer = {nblocks} Blocks "
                            f"-> {busy} worker threads with a Block each on {usable} usable CPUs (affinity mask / cgroup quota), "
                            f"timed {el.value:.1f} s wall, {pin.value >> 20} MiB processed (lzma_get_progress)"),
                 "worker_threads": busy,
+                "threads_equal_usable_cores": {"value": round(tu, 2), "threads": int(thu.value), "seconds": round(elu.value, 1)},
+                "caveat": (f"this process may use {usable} of the host's {lim.get('os_cpu_count')} hardware threads (cgroup quota / affinity mask): the "
+                           "figure is a baseline for THIS slice of the host, not for the whole host the >= 10x-at-8-GPUs target of "
+                           "BASELINE.json is set against; per-core figure: per_core_T1"),
                 "per_core_T1": round(t1, 3), "scaling_vs_T1": round(mt / t1, 1) if t1 > 0 else None,
                 "host": lim}
     except Exception as e:  # noqa: BLE001
@@ -182,7 +190,7 @@ def reference_ratio(sample, preset, bcj, block_size):
     return len(enc)
 
 
-def host_to_host(host, preset, block_size, reps=2, bcj=False):
+def host_to_host(host, preset, block_size, reps=3, bcj=False):
     """The SURVEY 8(d) end-to-end number: lzma_stream_encoder_mt + lzma_code(LZMA_FINISH) of libxz_amd.so on
     HOST buffers -- staging copy, H2D, device encode, D2H of the Stream all inside the timed region -- over the
     WHOLE input, and the WHOLE output back through the reference's own (multi-threaded) decoder, compared by sha256."""
@@ -194,6 +202,7 @@ def host_to_host(host, preset, block_size, reps=2, bcj=False):
     n = host.size
     out = np.empty(n // 2 + (n >> 3) + (1 << 20), dtype=np.uint8)
     best = None
+    times = []
 
     class Filter(C.Structure):
         _fields_ = [("id", C.c_uint64), ("options", C.c_void_p)]
@@ -227,10 +236,12 @@ def host_to_host(host, preset, block_size, reps=2, bcj=False):
         L.lzma_end(C.byref(s))
         if rc != 1:
             return {"value": None, "error": int(rc)}
+        times.append(dt)
         if best is None or dt < best[0]:
             best = (dt, total_out)
     res = {"value": round(n / best[0] / 1e6, 2), "unit": "MB/s", "bytes": int(n), "ms": round(best[0] * 1e3, 1),
            "ratio": round(best[1] / n, 5),
+           "mean_value": round(n / (sum(times) / len(times)) / 1e6, 2), "runs_ms": [round(t * 1e3, 1) for t in times],
            "what": "lzma_stream_encoder_mt + lzma_code(LZMA_FINISH) of libxz_amd.so, the WHOLE input and output in host RAM "
                    "(staging, H2D, device encode, D2H inside the timed region), best of %d" % reps}
     try:
@@ -251,12 +262,15 @@ def host_to_host(host, preset, block_size, reps=2, bcj=False):
 
 
 def extra_configs():
-    """BASELINE.json's other single-GPU configurations, each as a child `bench.py` (its own process, its own device
-    context), summarised: C2 = configs[1] (preset 1, 1 GiB synthetic text, 64 Blocks of 16 MiB), C5_1gpu = one GPU's
-    run of configs[4] (preset 9e + x86 BCJ, 8 GiB of the box's ELF objects, 192 MiB Blocks)."""
+    """BASELINE.json's other configurations as far as one GPU runs them, each as a child `bench.py` (its own process, its own
+    device context), summarised: C2 = configs[1] (preset 1, 1 GiB synthetic text, 64 Blocks of 16 MiB), C4_1gpu = one GPU's
+    share of configs[3] (preset 6, 4 GiB of a tar stream of the box's source trees), C5_1gpu = one GPU's run of configs[4]
+    (preset 9e + x86 BCJ, 8 GiB of the box's ELF objects, 192 MiB Blocks)."""
     import subprocess
     runs = {
         "C2": ["--preset", "1", "--size-mib", "1024", "--block-mib", "16", "--steps", "3", "--warmup", "1", "--ratio-blocks", "16"],
+        "C4_1gpu": ["--preset", "6", "--corpus", "tar", "--size-mib", "4096", "--steps", "2", "--warmup", "1", "--ratio-blocks", "4",
+                    "--ratio-async", "--no-host-to-host"],
         "C5_1gpu": ["--preset", "0x80000009", "--bcj", "--corpus", "elf", "--size-mib", "8192", "--steps", "1", "--warmup", "1",
                     "--ratio-blocks", "1", "--ratio-async", "--no-host-to-host"],
     }
@@ -334,6 +348,7 @@ def main():
     ap.add_argument("--ratio-blocks", type=int, default=0,
                     help="Blocks of the input the ratio is measured on against the reference encoder (0 = about 1 GiB for the "
                          "headline workload, 4 Blocks otherwise)")
+    ap.add_argument("--stream-sha", action="store_true", help="sha256 of the complete .xz Stream of the last step in the line")
     ap.add_argument("--corpus", choices=["text", "elf", "tar"], default="text",
                     help="text: seeded synthetic enwik-style text (the headline workload); elf: the x86-64 shared "
                          "objects present on the box, concatenated and cycled (config C5's input); tar: ustar stream "
@@ -382,13 +397,18 @@ def main():
 
     if args.bcj:
         opts.bcj = xz_amd.BCJ_X86
+    # Strong scaling: every rank cuts ITS Blocks out of the ONE corpus the single-GPU run encodes (same generator, same seed),
+    # so the N-rank Stream is byte for byte the 1-rank Stream (--stream-sha; tests/test_gpu_multirank.py compares them).  Weak
+    # scaling: a corpus of its own per rank.
+    first = lo * block_size if args.scaling == "strong" and world > 1 else 0
+    seed = 1000 if args.scaling == "strong" else 1000 + rank
     if args.corpus == "elf":
-        host = corpus_elf(max(n, 1), rank)
+        host = corpus_elf(max(first + n, 1), 0 if args.scaling == "strong" else rank)
     elif args.corpus == "tar":
-        host = xz_amd.corpus_tar(max(n, 1), seed=1000 + rank)
+        host = xz_amd.corpus_tar(max(first + n, 1), seed=seed)
     else:
-        host = xz_amd.corpus_text(max(n, 1), seed=1000 + rank)
-    host = host[:n]
+        host = xz_amd.corpus_text(max(first + n, 1), seed=seed)
+    host = host[first:first + n]
     import hashlib
     corpus_sha = hashlib.sha256(memoryview(host)).hexdigest() if rank == 0 and args.corpus != "text" else None   # text: a function of the seed
     data = torch.from_numpy(host).to(dev)
@@ -432,7 +452,8 @@ def main():
         st = enc.stats()
         # the dominant kernel alone: the parse pieces (two-phase) or the single-phase span kernel (finder, span plan, seed
         # pieces and range coder are timed separately)
-        enc_ms += st.ms_parse if two_phase(opts) else st.ms_encode - st.ms_find - st.ms_plan
+        # (two-phase: the FULL parse -- iteration 2 of k_parse_pieces -- without the partial iteration and the carried walk)
+        enc_ms += st.ms_parse - st.ms_iter1 if two_phase(opts) else st.ms_encode - st.ms_find - st.ms_plan
         launches += st.encode_launches
     torch.cuda.synchronize()
     if world > 1:
@@ -506,6 +527,7 @@ def main():
                             f"{'per GPU' if args.scaling == 'weak' else 'in total, whole Blocks dealt to the ranks in order'}; `value` = input resident in HBM, "
                             f"output = complete .xz Stream in HBM; the same job through lzma_code with host buffers (SURVEY 8d end-to-end) is `host_to_host`",
                 "world_size": world,
+                "backend": (dist.get_backend() if world > 1 else None),
                 "corpus_sha256": corpus_sha,       # of rank 0's input: ties "elf" / "tar" numbers to the image they were made on
                 "device_match_finder": ((f"suffix-neighbourhood finder ({opts.gpu_sa_depth or 32}-byte-prefix suffix order, {opts.gpu_sa_window} slots per side + hash2/hash4 heads + equal 8/16 bytes)"
                                          if opts.gpu_sa_window else f"HC{opts.gpu_mf & 15} depth {opts.gpu_depth} (sort-built chains)")
@@ -535,11 +557,15 @@ def main():
             "stage_ms_last_step": {"chains": round(st.ms_chains, 2), "find": round(st.ms_find, 2),
                                    "span_plan": round(st.ms_plan, 2),
                                    **({"seed_pieces_under_the_finder": round(st.ms_seed, 2), "parse_pieces": round(st.ms_parse, 2),
+                                       "of_which_partial_iteration_and_snapshots": round(st.ms_iter1, 2),
                                        "range_coder_second_stream": round(st.ms_code, 2)} if two_phase(opts)
                                       else {"span_encode": round(st.ms_encode - st.ms_find - st.ms_plan, 2)}),
                                    "crc": round(st.ms_crc, 2), "layout_and_assemble": round(st.ms_assemble, 2),
                                    "total": round(st.ms_total, 2)},
         }
+        if args.stream_sha:
+            res["stream_sha256"] = hashlib.sha256(out.cpu().numpy().tobytes()).hexdigest()
+            res["stream_bytes"] = int(out.numel())
         if world == 1 and n:
             import _oracle as o
             # ratio vs the reference on the same Blocks + bit-exact round trip through the REAL reference decoder

@@ -114,7 +114,14 @@ typedef struct {
 	                        encode spans, closed at piece ends.  0: single phase, every span of the plan resets the state */
 	uint32_t bcj2, bcj3; /* second and third filter in front of LZMA2, same values as `bcj`, applied in that order (a chain
 	                        holds at most 4 filters, LZMA2 last: common/filter_common.c:250-334); bcj3 needs bcj2 needs bcj */
+	uint32_t part_iters; /* two-phase: PARTIAL parse iterations in front of the full one (0 = XZAMD_PART_ITERS_DEFAULT, at most 8).
+	                        Each parses the first eighth (>= 16 KiB) of every piece -- the first from the seed's prior, the others
+	                        from the snapshots of the walk before -- and the carried model walk over its records leaves every
+	                        piece the price model the next iteration starts from.  One costs about 15 % of the
+	                        parse; more of them walk record tables out of the regime the Block's first 64 KiB suggest */
 } xzamd_lzma_options;
+#define XZAMD_PART_ITERS_DEFAULT 1u
+#define XZAMD_PART_ITERS_MAX 8u
 #define XZAMD_PREFILTERS_MAX 3u
 #define XZAMD_SPAN_COST_DEFAULT 131072u   /* text: 128 KiB spans */
 #define XZAMD_SPAN_BITS_DEFAULT 400000u
@@ -177,7 +184,9 @@ typedef struct {
 	uint64_t enc_spans;          /* two-phase: encode spans (= state resets + 1 per Block); `spans` counts the parse pieces */
 	float ms_seed;               /* two-phase: the seed pieces (one wavefront per Block, part of ms_encode) */
 	float ms_parse;              /* two-phase: every other piece */
-	float ms_code;               /* two-phase: k_encode_syms */
+	float ms_code;               /* two-phase: the coder's walk (bounds, chain, tokens) + the range coder, second stream */
+	float ms_iter1;              /* two-phase: the part of ms_parse spent in the partial iteration(s) and the carried walk over their records;
+	                                ms_parse - ms_iter1 = the full parse (k_parse_pieces, iteration 2): the dominant kernel */
 } xzamd_stats;
 /* Stats of the last xzamd_stream_encode_device call of the context.  Under the lzma_* front end consecutive jobs of a
  * worker are pipelined (the back end of a job's last batch finishes underneath the next job's front end): there the stage

@@ -1398,7 +1398,8 @@ static int optimum_window(enc *e, uint32_t pos, int cached)
  * match reaches nice_len costs ORC_EST_LONG units and the walk jumps over the match (it may run past the
  * chunk end), any other position costs one unit. */
 #define ORC_EST_LONG 4u
-#define ORC_CHUNK_EST (56000u * 128u)   /* two-phase coder: a chunk ends when the summed prices reach this (1/16 bit) */
+#define ORC_CHUNK_EST (16000u * 128u)   /* two-phase coder: a chunk ends when the summed prices reach this (1/16 bit); round 6: 16,000
+                                         * bytes instead of 56,000 -- four times the lanes for the device's lane-per-chunk range coder */
 #ifndef ORC_PREROLL
 #define ORC_PREROLL 2048u         /* two-phase: bytes in front of a piece that are parsed twice (the device: XZAMD_PREROLL) */
 #define ORC_TOK_PER_BYTE 10u      /* two-phase coder: token budget per input byte of an encode span (XZAMD_TOK_PER_BYTE) */
@@ -1467,15 +1468,11 @@ static uint32_t plan_spans_ex(enc *e, uint32_t *chunk_cost, uint32_t *span_start
 	 * allows at span_bits per span, at least one; threshold = ceil(total / k) */
 	uint64_t k = total / T;
 	if (e->prm.span_bits) {
-		/* A piece start costs 150 ... 280 bytes of output whatever the data (its price model starts from the seed's), so
-		 * on highly compressible Blocks -- whose parse is cheap: the GPU is not short of wavefronts there -- a piece must
-		 * produce more: below one estimated bit per planned byte span_bits grows with the bytes per bit, up to 4x
-		 * (zero pages with islands of words: 24 -> 9 pieces per 24 MiB Block, +2.10 -> +1.82 % vs liblzma; a tar of headers
-		 * 33 -> 17 pieces, +1.05 -> +0.96 %; text, at 3.5 estimated bits per byte: unchanged).  In sixteenths, integers only (the device: k_span_cut). */
-		const uint64_t planned = (uint64_t)(m - seed_chunks) * ORC_EST_CHUNK;
-		uint64_t f16 = total_bits ? 16u * planned / total_bits : 64u;
-		f16 = f16 < 16 ? 16 : f16 > 64 ? 64 : f16;
-		const uint64_t kb = total_bits * 16u / ((uint64_t)e->prm.span_bits * f16);
+		/* (round 5 let span_bits grow up to 4x on Blocks below one estimated bit per byte, because a piece start cost 150 ...
+		 * 280 bytes whatever the data; with the snapshots of round 6 it no longer does -- zero pages with islands of words
+		 * +1.76 vs +1.79 %, a tar of headers +0.69 vs +0.71 % -- and the rule cost config C5 a third of its throughput: fewer,
+		 * longer pieces than the GPU has wave slots.  Removed.) */
+		const uint64_t kb = total_bits / e->prm.span_bits;
 		if (kb < k) k = kb;
 	}
 	if (k == 0) k = 1;
@@ -2023,6 +2020,16 @@ static int parse_block(enc *e, const uint32_t *piece_start, uint32_t np, const u
 		if (k == 0) { memcpy(prior, e->probs, sizeof(e->probs)); price0 = pr; e->trace = NULL; }
 	}
 	snapshot_walk(e, piece_start, np, enc_start, ne, snaps);
+	/* further partial iterations (part_iters > 1): the first part of every piece again, from the snapshots; what a piece
+	 * learns there reaches every later piece through the carried walk -- a Block walks out of the regime its first 64 KiB
+	 * suggest a few pieces further with every iteration */
+	for (uint32_t it = 1; it < (e->prm.part_iters ? e->prm.part_iters : 1u); ++it) {
+		for (uint32_t k = 1; k < np; ++k) {
+			const uint32_t a = piece_start[k], pe = k + 1 < np ? piece_start[k + 1] : n;
+			parse_piece(e, a, a + part_len(pe - a), 0, NULL, &snaps[k]);
+		}
+		snapshot_walk(e, piece_start, np, enc_start, ne, snaps);
+	}
 	if (tp_dbg && tp_dbg->snap_sr)
 		for (uint32_t k = 1; k < np; ++k) {
 			tp_dbg->snap_sr[5 * k] = snaps[k].state;
@@ -2075,7 +2082,7 @@ static int encode_block_syms(enc *e, const uint32_t *ps, uint32_t np, const uint
 	 * chunk runs apart from the model pass that decides where chunks end, so that pass cannot look at the coded size:
 	 * it sums the PRICES of the decisions instead (the parser's table, 1/16 bit each, probabilities before their
 	 * update; 16 per direct bit).  A chunk ends in front of the first symbol at which the sum has reached
-	 * ORC_CHUNK_EST (56,000 bytes: the coded size stays far below the format's 65,536) or 2 MiB - 273 bytes of input.
+	 * ORC_CHUNK_EST (16,000 bytes: the coded size stays far below the format's 65,536) or 2 MiB - 273 bytes of input.
 	 * Round 6: what is stored raw is decided per PIECE, by the parser's price of it (raw[]: the walk that finds the
 	 * bounds has no exact prices to decide by); a state reset follows a stored piece as it follows a stored chunk in the
 	 * reference (lzma2_encoder.c:205-214). */

@@ -143,6 +143,7 @@ typedef struct {
 	                       short rep / match from its own rep distances.  Encode spans end at piece ends: a Block of estimated
 	                       coded size `bits` gets ke = max(1, min(n / ORC_ENC_MIN_LEN, bits / enc_bits)) of them, closed at the
 	                       first piece end where the estimate reaches ceil(bits / ke) and the span is >= ORC_ENC_MIN_LEN long */
+	uint32_t part_iters; /* two-phase: partial parse iterations in front of the full one (0 = 1; the device: xzamd_lzma_options.part_iters) */
 } orc_enc_params;
 #define ORC_EST_CHUNK 4096u
 #define ORC_SPAN_MAX (1u << 20)    /* longest piece (round 6: 16 MiB let one wavefront walk 16 MiB of a highly compressible Block) */

@@ -398,9 +398,74 @@ def cycled_tree(n, seed=123):
 
 REVIEW_CLASSES = {"rgba": rgba_image, "varint": varint_records, "cjk": cjk_text, "cycled_tree": cycled_tree}
 
+
+# ---- a seeded random CLASS generator (round-5 review: "so that the tolerance is a property, not a list"): tables of records of
+# width 1 .. 64 whose fields are drawn from {counter, random walk, enum, noise bits, text, constant}, optionally a mixture of two
+# such tables in alternating segments.  Integer arithmetic only (numpy Generator.integers: the streams do not depend on libm).
+_WORDS = (b"the of and to in is that for it as was with be by on not he this are or his from at which but have an had they you were "
+          b"their one all we can her has there been if more when will would who so no said what up its about than into them").split()
+
+
+def _field(rng, kind, nrec, fw):
+    """(nrec, fw) uint8: one field of the table"""
+    np = _np()
+    if kind == 0:                                     # counter: start + step * i, little or big endian
+        v = int(rng.integers(0, 1 << 30)) + int(rng.integers(1, 1 << int(rng.integers(1, 12)))) * np.arange(nrec, dtype=np.uint64)
+    elif kind == 1:                                   # random walk with small steps
+        k = 1 << int(rng.integers(1, 10))
+        v = (int(rng.integers(0, 1 << 30)) + np.cumsum(rng.integers(-k, k + 1, nrec))).astype(np.uint64)
+    elif kind == 2:                                   # enum: one of m values, skewed
+        m = int(rng.integers(2, 17))
+        vals = rng.integers(0, 1 << 62, m).astype(np.uint64)
+        idx = np.minimum(rng.integers(0, m, nrec), rng.integers(0, m, nrec))
+        v = vals[idx]
+    elif kind == 3:                                   # noise in the low b bits of every byte, the rest constant
+        b = int(rng.integers(1, 9))
+        base = rng.integers(0, 256, fw).astype(np.uint8) & np.uint8((0xFF << b) & 0xFF)
+        return base[None, :] | rng.integers(0, 1 << b, (nrec, fw)).astype(np.uint8)
+    elif kind == 4:                                   # text: words from a small vocabulary, cut / padded to the field
+        joined = b" ".join(_WORDS[int(i)] for i in rng.integers(0, len(_WORDS), 4096))
+        buf = np.frombuffer((joined * ((nrec * fw) // len(joined) + 2))[:nrec * fw + 4096], dtype=np.uint8)
+        off = int(rng.integers(0, 4096))
+        return buf[off:off + nrec * fw].reshape(nrec, fw).copy()
+    else:                                             # constant
+        return np.broadcast_to(rng.integers(0, 256, fw).astype(np.uint8), (nrec, fw)).copy()
+    by = (v[:, None] >> (8 * np.arange(fw, dtype=np.uint64))[None, :]).astype(np.uint8)
+    return by[:, ::-1] if int(rng.integers(0, 2)) else by
+
+
+def _table(rng, n):
+    np = _np()
+    width = int(rng.integers(1, 65))
+    nrec = n // width + 1
+    cols, col = [], 0
+    while col < width:
+        fw = min(width - col, int(rng.choice([1, 1, 2, 2, 4, 4, 8, 3, 6, 12])))
+        cols.append(_field(rng, int(rng.integers(0, 6)), nrec, fw))
+        col += fw
+    return np.concatenate(cols, axis=1).tobytes()[:n]
+
+
+def random_class(seed, n):
+    """Draw number `seed` of the random class generator: n bytes."""
+    np = _np()
+    rng = np.random.default_rng(1_000_003 * (seed + 1))
+    a = _table(rng, n)
+    if int(rng.integers(0, 3)) != 0:
+        return a
+    b = _table(rng, n)                                # a mixture: alternating segments of two tables
+    seg = int(rng.integers(64, 2049)) << 10
+    out, pos, which = [], 0, 0
+    while pos < n:
+        out.append((b if which else a)[pos:pos + seg])
+        pos += seg
+        which ^= 1
+    return b"".join(out)[:n]
+
 NUMERIC_CLASSES = {
     "f32sine": f32_sine, "f32two": f32_two_sines, "f32mesh": f32_mesh, "fasta": fasta_repeats, "sparse": sparse_text,
     "html": html_rows, "csv": csv_sensors, "pcm16": pcm16_stereo, "f64sine": f64_sine, "int32walk": int32_walk, "structs24": structs24, "hexids": hex_ids,
+    "rec7": lambda n: short_records(7, n),          # (known outside in round 5: +1.66 / +2.85 %; round 6: +0.04 / +0.60 %)
 }
 # Classes known to lie OUTSIDE the stated tolerance, kept in the tests so that the number is measured and pinned, not hidden:
 # relocs (preset 6, 24 MiB: +4.9 %): liblzma settles into coding every record as an 11-byte match (the constant r_info + two
@@ -409,7 +474,9 @@ NUMERIC_CLASSES = {
 # suffix neighbours (about 3 bits farther), so the parser stays with rep0 + two literals.  The real .rela.dyn section of
 # libMIOpen.so (24-byte records with more regular addends) is inside: +2.1 %.
 # rec13 / rec7 (short_records): regime-sensitive, see its docstring.
-KNOWN_OUTSIDE = {"relocs": (reloc_table, 0.06), "rec13": (lambda n: short_records(13, n), 0.07), "rec7": (lambda n: short_records(7, n), 0.05)}
+# measured and pinned with their own bound (round 6: +3.90 / +3.28 % and +3.61 / -4.67 % at presets 6 / 9e; round 5: +4.57 and +5.77 %):
+# the parser's path through the model's equilibria, not the pieces -- DESIGN.md section 5, "tables of records"
+KNOWN_OUTSIDE = {"relocs": (reloc_table, 0.045), "rec13": (lambda n: short_records(13, n), 0.045)}
 
 
 def elf_metadata(n):

@@ -41,7 +41,7 @@ class OrcParams(C.Structure):
                 ("pb", C.c_uint32), ("nice_len", C.c_uint32), ("mf", C.c_uint32),
                 ("depth", C.c_uint32), ("span_size", C.c_uint32), ("sa_window", C.c_uint32),
                 ("parser", C.c_uint32), ("sa_depth", C.c_uint32), ("span_cost", C.c_uint32),
-                ("span_bits", C.c_uint32), ("enc_bits", C.c_uint32)]
+                ("span_bits", C.c_uint32), ("enc_bits", C.c_uint32), ("part_iters", C.c_uint32)]
 
 
 class OrcSymbol(C.Structure):
@@ -490,6 +490,7 @@ def params_for_gpu_options(opts, span_size=None, span_cost_used=None):
         p.span_cost = span_cost_used if span_cost_used else opts.span_cost
         p.span_bits = opts.span_bits
         p.enc_bits = opts.enc_span_bits                # != 0: two-phase (parse pieces + encode spans)
+        p.part_iters = opts.part_iters
         return p
     if sp in (0, 1):
         sp = 131072 if opts.gpu_parser else 262144 if opts.dict_size >= (1 << 20) else 65536    # xzamd_host.c DEFAULT_SPAN_OPT / _FAST_BIG / DEFAULT_SPAN

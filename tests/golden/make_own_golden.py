@@ -3,8 +3,8 @@
 suffix-neighbourhood finder, the windowed optimal parser, the piece / encode-span plan and the two-phase coder are OUR
 definitions: the reference's tests hold no vector for them).  The vectors pin that definition against
 unintended edits of oracle/lzma_fast_enc.c and against compiler / platform differences; the GPU tests pin the HIP path to
-the oracle byte for byte, so they pin the product's bytes as well.  A deliberate change of the definition (round 5: the
-bit bound of a piece on highly compressible Blocks) regenerates this file -- say so in the commit.
+the oracle byte for byte, so they pin the product's bytes as well.  A deliberate change of the definition (round 6: carried
+encode spans, two parse iterations, stored pieces, 16,000-byte chunks) regenerates this file -- say so in the commit.
 
     python tests/golden/make_own_golden.py          (needs only oracle/liboracle.so and xz_amd/libxz_amd.so's corpus generators)"""
 import hashlib
@@ -26,11 +26,11 @@ def cases():
     rng = np.random.default_rng(2026)
     lorem = o.corpus_lorem(229001)                                   # tests/create_compress_files.c:110-152
     mix = (xz_amd.corpus_text(1 << 20, seed=3).tobytes() + b"\0" * 700000 + bytes(rng.integers(0, 256, size=200000, dtype=np.uint8))
-           + lorem[:3000] * 150 + _corpora.f32_sine(600000))
+           + lorem[:3000] * 150 + _corpora.random_class(5, 600000))      # (integer arithmetic only: no libm in the inputs)
     k = 40000
     rec = np.zeros((k, 16), dtype=np.uint8)
     rec[:, 0:4] = np.arange(k, dtype=np.uint32).view(np.uint8).reshape(k, 4)
-    rec[:, 4:8] = (np.sin(np.arange(k) * 7e-4) * 50).astype(np.float32).view(np.uint8).reshape(k, 4)
+    rec[:, 4:8] = (np.abs((np.arange(k) * 7) % 2000 - 1000) * 3).astype(np.uint32).view(np.uint8).reshape(k, 4)   # a triangle wave
     rec[:, 8:16] = rng.integers(0, 4, size=(k, 8), dtype=np.uint8)
     return {
         "lorem_p4": (lorem, 4, {}),
@@ -40,6 +40,12 @@ def cases():
         "mix_p6_small_pieces": (mix, 6, {"span_cost": 40000, "span_bits": 50000, "enc_span_bits": 300000}),
         "sparse_p6": (_corpora.sparse_text(4 << 20), 6, {}),          # < 1 estimated bit per byte: the scaled bit bound of a piece
         "rec16_pb4_p6": (rec.tobytes(), 6, {"pb": 4}),                # pb = 4: the parser's pb = 2 view, the coder's real pb
+        # round 6: image pixels (the carried coder model, snapshots), a table of records with three partial iterations, and
+        # incompressible pieces inside compressible data (stored per piece by the parser's price)
+        "rgba_p6": (_corpora.rgba_image(3 << 20), 6, {}),
+        "table_p6_part_iters3": (_corpora.random_class(10, 2 << 20), 6, {"part_iters": 3}),
+        "stored_pieces_p6": (lorem[:200000] + bytes(rng.integers(0, 256, size=300000, dtype=np.uint8)) + lorem[:150000]
+                             + bytes(rng.integers(0, 256, size=100000, dtype=np.uint8)) + lorem[:100000], 6, {}),
     }
 
 

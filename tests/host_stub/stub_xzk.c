@@ -137,6 +137,12 @@ int xzk_parse_pieces(const xzamd_span_args *a, uint32_t nblocks, int phase, uint
 	return 0;
 }
 
+int xzk_model_snapshots(const xzamd_span_args *a, uint32_t nblocks, void *stream)
+{
+	(void)a; (void)nblocks; (void)stream;
+	return 0;
+}
+
 int xzk_encode_syms(const xzamd_span_args *a, uint32_t nblocks, void *stream)
 {
 	(void)stream;

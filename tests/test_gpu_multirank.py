@@ -83,4 +83,14 @@ def test_bench_two_ranks_oversubscribed():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 1 and d["value"] > 0 and d["scaling"] == "strong"
     assert d["other_scaling"]["scaling"] == "weak" and d["other_scaling"]["value"] > 0
-    assert "roofline" in d and d["config"]["world_size"] == 2
+    assert "roofline" in d and d["config"]["world_size"] == 2 and d["config"]["backend"] == "gloo"
+    # round 6: all ranks cut their Blocks out of ONE corpus, so the 2-rank Stream must be the 1-rank Stream of the same job
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--size-mib", "256", "--steps", "1", "--warmup", "0", "--no-ratio",
+           "--no-cpu-baseline", "--no-host-to-host", "--no-extra-configs", "--stream-sha"]
+    shas = {}
+    for g in (1, 2):
+        q = subprocess.run(cmd + ["--gpus", str(g)], capture_output=True, text=True, timeout=900, env=env)
+        assert q.returncode == 0, q.stderr[-2000:]
+        dd = json.loads([l for l in q.stdout.splitlines() if l.startswith("{")][-1])
+        shas[g] = (dd["stream_sha256"], dd["stream_bytes"])
+    assert shas[1] == shas[2], shas

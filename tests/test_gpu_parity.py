@@ -299,6 +299,7 @@ def test_two_phase_stages_identical_to_oracle(enc, preset, single_phase):
         blk = mix[b * bs:(b + 1) * bs]
         starts, estarts = o.orc_piece_plan(blk, prm)
         assert cnt[b] == len(starts) and (tab[b, :cnt[b], 0] == starts + b * bs).all(), ("pieces", b)
+        assert int((tab[b, :cnt[b], 1] - tab[b, :cnt[b], 0]).max()) <= 1 << 20          # no piece longer than 1 MiB (round 6)
         if len(blk) > 65536:
             assert starts[1] == 65536                                   # the seed piece
         assert ecnt[b] == len(estarts) and (etab[b, :ecnt[b], 0] == estarts + b * bs).all(), ("encode spans", b)
@@ -324,6 +325,32 @@ def test_two_phase_stages_identical_to_oracle(enc, preset, single_phase):
     assert o.first_diff(got, o.orc_xz_stream(mix, prm, bs)) == -1
     rr, rdec = o.ref_decode(got, len(mix) + 16)
     assert rr == 1 and rdec == mix
+
+
+@pytest.mark.parametrize("part_iters", [2, 4])
+def test_two_phase_part_iters_identical_to_oracle(enc, part_iters):
+    """xzamd_lzma_options.part_iters: several PARTIAL parse iterations in front of the full one (each from the snapshots of the
+    carried model walk over the records of the one before): byte-identical to the oracle, decodable by liblzma, and no larger
+    than with one (a table of records "constants + counter + enum" is where the iterations pay: DESIGN.md 3.4b)."""
+    import xz_amd
+    import _corpora
+    data = _corpora.random_class(10, 3 << 20) + xz_amd.corpus_text(2 << 20, seed=5).tobytes()
+    bs = 1 << 22
+    sizes = {}
+    for it in (1, part_iters):
+        opts = xz_amd.preset_options(6)
+        opts.span_cost = 50000
+        opts.span_bits = 0
+        opts.enc_span_bits = 300000
+        opts.part_iters = it
+        got, _ = gpu_encode(enc, data, opts, bs)
+        prm = o.params_for_gpu_options(opts)
+        assert prm.part_iters == it
+        assert o.first_diff(got, o.orc_xz_stream(data, prm, bs)) == -1, it
+        rr, rdec = o.ref_decode(got, len(data) + 16)
+        assert rr == 1 and rdec == data
+        sizes[it] = len(got)
+    assert sizes[part_iters] <= sizes[1] * 1.002, sizes
 
 
 @pytest.mark.parametrize("pb,lc,lp", [(3, 3, 0), (4, 3, 0), (4, 0, 2)])
@@ -472,8 +499,9 @@ def test_full_size_blocks_identical_to_oracle(enc):
             assert rr == 1 and rdec == data, name
 
 
-SIZE_TOLERANCE = 0.02       # presets 4-9, full Blocks of 23 classes: measured max +1.82 % at preset 6 (zero pages with islands of random
-                            # words; every other class <= +1.46 %) and +1.70 % at 9e (ELF metadata) (round 5, final tree)
+SIZE_TOLERANCE = 0.025      # presets 4-9, full Blocks of 28 named classes: measured max +2.35 % at preset 6 (a cycled source tree; RGBA pixels
+                            # +2.25 %, every other class <= +1.84 %) and +2.30 % at 9e (RGBA pixels) (round 6; round 5 stated 2.0 % over the 23
+                            # classes it had been tuned on and measured +10.9 % on RGBA pixels, +3.8 % on varint records outside them)
 SIZE_TOLERANCE_FAST = 0.01  # presets 1-3, default spans (256 KiB state-reset spans): measured max +0.72 % (HTML rows)
 
 
@@ -520,6 +548,12 @@ def _tolerance_cases(preset):
     meta = _corpora.elf_metadata(n_new)      # round 5: +4.3 ... +4.9 % before the coder kept the parser's rep / match choice
     if meta is not None:
         cases["elf_metadata"] = meta
+    # round 6: the classes the round-5 review probed and found outside (image pixels +10.9 %, varint records +3.8 %, a cycled
+    # source tree +2.2 %, CJK text +1.9 %: every piece settled into a worse regime than a continuous parse)
+    for name, gen in _corpora.REVIEW_CLASSES.items():
+        d = gen(n_new)
+        if d is not None:
+            cases[name] = d
     for name, (gen, _) in _corpora.KNOWN_OUTSIDE.items():          # measured and pinned with their own (looser) bound
         cases[name] = gen(n_new)
     return cases
@@ -549,6 +583,41 @@ def test_size_within_tolerance_of_reference(enc, preset):
     import _corpora
     over = {k: v for k, v in report.items() if v > 100.0 * (_corpora.KNOWN_OUTSIDE[k][1] if k in _corpora.KNOWN_OUTSIDE else SIZE_TOLERANCE)}
     assert not over, (hex(preset), report)
+
+
+RANDOM_TABLE_DRAWS = 32
+
+
+def test_size_distribution_over_random_record_tables(enc):
+    """The stated tolerance as a PROPERTY, not a list (round-5 review): full 24 MiB Blocks of RANDOM_TABLE_DRAWS draws of the
+    seeded random class generator (tests/_corpora.random_class: tables of records of width 1 .. 64 with counter / random-walk /
+    enum / noise-bit / text / constant fields, a third of them mixtures of two tables) through the product path at preset 6,
+    against the real liblzma on the same Block.  Tables of records are where two codings of the same bytes cost about the same
+    under their own adapted model, and which one an encoder settles into decides +-10 %: the distribution is what is pinned --
+    its median, the share of the draws inside the stated tolerance -- and printed in full."""
+    import concurrent.futures as cf
+    import xz_amd
+    import _corpora
+    if not o.have_ref():
+        pytest.skip("oracle/_ref not built")
+    opts = xz_amd.preset_options(6)
+    bs = xz_amd.mt_block_size(opts)
+    n = 24 << 20
+    report = {}
+    with cf.ThreadPoolExecutor(max_workers=16) as pool:
+        datas = {s: _corpora.random_class(s, n) for s in range(RANDOM_TABLE_DRAWS)}
+        refs = {s: pool.submit(o.ref_encode_mt, d, 6, 2, bs) for s, d in datas.items()}
+        for s, d in datas.items():
+            got = gpu_encode(enc, d, opts, bs)[0]
+            r, dec = o.ref_decode(got, n + 16)
+            assert r == 1 and dec == d, ("liblzma decoder", s)
+            report[s] = round(100.0 * (len(got) / len(refs[s].result()) - 1), 2)
+    v = np.array(list(report.values()))
+    inside = float((v <= 100.0 * SIZE_TOLERANCE).mean())
+    print("size vs liblzma over random record tables, preset 6:", report, "median", float(np.median(v)), "inside", inside,
+          "p90", float(np.percentile(v, 90)), "max", float(v.max()), "min", float(v.min()))
+    assert float(np.median(v)) <= 1.0, report
+    assert inside >= 0.70, report
 
 
 @pytest.mark.parametrize("preset", [1, 3])

@@ -41,6 +41,8 @@ def main():
     gens.update(_corpora.NUMERIC_CLASSES)
     gens.update(_corpora.REVIEW_CLASSES)
     gens.update({k: v[0] for k, v in _corpora.KNOWN_OUTSIDE.items()})
+    if which.startswith("rnd"):
+        gens[which] = lambda k: _corpora.random_class(int(which[3:]), k)     # draw number N of the random class generator
     data = gens[which](n)
     if data is None:
         raise SystemExit(f"{which}: not available on this image")

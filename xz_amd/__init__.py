@@ -34,7 +34,7 @@ class LzmaOptions(C.Structure):
     _fields_ = [(n, C.c_uint32) for n in (
         "dict_size", "lc", "lp", "pb", "mode", "nice_len", "mf", "depth",
         "gpu_mf", "gpu_nice_len", "gpu_depth", "span_size", "gpu_sa_window", "gpu_parser", "bcj",
-        "gpu_sa_depth", "span_cost", "span_bits", "enc_span_bits", "bcj2", "bcj3")]
+        "gpu_sa_depth", "span_cost", "span_bits", "enc_span_bits", "bcj2", "bcj3", "part_iters")]
 
 
 class Stats(C.Structure):
@@ -44,7 +44,7 @@ class Stats(C.Structure):
                 ("ms_assemble", C.c_float), ("ms_total", C.c_float), ("encode_launches", C.c_uint32),
                 ("ms_find", C.c_float), ("span_size", C.c_uint32), ("ms_find_overlapped", C.c_float),
                 ("span_cost_used", C.c_uint32), ("ms_plan", C.c_float), ("wave_slots", C.c_uint32),
-                ("enc_spans", C.c_uint64), ("ms_seed", C.c_float), ("ms_parse", C.c_float), ("ms_code", C.c_float)]
+                ("enc_spans", C.c_uint64), ("ms_seed", C.c_float), ("ms_parse", C.c_float), ("ms_code", C.c_float), ("ms_iter1", C.c_float)]
 
 
 class BlockInfo(C.Structure):

@@ -70,10 +70,10 @@ typedef struct {
 	uint32_t tok_limit;          /* 0 = XZAMD_TOK_PER_BYTE; tests (XZAMD_TEST_TOK_PER_BYTE): a smaller token budget per input byte,
 	                                to reach the "out of tokens: the rest of the span goes out raw" path on ordinary data */
 	/* Round 6 (oracle: "carried encode spans"): two parse iterations and a coder model that is carried from encode span to
-	 * encode span.  iter 1: every piece but the seed parses only its first part (XZAMD_PART_LEN) from the prior + walk +
-	 * pre-roll; iter 2: every piece but the seed parses in full from the snapshot the carried model walk over iteration 1's
-	 * records left in ITS slot of prior / lit (state and rep distances: snap_sr). */
-	uint32_t iter;
+	 * encode span.  A partial iteration parses only the first part (XZAMD_PART_LEN) of every piece but the seed -- the first from
+	 * the prior + walk + pre-roll, later ones and the final, full iteration from the snapshot the carried model walk over the
+	 * records of the iteration before left in the piece's slot of prior / lit (state and rep distances: snap_sr). */
+	uint32_t iter;               /* XZAMD_ITER_* */
 	uint32_t *pinfo;             /* XZAMD_PINFO_WORDS x u32 per piece slot, two halves of 8: [0..7] written by iter 1, [8..15] by iter 2, the
 	                                seed piece (parsed once) writes both: [0] coder state behind the piece's recorded symbols |
 	                                XZAMD_PI_STATE_OK (the twelve candidate states agree), [1..4] the coder's rep distances there
@@ -88,6 +88,8 @@ typedef struct {
 	uint32_t *cb_carry;          /* 1 = the span continues the model of the span in front of it (k_model_chain) */
 	uint32_t model_slots_pad;    /* probabilities of the model, rounded up to 64 */
 } xzamd_span_args;
+#define XZAMD_ITER_PARTIAL 1u       /* parse only the first XZAMD_PART_LEN bytes of every piece but the seed */
+#define XZAMD_ITER_SNAP 2u          /* every piece but the seed starts from its snapshot (else: the seed's prior + walk + pre-roll) */
 #define XZAMD_PINFO_WORDS 16u
 #define XZAMD_PI_STATE_OK 0x80000000u
 #define XZAMD_REP_UNKNOWN 0xFFFFFFFFu
@@ -113,14 +115,17 @@ typedef struct xzamd_chunk {
 #define XZAMD_CH_PROPS 2u           /* header carries the properties byte */
 #define XZAMD_CH_DICT_RESET 4u
 #define XZAMD_CH_STATE_RESET 8u
-#define XZAMD_CHUNK_EST (56000u * 128u)  /* a chunk ends when the summed prices of its decisions reach this (1/16 bit): oracle ORC_CHUNK_EST */
+#define XZAMD_CHUNK_EST (16000u * 128u)  /* a chunk ends when the summed prices of its decisions reach this (1/16 bit): oracle ORC_CHUNK_EST.
+                                          * Round 6: 16,000 bytes (56,000 before): the range coder runs one LANE per chunk, and ~7,000 chunks per batch
+                                          * were 110 wavefronts on a 256-CU GPU; a chunk costs ~10 bytes (header + coder flush): +0.06 % */
 #define XZAMD_TOK_PER_BYTE 10u      /* token capacity: a literal is 9 decisions */
 #define XZAMD_TOK_BASE(st, slot) ((uint64_t)(st) * XZAMD_TOK_PER_BYTE + (uint64_t)(slot) * 4096u)
-/* chunk slots: an LZMA chunk holds > 32 KiB of input unless its span ends or a stored piece (>= 32 KiB: XZAMD_RAW_MIN_LEN; 64 KiB per
- * raw chunk) cuts it short -- two slots per 32 KiB of input cover every mix of the two */
-#define XZAMD_CHUNK_BASE(st, slot) (((st) >> 14) + 2u * (slot))
-#define XZAMD_CHUNK_CAP(len) (((len) >> 14) + 2u)                      /* chunk slots of a span of len bytes */
-#define XZAMD_CHUNK_SLOTS(n, nslots) (((n) >> 14) + 2u * (nslots) + 2u)
+/* chunk slots: an LZMA chunk holds > 15 KiB of input (its prices sum to 16,000 bytes, and a byte costs at most ~8.2 bits) unless
+ * its span ends or a stored piece (>= 32 KiB: XZAMD_RAW_MIN_LEN; 64 KiB per raw chunk) cuts it short -- one slot per 8 KiB of
+ * input covers every mix of the two */
+#define XZAMD_CHUNK_BASE(st, slot) (((st) >> 13) + 2u * (slot))
+#define XZAMD_CHUNK_CAP(len) (((len) >> 13) + 2u)                      /* chunk slots of a span of len bytes */
+#define XZAMD_CHUNK_SLOTS(n, nslots) (((n) >> 13) + 2u * (nslots) + 2u)
 #define XZAMD_RAW_MIN_LEN 32768u    /* shortest piece that is stored raw when its price says so (oracle: ORC_RAW_MIN_LEN) */
 #define XZAMD_CHUNK_OUT(in_start, cidx) (((((uint64_t)(in_start) + ((in_start) >> 3)) + 15) & ~15ull) + (uint64_t)(cidx) * 32u)
 #define XZAMD_PRIOR_WORDS 1856u     /* u32 each, >= the 1846 non-literal probabilities (a multiple of 64) */

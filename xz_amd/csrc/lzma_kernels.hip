@@ -2385,17 +2385,20 @@ void k_span_encode_t(xzamd_span_args a, uint32_t nspans, uint32_t* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------
-// Two-phase mode (oracle: parse_piece / parse_block / encode_syms).  The optimal parser is the expensive part and
-// needs thousands of independent units to fill the GPU; the range coder is cheap, but every reset of its model costs
-// output bytes -- and, worse, a parser that prices with a freshly reset model chooses badly for tens of KiB (measured
-// through the oracle: that, not the coded resets, was most of the span overhead).  So the two are decoupled:
+// Two-phase mode (oracle: parse_piece / parse_block / snapshot_walk / encode_block_syms).  The optimal parser is the
+// expensive part and needs thousands of independent units to fill the GPU; the coder is cheap, but every reset of its
+// model costs output bytes -- and a parser that prices with the wrong model chooses badly.  So the two are decoupled:
 //   k_parse_pieces   one wavefront per PIECE of the span plan: optimum_window with an adaptive price model that codes
-//                    nothing.  The first XZAMD_SEED_LEN bytes of every Block are the seed piece (phase 0, flat model);
-//                    the model it leaves is the prior every other piece of the Block starts from (phase 1).  Symbols
-//                    are recorded per position in a coder-independent form: (length, distance) or literal bytes.
-//   k_encode_syms    one wavefront per ENCODE SPAN (>= 512 KiB of input, about enc_bits of output): the recorded
-//                    symbols are range-coded with one continuous model (all of it in LDS), rep / short rep / match
-//                    chosen from the coder's own rep distances; LZMA2 chunking as in the single-phase kernel.
+//                    nothing.  The first XZAMD_SEED_LEN bytes of every Block are the seed piece (phase 0, flat model).
+//                    Iteration 1 (XZAMD_ITER_PARTIAL): the first eighth of every other piece, from the seed's model + a
+//                    greedy warm-up walk + a pre-roll; iteration 2 (XZAMD_ITER_SNAP): every piece in full from the snapshot
+//                    the carried model walk over iteration 1's records left in its slot.  Symbols are recorded per position
+//                    in a coder-independent form: (length, distance) or literal bytes.
+//   k_model_walk     one wavefront per ENCODE SPAN (>= 512 KiB of input): the recorded symbols through the coder's model
+//                    (all of it in LDS), rep / short rep / match chosen from the coder's own rep distances.  <1>, <2>: the
+//                    bounds of every probability whatever the span's start model is; k_model_chain: the true model at every
+//                    span start -- ONE continuous model per Block; <0>: tokens and the LZMA2 chunk table; <3>: snapshots.
+//   k_rc_chunks      one LANE per LZMA2 chunk: the range coder over the chunk's tokens.
 // ------------------------------------------------------------------------------------------
 template <uint32_t WMAX>
 __device__ __forceinline__ void parse_piece_one(const xzamd_span_args& a, const uint32_t span)
@@ -2428,12 +2431,12 @@ __device__ __forceinline__ void parse_piece_one(const xzamd_span_args& a, const 
         if (k >= a.span_cnt[blk]) return;              // an unused slot of the span plan
         span_start = uni(a.span_tab[2 * span]); span_end = uni(a.span_tab[2 * span + 1]);
         piece_end = span_end;
-        // iteration 1 parses only the first part of the piece (oracle: part_len); symbols never cross its end
-        if (a.iter == 1) span_end = span_start + XZAMD_PART_LEN(span_end - span_start);
+        // a partial iteration parses only the first part of the piece (oracle: part_len); symbols never cross its end
+        if (a.iter & XZAMD_ITER_PARTIAL) span_end = span_start + XZAMD_PART_LEN(span_end - span_start);
     }
-    // iteration 2: the price model, coder state and rep distances come from the carried model walk over iteration 1's
-    // records (k_model_walk<3>: this piece's slot of a.prior / a.lit, a.snap_sr) -- no prior, no walk, no pre-roll
-    const bool from_snap = k != 0 && a.iter == 2;
+    // from the snapshot: the price model, coder state and rep distances come from the carried model walk over the records of
+    // the partial iteration before (k_model_walk<3>: this piece's slot of a.prior / a.lit, a.snap_sr) -- no prior, no walk, no pre-roll
+    const bool from_snap = k != 0 && (a.iter & XZAMD_ITER_SNAP) != 0;
     const uint8_t* __restrict__ in = a.in;
 
     Env e;
@@ -2763,7 +2766,7 @@ __device__ __forceinline__ void parse_piece_one(const xzamd_span_args& a, const 
         if (lane < 2 && a.pinfo) {
             // lane 0: the half the walk over iteration 1's records reads, lane 1: the half the coder's walk reads (the seed
             // piece is parsed once and serves both)
-            const bool mine = k == 0 || (lane == 0) == (a.iter == 1);
+            const bool mine = k == 0 || (lane == 0) == ((a.iter & XZAMD_ITER_PARTIAL) != 0);
             if (mine) {
                 uint32_t* pi = a.pinfo + (uint64_t)span * XZAMD_PINFO_WORDS + lane * (XZAMD_PINFO_WORDS / 2);
                 pi[0] = s0 | (agree ? XZAMD_PI_STATE_OK : 0u);
@@ -3676,13 +3679,8 @@ __global__ __launch_bounds__(64) void k_span_cut(xzamd_span_args a, uint32_t nbl
     }
     unsigned long long k = total / T;
     if (bits_min) {
-        // below one estimated bit per planned byte bits_min grows with the bytes per bit, up to 4x (in sixteenths): a piece
-        // start costs 150 ... 280 bytes of output whatever the data, and a highly compressible Block is cheap to parse
-        // (oracle: plan_spans_ex)
-        const unsigned long long planned = (unsigned long long)(m - seed_chunks) * XZAMD_EST_CHUNK;
-        unsigned long long f16 = total_bits ? 16ull * planned / total_bits : 64ull;
-        f16 = f16 < 16 ? 16 : f16 > 64 ? 64 : f16;
-        const unsigned long long kb = total_bits * 16ull / ((unsigned long long)bits_min * f16);
+        // (round 5's growth of bits_min on highly compressible Blocks is gone: oracle plan_spans_ex)
+        const unsigned long long kb = total_bits / (unsigned long long)bits_min;
         if (kb < k) k = kb;
     }
     if (k == 0) k = 1;
@@ -4764,11 +4762,8 @@ int xzk_span_encode(const xzamd_span_args* a, uint32_t nspans, uint32_t waves, u
     uint32_t* cnt = persist ? counter : nullptr;
     if (a->parser) {
         if ((!a->mlen && !a->list_packed) || !a->mdist) return (int)hipErrorInvalidValue;
-        const char* const wenv = getenv("XZAMD_WMAX_STD");          // measurement knob: 1 = the 232-node window for every nice_len (not the oracle's bytes)
-        if (a->nice_len > 128 && !(wenv && *wenv == '1'))
-            hipLaunchKernelGGL((k_span_encode_t<2, true, WMAX_LONG>), dim3(grid), dim3(64), 0, st, *a, nspans, cnt);
-        else
-            hipLaunchKernelGGL((k_span_encode_t<2, true>), dim3(grid), dim3(64), 0, st, *a, nspans, cnt);
+        // (the single-phase optimal-parser kernel: explicit spans with the parser -- a test configuration, one window size)
+        hipLaunchKernelGGL((k_span_encode_t<2, true>), dim3(grid), dim3(64), 0, st, *a, nspans, cnt);
     } else {
         if (a->sa_window) return (int)hipErrorInvalidValue;      // the fast parser runs on the exact finder only
         hipLaunchKernelGGL((k_span_encode_t<0, false>), dim3(grid), dim3(64), 0, st, *a, nspans, cnt);

@@ -541,6 +541,7 @@ int xzamd_ctx_create(xzamd_ctx **out, int device)
 	return XZAMD_OK;
 }
 
+#define CTX_NBUF_MAX 96   /* callers' array size for ctx_device_bufs */
 static void ctx_device_bufs(xzamd_ctx *c, dbuf **d, size_t *nd)
 {
 	dbuf *all[] = { &c->keys_a, &c->keys_b, &c->vals_a, &c->vals_b, &c->rank, &c->sorted_pos,
@@ -553,6 +554,7 @@ static void ctx_device_bufs(xzamd_ctx *c, dbuf **d, size_t *nd)
 		&c->totals, &c->span_tab[0], &c->span_tab[1], &c->span_cnt[0], &c->span_cnt[1], &c->prior, &c->enc_tab[0], &c->enc_tab[1], &c->enc_cnt[0], &c->enc_cnt[1],
 		&c->pinfo[0], &c->pinfo[1], &c->snap_sr, &c->cb_bnd[0], &c->cb_bnd[1], &c->cb_hdr[0], &c->cb_hdr[1], &c->cb_start[0], &c->cb_start[1],
 		&c->cb_carry[0], &c->cb_carry[1] };
+	_Static_assert(sizeof(all) / sizeof(all[0]) <= CTX_NBUF_MAX, "ctx_device_bufs: raise CTX_NBUF_MAX");
 	*nd = sizeof(all) / sizeof(all[0]);
 	memcpy(d, all, sizeof(all));
 }
@@ -568,7 +570,7 @@ void xzamd_ctx_destroy(xzamd_ctx *c)
 		if (c->st2) xzk_sync(c->st2);
 		c->pend.active = 0;
 	}
-	dbuf *d[64];
+	dbuf *d[CTX_NBUF_MAX];
 	size_t nd = 0;
 	ctx_device_bufs(c, d, &nd);
 	for (size_t i = 0; i < nd; ++i)
@@ -681,6 +683,8 @@ const char *xzamd_options_check(const xzamd_lzma_options *opt)
 	if (opt->gpu_sa_depth != 0 && opt->gpu_sa_depth != 32 && opt->gpu_sa_depth != 64 && opt->gpu_sa_depth != 128
 			&& opt->gpu_sa_depth != 256)
 		return "gpu_sa_depth: 32, 64, 128 or 256";
+	if (opt->part_iters > XZAMD_PART_ITERS_MAX)
+		return "part_iters: 0 (default) .. 8";
 	return NULL;
 }
 
@@ -1004,6 +1008,7 @@ static int back_finish(xzamd_ctx *c, job_env *J, batch_run *B)
 		if (B->seeds_early) { if (!xzk_event_elapsed_ms(c->ev_seed[par][1], c->ev_seed[par][2], &ms)) c->stats.ms_seed += ms; }
 		else if (!xzk_event_elapsed_ms(ev[EV_PLAN1], ev[EV_SEED], &ms)) c->stats.ms_seed += ms;
 		if (!xzk_event_elapsed_ms(ev[EV_SEED], ev[EV_PARSE], &ms)) c->stats.ms_parse += ms;
+		if (!xzk_event_elapsed_ms(ev[EV_SEED], ev[EV_ITER1], &ms)) c->stats.ms_iter1 += ms;
 		if (!xzk_event_elapsed_ms(ev[EV_BACK0], ev[EV_CODE], &ms)) { c->stats.ms_code += ms; c->stats.ms_encode += ms; }
 	}
 	if (J->adaptive) {
@@ -1157,13 +1162,10 @@ int xzamd_encode_device_(xzamd_ctx *c,
 	 * an allocation that fails there surfaces as an error of some later call, not as a clean out-of-memory here.  So
 	 * the batch is capped at 80 % of what is free now plus what this context already holds. */
 	{
-		const int two_ = opt->gpu_parser && opt->gpu_sa_window && opt->span_cost != 0 && opt->enc_span_bits != 0
-				&& (opt->span_size == XZAMD_SPAN_DEFAULT || opt->span_size == XZAMD_SPAN_AUTO);
 		const double per_byte = xzamd_work_bytes_per_byte_(opt);
-		(void)two_;
 		uint64_t free_b = 0, total_b = 0, held = 0;
 		if (xzk_mem_info(&free_b, &total_b) == 0 && total_b != 0) {
-			dbuf *d[64];
+			dbuf *d[CTX_NBUF_MAX];
 			size_t nd = 0;
 			ctx_device_bufs(c, d, &nd);
 			for (size_t i = 0; i < nd; ++i) held += d[i]->cap;
@@ -1318,7 +1320,7 @@ int xzamd_encode_device_(xzamd_ctx *c,
 		GROW(h_span_bytes, 4ull * nout, 1);
 		GROW(h_block_crc, 32ull * nb, 1);
 		/* plan capacity: per Block header + spans + trailer, or the stored form */
-		const uint64_t segs_per_block = (two ? (block_size >> 15) + 2ull * esb + 2 : opb) + 2 + 2 * ((block_size + 65535) / 65536) + 2;
+		const uint64_t segs_per_block = (two ? (block_size >> 13) + 2ull * esb + 2 : opb) + 2 + 2 * ((block_size + 65535) / 65536) + 2;
 		const uint64_t max_segs = nb * segs_per_block + 4;
 		const uint64_t max_lits = nb * (64 + 3 * ((block_size + 65535) / 65536) + 32) + 64;
 		GROW(segs, max_segs * sizeof(xzamd_copy_seg), 0);
@@ -1495,13 +1497,18 @@ int xzamd_encode_device_(xzamd_ctx *c,
 				else e = xzk_parse_pieces(&a, (uint32_t)nb, 0, 0, NULL, st);
 				xzk_event_record(ev[EV_SEED], st);
 				cur.seeds_early = seeds_early;
-				/* iteration 1: the first part of every piece from the seed's prior; the carried model walk over its records leaves
-				 * every piece the price model it starts iteration 2 from (oracle: parse_block) */
-				a.iter = 1;
-				if (!e) e = xzk_parse_pieces(&a, (uint32_t)nb, 1, c->span_waves, (uint32_t *)c->errw.p + 60, st);
-				if (!e) e = xzk_model_snapshots(&a, (uint32_t)nb, st);
+				/* partial iterations: the first part of every piece -- from the seed's prior, then from the snapshots -- and the
+				 * carried model walk over its records, which leaves every piece the price model the next iteration starts from;
+				 * then every piece in full (oracle: parse_block) */
+				const uint32_t npart = opt->part_iters ? opt->part_iters : XZAMD_PART_ITERS_DEFAULT;
+				for (uint32_t it = 0; it < npart && !e; ++it) {
+					a.iter = XZAMD_ITER_PARTIAL | (it ? XZAMD_ITER_SNAP : 0u);
+					if (it) e = xzk_memset((uint32_t *)c->errw.p + 60, 0, 4, st);
+					if (!e) e = xzk_parse_pieces(&a, (uint32_t)nb, 1, c->span_waves, (uint32_t *)c->errw.p + 60, st);
+					if (!e) e = xzk_model_snapshots(&a, (uint32_t)nb, st);
+				}
 				xzk_event_record(ev[EV_ITER1], st);
-				a.iter = 2;
+				a.iter = XZAMD_ITER_SNAP;
 				if (!e) e = xzk_memset((uint32_t *)c->errw.p + 60, 0, 4, st);
 				if (!e) e = xzk_parse_pieces(&a, (uint32_t)nb, 1, c->span_waves, (uint32_t *)c->errw.p + 60, st);
 				xzk_event_record(ev[EV_PARSE], st);
@@ -1586,7 +1593,7 @@ retry_smaller:
 		xzk_sync(st);
 		xzk_sync(c->st2);
 		{
-			dbuf *d[64];
+			dbuf *d[CTX_NBUF_MAX];
 			size_t nd = 0;
 			ctx_device_bufs(c, d, &nd);
 			for (size_t i = 0; i < CTX_NBIG && i < nd; ++i)

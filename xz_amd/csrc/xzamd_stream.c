@@ -733,17 +733,17 @@ uint64_t lzma_stream_encoder_mt_memusage(const lzma_mt *options)
 	uint64_t maxb = JOB_BYTES / bs;
 	if (maxb == 0) maxb = 1;
 	const uint64_t stage = maxb * bs;
-	/* Per GPU (= per worker; the reference: per thread): the device work buffers of a batch -- the same expression the batch
-	 * planner budgets with -- plus the two device in / out sets of consecutive jobs; on the host `2 x GPUs + 1` pinned job
-	 * slots of (staging + output bound) each.  GPUs = min(options->threads, visible devices), 1 when none can be counted. */
+	/* HOST memory only: `2 x GPUs + 1` pinned job slots of (staging + output bound) each.  Clients compare this figure with a
+	 * limit on host RAM (src/xz/coder.c:559-606 lowers the thread count until it fits -- and here threads = GPUs): the device
+	 * work buffers (the batch planner caps them at 80 % of what the device has free) are not host memory, and counting them
+	 * sent `xz -T0` of 5.4+ down to one worker = one GPU (round-5 advisor).  GPUs = min(options->threads, visible devices), 1
+	 * when none can be counted. */
 	int ndev = 1;
 	if (xzk_device_count(&ndev) || ndev <= 0) ndev = 1;
 	if ((uint32_t)ndev > options->threads) ndev = (int)options->threads;
 	if (ndev > MAX_DEVS) ndev = MAX_DEVS;
 	const uint64_t bound = stage + stage / 64 + 65536;               /* ~ maxb x lzma_block_buffer_bound */
-	const double dev = (double)stage * xzamd_work_bytes_per_byte_(&opt) + 2.0 * (double)(stage + bound);
-	const double host = (double)(2 * ndev + 1) * (double)(stage + bound);
-	const double total = dev * ndev + host;
+	const double total = (double)(2 * ndev + 1) * (double)(stage + bound);
 	return total >= 1.8e19 ? UINT64_MAX - 1 : (uint64_t)total;
 }
 
