@@ -508,7 +508,8 @@ int xzamd_ctx_create(xzamd_ctx **out, int device)
 	c->prog_mu_ok = 1;
 	/* from here on every failure goes through xzamd_ctx_destroy (streams and events already made are released) */
 	if (xzk_stream_create(&c->own_stream)) { c->own_stream = NULL; xzamd_ctx_destroy(c); return XZAMD_DEVICE_ERROR; }
-	if (xzk_stream_create(&c->st2)) { c->st2 = NULL; xzamd_ctx_destroy(c); return XZAMD_DEVICE_ERROR; }
+	/* (XZAMD_ST2_LOW=1, measurement knob: the back end's stream at the device's lowest priority) */
+	if ((getenv("XZAMD_ST2_LOW") ? xzk_stream_create_low(&c->st2) : xzk_stream_create(&c->st2))) { c->st2 = NULL; xzamd_ctx_destroy(c); return XZAMD_DEVICE_ERROR; }
 	if (xzk_event_create(&c->ev_sha)) { c->ev_sha = NULL; xzamd_ctx_destroy(c); return XZAMD_DEVICE_ERROR; }
 	if (xzk_stream_create(&c->st3)) { c->st3 = NULL; xzamd_ctx_destroy(c); return XZAMD_DEVICE_ERROR; }
 	for (int i = 0; i < 6; ++i)
