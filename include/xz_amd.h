@@ -125,7 +125,9 @@ typedef struct {
 #define XZAMD_PREFILTERS_MAX 3u
 #define XZAMD_SPAN_COST_DEFAULT 131072u   /* text: 128 KiB spans */
 #define XZAMD_SPAN_BITS_DEFAULT 400000u
+#ifndef XZAMD_ENC_SPAN_BITS_DEFAULT
 #define XZAMD_ENC_SPAN_BITS_DEFAULT 1600000u   /* about 200 KB of output per encode span */
+#endif
 #define XZAMD_SPAN_MIN_LEN 65536u         /* shortest cost-balanced span */
 #define XZAMD_BCJ_X86 4u    /* LZMA_FILTER_X86, api/lzma/bcj.h:20 */
 #define XZAMD_BCJ_ARM64 0x0Au   /* LZMA_FILTER_ARM64, api/lzma/bcj.h (simple/arm64.c), start offset 0 */

@@ -645,10 +645,13 @@ static void rc_shift_low(enc *e)
  * value stays between them, and once they meet the value is KNOWN without knowing the start.  Until then the bits of the
  * slot are counted (the device logs them: the chain kernel replays them on the true start value), at most ORC_LOG_CAP. */
 #define ORC_LOG_CAP 1023u
+static uint32_t orc_log_cap;      /* tests: fewer logged bits (orc_set_log_cap; the device: XZAMD_TEST_LOG_CAP) */
+void orc_set_log_cap(uint32_t v) { orc_log_cap = v >= 1 && v < ORC_LOG_CAP ? v : 0; }
+#define LOG_CAP_NOW (orc_log_cap ? orc_log_cap : ORC_LOG_CAP)
 static inline void bnd_update(enc *e, uint32_t idx, uint32_t bit)
 {
 	uint32_t lo = e->blo[idx], hi = e->bhi[idx];
-	if (lo != hi && e->bcnt[idx] < ORC_LOG_CAP) ++e->bcnt[idx];
+	if (lo != hi && e->bcnt[idx] < LOG_CAP_NOW) ++e->bcnt[idx];
 	e->blo[idx] = (uint16_t)(bit ? lo - (lo >> 5) : lo + ((2048 - lo) >> 5));
 	e->bhi[idx] = (uint16_t)(bit ? hi - (hi >> 5) : hi + ((2048 - hi) >> 5));
 }
@@ -1917,7 +1920,7 @@ static int bnd_failed(const enc *e)
 {
 	const uint32_t total = P_LITERAL + (0x300u << (e->prm.lc + e->prm.lp));
 	for (uint32_t i = 0; i < total; ++i)
-		if (e->blo[i] != e->bhi[i] && e->bcnt[i] >= ORC_LOG_CAP) return 1;
+		if (e->blo[i] != e->bhi[i] && e->bcnt[i] >= LOG_CAP_NOW) return 1;
 	return 0;
 }
 

@@ -173,6 +173,8 @@ typedef struct {
 	uint64_t *price;
 	uint32_t *carry;
 } orc_two_phase_dbg;
+/* tests: at most v logged bits per encode span and probability (0 = ORC_LOG_CAP); the device: XZAMD_TEST_LOG_CAP */
+void orc_set_log_cap(uint32_t v);
 int orc_two_phase_debug(const uint8_t *in, uint32_t n, const orc_enc_params *p, orc_two_phase_dbg *d);
 /* Two-phase mode: orc_lzma2_encode_block and orc_parse_dump in one pass (full-size parity tests). */
 int orc_lzma2_encode_block_syms(const uint8_t *in, uint32_t n, const orc_enc_params *p,

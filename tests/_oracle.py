@@ -590,6 +590,14 @@ def first_diff(a, b):
     return -1 if len(a) == len(b) else n
 
 
+def orc_set_log_cap(v):
+    """Tests only: logged bits per encode span and probability of the carried model walk (0 = default); the device: XZAMD_TEST_LOG_CAP."""
+    f = orc().orc_set_log_cap
+    f.restype = None
+    f.argtypes = [C.c_uint32]
+    f(v)
+
+
 def orc_set_tok_per_byte(v):
     """Tests only: token budget per input byte of the two-phase coder (0 = default); the device: XZAMD_TEST_TOK_PER_BYTE."""
     f = orc().orc_set_tok_per_byte

@@ -430,6 +430,44 @@ def test_two_phase_token_budget_overflow_identical_to_oracle(enc, monkeypatch):
     assert again == full
 
 
+def test_carry_fallback_identical_to_oracle(enc, monkeypatch):
+    """What cannot be carried falls back to a state reset for the rest of the Block: a probability whose bounds
+    have not met within the logged bits of a span.  With 1023 bits per span and slot that needs a strictly periodic bit sequence;
+    reached on ordinary data by turning the cap down on both sides (XZAMD_TEST_LOG_CAP / orc_set_log_cap): the carry decisions,
+    the bytes (identical to the oracle) and the round trip through liblzma."""
+    import xz_amd
+    data = xz_amd.corpus_text(5 << 20, seed=9).tobytes() + o.corpus_lorem(3 << 20)
+    bs = 4 << 20
+    opts = xz_amd.preset_options(6)
+    opts.enc_span_bits = 400000
+    prm = o.params_for_gpu_options(opts)
+    full, _ = gpu_encode(enc, data, opts, bs)
+    esb = bs // (512 << 10) + 1
+    assert (enc.debug_fetch(16, 2 * esb).reshape(2, esb)[:, 1:4] == 1).all()          # (carried, with the real cap)
+    try:
+        for cap in (8, 300):
+            monkeypatch.setenv("XZAMD_TEST_LOG_CAP", str(cap))
+            o.orc_set_log_cap(cap)
+            got, _ = gpu_encode(enc, data, opts, bs)
+            gcarry = enc.debug_fetch(16, 2 * esb).reshape(2, esb)
+            for b in range(2):
+                blk = data[b * bs:(b + 1) * bs]
+                starts, estarts = o.orc_piece_plan(blk, prm)
+                ocarry = o.orc_two_phase_debug(blk, prm, len(starts), len(estarts))[3]
+                assert (gcarry[b, 1:len(estarts)] == ocarry[1:]).all(), (cap, b, gcarry[b, :len(estarts)], ocarry)
+                if cap == 8:
+                    assert (ocarry[2:] == 0).all()                    # nothing merges within 8 bits: from the second span on, resets
+            assert o.first_diff(got, o.orc_xz_stream(data, prm, bs)) == -1, cap
+            rr, rdec = o.ref_decode(got, len(data) + 16)
+            assert rr == 1 and rdec == data
+            assert len(got) >= len(full)
+    finally:
+        o.orc_set_log_cap(0)
+        monkeypatch.delenv("XZAMD_TEST_LOG_CAP", raising=False)
+    again, _ = gpu_encode(enc, data, opts, bs)
+    assert again == full
+
+
 def test_output_independent_of_batching_and_feeding(enc):
     """The compressed bytes of presets 4-9 are a function of (input, options, block size) only: the same Stream whatever
     the device batch size (one batch, many small batches, the pipelined two-stream path) and however the client feeds

@@ -87,6 +87,8 @@ typedef struct {
 	uint16_t *cb_start;          /* model_slots_pad x u16: the model at the span start (k_model_chain) */
 	uint32_t *cb_carry;          /* 1 = the span continues the model of the span in front of it (k_model_chain) */
 	uint32_t model_slots_pad;    /* probabilities of the model, rounded up to 64 */
+	uint32_t log_cap;            /* 0 = XZAMD_LOG_CAP; tests (XZAMD_TEST_LOG_CAP): fewer logged bits per span and probability, to reach the
+	                                "not merged: the rest of the Block is not carried" fall-back on ordinary data */
 } xzamd_span_args;
 #define XZAMD_ITER_PARTIAL 1u       /* parse only the first XZAMD_PART_LEN bytes of every piece but the seed */
 #define XZAMD_ITER_SNAP 2u          /* every piece but the seed starts from its snapshot (else: the seed's prior + walk + pre-roll) */
@@ -130,7 +132,9 @@ typedef struct xzamd_chunk {
 #define XZAMD_CHUNK_OUT(in_start, cidx) (((((uint64_t)(in_start) + ((in_start) >> 3)) + 15) & ~15ull) + (uint64_t)(cidx) * 32u)
 #define XZAMD_PRIOR_WORDS 1856u     /* u32 each, >= the 1846 non-literal probabilities (a multiple of 64) */
 #define XZAMD_SEED_LEN 65536u       /* two-phase: the first piece of every Block (oracle: ORC_SEED_LEN) */
+#ifndef XZAMD_ENC_MIN_LEN
 #define XZAMD_ENC_MIN_LEN (512u << 10)  /* shortest encode span (but the last of a Block) */
+#endif
 #define XZAMD_WARM 16384u          /* two-phase: bytes in front of the pre-roll walked greedily to train the price model (oracle: ORC_WARM) */
 #define XZAMD_PREROLL 2048u         /* two-phase: bytes in front of a piece that are parsed twice (oracle: ORC_PREROLL) */
 #define XZAMD_SPAN_SLACK 4112u      /* 4096 + 16 bytes of scratch per span slot on top of 9/8 of the input */

@@ -515,6 +515,7 @@ struct RC {
     uint32_t est;       // summed prices of the current chunk's decisions, 1/16 bit
     const uint8_t* ptab;
     uint32_t* log;      // k_model_bounds (rc_emit<.., BND>): the logged bits of the span, XZAMD_LOG_WORDS per probability
+    uint32_t log_cap;   // at most this many per probability (XZAMD_LOG_CAP)
 #ifdef XZAMD_TIMING
     uint64_t tm_run;    // cycles inside rc_run (profiling builds only)
     uint64_t tm_bits;
@@ -969,7 +970,7 @@ __device__ __forceinline__ void rc_emit(RC& rc, uint16_t* probs, plit_t* lit, ui
         if (s.hit && !direct) {
             const uint32_t v = M[idx];
             uint32_t lo = v & 0x7FFu, hi = (v >> 11) & 0x7FFu, nb = v >> 22;
-            if (lo != hi && nb < XZAMD_LOG_CAP) {
+            if (lo != hi && nb < rc.log_cap) {
                 if (bit) atomicOr(rc.log + (uint64_t)idx * XZAMD_LOG_WORDS + (nb >> 5), 1u << (nb & 31u));
                 ++nb;
             }
@@ -2487,7 +2488,7 @@ __device__ __forceinline__ void parse_piece_one(const xzamd_span_args& a, const 
     z.state = 0; z.rep0 = z.rep1 = z.rep2 = z.rep3 = 0;
     RC rc;                                              // never codes: encode_symbol_t<false, .> only adapts the model
     rc.cpos = 0; rc.out = nullptr; rc.reset();
-    rc.ptab = nullptr; rc.est = 0; rc.tok = nullptr; rc.log = nullptr;
+    rc.ptab = nullptr; rc.est = 0; rc.tok = nullptr; rc.log = nullptr; rc.log_cap = 0;
     const GProbs probs{z.gp};
     uint16_t* const no_lds = nullptr;                   // encode_symbol_t<.., PG = true> never touches its LDS argument
 
@@ -2888,6 +2889,7 @@ __global__ __launch_bounds__(64) void k_model_walk(xzamd_span_args a, uint32_t n
     RC rc;
     rc.cpos = 0; rc.out = nullptr; rc.reset();
     rc.log = BND ? a.cb_log + (uint64_t)slot * a.model_slots_pad * XZAMD_LOG_WORDS : nullptr;
+    rc.log_cap = a.log_cap ? a.log_cap : XZAMD_LOG_CAP;
 
     // how the span starts
     uint32_t hflags = 0;
@@ -3092,7 +3094,7 @@ __global__ __launch_bounds__(64) void k_model_walk(xzamd_span_args a, uint32_t n
         for (uint32_t i = lane; i < nprob; i += 64) {
             const uint32_t v = enc_pool[i];
             gb[i] = v;
-            bad = bad || ((v & 0x7FFu) != ((v >> 11) & 0x7FFu) && (v >> 22) >= XZAMD_LOG_CAP);
+            bad = bad || ((v & 0x7FFu) != ((v >> 11) & 0x7FFu) && (v >> 22) >= rc.log_cap);
         }
         if (__builtin_amdgcn_ballot_w64(bad) != 0 || tok_full) hflags |= XZAMD_CB_BAD_END;
         if (lane == 0) a.cb_hdr[slot] = hflags;

@@ -1417,6 +1417,12 @@ int xzamd_encode_device_(xzamd_ctx *c,
 				const unsigned long v = tl ? strtoul(tl, NULL, 10) : 0;
 				a.tok_limit = v >= 1 && v < XZAMD_TOK_PER_BYTE ? (uint32_t)v : 0;
 			}
+			{
+				/* test knob: fewer logged bits per span and probability (never more: the log is what it is) */
+				const char *lc_ = getenv("XZAMD_TEST_LOG_CAP");
+				const unsigned long v = lc_ ? strtoul(lc_, NULL, 10) : 0;
+				a.log_cap = v >= 1 && v < XZAMD_LOG_CAP ? (uint32_t)v : 0;
+			}
 			a.tok = (uint16_t *)c->tok.p;
 			a.chunks = (xzamd_chunk *)c->chunks.p;
 			a.pinfo = (uint32_t *)c->pinfo[par].p;
