@@ -110,7 +110,7 @@ typedef struct {
 	                        (the first 64 KiB of a Block are the seed piece, parsed from the flat model; what it leaves is
 	                        the prior of every other piece) and records (length, distance) / literal symbols; a second
 	                        kernel range-codes them with ONE continuous model per encode span -- state resets only there.
-	                        A Block of estimated coded size `bits` gets max(1, min(size / 512 KiB, bits / enc_span_bits))
+	                        A Block of estimated coded size `bits` gets max(1, min(size / 256 KiB, bits / enc_span_bits))
 	                        encode spans, closed at piece ends.  0: single phase, every span of the plan resets the state */
 	uint32_t bcj2, bcj3; /* second and third filter in front of LZMA2, same values as `bcj`, applied in that order (a chain
 	                        holds at most 4 filters, LZMA2 last: common/filter_common.c:250-334); bcj3 needs bcj2 needs bcj */
@@ -126,7 +126,7 @@ typedef struct {
 #define XZAMD_SPAN_COST_DEFAULT 131072u   /* text: 128 KiB spans */
 #define XZAMD_SPAN_BITS_DEFAULT 400000u
 #ifndef XZAMD_ENC_SPAN_BITS_DEFAULT
-#define XZAMD_ENC_SPAN_BITS_DEFAULT 1600000u   /* about 200 KB of output per encode span */
+#define XZAMD_ENC_SPAN_BITS_DEFAULT 800000u    /* about 100 KB of output per encode span (round 5: 1,600,000) */
 #endif
 #define XZAMD_SPAN_MIN_LEN 65536u         /* shortest cost-balanced span */
 #define XZAMD_BCJ_X86 4u    /* LZMA_FILTER_X86, api/lzma/bcj.h:20 */
@@ -259,7 +259,7 @@ int xzamd_trace_read(xzamd_ctx *ctx, uint32_t *out, uint32_t cap, uint32_t *coun
 #define XZAMD_DEBUG_SPAN_EST 7      /* per 4 KiB chunk: work estimates of every Block, then the bit estimates */
 #define XZAMD_DEBUG_SYM_LEN 9       /* two-phase: u16 per position, valid at symbol starts (0 = literal) */
 #define XZAMD_DEBUG_SYM_DIST 10     /* two-phase: u32 per position (distance / literal bytes) */
-#define XZAMD_DEBUG_ENC_TAB 11      /* two-phase: (first byte, end) per encode-span slot, slots = Block * (block_size / 512 KiB + 1) + j */
+#define XZAMD_DEBUG_ENC_TAB 11      /* two-phase: (first byte, end) per encode-span slot, slots = Block * (block_size / 256 KiB + 1) + j */
 #define XZAMD_DEBUG_ENC_CNT 12      /* encode spans per Block */
 #define XZAMD_DEBUG_PINFO 13        /* two-phase: 16 x u32 per piece slot ([0..7] iteration 1, [8..15] iteration 2: state | ok << 31, rep distances, raw) */
 #define XZAMD_DEBUG_SNAP_SR 14      /* 8 x u32 per piece slot: state and rep distances a piece starts iteration 2 with */

@@ -148,7 +148,7 @@ typedef struct {
 #define ORC_EST_CHUNK 4096u
 #define ORC_SPAN_MAX (1u << 20)    /* longest piece (round 6: 16 MiB let one wavefront walk 16 MiB of a highly compressible Block) */
 #define ORC_SEED_LEN 65536u
-#define ORC_ENC_MIN_LEN (512u << 10)
+#define ORC_ENC_MIN_LEN (256u << 10)
 
 /* The span plan of one Block under p->span_cost: chunk_cost (optional, 2 * ceil(n / ORC_EST_CHUNK) entries: work
  * estimates, then bit estimates) receives the per-chunk estimates, span_start (optional, capacity span_cap) the first byte of every span; returns the

@@ -282,7 +282,7 @@ def test_two_phase_stages_identical_to_oracle(enc, preset, single_phase):
         assert rr == 1 and rdec == mix
         assert st.enc_spans == 0
         return
-    spb, esb = bs // 65536 + 2, bs // (512 << 10) + 1
+    spb, esb = bs // 65536 + 2, bs // (256 << 10) + 1
     tab = enc.debug_fetch(5, 2 * nb * spb).reshape(nb, spb, 2)
     cnt = enc.debug_fetch(6, nb)
     etab = enc.debug_fetch(11, 2 * nb * esb).reshape(nb, esb, 2)
@@ -304,7 +304,7 @@ def test_two_phase_stages_identical_to_oracle(enc, preset, single_phase):
             assert starts[1] == 65536                                   # the seed piece
         assert ecnt[b] == len(estarts) and (etab[b, :ecnt[b], 0] == estarts + b * bs).all(), ("encode spans", b)
         assert set(estarts) <= set(starts)                               # encode spans end at piece ends
-        assert (np.diff(estarts) >= (512 << 10)).all()
+        assert (np.diff(estarts) >= (256 << 10)).all()
         eends = np.append(estarts[1:], len(blk)) + b * bs
         assert (etab[b, :ecnt[b], 1] == eends).all()
         osr, _, oprice, ocarry = o.orc_two_phase_debug(blk, prm, len(starts), len(estarts))
@@ -388,7 +388,7 @@ def test_two_phase_pb_above_two_identical_to_oracle(enc, pb, lc, lp):
         sl, sd = o.orc_parse_dump(blk, prm)
         bad = _walk_symbols(sl, sd, gsl[b * bs:b * bs + len(blk)], gsd[b * bs:b * bs + len(blk)], len(blk))
         assert bad is None, ("symbol records", b, bad)
-    # default spans of the product (work target 131072, 1.6 Mbit encode spans)
+    # default spans of the product (work target 131072, 0.8 Mbit encode spans)
     opts = xz_amd.preset_options(6)
     opts.pb, opts.lc, opts.lp = pb, lc, lp
     got, _ = gpu_encode(enc, mix, opts, bs)
@@ -442,7 +442,7 @@ def test_carry_fallback_identical_to_oracle(enc, monkeypatch):
     opts.enc_span_bits = 400000
     prm = o.params_for_gpu_options(opts)
     full, _ = gpu_encode(enc, data, opts, bs)
-    esb = bs // (512 << 10) + 1
+    esb = bs // (256 << 10) + 1
     assert (enc.debug_fetch(16, 2 * esb).reshape(2, esb)[:, 1:4] == 1).all()          # (carried, with the real cap)
     try:
         for cap in (8, 300):

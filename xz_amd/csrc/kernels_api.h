@@ -133,7 +133,9 @@ typedef struct xzamd_chunk {
 #define XZAMD_PRIOR_WORDS 1856u     /* u32 each, >= the 1846 non-literal probabilities (a multiple of 64) */
 #define XZAMD_SEED_LEN 65536u       /* two-phase: the first piece of every Block (oracle: ORC_SEED_LEN) */
 #ifndef XZAMD_ENC_MIN_LEN
-#define XZAMD_ENC_MIN_LEN (512u << 10)  /* shortest encode span (but the last of a Block) */
+#define XZAMD_ENC_MIN_LEN (256u << 10)  /* shortest encode span (but the last of a Block).  Round 6: 256 KiB (512 before): the spans no longer
+                                         * reset the coder's model, so their length is a matter of parallelism alone -- twice the wavefronts
+                                         * for the coder's walks: 4 GiB on one GPU 559 -> 567 MB/s, one rank's 512 MiB of an 8-GPU run 424 -> 446 */
 #endif
 #define XZAMD_WARM 16384u          /* two-phase: bytes in front of the pre-roll walked greedily to train the price model (oracle: ORC_WARM) */
 #define XZAMD_PREROLL 2048u         /* two-phase: bytes in front of a piece that are parsed twice (oracle: ORC_PREROLL) */

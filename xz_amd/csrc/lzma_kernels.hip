@@ -2395,7 +2395,7 @@ void k_span_encode_t(xzamd_span_args a, uint32_t nspans, uint32_t* __restrict__ 
 //                    greedy warm-up walk + a pre-roll; iteration 2 (XZAMD_ITER_SNAP): every piece in full from the snapshot
 //                    the carried model walk over iteration 1's records left in its slot.  Symbols are recorded per position
 //                    in a coder-independent form: (length, distance) or literal bytes.
-//   k_model_walk     one wavefront per ENCODE SPAN (>= 512 KiB of input): the recorded symbols through the coder's model
+//   k_model_walk     one wavefront per ENCODE SPAN (>= 256 KiB of input): the recorded symbols through the coder's model
 //                    (all of it in LDS), rep / short rep / match chosen from the coder's own rep distances.  <1>, <2>: the
 //                    bounds of every probability whatever the span's start model is; k_model_chain: the true model at every
 //                    span start -- ONE continuous model per Block; <0>: tokens and the LZMA2 chunk table; <3>: snapshots.

@@ -1075,7 +1075,7 @@ double xzamd_work_bytes_per_byte_(const xzamd_lzma_options *opt)
 	if (opt->gpu_parser) per_byte += 32.0 + 2.0 + (list_packed ? 0.0 : 16.0);
 	if (two_) per_byte += 12.0 + 2.0 * XZAMD_TOK_PER_BYTE + 0.3;     /* recorded parse x 2, tokens, piece models in L2 */
 	if (two_) {
-		/* the carried model walk: bounds, logged bits and start model per encode-span slot (>= 512 KiB of input), two sets */
+		/* the carried model walk: bounds, logged bits and start model per encode-span slot (>= 256 KiB of input), two sets */
 		const double mslots = (double)((1846u + (0x300u << (opt->lc + opt->lp)) + 63u) & ~63u);
 		per_byte += 2.0 * (4.0 * XZAMD_LOG_WORDS + 6.0) * mslots / (double)XZAMD_ENC_MIN_LEN;
 	}

@@ -107,6 +107,7 @@ struct lzma_internal_s {
 	uint32_t timeout_ms;
 	enum sseq sseq;
 	uint64_t stage_max;
+	uint64_t test_job_min;       /* XZAMD_TEST_JOB_MIN_MIB << 20 (tests: reach the growing-jobs path on small inputs), 0 = none */
 	/* workers */
 	devslot dev[MAX_DEVS]; int ndev;
 	uint64_t seen_in;             /* input bytes staged since the stream was initialised (sizes the jobs of several GPUs) */
@@ -693,6 +694,10 @@ lzma_ret lzma_stream_encoder_mt(lzma_stream *strm, const lzma_mt *options)
 	if (maxb == 0) maxb = 1;
 	if (maxb * block_size >= (1ull << 31)) maxb = ((1ull << 31) - 1) / block_size;
 	in->stage_max = maxb * block_size;
+	{
+		const char *e = getenv("XZAMD_TEST_JOB_MIN_MIB");
+		in->test_job_min = e && atoi(e) > 0 ? (uint64_t)atoi(e) << 20 : 0;
+	}
 	if (pthread_mutex_init(&in->mu, NULL)) { internal_free(in); return LZMA_MEM_ERROR; }
 	pthread_cond_init(&in->cv_work, NULL);
 	{
@@ -928,10 +933,7 @@ static lzma_ret stream_code(lzma_internal *in, const uint8_t *inb, size_t *in_po
 					 * input (the reference hands a Block to every thread as soon as it is full, stream_encoder_mt.c:599-665). */
 					uint64_t cap = in->seen_in / (uint64_t)in->ndev;
 					uint64_t floor_b = 256ull << 20;
-					{
-						const char *e = getenv("XZAMD_TEST_JOB_MIN_MIB");      /* test knob: reach the growing-jobs path on small inputs */
-						if (e && atoi(e) > 0) floor_b = (uint64_t)atoi(e) << 20;
-					}
+					if (in->test_job_min) floor_b = in->test_job_min;       /* (XZAMD_TEST_JOB_MIN_MIB, read once at init) */
 					if (cap < floor_b) cap = floor_b;
 					cap = (cap / in->block_size) * in->block_size;
 					if (cap < in->block_size) cap = in->block_size;
@@ -961,8 +963,12 @@ static lzma_ret stream_code(lzma_internal *in, const uint8_t *inb, size_t *in_po
 					continue;
 				}
 				if (j->stage_len == j->stage_cap) {
-					/* second growth step goes straight to the full batch: each step is a pinned allocation + copy */
-					uint64_t nc = j->stage_cap ? in->stage_max : in->block_size;
+					/* second growth step goes straight to what this job may hold (job_max: the full batch with one GPU; with
+					 * several, while the jobs still grow with the input, no more than that -- round-5 advisor: 2 x GPUs + 1 slots
+					 * of 1.25 GiB pinned each were 21 GiB at 8 GPUs for jobs of 256 ... 512 MiB); each step is a pinned allocation
+					 * + copy, and a slot whose job_max has risen since grows again */
+					uint64_t nc = j->stage_cap ? job_max : in->block_size;
+					if (nc <= j->stage_cap) nc = in->stage_max;
 					if (nc < (1u << 20)) nc = 1u << 20;
 					if (nc > in->stage_max) nc = in->stage_max;
 					lzma_ret r = grow_pinned(&j->stage, &j->stage_cap, j->stage_len, nc);
