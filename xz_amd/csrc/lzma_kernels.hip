@@ -968,7 +968,9 @@ __device__ __forceinline__ void rc_emit(RC& rc, uint16_t* probs, plit_t* lit, ui
     if constexpr (BND) {
         uint32_t* const M = reinterpret_cast<uint32_t*>(probs);
         if (s.hit && !direct) {
-            const uint32_t v = M[idx];
+            // (LITG: the literal coders' bounds live in the span's slice of cb_bnd in global memory, read and written past L1)
+            const bool glob = LITG && idx >= P_LITERAL;
+            const uint32_t v = glob ? lit_load(reinterpret_cast<const uint32_t*>(lit) + (idx - P_LITERAL)) : M[idx];
             uint32_t lo = v & 0x7FFu, hi = (v >> 11) & 0x7FFu, nb = v >> 22;
             if (lo != hi && nb < rc.log_cap) {
                 if (bit) atomicOr(rc.log + (uint64_t)idx * XZAMD_LOG_WORDS + (nb >> 5), 1u << (nb & 31u));
@@ -976,7 +978,9 @@ __device__ __forceinline__ void rc_emit(RC& rc, uint16_t* probs, plit_t* lit, ui
             }
             lo = bit ? lo - (lo >> 5) : lo + ((2048u - lo) >> 5);
             hi = bit ? hi - (hi >> 5) : hi + ((2048u - hi) >> 5);
-            M[idx] = lo | (hi << 11) | (nb << 22);
+            const uint32_t nv = lo | (hi << 11) | (nb << 22);
+            if (glob) lit_store(reinterpret_cast<uint32_t*>(lit) + (idx - P_LITERAL), nv);
+            else M[idx] = nv;
         }
         rc.tok += total;
         return;
@@ -1964,6 +1968,9 @@ template <int FINDER, bool OPT, uint32_t WMAX>      // FINDER: 0 = exact HC3/HC4
 #ifndef XZAMD_WAVES_FAST
 #define XZAMD_WAVES_FAST 4
 #endif
+#ifndef XZAMD_WALK_LITG_DEFAULT
+#define XZAMD_WALK_LITG_DEFAULT true
+#endif
 #ifndef XZAMD_WAVES_OPT
 #define XZAMD_WAVES_OPT 4
 #endif
@@ -2839,7 +2846,11 @@ __device__ __forceinline__ void symrow_load(const xzamd_span_args& a, uint32_t p
 //   MODE 2  bounds, and MODE 3 snapshots, over the records of parse iteration 1 (only the first XZAMD_PART_LEN bytes of a
 //                             piece have them): the model every piece starts iteration 2 from goes into ITS slot of
 //                             a.prior / a.lit (u32 each), coder state and rep distances into a.snap_sr
-template <int MODE>
+// LITG: the literal coders (6,144 of the 7,990 probabilities at lc = 3) live in global memory -- the span's slice of cb_bnd,
+// u32 each, L2-resident while the span is walked -- and LDS holds the 1,846 others: 7.4 KiB (bounds) / 3.8 KiB per wavefront instead
+// of 32 / 16 KiB, so that a CU holds several times the wavefronts (these walks are bound by the latency of their dependent
+// instructions; the single-phase span kernels made the same trade).
+template <int MODE, bool LITG>
 __global__ __launch_bounds__(64) void k_model_walk(xzamd_span_args a, uint32_t nslots)
 {
     constexpr bool BND = MODE == 1 || MODE == 2, SUB = MODE >= 2, TOKM = MODE == 0;
@@ -2855,8 +2866,12 @@ __global__ __launch_bounds__(64) void k_model_walk(xzamd_span_args a, uint32_t n
     const uint32_t span_start = uni(a.enc_tab[2 * slot]), span_end = uni(a.enc_tab[2 * slot + 1]);
     const uint8_t* __restrict__ in = a.in;
     const uint32_t nprob = P_LITERAL + (0x300u << (a.lc + a.lp));
-    const uint32_t model_words = BND ? nprob : (nprob + 1) / 2;
+    const uint32_t nlds = LITG ? (uint32_t)P_LITERAL : nprob;                  // probabilities held in LDS
+    const uint32_t model_words = BND ? nlds : (nlds + 1) / 2;
     uint8_t* const ptab = reinterpret_cast<uint8_t*>(enc_pool + model_words);
+    // LITG: the literal coders' working array (bounds, or plain probabilities: k_model_chain has read the bounds by then)
+    uint32_t* const litw = a.cb_bnd + (uint64_t)slot * a.model_slots_pad + P_LITERAL;
+    const uint32_t nlit = nprob - P_LITERAL;
     if (!BND) {
         for (uint32_t t = lane; t < 128; t += 64) {         // bit price table (price_tablegen.c:31-58)
             uint32_t wv = t * 16 + 8, bit_count = 0;
@@ -2883,7 +2898,7 @@ __global__ __launch_bounds__(64) void k_model_walk(xzamd_span_args a, uint32_t n
     Lz z;
     z.lc = a.lc; z.lp = a.lp; z.pb = SUB ? min(a.pb, 2u) : a.pb;     // (the snapshots are the PARSER's price model: its pb view)
     z.cnt_len = z.cnt_match = z.cnt_align = 0;
-    z.lit = nullptr;
+    z.lit = LITG ? reinterpret_cast<plit_t*>(litw) : nullptr;
     z.gp = nullptr;
     z.state = 0; z.rep0 = z.rep1 = z.rep2 = z.rep3 = 0;
     RC rc;
@@ -2909,14 +2924,19 @@ __global__ __launch_bounds__(64) void k_model_walk(xzamd_span_args a, uint32_t n
     if (!BND && k != 0) carry = uni(a.cb_carry[slot]);
     if (BND) {
         const uint32_t v0 = known ? (1024u | 1024u << 11) : (31u | 2017u << 11);
-        for (uint32_t i = lane; i < nprob; i += 64) enc_pool[i] = v0;
+        for (uint32_t i = lane; i < nlds; i += 64) enc_pool[i] = v0;
+        if (LITG) for (uint32_t i = lane; i < nlit; i += 64) lit_store(litw + i, v0);
     } else if (k != 0 && carry == 1) {
-        const uint32_t* s32 = reinterpret_cast<const uint32_t*>(a.cb_start + (uint64_t)slot * a.model_slots_pad);
+        const uint16_t* s16 = a.cb_start + (uint64_t)slot * a.model_slots_pad;
+        const uint32_t* s32 = reinterpret_cast<const uint32_t*>(s16);
         for (uint32_t i = lane; i < model_words; i += 64) enc_pool[i] = s32[i];
+        if (LITG) for (uint32_t i = lane; i < nlit; i += 64) lit_store(litw + i, (uint32_t)s16[P_LITERAL + i]);
     } else {
         for (uint32_t i = lane; i < model_words; i += 64) enc_pool[i] = 0x04000400u;
+        if (LITG) for (uint32_t i = lane; i < nlit; i += 64) lit_store(litw + i, 1024u);
         z.state = 0; z.rep0 = z.rep1 = z.rep2 = z.rep3 = 0;
     }
+    if (LITG) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     wave_sync();
 
     uint16_t* const tok0 = TOKM ? a.tok + XZAMD_TOK_BASE(span_start, slot) : nullptr;
@@ -2978,8 +2998,13 @@ __global__ __launch_bounds__(64) void k_model_walk(xzamd_span_args a, uint32_t n
         }
         if (need_state_reset && !(k != 0 && carry == 1 && cur == span_start)) {
             // lzma_lzma_encoder_reset (lzma_encoder.c:529-598); the flag stays set until a chunk header has announced it
-            if (BND) { for (uint32_t i = lane; i < nprob; i += 64) enc_pool[i] = 1024u | 1024u << 11; }
+            if (BND) { for (uint32_t i = lane; i < nlds; i += 64) enc_pool[i] = 1024u | 1024u << 11; }
             else { for (uint32_t i = lane; i < model_words; i += 64) enc_pool[i] = 0x04000400u; }
+            if (LITG) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                for (uint32_t i = lane; i < nlit; i += 64) lit_store(litw + i, BND ? (1024u | 1024u << 11) : 1024u);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
             wave_sync();
             z.state = 0; z.rep0 = z.rep1 = z.rep2 = z.rep3 = 0;
         }
@@ -3010,7 +3035,11 @@ __global__ __launch_bounds__(64) void k_model_walk(xzamd_span_args a, uint32_t n
                 uint32_t* gp = a.prior + ps_ * XZAMD_PRIOR_WORDS;
                 plit_t* gl = reinterpret_cast<plit_t*>(a.lit) + ps_ * (0x300ull << (a.lc + a.lp));
                 for (uint32_t i = lane; i < P_LITERAL; i += 64) gp[i] = probs[i];
-                for (uint32_t i = lane; i < nprob - P_LITERAL; i += 64) gl[i] = (plit_t)probs[P_LITERAL + i];
+                if (LITG) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the literal updates so far
+                    for (uint32_t i = lane; i < nlit; i += 64) gl[i] = (plit_t)lit_load(litw + i);
+                } else
+                    for (uint32_t i = lane; i < nlit; i += 64) gl[i] = (plit_t)probs[P_LITERAL + i];
                 if (lane == 0) {
                     uint32_t* sr = a.snap_sr + ps_ * 8u;
                     sr[0] = z.state;                  // a parser's rep distances must be real ones: unknown -> 0, as after a reset
@@ -3059,7 +3088,7 @@ __global__ __launch_bounds__(64) void k_model_walk(xzamd_span_args a, uint32_t n
                 cur = span_end;
                 break;
             }
-            encode_symbol_t<false, false, TOKM, false, BND>(rc, probs, z, cur - block_start, back, len, l3);
+            encode_symbol_t<false, LITG, TOKM, false, BND>(rc, probs, z, cur - block_start, back, len, l3);
             cur += len;
         }
         if (failed) break;
@@ -3091,9 +3120,10 @@ __global__ __launch_bounds__(64) void k_model_walk(xzamd_span_args a, uint32_t n
         // what k_model_chain needs of the span: the bounds, and whether the span can hand its model on at all
         uint32_t* gb = a.cb_bnd + (uint64_t)slot * a.model_slots_pad;
         bool bad = false;
+        if (LITG) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         for (uint32_t i = lane; i < nprob; i += 64) {
-            const uint32_t v = enc_pool[i];
-            gb[i] = v;
+            const uint32_t v = (LITG && i >= P_LITERAL) ? lit_load(gb + i) : enc_pool[i];
+            if (!(LITG && i >= P_LITERAL)) gb[i] = v;
             bad = bad || ((v & 0x7FFu) != ((v >> 11) & 0x7FFu) && (v >> 22) >= rc.log_cap);
         }
         if (__builtin_amdgcn_ballot_w64(bad) != 0 || tok_full) hflags |= XZAMD_CB_BAD_END;
@@ -4794,6 +4824,18 @@ int xzk_parse_pieces(const xzamd_span_args* a, uint32_t nblocks, int phase, uint
 
 // Two-phase mode, phase 2: the model pass (one wavefront per encode-span slot, the whole model in LDS) and the range
 // coder (one lane per chunk slot).
+// XZAMD_WALK_LITG=0 / 1 (measurement knob): the literal coders of the model walks in LDS / in global memory
+static bool walk_litg()
+{
+    const char* e = getenv("XZAMD_WALK_LITG");
+    return e ? *e == '1' : XZAMD_WALK_LITG_DEFAULT;
+}
+static uint32_t walk_lds(const xzamd_span_args* a)
+{
+    const uint32_t n = walk_litg() ? (uint32_t)P_LITERAL : P_LITERAL + (0x300u << (a->lc + a->lp));
+    return ((((n + 1) / 2) * 4 + 128) + 15) & ~15u;
+}
+
 // the bounds walk and the chain: what every encode span starts from (sub: over the records of parse iteration 1)
 static int carried_starts(const xzamd_span_args* a, uint32_t nblocks, bool sub, hipStream_t st)
 {
@@ -4804,9 +4846,15 @@ static int carried_starts(const xzamd_span_args* a, uint32_t nblocks, bool sub, 
     const uint32_t nprob = P_LITERAL + (0x300u << (a->lc + a->lp));
     hipError_t e = hipMemsetAsync(a->cb_log, 0, (size_t)nslots * a->model_slots_pad * XZAMD_LOG_WORDS * 4, st);
     if (e != hipSuccess) return (int)e;
-    const uint32_t lds = (nprob * 4 + 15) & ~15u;
-    if (sub) hipLaunchKernelGGL(k_model_walk<2>, dim3(nslots), dim3(64), lds, st, *a, nslots);
-    else hipLaunchKernelGGL(k_model_walk<1>, dim3(nslots), dim3(64), lds, st, *a, nslots);
+    const bool litg = walk_litg();
+    const uint32_t lds = ((litg ? (uint32_t)P_LITERAL : nprob) * 4 + 15) & ~15u;
+    if (sub) {
+        if (litg) hipLaunchKernelGGL((k_model_walk<2, true>), dim3(nslots), dim3(64), lds, st, *a, nslots);
+        else hipLaunchKernelGGL((k_model_walk<2, false>), dim3(nslots), dim3(64), lds, st, *a, nslots);
+    } else {
+        if (litg) hipLaunchKernelGGL((k_model_walk<1, true>), dim3(nslots), dim3(64), lds, st, *a, nslots);
+        else hipLaunchKernelGGL((k_model_walk<1, false>), dim3(nslots), dim3(64), lds, st, *a, nslots);
+    }
     hipLaunchKernelGGL(k_model_chain, dim3((a->model_slots_pad + 255) / 256, nblocks), dim3(256), 0, st, *a, nblocks);
     return (int)hipGetLastError();
 }
@@ -4823,8 +4871,9 @@ int xzk_encode_syms(const xzamd_span_args* a, uint32_t nblocks, void* stream_)
     if (r) return r;
     hipError_t e = hipMemsetAsync(a->chunks, 0, (size_t)nch * sizeof(xzamd_chunk), st);
     if (e != hipSuccess) return (int)e;
-    const uint32_t lds = ((((P_LITERAL + (0x300u << (a->lc + a->lp)) + 1) / 2) * 4 + 128) + 15) & ~15u;
-    hipLaunchKernelGGL(k_model_walk<0>, dim3(nslots), dim3(64), lds, st, *a, nslots);
+    const uint32_t lds = walk_lds(a);
+    if (walk_litg()) hipLaunchKernelGGL((k_model_walk<0, true>), dim3(nslots), dim3(64), lds, st, *a, nslots);
+    else hipLaunchKernelGGL((k_model_walk<0, false>), dim3(nslots), dim3(64), lds, st, *a, nslots);
     hipLaunchKernelGGL(k_rc_chunks, dim3((nch + 63) / 64), dim3(64), 0, st, *a, nch);
     return (int)hipGetLastError();
 }
@@ -4838,8 +4887,9 @@ int xzk_model_snapshots(const xzamd_span_args* a, uint32_t nblocks, void* stream
     const uint32_t nslots = nblocks * a->max_esb;
     int r = carried_starts(a, nblocks, true, st);
     if (r) return r;
-    const uint32_t lds = ((((P_LITERAL + (0x300u << (a->lc + a->lp)) + 1) / 2) * 4 + 128) + 15) & ~15u;
-    hipLaunchKernelGGL(k_model_walk<3>, dim3(nslots), dim3(64), lds, st, *a, nslots);
+    const uint32_t lds = walk_lds(a);
+    if (walk_litg()) hipLaunchKernelGGL((k_model_walk<3, true>), dim3(nslots), dim3(64), lds, st, *a, nslots);
+    else hipLaunchKernelGGL((k_model_walk<3, false>), dim3(nslots), dim3(64), lds, st, *a, nslots);
     return (int)hipGetLastError();
 }
 
