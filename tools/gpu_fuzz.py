@@ -33,6 +33,7 @@ for case in range(ncases):
         opts.span_cost = int(rng.choice([20000, 50000, 131072]))
         opts.span_bits = int(rng.choice([0, 100000]))
         opts.enc_span_bits = int(rng.choice([0, 100000, 400000, 1600000]))
+        opts.part_iters = int(rng.choice([0, 0, 2, 3]))         # (round 6: partial parse iterations in front of the full one)
     if rng.random() < 0.2:
         opts.gpu_nice_len = int(rng.integers(max(4, opts.gpu_mf & 15), 274))
     if rng.random() < 0.15:
