@@ -27,6 +27,7 @@ xz_amd.corpus_text(mib << 20, seed=1000).tofile(src)
 def run(path, env_extra, reps):
     best = None
     out_bytes = 0
+    runs = []
     for _ in range(reps):
         env = dict(os.environ, LD_PRELOAD=pre, **env_extra)
         t0 = time.perf_counter()
@@ -35,14 +36,15 @@ def run(path, env_extra, reps):
         if p.returncode != 0:
             return {"error": p.stderr.decode()[-500:]}
         out_bytes = int(p.stdout.split()[0])
+        runs.append(round(dt, 2))
         best = dt if best is None or dt < best else best
     n = os.path.getsize(path)
-    return {"MB/s": round(n / best / 1e6, 1), "seconds": round(best, 2), "in_bytes": n, "out_bytes": out_bytes, "ratio": round(out_bytes / n, 5)}
+    return {"MB/s": round(n / best / 1e6, 1), "seconds": round(best, 2), "in_bytes": n, "out_bytes": out_bytes, "ratio": round(out_bytes / n, 5), "runs_s": runs}
 
 
 res = {"tool": "xz " + subprocess.run([xz, "--version"], capture_output=True, text=True).stdout.split("\n")[0],
        "command": f"LD_PRELOAD=libxz_amd_preload.so xz -T0 -{preset} -c FILE | wc -c", "tmp": tmp,
-       "gpu": run(src, {}, 2)}
+       "gpu": run(src, {}, 3)}
 small = os.path.join(tmp, "xzamd_cli_bench_small.bin")
 with open(src, "rb") as f, open(small, "wb") as g:
     g.write(f.read(cpu_mib << 20))

@@ -317,8 +317,9 @@ static lzma_ret job_launch(lzma_internal *in, devslot *d, job *j, int io, int *r
 		if (!j->binfo) { j->binfo_cap = 0; return LZMA_MEM_ERROR; }
 		j->binfo_cap = nb;
 	}
-	lzma_ret r = grow_pinned(&j->out, &j->out_cap, 0, bound);
-	if (r != LZMA_OK) return r;
+	/* (the pinned output slot is sized in job_collect, when the job's encoded size is known: a pinned allocation costs about a
+	 * second per GiB and holds up every other HIP call of the process meanwhile -- round 6: three slots of the full bound were
+	 * 3.9 GiB, most of it never written) */
 	/* XZAMD_TEST_FAIL_JOB=k (tests): the k-th job behaves as if the device had failed */
 	const char *tf = getenv("XZAMD_TEST_FAIL_JOB");
 	const int injected = tf && *tf && (uint64_t)atoll(tf) == j->seq;
@@ -338,8 +339,13 @@ static lzma_ret job_launch(lzma_internal *in, devslot *d, job *j, int io, int *r
 static lzma_ret job_collect(lzma_internal *in, devslot *d, job *j, int io, int rc, uint64_t out_size)
 {
 	const uint64_t n = j->stage_len;
-	if (rc == XZAMD_OK && out_size > j->out_cap)
-		rc = XZAMD_PROG_ERROR;
+	if (rc == XZAMD_OK && out_size > j->out_cap) {
+		/* the pinned slot the encoded Blocks are downloaded into: what this job needs, in steps of 64 MiB */
+		const uint64_t bound = xzamd_stream_buffer_bound(n, in->block_size);
+		uint64_t want = (out_size + (64ull << 20) - 1) & ~((64ull << 20) - 1);
+		if (want > bound) want = bound;
+		if (grow_pinned(&j->out, &j->out_cap, 0, want) != LZMA_OK) return LZMA_MEM_ERROR;
+	}
 	void *cs = xzamd_ctx_stream_(d->ctx);
 	if (rc == XZAMD_OK && (xzk_d2h(j->out, d->io[io].d_out, out_size, cs) || xzk_sync(cs)))
 		rc = XZAMD_DEVICE_ERROR;
@@ -351,7 +357,7 @@ static lzma_ret job_collect(lzma_internal *in, devslot *d, job *j, int io, int r
 		 * failures (XZAMD_PROG_ERROR) are never papered over this way. */
 		const char *sf = getenv("XZAMD_STORED_ON_DEVICE_ERROR");
 		uint64_t nblocks = 0;
-		if (sf && *sf == '1'
+		if (sf && *sf == '1' && grow_pinned(&j->out, &j->out_cap, 0, xzamd_stream_buffer_bound(n, in->block_size)) == LZMA_OK
 				&& xzamd_stored_blocks_host_(j->stage, n, in->block_size, in->check, j->out, j->out_cap, &out_size,
 						j->binfo, j->binfo_cap, &nblocks) == XZAMD_OK) {
 			if (getenv("XZAMD_VERBOSE"))
