@@ -1665,12 +1665,29 @@ static void record_literal(enc *e, uint32_t pos, int first_of_piece)
  * a.prior / a.lit and a.snap_sr) */
 typedef struct { uint16_t probs[P_TOTAL_MAX]; uint32_t state, reps[4]; } snap;
 
-/* First iteration: only the first part of a piece is parsed (ORC_PART_MIN bytes or an eighth of it, whichever is more) */
+/* First iteration: only the first part of a piece is parsed: an eighth of it (part_end_of), at least ORC_PART_MIN bytes */
 #define ORC_PART_MIN 16384u
-static uint32_t part_len(uint32_t len)
+
+/* Where the first part of the piece [a, pe) ends: behind the chunk at which an eighth of the piece's ESTIMATED WORK (the plan's
+ * per-4-KiB estimates, est_chunk) has been seen, at least ORC_PART_MIN bytes.  By work, not by bytes: the pieces of a plan hold
+ * about equal work, but a piece of mixed density may hold most of it in its first bytes, and the partial iteration is one launch
+ * whose length is its heaviest part (the device, config C5: 667 ms per batch with byte-based parts of a 1,943 ms full parse). */
+static uint32_t part_end_of(const uint32_t *cc, uint32_t a, uint32_t pe)
 {
-	if (len <= ORC_PART_MIN) return len;
-	return (len >> 3) < ORC_PART_MIN ? ORC_PART_MIN : len >> 3;
+	if (pe - a <= ORC_PART_MIN) return pe;
+	const uint32_t c0 = a / ORC_EST_CHUNK, c1 = (pe + ORC_EST_CHUNK - 1) / ORC_EST_CHUNK;
+	uint64_t total = 0, acc = 0;
+	for (uint32_t c = c0; c < c1; ++c) total += cc[c];
+	const uint64_t target = (total + 7) / 8;
+	/* the chunk boundary NEAREST to where the eighth is reached (a part that always ended behind the chunk in which it is
+	 * reached would be half a chunk too long on average: 10 % more work for the usual 16 ... 32 KiB part) */
+	for (uint32_t c = c0; c < c1; ++c) {
+		const uint64_t b64 = (uint64_t)c * ORC_EST_CHUNK;
+		if (acc + cc[c] / 2 >= target && b64 >= (uint64_t)a + ORC_PART_MIN)
+			return (uint32_t)b64;
+		acc += cc[c];
+	}
+	return pe;
 }
 
 /* Parses [start, end) of the piece that starts at `start` (end = the piece end, or the end of its first part in the first
@@ -1854,7 +1871,7 @@ static uint64_t parse_piece(enc *e, uint32_t start, uint32_t end, int first_in_b
  *
  * Two iterations of the parse.  The price model a piece starts from decides which of several self-consistent codings its
  * parser settles into; a model trained on other data than the piece's own neighbourhood costs up to 10 % on image pixels
- * (round-5 review).  So: iteration 1 parses only the first part of every piece (part_len(): an eighth, >= 16 KiB) from the
+ * (round-5 review).  So: iteration 1 parses only the first part of every piece (part_end_of(): an eighth of its estimated work, >= 16 KiB) from the
  * seed's prior + warm-up walk + pre-roll as round 5 did; the carried model walk over THOSE records (a continuous model over a
  * sample of the Block) leaves a snapshot at every piece start; iteration 2 parses every piece in full from its snapshot. */
 #define ORC_REP_UNKNOWN 0xFFFFFFFFu
@@ -1948,9 +1965,8 @@ static uint32_t record_back(enc *e, uint32_t cur, uint32_t *len_out)
 /* The carried model walk over the FIRST iteration's records (only the first part of every piece has them): one continuous
  * model per Block, carried across the encode spans as the coder's is, nothing coded; snaps[j] = model, state and rep
  * distances when the walk reaches piece j (j >= 1).  The price model is the parser's: it runs with the parser's pb. */
-static void snapshot_walk(enc *e, const uint32_t *ps, uint32_t np, const uint32_t *es, uint32_t ne, snap *snaps)
+static void snapshot_walk(enc *e, const uint32_t *ps, uint32_t np, const uint32_t *es, uint32_t ne, const uint32_t *pend, snap *snaps)
 {
-	const uint32_t n = e->n;
 	uint32_t ke = 0;
 	int failed = 0;
 	lzma_state_reset(e);
@@ -1958,13 +1974,13 @@ static void snapshot_walk(enc *e, const uint32_t *ps, uint32_t np, const uint32_
 	e->bnd_on = 1;
 	bnd_reset(e, 1);
 	for (uint32_t j = 0; j < np; ++j) {
-		const uint32_t a = ps[j], pe = j + 1 < np ? ps[j + 1] : n, b = j == 0 ? pe : a + part_len(pe - a);   /* (the seed piece has all its records) */
+		const uint32_t a = ps[j], b = pend[j];            /* (pend[0] = the seed piece's end: it has all its records) */
 		if (ke + 1 < ne && a == es[ke + 1]) {
 			/* a span boundary: can the model be carried into this span? */
 			if (!failed && bnd_failed(e)) failed = 1;
 			++ke;
 			uint32_t st = 0, rp[4] = { 0, 0, 0, 0 };
-			if (!failed && lookback(e, ps[j - 1], j == 1 ? a : ps[j - 1] + part_len(a - ps[j - 1]), &st, rp)) failed = 1;
+			if (!failed && lookback(e, ps[j - 1], pend[j - 1], &st, rp)) failed = 1;
 			if (failed) lzma_state_reset(e);
 			else { e->state = st; memcpy(e->reps, rp, 16); }
 			e->rc_off = 1;
@@ -2000,14 +2016,20 @@ static orc_two_phase_dbg *tp_dbg;
 /* phase 1 of a whole Block: the seed piece; iteration 1 (the first part of every other piece, from the seed's model);
  * the carried model walk over its records; iteration 2 (every piece in full, from its snapshot).  raw[k] = 1: the parser's
  * own price of piece k says it does not shrink -- the coder stores it (encode_block_syms). */
-static int parse_block(enc *e, const uint32_t *piece_start, uint32_t np, const uint32_t *enc_start, uint32_t ne, uint8_t *raw)
+static int parse_block(enc *e, const uint32_t *piece_start, uint32_t np, const uint32_t *enc_start, uint32_t ne, uint8_t *raw,
+		const uint32_t *chunk_work)
 {
 	const uint32_t n = e->n;
 	e->sy_len = (uint16_t *)calloc((size_t)n + 1, 2);
 	e->sy_dist = (uint32_t *)calloc((size_t)n + 1, 4);
 	uint16_t *prior = (uint16_t *)malloc(sizeof(e->probs));
 	snap *snaps = (snap *)malloc(sizeof(snap) * (np ? np : 1));
-	if (!e->sy_len || !e->sy_dist || !prior || !snaps) { free(prior); free(snaps); return -3; }
+	uint32_t *pend = (uint32_t *)malloc(4 * (size_t)(np ? np : 1));
+	if (!e->sy_len || !e->sy_dist || !prior || !snaps || !pend) { free(prior); free(snaps); free(pend); return -3; }
+	for (uint32_t k = 0; k < np; ++k) {
+		const uint32_t a = piece_start[k], pe = k + 1 < np ? piece_start[k + 1] : n;
+		pend[k] = k == 0 ? pe : part_end_of(chunk_work, a, pe);
+	}
 	orc_trace *const tr = e->trace;
 	/* pb = 3, 4 (lzma/lzma_common.h:32-37): the price model of the parse pieces is the parser's alone -- the coder runs
 	 * its own continuous model with the real pb (encode_block_syms) -- and takes a pb = 2 view of the positions: the device
@@ -2017,21 +2039,20 @@ static int parse_block(enc *e, const uint32_t *piece_start, uint32_t np, const u
 	uint64_t price0 = 0;
 	e->trace = NULL;                /* the trace is the second iteration's (and the seed piece's) */
 	for (uint32_t k = 0; k < np; ++k) {
-		const uint32_t a = piece_start[k], pe = k + 1 < np ? piece_start[k + 1] : n;
+		const uint32_t a = piece_start[k];
 		if (k == 0) e->trace = tr;
-		const uint64_t pr = parse_piece(e, a, k == 0 ? pe : a + part_len(pe - a), k == 0, k == 0 ? NULL : prior, NULL);
+		const uint64_t pr = parse_piece(e, a, pend[k], k == 0, k == 0 ? NULL : prior, NULL);
 		if (k == 0) { memcpy(prior, e->probs, sizeof(e->probs)); price0 = pr; e->trace = NULL; }
 	}
-	snapshot_walk(e, piece_start, np, enc_start, ne, snaps);
+	snapshot_walk(e, piece_start, np, enc_start, ne, pend, snaps);
 	/* further partial iterations (part_iters > 1): the first part of every piece again, from the snapshots; what a piece
 	 * learns there reaches every later piece through the carried walk -- a Block walks out of the regime its first 64 KiB
 	 * suggest a few pieces further with every iteration */
 	for (uint32_t it = 1; it < (e->prm.part_iters ? e->prm.part_iters : 1u); ++it) {
 		for (uint32_t k = 1; k < np; ++k) {
-			const uint32_t a = piece_start[k], pe = k + 1 < np ? piece_start[k + 1] : n;
-			parse_piece(e, a, a + part_len(pe - a), 0, NULL, &snaps[k]);
+			parse_piece(e, piece_start[k], pend[k], 0, NULL, &snaps[k]);
 		}
-		snapshot_walk(e, piece_start, np, enc_start, ne, snaps);
+		snapshot_walk(e, piece_start, np, enc_start, ne, pend, snaps);
 	}
 	if (tp_dbg && tp_dbg->snap_sr)
 		for (uint32_t k = 1; k < np; ++k) {
@@ -2050,6 +2071,7 @@ static int parse_block(enc *e, const uint32_t *piece_start, uint32_t np, const u
 	e->trace = tr;
 	free(prior);
 	free(snaps);
+	free(pend);
 	return 0;
 }
 
@@ -2299,9 +2321,11 @@ static int encode_block_impl(const uint8_t *in, uint32_t n, const orc_enc_params
 	if (p->enc_bits && p->span_cost && p->sa_window && p->parser == 1) {
 		const uint32_t scap = n / 4096 + 2;
 		uint32_t *ss = (uint32_t *)malloc((size_t)scap * 8), *es = ss + scap, ne = 0;
-		const uint32_t np = plan_spans_ex(e, NULL, ss, scap, es, scap, &ne);
+		uint32_t *cost = (uint32_t *)malloc(((size_t)n / ORC_EST_CHUNK + 2) * 8);
+		const uint32_t np = plan_spans_ex(e, cost, ss, scap, es, scap, &ne);
 		uint8_t *raw = (uint8_t *)calloc(np + 1, 1);
-		r = raw ? parse_block(e, ss, np, es, ne, raw) : -3;
+		r = raw && cost ? parse_block(e, ss, np, es, ne, raw, cost) : -3;
+		free(cost);
 		if (!r && sym_len && sym_dist) {
 			memcpy(sym_len, e->sy_len, (size_t)n * 2);
 			memcpy(sym_dist, e->sy_dist, (size_t)n * 4);
@@ -2401,8 +2425,10 @@ int orc_parse_dump(const uint8_t *in, uint32_t n, const orc_enc_params *p, uint1
 	if (!e) return -3;
 	const uint32_t scap = n / 4096 + 2;
 	uint32_t *ss = (uint32_t *)malloc((size_t)scap * 8), *es = ss + scap, ne = 0;
-	const uint32_t np = plan_spans_ex(e, NULL, ss, scap, es, scap, &ne);
-	const int r = parse_block(e, ss, np, es, ne, NULL);
+	uint32_t *cost = (uint32_t *)malloc(((size_t)n / ORC_EST_CHUNK + 2) * 8);
+	const uint32_t np = plan_spans_ex(e, cost, ss, scap, es, scap, &ne);
+	const int r = parse_block(e, ss, np, es, ne, NULL, cost);
+	free(cost);
 	if (!r) {
 		memcpy(sym_len, e->sy_len, (size_t)n * 2);
 		memcpy(sym_dist, e->sy_dist, (size_t)n * 4);

@@ -70,7 +70,7 @@ typedef struct {
 	uint32_t tok_limit;          /* 0 = XZAMD_TOK_PER_BYTE; tests (XZAMD_TEST_TOK_PER_BYTE): a smaller token budget per input byte,
 	                                to reach the "out of tokens: the rest of the span goes out raw" path on ordinary data */
 	/* Round 6 (oracle: "carried encode spans"): two parse iterations and a coder model that is carried from encode span to
-	 * encode span.  A partial iteration parses only the first part (XZAMD_PART_LEN) of every piece but the seed -- the first from
+	 * encode span.  A partial iteration parses only the first part (part_tab) of every piece but the seed -- the first from
 	 * the prior + walk + pre-roll, later ones and the final, full iteration from the snapshot the carried model walk over the
 	 * records of the iteration before left in the piece's slot of prior / lit (state and rep distances: snap_sr). */
 	uint32_t iter;               /* XZAMD_ITER_* */
@@ -79,6 +79,8 @@ typedef struct {
 	                                XZAMD_PI_STATE_OK (the twelve candidate states agree), [1..4] the coder's rep distances there
 	                                (XZAMD_REP_UNKNOWN: not named by the piece), [5] 1 = the parser's price of the piece says it does not
 	                                shrink: stored raw (full parses only) */
+	uint32_t *part_tab;          /* per piece slot: where its first part ends (xzk_span_plan: an eighth of the piece's estimated work, at least
+	                                XZAMD_PART_MIN bytes; the seed piece: its end) -- what a partial iteration parses */
 	uint32_t *snap_sr;           /* 8 x u32 per piece slot: [0] state, [1..4] rep distances a piece of iter 2 starts with */
 	/* the carried model walk (k_model_bounds / k_model_chain / k_model_syms), per encode-span slot */
 	uint32_t *cb_bnd;            /* model_slots_pad x u32: lo | hi << 11 | logged bits << 22 of every probability over the span */
@@ -90,13 +92,12 @@ typedef struct {
 	uint32_t log_cap;            /* 0 = XZAMD_LOG_CAP; tests (XZAMD_TEST_LOG_CAP): fewer logged bits per span and probability, to reach the
 	                                "not merged: the rest of the Block is not carried" fall-back on ordinary data */
 } xzamd_span_args;
-#define XZAMD_ITER_PARTIAL 1u       /* parse only the first XZAMD_PART_LEN bytes of every piece but the seed */
+#define XZAMD_ITER_PARTIAL 1u       /* parse only the first part (part_tab) of every piece but the seed */
 #define XZAMD_ITER_SNAP 2u          /* every piece but the seed starts from its snapshot (else: the seed's prior + walk + pre-roll) */
 #define XZAMD_PINFO_WORDS 16u
 #define XZAMD_PI_STATE_OK 0x80000000u
 #define XZAMD_REP_UNKNOWN 0xFFFFFFFFu
-#define XZAMD_PART_MIN 16384u       /* iter 1 parses the first max(XZAMD_PART_MIN, length / 8) bytes of a piece (oracle: part_len) */
-#define XZAMD_PART_LEN(len) ((len) <= XZAMD_PART_MIN ? (len) : ((len) >> 3) < XZAMD_PART_MIN ? XZAMD_PART_MIN : (len) >> 3)
+#define XZAMD_PART_MIN 16384u       /* shortest first part of a piece (oracle: ORC_PART_MIN) */
 #define XZAMD_LOG_WORDS 32u         /* 1023 logged bits per span and probability (oracle: ORC_LOG_CAP) */
 #define XZAMD_LOG_CAP 1023u
 #define XZAMD_CB_BAD_END 1u         /* a probability has not merged within XZAMD_LOG_CAP logged bits, or the span ran out of tokens */

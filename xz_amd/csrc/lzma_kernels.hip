@@ -2440,7 +2440,7 @@ __device__ __forceinline__ void parse_piece_one(const xzamd_span_args& a, const 
         span_start = uni(a.span_tab[2 * span]); span_end = uni(a.span_tab[2 * span + 1]);
         piece_end = span_end;
         // a partial iteration parses only the first part of the piece (oracle: part_len); symbols never cross its end
-        if (a.iter & XZAMD_ITER_PARTIAL) span_end = span_start + XZAMD_PART_LEN(span_end - span_start);
+        if (a.iter & XZAMD_ITER_PARTIAL) span_end = uni(a.part_tab[span]);
     }
     // from the snapshot: the price model, coder state and rep distances come from the carried model walk over the records of
     // the partial iteration before (k_model_walk<3>: this piece's slot of a.prior / a.lit, a.snap_sr) -- no prior, no walk, no pre-roll
@@ -2843,7 +2843,7 @@ __device__ __forceinline__ void symrow_load(const xzamd_span_args& a, uint32_t p
 //   MODE 1  k_model_bounds    the same walk with two values per probability, lo (from 31) and hi (from 2017): whatever the
 //                             start model is, the true value stays between them (the update is monotone); until they meet the
 //                             slot's bits are logged for k_model_chain
-//   MODE 2  bounds, and MODE 3 snapshots, over the records of parse iteration 1 (only the first XZAMD_PART_LEN bytes of a
+//   MODE 2  bounds, and MODE 3 snapshots, over the records of parse iteration 1 (only the first part of a piece, a.part_tab, of a
 //                             piece have them): the model every piece starts iteration 2 from goes into ITS slot of
 //                             a.prior / a.lit (u32 each), coder state and rep distances into a.snap_sr
 // LITG: the literal coders (6,144 of the 7,990 probabilities at lc = 3) live in global memory -- the span's slice of cb_bnd,
@@ -2956,7 +2956,8 @@ __global__ __launch_bounds__(64) void k_model_walk(xzamd_span_args a, uint32_t n
     uint32_t f_pos = 0, f_back = 0, f_len = 0, f_d = 0;
     uint32_t cur = span_start;
     uint32_t p_end = uni(ptb[2 * pj + 1]);                           // end of the piece that holds cur
-    uint32_t seg_end = SUB && pj != 0 ? span_start + XZAMD_PART_LEN(p_end - span_start) : p_end;   // end of what is walked of it (the seed piece has all its records)
+    const uint32_t* __restrict__ ptp = a.part_tab + (uint64_t)blk * a.max_spb;           // SUB: where the parsed part of a piece ends
+    uint32_t seg_end = SUB ? uni(ptp[pj]) : p_end;   // end of what is walked of it (the seed piece has all its records)
     uint32_t raw_until = (!SUB && uni(pinfo[(uint64_t)pj * XZAMD_PINFO_WORDS + 5])) ? p_end : span_start;
     bool fresh_piece = true;                                          // cur is a piece start that has not been looked at
     SymRow R;
@@ -3025,7 +3026,7 @@ __global__ __launch_bounds__(64) void k_model_walk(xzamd_span_args a, uint32_t n
                 if (cur >= span_end) break;
                 ++pj;
                 p_end = uni(ptb[2 * pj + 1]);
-                seg_end = SUB ? cur + XZAMD_PART_LEN(p_end - cur) : p_end;
+                seg_end = SUB ? uni(ptp[pj]) : p_end;
                 fresh_piece = true;
                 if (!SUB && uni(pinfo[(uint64_t)pj * XZAMD_PINFO_WORDS + 5])) { raw_until = p_end; piece_break = true; break; }
             }
@@ -3775,6 +3776,33 @@ __global__ __launch_bounds__(64) void k_span_cut(xzamd_span_args a, uint32_t nbl
         span_key[(uint64_t)b * a.max_spb + ns - 1] = ~(uint32_t)min(carry_w ? carry_w : 1ull, 0xFFFFFFFEull);
         if (two) { etab[2 * ne - 1] = be; enc_cnt[b] = ne; }
     }
+}
+
+// Where the first part of every piece ends (oracle: part_end_of): behind the 4 KiB chunk at which an eighth of the piece's
+// estimated work has been seen, at least XZAMD_PART_MIN bytes; the seed piece's part is the whole of it.  One thread per piece slot.
+__global__ __launch_bounds__(256) void k_part_ends(xzamd_span_args a, uint32_t nblocks, uint32_t cpb, const uint32_t* __restrict__ est,
+        uint32_t* __restrict__ part_tab)
+{
+    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= nblocks * a.max_spb) return;
+    const uint32_t blk = slot / a.max_spb, k = slot - blk * a.max_spb;
+    if (k >= a.span_cnt[blk]) return;
+    const uint32_t bs = blk * a.block_size;
+    const uint32_t s0 = a.span_tab[2 * slot], pe = a.span_tab[2 * slot + 1];
+    uint32_t end = pe;
+    if (k != 0 && pe - s0 > XZAMD_PART_MIN) {
+        const uint32_t* wk = est + (uint64_t)blk * cpb;
+        const uint32_t c0 = (s0 - bs) / XZAMD_EST_CHUNK, c1 = (pe - bs + XZAMD_EST_CHUNK - 1) / XZAMD_EST_CHUNK;
+        unsigned long long total = 0, acc = 0;
+        for (uint32_t c = c0; c < c1; ++c) total += wk[c];
+        const unsigned long long target = (total + 7) / 8;
+        for (uint32_t c = c0; c < c1; ++c) {             // the chunk boundary nearest to where the eighth is reached
+            const uint64_t b64 = (uint64_t)bs + (uint64_t)c * XZAMD_EST_CHUNK;
+            if (acc + wk[c] / 2 >= target && b64 >= (uint64_t)s0 + XZAMD_PART_MIN) { end = (uint32_t)b64; break; }
+            acc += wk[c];
+        }
+    }
+    part_tab[slot] = end;
 }
 
 // Exact HC3/HC4 finder in list form (optimal parser over the reference's match finder; test
@@ -4766,6 +4794,11 @@ int xzk_span_plan(const xzamd_span_args* a, uint32_t nblocks, uint32_t* est, uns
     hipLaunchKernelGGL(k_span_est, dim3((uint32_t)((nch + 255) / 256)), dim3(256), 0, st, *a, nblocks, cpb, est, totals);
     hipLaunchKernelGGL(k_span_cut, dim3(nblocks), dim3(64), 0, st, *a, nblocks, cpb, est, totals, span_tab, span_cnt,
             cost_min, bits_min, min_len, enc_tab, enc_cnt, key_a);
+    if (a->part_tab) {
+        xzamd_span_args a2 = *a;
+        a2.span_tab = span_tab; a2.span_cnt = span_cnt;
+        hipLaunchKernelGGL(k_part_ends, dim3((nslots + 255) / 256), dim3(256), 0, st, a2, nblocks, cpb, est, a->part_tab);
+    }
     // launch order: span slots by estimated work, heaviest first (a launch then ends with its short spans instead of
     // waiting for a heavy one that happened to start late); the order does not change a byte of the output
     hipLaunchKernelGGL(k_iota, dim3(grid_for(nslots, 256, 4096)), dim3(256), 0, st, val_a, nslots);

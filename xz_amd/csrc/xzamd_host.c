@@ -428,7 +428,7 @@ struct xzamd_ctx {
 	dbuf keys_a, keys_b, vals_a, vals_b, rank, sorted_pos, prev2, prev3, prev4, prev8, prev16, prev24, prev32, key64_a, key64_b, sa, sa_rank, sort_tmp;
 	dbuf scratch, span_bytes, strip_crc, block_crc, segs, lits, trace, errw, errw2, litp, mlen, mdist, bcj[2], bcjt;
 	dbuf est, totals, span_tab[2], span_cnt[2], mtop, order;       /* span plan (kernels_api.h); the piece table per pipeline parity: the coder's walk reads it */
-	dbuf pinfo[2], snap_sr;                                        /* per piece: what its parser leaves for the coder's walk; what a piece of iteration 2 starts with */
+	dbuf pinfo[2], snap_sr, part_tab;                                        /* per piece: what its parser leaves for the coder's walk; what a piece of iteration 2 starts with */
 	dbuf cb_bnd[2], cb_log[2], cb_hdr[2], cb_start[2], cb_carry[2]; /* carried model walk: [0] over iteration 1's records (front end), [1] the coder's (back end) */
 	dbuf sym_len[2], sym_dist[2], prior, enc_tab[2], enc_cnt[2];   /* two-phase mode ([2]: one set per pipeline parity) */
 	dbuf tok, chunks, h_chunks;                                    /* coder of the two-phase mode: tokens, chunk table */
@@ -553,7 +553,7 @@ static void ctx_device_bufs(xzamd_ctx *c, dbuf **d, size_t *nd)
 		&c->chunks,
 		&c->span_bytes, &c->strip_crc, &c->block_crc, &c->segs, &c->lits, &c->trace, &c->errw, &c->errw2,
 		&c->totals, &c->span_tab[0], &c->span_tab[1], &c->span_cnt[0], &c->span_cnt[1], &c->prior, &c->enc_tab[0], &c->enc_tab[1], &c->enc_cnt[0], &c->enc_cnt[1],
-		&c->pinfo[0], &c->pinfo[1], &c->snap_sr, &c->cb_bnd[0], &c->cb_bnd[1], &c->cb_hdr[0], &c->cb_hdr[1], &c->cb_start[0], &c->cb_start[1],
+		&c->pinfo[0], &c->pinfo[1], &c->snap_sr, &c->part_tab, &c->cb_bnd[0], &c->cb_bnd[1], &c->cb_hdr[0], &c->cb_hdr[1], &c->cb_start[0], &c->cb_start[1],
 		&c->cb_carry[0], &c->cb_carry[1] };
 	_Static_assert(sizeof(all) / sizeof(all[0]) <= CTX_NBUF_MAX, "ctx_device_bufs: raise CTX_NBUF_MAX");
 	*nd = sizeof(all) / sizeof(all[0]);
@@ -1290,6 +1290,7 @@ int xzamd_encode_device_(xzamd_ctx *c,
 			GROW(tok, 2ull * ((uint64_t)n * XZAMD_TOK_PER_BYTE + 4096ull * nenc + 64), 0);
 			GROW(pinfo[par], 4ull * XZAMD_PINFO_WORDS * nspans, 0);
 			GROW(snap_sr, 32ull * nspans, 0);
+			GROW(part_tab, 4ull * nspans + 16, 0);
 			for (int f = 0; f < 2; ++f) {
 				GROW(cb_bnd[f], 4ull * mslots * nenc, 0);
 				GROW(cb_log[f], 4ull * XZAMD_LOG_WORDS * mslots * nenc, 0);
@@ -1427,6 +1428,7 @@ int xzamd_encode_device_(xzamd_ctx *c,
 			a.chunks = (xzamd_chunk *)c->chunks.p;
 			a.pinfo = (uint32_t *)c->pinfo[par].p;
 			a.snap_sr = (uint32_t *)c->snap_sr.p;
+			a.part_tab = (uint32_t *)c->part_tab.p;
 			a.model_slots_pad = mslots;
 			/* (the front end's set of the carried-walk buffers; the back end switches to its own below) */
 			a.cb_bnd = (uint32_t *)c->cb_bnd[0].p; a.cb_log = (uint32_t *)c->cb_log[0].p; a.cb_hdr = (uint32_t *)c->cb_hdr[0].p;
