@@ -102,22 +102,24 @@ typedef struct {
 	                        fills the GPU: 0.8 .. 2 x span_cost, chosen so that the rounds of the launch are full; the target
 	                        used is reported in xzamd_stats.span_cost_used).  0: spans of span_size bytes */
 	uint32_t span_bits;  /* with span_cost: a Block whose estimated coded size is `bits` (greedy parse over the match lists)
-	                        gets at most bits / span_bits spans: a state reset costs a few hundred bytes whatever the data,
-	                        so what bounds the number of resets is the Block's OUTPUT (highly compressible Blocks: fewer,
-	                        longer spans) */
+	                        gets at most bits / span_bits spans (no span longer than 1 MiB): a piece start costs output bytes
+	                        whatever the data, so what bounds their number is the Block's OUTPUT (highly compressible Blocks:
+	                        fewer, longer spans) */
 	uint32_t enc_span_bits; /* != 0 with cost-balanced spans: TWO-PHASE encode.  The spans of the plan are
 	                        parse PIECES: the optimal parser runs over each with an adaptive price model that codes nothing
 	                        (the first 64 KiB of a Block are the seed piece, parsed from the flat model; what it leaves is
-	                        the prior of every other piece) and records (length, distance) / literal symbols; a second
-	                        kernel range-codes them with ONE continuous model per encode span -- state resets only there.
+	                        the prior of the partial iteration; the full one starts every piece from a snapshot, part_iters) and
+	                        records (length, distance) / literal symbols; the coder then walks them per ENCODE SPAN, in parallel,
+	                        with ONE continuous model per Block (the model is carried from span to span exactly; a
+	                        state reset only at the Block start, behind a stored piece, or where the carry falls back).
 	                        A Block of estimated coded size `bits` gets max(1, min(size / 256 KiB, bits / enc_span_bits))
 	                        encode spans, closed at piece ends.  0: single phase, every span of the plan resets the state */
 	uint32_t bcj2, bcj3; /* second and third filter in front of LZMA2, same values as `bcj`, applied in that order (a chain
 	                        holds at most 4 filters, LZMA2 last: common/filter_common.c:250-334); bcj3 needs bcj2 needs bcj */
 	uint32_t part_iters; /* two-phase: PARTIAL parse iterations in front of the full one (0 = XZAMD_PART_ITERS_DEFAULT, at most 8).
-	                        Each parses the first eighth (>= 16 KiB) of every piece -- the first from the seed's prior, the others
+	                        Each parses the first eighth (of its estimated work; >= 16 KiB) of every piece -- the first from the seed's prior, the others
 	                        from the snapshots of the walk before -- and the carried model walk over its records leaves every
-	                        piece the price model the next iteration starts from (DESIGN.md 3.4).  One costs about 15 % of the
+	                        piece the price model the next iteration starts from (DESIGN.md 3.4b).  One costs about 15 % of the
 	                        parse; more of them walk record tables out of the regime the Block's first 64 KiB suggest */
 } xzamd_lzma_options;
 #define XZAMD_PART_ITERS_DEFAULT 1u
