@@ -303,6 +303,32 @@ def extra_configs():
     return out
 
 
+def ref_size_child(size_mib, preset, block_size, threads):
+    """Child of the default run (`--ref-size-child`): the reference MT encoder over the WHOLE headline input (the same
+    seeded corpus) on `threads` host threads at low priority, while the parent's other child runs keep the GPU busy;
+    prints {"ref_bytes", "seconds", "threads"}.  No GPU, no torch."""
+    import ctypes as C
+    import numpy as np
+    import _oracle as o
+    try:
+        os.nice(19)
+    except OSError:
+        pass
+    n = size_mib << 20
+    host = xz_amd.corpus_text(n, seed=1000)
+    cap = n // 2 + (64 << 20)
+    out = np.empty(cap, dtype=np.uint8)
+    got = C.c_size_t(0)
+    f = o.ref().ref_encode_mt
+    f.restype = C.c_int
+    f.argtypes = [C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint64, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    t0 = time.perf_counter()
+    r = f(host.ctypes.data, n, preset, threads, block_size, 4, out.ctypes.data, cap, C.byref(got))
+    print(json.dumps({"rc": int(r), "ref_bytes": int(got.value), "seconds": round(time.perf_counter() - t0, 1), "threads": threads,
+                      "in_bytes": n}), flush=True)
+    return 0 if r == 1 else 1
+
+
 def relaunch_under_torchrun(args_list, n):
     """`python bench.py --gpus N` with N > 1: spawn the N ranks ourselves (one process per GPU, RCCL)."""
     import socket
@@ -349,12 +375,18 @@ def main():
                     help="Blocks of the input the ratio is measured on against the reference encoder (0 = about 1 GiB for the "
                          "headline workload, 4 Blocks otherwise)")
     ap.add_argument("--stream-sha", action="store_true", help="sha256 of the complete .xz Stream of the last step in the line")
+    ap.add_argument("--ref-size-child", type=int, default=0, metavar="THREADS",
+                    help="(internal) only run the reference encoder over the whole text corpus of --size-mib on THREADS host threads and print its size")
     ap.add_argument("--corpus", choices=["text", "elf", "tar"], default="text",
                     help="text: seeded synthetic enwik-style text (the headline workload); elf: the x86-64 shared "
                          "objects present on the box, concatenated and cycled (config C5's input); tar: ustar stream "
                          "of the box's source trees, cycled with a per-cycle perturbation (config C4's input)")
     args = ap.parse_args()
 
+    if args.ref_size_child:
+        o_ = xz_amd.preset_options(args.preset)
+        sys.exit(ref_size_child(args.size_mib, args.preset, (args.block_mib << 20) if args.block_mib else xz_amd.mt_block_size(o_),
+                                args.ref_size_child))
     if args.gpus > 1 and "RANK" not in os.environ:
         sys.exit(relaunch_under_torchrun(sys.argv[1:], args.gpus))
     rank = int(os.environ.get("RANK", "0"))
@@ -623,7 +655,38 @@ def main():
                     xz_amd.lib().xzamd_release_parked()
                 except Exception:  # noqa: BLE001
                     pass
+                # the ratio on the WHOLE job, not on a sample: the reference encodes all 4 GiB on the host cores (low priority,
+                # three CPUs left to the children) underneath the child runs of `configs`, which keep the GPU busy meanwhile
+                ref_child = None
+                try:
+                    import subprocess
+                    if o.have_ref():
+                        lim_ = cpu_limits()
+                        ncpu = int(min(lim_.get("sched_getaffinity") or 16, lim_.get("cgroup_quota_cpus") or 1e9, os.cpu_count() or 16))
+                        ref_child = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--ref-size-child", str(max(1, ncpu - 3)),
+                                                      "--size-mib", str(args.size_mib), "--preset", str(args.preset)],
+                                                     stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+                except Exception:  # noqa: BLE001
+                    ref_child = None
                 res["configs"] = extra_configs()
+                if ref_child is not None:
+                    try:
+                        so, _ = ref_child.communicate(timeout=900)
+                        d_ = json.loads([l for l in so.splitlines() if l.startswith("{")][-1])
+                        if d_.get("rc") == 1 and d_.get("in_bytes") == n:
+                            res["ratio"]["whole_job"] = {
+                                "ours_bytes": local_out_bytes, "reference_bytes": d_["ref_bytes"],
+                                "ours": round(local_out_bytes / n, 5), "reference": round(d_["ref_bytes"] / n, 5),
+                                "size_vs_reference_pct": round(100.0 * (local_out_bytes / d_["ref_bytes"] - 1), 2),
+                                "what": (f"the complete .xz Stream of the timed job against liblzma 5.8.3 lzma_stream_encoder_mt (preset "
+                                         f"{args.preset & 31}, same Block size) over the same {n >> 20} MiB, {d_['threads']} host threads at nice 19, "
+                                         f"{d_['seconds']} s, run underneath the child runs of `configs`")}
+                    except Exception as e:  # noqa: BLE001
+                        res["ratio"]["whole_job"] = {"error": str(e)}
+                        try:
+                            ref_child.kill()
+                        except Exception:  # noqa: BLE001
+                            pass
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()

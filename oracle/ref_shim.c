@@ -45,6 +45,17 @@ int ref_encode_mt(const uint8_t *in, size_t in_size, uint32_t preset,
 	return (int)r;
 }
 
+/* The reference's one-shot API (common/easy_buffer_encoder.c:16-27 -> stream_buffer_encoder.c:43-141): ONE Block
+ * whatever the input size.  Returns lzma_ret (0 = LZMA_OK). */
+int ref_easy_buffer_encode(const uint8_t *in, size_t in_size, uint32_t preset, int check,
+		uint8_t *out, size_t out_cap, size_t *out_size)
+{
+	size_t pos = 0;
+	lzma_ret r = lzma_easy_buffer_encode(preset, (lzma_check)check, NULL, in, in_size, out, &pos, out_cap);
+	*out_size = pos;
+	return (int)r;
+}
+
 /* Same, but with an explicit LZMA2 option set (filters[] = {LZMA2}). */
 int ref_encode_mt_opts(const uint8_t *in, size_t in_size,
 		uint32_t dict_size, uint32_t lc, uint32_t lp, uint32_t pb,

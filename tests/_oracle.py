@@ -231,6 +231,20 @@ def ref_encode_mt(data, preset, threads=1, block_size=0, check=4):
     return out[: n.value].tobytes()
 
 
+def ref_easy_buffer_encode(data, preset, check=4):
+    """The reference's one-shot lzma_easy_buffer_encode: one Block whatever the size."""
+    data = as_u8(data)
+    cap = len(data) + len(data) // 4 + 65536
+    out = np.empty(cap, dtype=np.uint8)
+    n = C.c_size_t(0)
+    f = ref().ref_easy_buffer_encode
+    f.restype = C.c_int
+    f.argtypes = [C.c_void_p, C.c_size_t, C.c_uint32, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    r = f(_ptr(data), len(data), preset, check, _ptr(out), cap, C.byref(n))
+    assert r == 0, r
+    return out[: n.value].tobytes()
+
+
 def ref_encode_mt_x86(data, preset, threads=1, block_size=0, check=4):
     """Reference MT encoder with the chain {x86 BCJ, LZMA2(preset)}."""
     data = as_u8(data)

@@ -286,6 +286,23 @@ int main(int argc, char **argv)
 		unsetenv("XZAMD_TEST_FAIL_JOB");
 		free(alt);
 	}
+	/* 10. the one-shot API writes ONE Block whatever the input size, like the reference (stream_buffer_encoder.c:91-101):
+	 * 5 MiB at preset 1, whose default Block size is 3 MiB.  11: when the device cannot hold such a Block (here: an
+	 * allocation limit) the MT layout is written instead */
+	{
+		unsetenv("XZAMD_BATCH_MIB");
+		size_t pos = 0;
+		CHECK(lzma_easy_buffer_encode(1, LZMA_CHECK_CRC64, NULL, in, n1, out, &pos, n1 + (n1 >> 2) + (1u << 20)) == LZMA_OK);
+		save(dir, "case10.in", in, n1);
+		save(dir, "case10.xz", out, pos);
+		xzamd_release_parked();
+		setenv("XZAMD_TEST_ALLOC_LIMIT_MIB", getenv("DRIVER_ALLOC_LIMIT_MIB") ? getenv("DRIVER_ALLOC_LIMIT_MIB") : "20", 1);
+		pos = 0;
+		CHECK(lzma_easy_buffer_encode(1, LZMA_CHECK_CRC64, NULL, in, n1, out, &pos, n1 + (n1 >> 2) + (1u << 20)) == LZMA_OK);
+		save(dir, "case11.in", in, n1);
+		save(dir, "case11.xz", out, pos);
+		unsetenv("XZAMD_TEST_ALLOC_LIMIT_MIB");
+	}
 	xzamd_release_parked();
 	free(in);
 	free(out);

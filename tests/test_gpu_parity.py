@@ -1264,6 +1264,47 @@ def test_one_shot_buffer_api():
     assert L.lzma_easy_buffer_encode(6, 4, None, data, len(data), None, C.byref(pos), 0) == 11            # LZMA_PROG_ERROR
 
 
+def test_one_shot_single_block_layout(monkeypatch):
+    """The one-shot API writes ONE Block whatever the input size, as the reference does (stream_buffer_encoder.c:91-101
+    -> lzma_block_buffer_encode): 10 MiB at preset 1 (default Block size 3 MiB) with one span per Block is byte for byte
+    the reference's lzma_easy_buffer_encode; 60 MiB at preset 6 (default Block size 24 MiB) is one Block, equal to the
+    oracle's Stream at block_size = input size, and decodes through the reference."""
+    import ctypes as C
+    import xz_amd
+    if not o.have_ref():
+        pytest.skip("oracle/_ref not built")
+    L = xz_amd.lib()
+    L.lzma_stream_buffer_bound.restype = C.c_size_t
+    L.lzma_stream_buffer_bound.argtypes = [C.c_size_t]
+    L.lzma_easy_buffer_encode.argtypes = [C.c_uint32, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p,
+                                          C.POINTER(C.c_size_t), C.c_size_t]
+
+    def one_shot(data, preset):
+        out = C.create_string_buffer(L.lzma_stream_buffer_bound(len(data)))
+        pos = C.c_size_t(0)
+        assert L.lzma_easy_buffer_encode(preset, 4, None, data, len(data), out, C.byref(pos), len(out)) == 0
+        return out.raw[:pos.value]
+
+    data = o.corpus_mixed(10 << 20, 31)
+    monkeypatch.setenv("XZAMD_SPAN_KIB", str(64 << 10))          # one span per Block: the reference's own coding
+    got = one_shot(data, 1)
+    monkeypatch.delenv("XZAMD_SPAN_KIB")
+    want = o.ref_easy_buffer_encode(data, 1)
+    assert o.first_diff(got, want) == -1
+    r, dec, nb = o.orc_xz_decode(got, len(data) + 16)
+    assert r == 0 and nb == 1 and dec == data
+
+    data = xz_amd.corpus_text(60 << 20, seed=77).tobytes()
+    got = one_shot(data, 6)
+    r, dec, nb = o.orc_xz_decode(got, len(data) + 16)
+    assert r == 0 and nb == 1 and dec == data
+    rr, rdec = o.ref_decode(got, len(data) + 16)
+    assert rr == 1 and rdec == data
+    opts = xz_amd.preset_options(6)
+    want = o.orc_xz_stream(data, o.params_for_gpu_options(opts), len(data))
+    assert o.first_diff(got, want) == -1
+
+
 def test_lzma_code_semantics(tmp_path):
     """Option validation and action sequencing as in get_options (stream_encoder_mt.c:956-1000) and
     lzma_code (common/common.c:203-376), driven through ctypes."""

@@ -42,7 +42,8 @@ def test_host_layer_under_sanitizers(tmp_path, kind, flags):
     p = subprocess.run([exe, str(outdir)], capture_output=True, text=True, env=env, timeout=900)
     assert p.returncode == 0 and "driver: ok" in p.stdout, (p.stdout[-2000:], p.stderr[-6000:])
     assert "runtime error" not in p.stderr and "ERROR: AddressSanitizer" not in p.stderr and "WARNING: ThreadSanitizer" not in p.stderr, p.stderr[-6000:]
-    expect_blocks = {"case1": 21, "case2": 4, "case3": 12, "case5": None, "case6": 0, "case7": 13, "case8": 21, "case9": 21}
+    expect_blocks = {"case1": 21, "case2": 4, "case3": 12, "case5": None, "case6": 0, "case7": 13, "case8": 21, "case9": 21,
+                     "case10": 1, "case11": 2}
     for case, nb_want in expect_blocks.items():
         data = open(outdir / f"{case}.in", "rb").read()
         xz = open(outdir / f"{case}.xz", "rb").read()

@@ -43,7 +43,9 @@ for cfg in args or ["default:"]:
         out, _ = enc.encode(t, opts=opts)
         torch.cuda.synchronize(); dt = time.time() - t0
         st = enc.stats()
-    print(f"{name:24s} {n/dt/1e6:8.1f} MB/s ratio {out.numel()/n:.5f} | chains {st.ms_chains:7.1f} find {st.ms_find:6.1f} (+{st.ms_find_overlapped:6.1f} lo) "
+    import hashlib
+    sha = hashlib.sha256(out.cpu().numpy().tobytes()).hexdigest()[:12] if os.environ.get("AB_SHA") else "-"
+    print(f"{name:24s} {n/dt/1e6:8.1f} MB/s ratio {out.numel()/n:.5f} sha {sha} | chains {st.ms_chains:7.1f} find {st.ms_find:6.1f} (+{st.ms_find_overlapped:6.1f} lo) "
           f"plan {st.ms_plan:5.1f} span {st.ms_encode-st.ms_find-st.ms_plan:7.1f} crc {st.ms_crc:5.1f} total {st.ms_total:7.1f} ms | spans {st.spans} cost {st.span_cost_used} slots {st.wave_slots}", flush=True)
     enc.close()
     del enc

@@ -1195,9 +1195,14 @@ void lzma_get_progress(lzma_stream *strm, uint64_t *progress_in, uint64_t *progr
 /* ------------------------------------------------------------------ */
 /* One-shot buffer API (common/stream_buffer_encoder.c:43-141,          */
 /* common/easy_buffer_encoder.c:16-27): same engine, no caller-visible  */
-/* streaming state.  The reference writes ONE Block here; this writes   */
-/* the MT layout (a Block per block_size bytes), which decodes the same.*/
+/* streaming state.  The reference writes ONE Block whatever the input  */
+/* size (:91-101, lzma_block_buffer_encode); so does this up to         */
+/* ONE_SHOT_SINGLE_MAX bytes -- the whole input is one device batch of  */
+/* one Block, cut into parse pieces / spans like any other Block.       */
+/* Above that (or when the device cannot hold such a Block) the MT      */
+/* layout is written, a Block per block_size bytes: it decodes the same.*/
 /* ------------------------------------------------------------------ */
+#define ONE_SHOT_SINGLE_MAX (1ull << 30)
 size_t lzma_stream_buffer_bound(size_t uncompressed_size)
 {
 	/* stream_buffer_encoder.c:24-40 semantics: 0 = too big */
@@ -1206,11 +1211,37 @@ size_t lzma_stream_buffer_bound(size_t uncompressed_size)
 	return b > (uint64_t)SIZE_MAX ? 0 : (size_t)b;
 }
 
+static lzma_ret buffer_encode_layout(const lzma_mt *mt, const lzma_allocator *allocator,
+		const uint8_t *in, size_t in_size, uint8_t *out, size_t *out_pos_ptr, size_t out_size);
+
 static lzma_ret buffer_encode(const lzma_mt *mt, const lzma_allocator *allocator,
 		const uint8_t *in, size_t in_size, uint8_t *out, size_t *out_pos_ptr, size_t out_size)
 {
 	if (out == NULL || out_pos_ptr == NULL || *out_pos_ptr > out_size || (in == NULL && in_size != 0))
 		return LZMA_PROG_ERROR;
+	if (mt->block_size == 0 && (uint64_t)in_size <= ONE_SHOT_SINGLE_MAX) {
+		/* one Block, as the reference writes it: block_size = the input size where that is more than the default */
+		xzamd_lzma_options opt;
+		uint64_t def_bs = 0;
+		int check = 0;
+		lzma_ret r = parse_options(mt, &opt, &def_bs, &check);
+		if (r != LZMA_OK)
+			return r;
+		if ((uint64_t)in_size > def_bs) {
+			lzma_mt one = *mt;
+			one.block_size = (uint64_t)in_size;
+			r = buffer_encode_layout(&one, allocator, in, in_size, out, out_pos_ptr, out_size);
+			/* a Block the device cannot hold (memory): fall through to the MT layout */
+			if (r != LZMA_MEM_ERROR && r != LZMA_OPTIONS_ERROR)
+				return r;
+		}
+	}
+	return buffer_encode_layout(mt, allocator, in, in_size, out, out_pos_ptr, out_size);
+}
+
+static lzma_ret buffer_encode_layout(const lzma_mt *mt, const lzma_allocator *allocator,
+		const uint8_t *in, size_t in_size, uint8_t *out, size_t *out_pos_ptr, size_t out_size)
+{
 	lzma_stream strm;
 	memset(&strm, 0, sizeof(strm));
 	strm.allocator = allocator;
