@@ -671,7 +671,7 @@ def main():
                 res["configs"] = extra_configs()
                 if ref_child is not None:
                     try:
-                        so, _ = ref_child.communicate(timeout=900)
+                        so, _ = ref_child.communicate(timeout=300)      # (it has had the minutes of the child runs already)
                         d_ = json.loads([l for l in so.splitlines() if l.startswith("{")][-1])
                         if d_.get("rc") == 1 and d_.get("in_bytes") == n:
                             res["ratio"]["whole_job"] = {

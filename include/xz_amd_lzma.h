@@ -165,8 +165,9 @@ uint32_t lzma_cputhreads(void);
 lzma_ret lzma_filters_update(lzma_stream *strm, const lzma_filter *filters);
 
 /* One-shot buffer API (common/stream_buffer_encoder.c:43-141, common/easy_buffer_encoder.c:16-27), same
- * return codes (LZMA_BUF_ERROR and *out_pos untouched if the output does not fit).  Unlike the reference,
- * which writes a single Block here, the Stream has the MT layout (one Block per default block_size). */
+ * return codes (LZMA_BUF_ERROR and *out_pos untouched if the output does not fit).  Like the reference the
+ * Stream holds a single Block whatever the input size (stream_buffer_encoder.c:91-101), up to 1 GiB of input;
+ * above that, or when the device cannot hold such a Block, the MT layout (one Block per default block_size). */
 size_t lzma_stream_buffer_bound(size_t uncompressed_size);
 lzma_ret lzma_stream_buffer_encode(lzma_filter *filters, lzma_check check, const lzma_allocator *allocator,
 		const uint8_t *in, size_t in_size, uint8_t *out, size_t *out_pos, size_t out_size);

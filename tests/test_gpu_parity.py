@@ -1267,7 +1267,7 @@ def test_one_shot_buffer_api():
 def test_one_shot_single_block_layout(monkeypatch):
     """The one-shot API writes ONE Block whatever the input size, as the reference does (stream_buffer_encoder.c:91-101
     -> lzma_block_buffer_encode): 10 MiB at preset 1 (default Block size 3 MiB) with one span per Block is byte for byte
-    the reference's lzma_easy_buffer_encode; 60 MiB at preset 6 (default Block size 24 MiB) is one Block, equal to the
+    the reference's lzma_easy_buffer_encode; 30 MiB at preset 6 (default Block size 24 MiB) is one Block, equal to the
     oracle's Stream at block_size = input size, and decodes through the reference."""
     import ctypes as C
     import xz_amd
@@ -1294,7 +1294,7 @@ def test_one_shot_single_block_layout(monkeypatch):
     r, dec, nb = o.orc_xz_decode(got, len(data) + 16)
     assert r == 0 and nb == 1 and dec == data
 
-    data = xz_amd.corpus_text(60 << 20, seed=77).tobytes()
+    data = xz_amd.corpus_text(30 << 20, seed=77).tobytes()
     got = one_shot(data, 6)
     r, dec, nb = o.orc_xz_decode(got, len(data) + 16)
     assert r == 0 and nb == 1 and dec == data

@@ -1156,12 +1156,9 @@ __device__ __forceinline__ bool change_pair(uint32_t small_dist, uint32_t big_di
 // Semantics are defined by oracle/lzma_fast_enc.c (build_sa / find_sn / optimum_window); the code
 // below is their wave-parallel form and must stay bit-exact with them.
 // ------------------------------------------------------------------------------------------
-// Optimal-parser window: nodes 0..WM, a template parameter of the parser.  WMAX_STD: LDS per wave <= 10 KiB -> 16 waves
-// per CU, what every option set with nice_len <= 128 runs.  WMAX_LONG (nice_len > 128: the extreme presets): matches
-// of 233..273 bytes fit a window and the tail re-parse weighs less -- 13 KiB per wave = 12 waves per CU, which is also
-// what 168 VGPRs per wave (3 per SIMD, a fifth of the scratch spills) allow.
+// Optimal-parser window: nodes 0..WM, a template parameter of the parser.  384 for every option set since round 5 (LDS per
+// wave <= 10 KiB -> 16 waves per CU); rounds 1-4 ran 232 nodes, and 360 at 12 waves per CU for nice_len > 128.
 constexpr uint32_t WMAX_STD = 384;
-constexpr uint32_t WMAX_LONG = 384;
 constexpr uint32_t PRICE_INF = 1u << 30;
 
 #ifdef XZAMD_TIMING
@@ -2799,7 +2796,7 @@ __device__ __forceinline__ void parse_piece_one(const xzamd_span_args& a, const 
 
 template <uint32_t WMAX = WMAX_STD>
 __global__ __launch_bounds__(64)
-__attribute__((amdgpu_waves_per_eu(WMAX > WMAX_STD ? 3 : XZAMD_WAVES_OPT, WMAX > WMAX_STD ? 3 : XZAMD_WAVES_OPT)))
+__attribute__((amdgpu_waves_per_eu(XZAMD_WAVES_OPT, XZAMD_WAVES_OPT)))
 void k_parse_pieces(xzamd_span_args a, uint32_t nslots, int phase, uint32_t* __restrict__ counter)
 {
     for (;;) {
@@ -4848,10 +4845,7 @@ int xzk_parse_pieces(const xzamd_span_args* a, uint32_t nblocks, int phase, uint
     const bool persist = phase != 0 && waves != 0 && counter != nullptr && waves < nitems;
     const uint32_t grid = persist ? waves : nitems;
     uint32_t* cnt = persist ? counter : nullptr;
-    if (a->nice_len > 128)
-        hipLaunchKernelGGL((k_parse_pieces<WMAX_LONG>), dim3(grid), dim3(64), 0, st, *a, nitems, phase, cnt);
-    else
-        hipLaunchKernelGGL((k_parse_pieces<WMAX_STD>), dim3(grid), dim3(64), 0, st, *a, nitems, phase, cnt);
+    hipLaunchKernelGGL((k_parse_pieces<WMAX_STD>), dim3(grid), dim3(64), 0, st, *a, nitems, phase, cnt);
     return (int)hipGetLastError();
 }
 
@@ -4931,7 +4925,6 @@ int xzk_span_occupancy(int parser, uint32_t nice_len, int* waves_per_cu)
 {
     int nb = 0;
     hipError_t e = !parser ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_span_encode_t<0, false>, 64, 0)
-            : nice_len > 128 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_span_encode_t<2, true, WMAX_LONG>, 64, 0)
             : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_span_encode_t<2, true>, 64, 0);
     *waves_per_cu = nb;
     return (int)e;

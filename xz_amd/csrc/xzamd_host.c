@@ -308,8 +308,7 @@ void xzamd_sn_defaults(xzamd_lzma_options *o)
 	o->gpu_sa_window = XZAMD_SA_WINDOW_MAX;
 	o->gpu_parser = 1;
 	o->gpu_sa_depth = o->gpu_nice_len <= 32 ? 32 : o->gpu_nice_len <= 64 ? 64 : 256;
-	/* nice_len > 128 (the extreme presets) asks for ratio first: twice the output per span on compressible Blocks,
-	 * and the longer parser window (kernels: WMAX_LONG) */
+	/* nice_len > 128 (the extreme presets) asks for ratio first: twice the output per span on compressible Blocks */
 	o->span_cost = XZAMD_SPAN_COST_DEFAULT;
 	o->span_bits = (o->gpu_nice_len > 128 ? 2 : 1) * XZAMD_SPAN_BITS_DEFAULT;
 	o->enc_span_bits = XZAMD_ENC_SPAN_BITS_DEFAULT;
