@@ -1193,13 +1193,18 @@ struct RoundL {
     uint32_t rp[4];     // list-driven parser: the four rep-match lengths
     uint32_t rl[4];     // the same, 0 when < 2 (usable rep matches)
     uint32_t pre;       // compound precheck: some rep source has two equal bytes right behind its first mismatch
-    uint64_t rm[4];     // mismatch masks of the four rep sources over the 64-byte row at x (bit o: offset o differs or is past the end)
+    uint32_t mlo, mhi;  // lane i < 4: mismatch mask of rep source i over the 64-byte row at x (bit o: offset o differs or is past the end)
     uint32_t l2a, l2b;  // rep0 run behind the byte after the longest / second longest match (list trailer)
     uint32_t L;         // per lane; lanes 60..63 = rep lengths (in-kernel finders)
     uint32_t SL, SD;    // kept matches sorted by length: lane r holds entry r (length, zero-based distance)
     uint32_t cnt;       // number of entries
     uint32_t longest;   // incl. the > nice_len extension
 };
+
+__device__ __forceinline__ uint64_t rm_of(const RoundL& R, uint32_t i)
+{
+    return ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)R.mhi, (int)i) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)R.mlo, (int)i);
+}
 
 // lane `dst` receives `v` from this lane (all lanes must execute; unused senders target lane 63)
 __device__ __forceinline__ uint32_t lane_scatter(uint32_t dst, uint32_t v)
@@ -1247,8 +1252,22 @@ __device__ __forceinline__ void rows_issue(const Env& e, uint32_t x, uint32_t en
     W.c2 = e.in[x - r2 - 1 + off]; W.c3 = e.in[x - r3 - 1 + off];
 }
 
+// A node with the rep distances of the node in front of it (reached by a literal, or by the same match or rep at another
+// length: 57 % of the nodes of the bench text): its four mismatch masks are that node's shifted down by one byte, and only
+// offset 63 is new -- ONE load (lanes 0..3: byte 63 of the four rep sources, every other lane: byte 63 of the text) in place
+// of the five rows.  Offset 63 is dead when fewer than 64 bytes are left (the masks' `dead` bits cover it).
+__device__ __forceinline__ void rows_issue_top(const Env& e, uint32_t x, uint32_t end,
+        uint32_t r0, uint32_t r1, uint32_t r2, uint32_t r3, Rows& W)
+{
+    const uint32_t lane = threadIdx.x;
+    const uint32_t off = end - x > 63u ? 63u : 0u;
+    const uint32_t back = lane == 0 ? r0 + 1 : lane == 1 ? r1 + 1 : lane == 2 ? r2 + 1 : lane == 3 ? r3 + 1 : 0u;
+    W.cx = e.in[x + off - back];
+}
+
+template <bool SHIFT = false>
 __device__ __forceinline__ void round_lists_rows(const Env& e, ListPre& LP, uint32_t x, uint32_t end,
-        uint32_t r0, uint32_t r1, uint32_t r2, uint32_t r3, const Rows& W, RoundL& R)
+        uint32_t r0, uint32_t r1, uint32_t r2, uint32_t r3, const Rows& W, RoundL& R, const bool shift = false)
 {
     const uint32_t lane = threadIdx.x;
     if (!(LP.valid && LP.pos == x)) lists_load(e, x, LP.sl, LP.sd, LP.tr);
@@ -1263,14 +1282,22 @@ __device__ __forceinline__ void round_lists_rows(const Env& e, ListPre& LP, uint
     // length, "usable" length, the compound precheck -- is then worked out by lane i for rep i with vector
     // instructions (the scalar unit is what bounds this kernel), and only the results go back to scalars.
     {
-        const uint32_t cx = W.cx, c0 = W.c0, c1 = W.c1, c2 = W.c2, c3 = W.c3;
         const uint64_t dead = buf_avail < 64 ? ~0ull << buf_avail : 0ull;
-        const uint64_t m0 = __builtin_amdgcn_ballot_w64(c0 != cx) | dead, m1 = __builtin_amdgcn_ballot_w64(c1 != cx) | dead;
-        const uint64_t m2 = __builtin_amdgcn_ballot_w64(c2 != cx) | dead, m3 = __builtin_amdgcn_ballot_w64(c3 != cx) | dead;
-        R.rm[0] = m0; R.rm[1] = m1; R.rm[2] = m2; R.rm[3] = m3;
-        const uint32_t lo = lane == 0 ? (uint32_t)m0 : lane == 1 ? (uint32_t)m1 : lane == 2 ? (uint32_t)m2 : (uint32_t)m3;
-        const uint32_t hi = lane == 0 ? (uint32_t)(m0 >> 32) : lane == 1 ? (uint32_t)(m1 >> 32)
-                : lane == 2 ? (uint32_t)(m2 >> 32) : (uint32_t)(m3 >> 32);
+        uint32_t lo, hi;
+        if (SHIFT && shift) {
+            // the masks of the node in front, one byte further on (lane i: rep i); bit 63 from the one load of rows_issue_top
+            const uint32_t nb = W.cx != lane_of(W.cx, 4) ? 0x80000000u : 0u;          // lanes 0..3 can differ
+            lo = (R.mlo >> 1) | (R.mhi << 31) | (uint32_t)dead;
+            hi = (R.mhi >> 1) | nb | (uint32_t)(dead >> 32);
+        } else {
+            const uint32_t cx = W.cx, c0 = W.c0, c1 = W.c1, c2 = W.c2, c3 = W.c3;
+            const uint64_t m0 = __builtin_amdgcn_ballot_w64(c0 != cx) | dead, m1 = __builtin_amdgcn_ballot_w64(c1 != cx) | dead;
+            const uint64_t m2 = __builtin_amdgcn_ballot_w64(c2 != cx) | dead, m3 = __builtin_amdgcn_ballot_w64(c3 != cx) | dead;
+            lo = lane == 0 ? (uint32_t)m0 : lane == 1 ? (uint32_t)m1 : lane == 2 ? (uint32_t)m2 : (uint32_t)m3;
+            hi = lane == 0 ? (uint32_t)(m0 >> 32) : lane == 1 ? (uint32_t)(m1 >> 32)
+                    : lane == 2 ? (uint32_t)(m2 >> 32) : (uint32_t)(m3 >> 32);
+        }
+        R.mlo = lo; R.mhi = hi;
         const uint32_t l = lo ? (uint32_t)__builtin_ctz(lo) : hi ? 32u + (uint32_t)__builtin_ctz(hi) : 64u;
         const uint32_t lu = l >= 2 ? l : 0u;
         // two equal bytes behind the first mismatch <=> bits l+1, l+2 clear (bit l is set)
@@ -1612,13 +1639,13 @@ __device__ __forceinline__ void compound_setup(const RoundL& RL, uint32_t j, uin
     bool ok[7];
     L1[0] = 0;
     ok[0] = RL.rp[0] == 0;                                     // rep0's byte differs here (buf_avail >= 1 inside a span)
-    l2[0] = ok[0] ? mask_run_after(RL.rm[0], 0) : 0;
+    l2[0] = ok[0] ? mask_run_after(rm_of(RL, 0), 0) : 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const uint32_t l = RL.rp[i];
         L1[1 + i] = l;
         ok[1 + i] = l >= 2 && l <= room && l < buf_avail && l < 64;
-        l2[1 + i] = ok[1 + i] ? mask_run_after(RL.rm[i], l) : 0;
+        l2[1 + i] = ok[1 + i] ? mask_run_after(rm_of(RL, i), l) : 0;
     }
     const uint32_t cnt = RL.cnt;
     L1[5] = cnt >= 1 ? RL.longest : 0;
@@ -2061,7 +2088,7 @@ __device__ __forceinline__ void span_encode_one(const xzamd_span_args& a, const 
     RoundL RL;
     RL.L = 0; RL.SL = 0; RL.SD = 0; RL.cnt = 0; RL.longest = 0; RL.l2a = RL.l2b = 0;
     RL.rp[0] = RL.rp[1] = RL.rp[2] = RL.rp[3] = 0;
-    RL.rm[0] = RL.rm[1] = RL.rm[2] = RL.rm[3] = 0;
+    RL.mlo = RL.mhi = 0;
     RL.rl[0] = RL.rl[1] = RL.rl[2] = RL.rl[3] = 0;
     RL.pre = 0;
     LenTab lt;
@@ -2138,7 +2165,7 @@ __device__ __forceinline__ void span_encode_one(const xzamd_span_args& a, const 
                         cached = false;
                         q_pos = q_end = 0;
                     } else if (RL.cnt == 0 && RL.rp[0] == 0 && RL.rp[1] < 2 && RL.rp[2] < 2 && RL.rp[3] < 2
-                            && mask_run_after(RL.rm[0], 0) < 2) {
+                            && mask_run_after(rm_of(RL, 0), 0) < 2) {
                         // nothing but a literal can leave node 0 (no match, no rep of two bytes, not even
                         // a short rep, no "literal + rep0" compound): the window would be that literal
                         // (incompressible data lives here)
@@ -2628,7 +2655,7 @@ __device__ __forceinline__ void parse_piece_one(const xzamd_span_args& a, const 
     RoundL RL;
     RL.L = 0; RL.SL = 0; RL.SD = 0; RL.cnt = 0; RL.longest = 0; RL.l2a = RL.l2b = 0;
     RL.rp[0] = RL.rp[1] = RL.rp[2] = RL.rp[3] = 0;
-    RL.rm[0] = RL.rm[1] = RL.rm[2] = RL.rm[3] = 0;
+    RL.mlo = RL.mhi = 0;
     RL.rl[0] = RL.rl[1] = RL.rl[2] = RL.rl[3] = 0;
     RL.pre = 0;
     LenTab lt;
@@ -2684,7 +2711,7 @@ __device__ __forceinline__ void parse_piece_one(const xzamd_span_args& a, const 
                 cached = false;
                 q_pos = q_end = 0;
             } else if (RL.cnt == 0 && RL.rp[0] == 0 && RL.rp[1] < 2 && RL.rp[2] < 2 && RL.rp[3] < 2
-                    && mask_run_after(RL.rm[0], 0) < 2) {
+                    && mask_run_after(rm_of(RL, 0), 0) < 2) {
                 cached = false;                         // nothing but a literal can leave this node
                 q_pos = q_end = 0;
             } else {
