@@ -56,7 +56,7 @@ def span_kernel_name(opts, pmc=False):
     """Name of the dominant kernel for these options (template args: finder source, parser, parser window)."""
     wm = 384            # one parser window for every option set since round 5 (lzma_kernels.hip: WMAX_STD == WMAX_LONG)
     if two_phase(opts):
-        return "k_parse_pieces<%du>" % wm if pmc else "k_parse_pieces<%d>" % wm
+        return "k_parse_pieces<%du" % wm if pmc else "k_parse_pieces<%d>" % wm       # (rocprofv3: `<384u, true>` = packed list records)
     finder = 2 if opts.gpu_parser else 0
     sep = ", " if pmc else ","
     if pmc:          # as rocprofv3 prints it

@@ -2432,7 +2432,7 @@ void k_span_encode_t(xzamd_span_args a, uint32_t nspans, uint32_t* __restrict__ 
 //                    span start -- ONE continuous model per Block; <0>: tokens and the LZMA2 chunk table; <3>: snapshots.
 //   k_rc_chunks      one LANE per LZMA2 chunk: the range coder over the chunk's tokens.
 // ------------------------------------------------------------------------------------------
-template <uint32_t WMAX>
+template <uint32_t WMAX, bool PACKED>
 __device__ __forceinline__ void parse_piece_one(const xzamd_span_args& a, const uint32_t span)
 {
     // LDS per wavefront: the DP nodes and the price tables -- 10,176 bytes at WMAX = 384 -> 16 wavefronts per CU.  The
@@ -2475,7 +2475,9 @@ __device__ __forceinline__ void parse_piece_one(const xzamd_span_args& a, const 
     e.in = in; e.rank = a.rank; e.sorted_pos = a.sorted_pos; e.prev2 = a.prev2; e.prev3 = a.prev3;
     e.nice = a.nice_len; e.depth = a.depth; e.hb = a.hash_bytes; e.cyclic = a.dict_size + 1;
     e.block_end = block_end; e.n_last = a.n - 1;
-    e.mlen = a.mlen; e.mdist = a.mdist; e.packed = a.list_packed;
+    // (the list format is a template parameter: the packed records -- every dictionary up to 8 MiB -- need neither the branch
+    // nor the pointer to the length array)
+    e.mlen = PACKED ? nullptr : a.mlen; e.mdist = a.mdist; e.packed = PACKED ? 1u : 0u;
     ListPre LP;
     LP.valid = false; LP.pos = 0; LP.sl = LP.sd = LP.tr = 0;
 
@@ -2821,7 +2823,7 @@ __device__ __forceinline__ void parse_piece_one(const xzamd_span_args& a, const 
 #endif
 }
 
-template <uint32_t WMAX = WMAX_STD>
+template <uint32_t WMAX = WMAX_STD, bool PACKED = true>
 __global__ __launch_bounds__(64)
 __attribute__((amdgpu_waves_per_eu(XZAMD_WAVES_OPT, XZAMD_WAVES_OPT)))
 void k_parse_pieces(xzamd_span_args a, uint32_t nslots, int phase, uint32_t* __restrict__ counter)
@@ -2834,10 +2836,10 @@ void k_parse_pieces(xzamd_span_args a, uint32_t nslots, int phase, uint32_t* __r
         }
         if (s >= nslots) break;
         if (phase == 0) {
-            parse_piece_one<WMAX>(a, s * a.max_spb);                 // s = Block: its seed piece
+            parse_piece_one<WMAX, PACKED>(a, s * a.max_spb);                 // s = Block: its seed piece
         } else {
             const uint32_t slot = a.order ? a.order[s] : s;
-            if (slot % a.max_spb != 0) parse_piece_one<WMAX>(a, slot);
+            if (slot % a.max_spb != 0) parse_piece_one<WMAX, PACKED>(a, slot);
         }
         if (counter == nullptr) break;
         __builtin_amdgcn_s_waitcnt(0);
@@ -4872,7 +4874,9 @@ int xzk_parse_pieces(const xzamd_span_args* a, uint32_t nblocks, int phase, uint
     const bool persist = phase != 0 && waves != 0 && counter != nullptr && waves < nitems;
     const uint32_t grid = persist ? waves : nitems;
     uint32_t* cnt = persist ? counter : nullptr;
-    hipLaunchKernelGGL((k_parse_pieces<WMAX_STD>), dim3(grid), dim3(64), 0, st, *a, nitems, phase, cnt);
+    // (specialised for the list format: a launch-time constant the compiler cannot see)
+    if (a->list_packed) hipLaunchKernelGGL((k_parse_pieces<WMAX_STD, true>), dim3(grid), dim3(64), 0, st, *a, nitems, phase, cnt);
+    else hipLaunchKernelGGL((k_parse_pieces<WMAX_STD, false>), dim3(grid), dim3(64), 0, st, *a, nitems, phase, cnt);
     return (int)hipGetLastError();
 }
 
