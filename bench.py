@@ -568,7 +568,7 @@ def main():
                                   else "lzma_lzma_optimum_fast semantics (greedy + 1-byte lazy)"),
                 "span_bytes": int(st.span_size) if st.span_size else f"cost-balanced (work target {int(st.span_cost_used)} per span, >= 64 KiB)",
                 "parallelism": (f"{world} x (two-phase: one wavefront per parse piece, {int(st.spans)} pieces on rank 0 incl. one 64 KiB seed piece per Block; "
-                                f"one wavefront per encode span, {int(st.enc_spans)} encode spans = coder state resets)" if two_phase(opts)
+                                f"one wavefront per encode span, {int(st.enc_spans)} encode spans walked in parallel with ONE continuous coder model per Block)" if two_phase(opts)
                                 else f"{world} x (one wavefront per span, {int(st.spans)} spans on rank 0)"),
             },
             "ratio": {"ours": round(local_out_bytes / max(n, 1), 5)},
