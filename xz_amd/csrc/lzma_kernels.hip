@@ -1441,11 +1441,7 @@ __device__ __forceinline__ void refresh_len_tables(PR probs, const uint8_t* ptab
             const uint32_t prr = (lane < 8 ? r0 : rm) + pr_tree(probs, ptab, P_REP_LEN + sub, 3, sym);
             v = pm | (prr << 16);
         }
-#ifdef XZAMD_V_MERGE
-        t.lo[ps] = lane < 16 ? v : t.hi[0];      // lengths 2..65 of position state ps in one register (lanes >= 16: the shared high tree)
-#else
         t.lo[ps] = v;
-#endif
     }
 }
 
@@ -1509,33 +1505,6 @@ __device__ __forceinline__ void lit_chunk(const uint8_t* __restrict__ in, const 
     const uint32_t mask = (0x100u << z.lp) - (0x100u >> z.lc);
     const plit_t* sub = z.lit + 3u * ((((upos << 8) + prev) & mask) << z.lc);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the coder's probability updates must have landed
-    uint32_t N[8], A[8], B[8];
-#ifdef XZAMD_V_LIT2
-    // two rounds of twelve gathers instead of one of twenty-four: half the registers at the peak, one more memory round trip per 64 nodes
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        uint32_t pn[4], pa[4], pb[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int i = 4 * h + k;
-            const uint32_t pre = (0x100u | cur) >> (8 - i);
-            const uint32_t bit = (cur >> (7 - i)) & 1;
-            pn[k] = lit_load(sub + pre);
-            pa[k] = lit_load(sub + 0x100u + (bit << 8) + pre);
-            pb[k] = lit_load(sub + 0x100u + ((bit ^ 1u) << 8) + pre);
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int i = 4 * h + k;
-            const uint32_t bit = (cur >> (7 - i)) & 1;
-            const uint32_t flip = (0u - bit) & 0x7FFu;
-            N[i] = ptab[(pn[k] ^ flip) >> 4];
-            A[i] = ptab[(pa[k] ^ flip) >> 4];
-            B[i] = ptab[(pb[k] ^ flip) >> 4];
-        }
-        asm volatile("" ::: "memory");
-    }
-#else
     uint32_t pn[8], pa[8], pb[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -1545,6 +1514,7 @@ __device__ __forceinline__ void lit_chunk(const uint8_t* __restrict__ in, const 
         pa[i] = lit_load(sub + 0x100u + (bit << 8) + pre);
         pb[i] = lit_load(sub + 0x100u + ((bit ^ 1u) << 8) + pre);
     }
+    uint32_t N[8], A[8], B[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const uint32_t bit = (cur >> (7 - i)) & 1;
@@ -1553,7 +1523,6 @@ __device__ __forceinline__ void lit_chunk(const uint8_t* __restrict__ in, const 
         A[i] = ptab[(pa[i] ^ flip) >> 4];
         B[i] = ptab[(pb[i] ^ flip) >> 4];
     }
-#endif
     uint32_t sufN[9];                      // sufN[k] = sum_{i>=k} N_i
     sufN[8] = 0;
 #pragma unroll
@@ -1609,12 +1578,8 @@ __device__ __forceinline__ void relax_lengths(const Work& w, const LenTab& lt, u
         for (uint32_t k = 0; k + 1 < LIST_K; ++k) idx_m += (lane_of(SLx, k) < l) ? 1u : 0u;   // entries >= cnt-1 hold "infinity"
         const uint32_t dist_m = __shfl(SD, idx_m);
         const uint32_t cur = w.n_price[j + l];
-#ifdef XZAMD_V_MERGE
-        const uint32_t lv = it == 0 ? lo_ps : it == 1 ? lt.hi[1] : it == 2 ? lt.hi[2] : it == 3 ? lt.hi[3] : lt.hi[4];
-#else
         const uint32_t hv = it == 0 ? lt.hi[0] : it == 1 ? lt.hi[1] : it == 2 ? lt.hi[2] : it == 3 ? lt.hi[3] : lt.hi[4];
         const uint32_t lv = (it == 0 && lane < 16) ? lo_ps : hv;
-#endif
         const uint32_t lpm = lv & 0xFFFFu, lpr = lv >> 16;
         // distance price = slot price (+ direct bits) + footer / align price: two table reads
         const uint32_t ds = l < 6 ? l - 2 : 3;
@@ -1885,24 +1850,15 @@ __device__ __forceinline__ bool optimum_window(const Env& e, const Work& w, List
             // length prices: LenTab holds length 2 + l + 64 * it in lane l (low half match, high half rep)
             const uint32_t lo_ps = (ps & 3) == 0 ? lt.lo[0] : (ps & 3) == 1 ? lt.lo[1] : (ps & 3) == 2 ? lt.lo[2] : lt.lo[3];
             const uint32_t i1 = lane < 7 && cp.L1 >= 2 ? cp.L1 - 2 : 0u;          // L1 <= 63: first pass of the table
-#ifdef XZAMD_V_MERGE
-            const uint32_t lenX = (uint32_t)__shfl((int)lo_ps, (int)(i1 & 63));     // X's length price (match | rep << 16)
-#else
             const uint32_t t_lo = (uint32_t)__shfl((int)lo_ps, (int)(i1 & 63)), t_hi0 = (uint32_t)__shfl((int)lt.hi[0], (int)(i1 & 63));
             const uint32_t lenX = i1 < 16 ? t_lo : t_hi0;                           // X's length price (match | rep << 16)
-#endif
             const uint32_t i2 = lane < 7 && cp.l2 >= 2 ? cp.l2 - 2 : 0u;            // l2 <= 127
             const uint32_t psn = (upos + cp.L1 + 1) & pbm & 3;
             const uint32_t u0 = (uint32_t)__shfl((int)lt.lo[0], (int)(i2 & 63)), u1 = (uint32_t)__shfl((int)lt.lo[1], (int)(i2 & 63));
             const uint32_t u2 = (uint32_t)__shfl((int)lt.lo[2], (int)(i2 & 63)), u3 = (uint32_t)__shfl((int)lt.lo[3], (int)(i2 & 63));
-            const uint32_t h1v = (uint32_t)__shfl((int)lt.hi[1], (int)(i2 & 63));
+            const uint32_t h0v = (uint32_t)__shfl((int)lt.hi[0], (int)(i2 & 63)), h1v = (uint32_t)__shfl((int)lt.hi[1], (int)(i2 & 63));
             const uint32_t ulo = psn == 0 ? u0 : psn == 1 ? u1 : psn == 2 ? u2 : u3;
-#ifdef XZAMD_V_MERGE
-            const uint32_t len2p = (i2 < 64 ? ulo : h1v) >> 16;                     // rep length price of the rep0 run
-#else
-            const uint32_t h0v = (uint32_t)__shfl((int)lt.hi[0], (int)(i2 & 63));
             const uint32_t len2p = (i2 < 16 ? ulo : i2 < 64 ? h0v : h1v) >> 16;     // rep length price of the rep0 run
-#endif
             // state chain: X -> literal -> long rep0
             const bool isrep = lane >= 1 && lane <= 4;
             const uint32_t sX = lane == 0 ? s : isrep ? (s < 7 ? 8u : 11u) : (s < 7 ? 7u : 10u);
