@@ -1217,21 +1217,29 @@ __device__ __forceinline__ uint32_t lane_scatter(uint32_t dst, uint32_t v)
 // position of the batch as a separate, fully parallel kernel.  The parser then streams the lists:
 // positions are visited strictly in order, so the record of x+1 is always in flight while x is
 // priced.  Only the four rep-match lengths depend on the parse; lanes 60..63 measure them here.
-struct ListPre { uint32_t pos; bool valid; uint32_t sl, sd, tr; };
+// (the record in flight is kept as it was loaded -- one register for the packed form, two for the other -- and taken apart
+// when its round is worked out, not when it is loaded: it is live across the whole node in front)
+struct ListPre { uint32_t pos; bool valid; uint32_t v, l16; };
 
 // One 32-byte record per position (see k_find_sn): lanes 0..6 = entries, lane 7 = trailer.
-__device__ __forceinline__ void lists_load(const Env& e, uint32_t x, uint32_t& sl, uint32_t& sd, uint32_t& tr)
+__device__ __forceinline__ void lists_load(const Env& e, uint32_t x, uint32_t& v, uint32_t& l16)
 {
     const uint32_t lane = threadIdx.x;
     x = x < e.n_last ? x : e.n_last;
     const uint64_t base = (uint64_t)x * LIST_W + (lane & (LIST_W - 1));
-    const uint32_t v = e.mdist[base];              // every lane loads (lanes >= LIST_W repeat the record): no exec masking
-    tr = v;                                        // lane LIST_K holds the trailer
+    v = e.mdist[base];                             // every lane loads (lanes >= LIST_W repeat the record): no exec masking
+    l16 = e.packed ? 0u : (uint32_t)e.mlen[base];
+}
+
+// lane LIST_K of `tr` holds the trailer
+__device__ __forceinline__ void lists_split(const Env& e, uint32_t v, uint32_t l16, uint32_t& sl, uint32_t& sd, uint32_t& tr)
+{
+    tr = v;
     if (e.packed) {
         sl = v >> 23; sd = v & 0x7FFFFFu;
     } else {
         sd = v;
-        sl = e.mlen[base];
+        sl = l16;
     }
 }
 
@@ -1270,9 +1278,10 @@ __device__ __forceinline__ void round_lists_rows(const Env& e, ListPre& LP, uint
         uint32_t r0, uint32_t r1, uint32_t r2, uint32_t r3, const Rows& W, RoundL& R, const bool shift = false)
 {
     const uint32_t lane = threadIdx.x;
-    if (!(LP.valid && LP.pos == x)) lists_load(e, x, LP.sl, LP.sd, LP.tr);
-    const uint32_t sl = LP.sl, sd = LP.sd, tv = LP.tr;
-    lists_load(e, x + 1, LP.sl, LP.sd, LP.tr);
+    if (!(LP.valid && LP.pos == x)) lists_load(e, x, LP.v, LP.l16);
+    uint32_t sl, sd, tv;
+    lists_split(e, LP.v, LP.l16, sl, sd, tv);
+    lists_load(e, x + 1, LP.v, LP.l16);
     LP.pos = x + 1;
     LP.valid = true;
     const uint32_t avail = end - x;
@@ -2034,7 +2043,7 @@ __device__ __forceinline__ void span_encode_one(const xzamd_span_args& a, const 
     e.block_end = block_end; e.n_last = a.n - 1;
     e.mlen = a.mlen; e.mdist = a.mdist; e.packed = a.list_packed;
     ListPre LP;
-    LP.valid = false; LP.pos = 0; LP.sl = LP.sd = LP.tr = 0;
+    LP.valid = false; LP.pos = 0; LP.v = LP.l16 = 0;
     Pre P;
     P.valid = false; P.pos = 0; P.ent = 0;
     P.a.rk = P.a.d2 = P.a.d3 = 0; P.an = P.a;
@@ -2479,7 +2488,7 @@ __device__ __forceinline__ void parse_piece_one(const xzamd_span_args& a, const 
     // nor the pointer to the length array)
     e.mlen = PACKED ? nullptr : a.mlen; e.mdist = a.mdist; e.packed = PACKED ? 1u : 0u;
     ListPre LP;
-    LP.valid = false; LP.pos = 0; LP.sl = LP.sd = LP.tr = 0;
+    LP.valid = false; LP.pos = 0; LP.v = LP.l16 = 0;
 
     Work w{};
 #ifdef XZAMD_TIMING
