@@ -81,15 +81,18 @@ typedef struct {
 	uint32_t gpu_mf;     /* XZAMD_MF_HC3 / XZAMD_MF_HC4 */
 	uint32_t gpu_nice_len;
 	uint32_t gpu_depth;  /* candidates taken from the main (3/4-byte hash) chain (exact finder only) */
-	uint32_t span_size;  /* bytes per independently coded span; XZAMD_SPAN_* */
+	uint32_t span_size;  /* bytes per independently coded span; XZAMD_SPAN_*.  With the optimal parser (gpu_parser = 1) an EXPLICIT
+	                        span size (also: XZAMD_SPAN_KIB in the environment) selects the single-phase kernel -- every span codes
+	                        with its own model, 8 wavefronts per CU: a test and measurement mode, several times slower than the
+	                        default (XZAMD_SPAN_DEFAULT / _AUTO: cost-balanced parse pieces + the two-phase encode) */
 	uint32_t gpu_sa_window; /* 0 = exact HC3/HC4 semantics of the reference; else the suffix-neighbourhood
 	                        finder (the BT4 successor): recency records among this many slots (<= 5) on
 	                        either side of a position in 32-byte-prefix suffix order, plus the nearest
 	                        equal hash2 / hash4 and equal 8 / 16 bytes; needs gpu_mf = HC4 and
 	                        gpu_parser = 1 */
-	uint32_t gpu_parser; /* 0 = lzma_lzma_optimum_fast semantics, 1 = windowed optimal parser (232-node DP over
-	                        per-position match lists incl. the reference's compound edges; needs pb <= 2,
-	                        else XZAMD_OPTIONS_ERROR) */
+	uint32_t gpu_parser; /* 0 = lzma_lzma_optimum_fast semantics, 1 = windowed optimal parser (384-node DP over
+	                        per-position match lists incl. the reference's compound edges; pb > 2 needs the two-phase
+	                        mode, i.e. no explicit span size, else XZAMD_OPTIONS_ERROR) */
 	uint32_t bcj;        /* 0 = chain {LZMA2}; XZAMD_BCJ_* / XZAMD_FILTER_DELTA(d) = that filter in front of LZMA2
 	                        (the FIRST filter of the chain when bcj2 / bcj3 below name more) */
 	uint32_t gpu_sa_depth; /* suffix-neighbourhood finder: prefix bytes the suffix order compares, 32 / 64 / 128 / 256
