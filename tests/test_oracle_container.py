@@ -110,3 +110,22 @@ def test_golden_mt_stream_hash():
         assert hashlib.sha256(data).hexdigest() == man["encode"][cname]["sha256"]
         s = o.orc_xz_stream(data, prm, 65536)
         assert hashlib.sha256(s).hexdigest() == man["encode"][cname]["mt_preset1_bs64k"]["sha256"], cname
+
+
+@needs_ref
+def test_bench_whole_job_reference_child():
+    """bench.py's `ratio.whole_job` leg: the child that runs the reference MT encoder over the whole (seeded) text corpus and
+    prints its size -- no GPU involved; the size must be what the reference gives for the same bytes in this process."""
+    import json
+    import os
+    import subprocess
+    import sys
+    import xz_amd
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--ref-size-child", "2", "--size-mib", "6", "--preset", "1"],
+                       capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    data = xz_amd.corpus_text(6 << 20, seed=1000)
+    want = o.ref_encode_mt(data, 1, threads=2, block_size=xz_amd.mt_block_size(xz_amd.preset_options(1)))
+    assert d["rc"] == 1 and d["in_bytes"] == 6 << 20 and d["ref_bytes"] == len(want)
