@@ -837,6 +837,64 @@ static int launch_chains(xzamd_ctx *c, const xzamd_lzma_options *opt, const uint
 #define HIPCHK(call, what) do { int e_ = (call); if (e_) return fail(c, XZAMD_DEVICE_ERROR, what, e_); } while (0)
 
 
+/* First half of a batch's back end, enqueued on the back-end stream: model pass + range coder (two-phase), Block checks,
+ * D2H of the sizes.  Everything it needs of its batch is in `back_args`, so that the batch loop can enqueue it where it
+ * likes: behind the structure build of the NEXT batch, beside its finder (the default for a batch that has one behind it), or
+ * right behind the batch's own front end, beside the next batch's sorts (XZAMD_BACK_BESIDE_BUILD=1; the last batch of a call). */
+typedef struct {
+	int valid;
+	xzamd_span_args a;
+	uint64_t nb, in_off, block_size;
+	uint32_t n, nch, nout;
+	int par, two, check, sha_early;
+	const uint8_t *d_in;
+	void *st, *stb;
+	void **ev;
+} back_args;
+
+static int back_enqueue(xzamd_ctx *c, back_args *B)
+{
+	void *stb = B->stb;
+	void **ev = B->ev;
+	const int par = B->par, two = B->two, check = B->check;
+	const uint64_t nb = B->nb, block_size = B->block_size;
+	const uint32_t n = B->n;
+	int e = 0;
+	B->valid = 0;
+	if (stb != B->st) e = xzk_stream_wait_event(stb, ev[EV_FRONT]);
+	xzk_event_record(ev[EV_BACK0], stb);
+	if (!e) e = xzk_memset(c->errw2.p, 0, 512, stb);
+	if (!e && two) {
+		xzamd_span_args a2 = B->a;
+		a2.err = (uint32_t *)c->errw2.p;
+		a2.cb_bnd = (uint32_t *)c->cb_bnd[1].p; a2.cb_log = (uint32_t *)c->cb_log[1].p; a2.cb_hdr = (uint32_t *)c->cb_hdr[1].p;
+		a2.cb_start = (uint16_t *)c->cb_start[1].p; a2.cb_carry = (uint32_t *)c->cb_carry[1].p;
+		e = xzk_encode_syms(&a2, (uint32_t)nb, stb);
+	}
+	xzk_event_record(ev[EV_CODE], stb);
+	if (e) return fail(c, XZAMD_DEVICE_ERROR, "encode_syms launch", e);
+	/* Block checks */
+	if (check == XZAMD_CHECK_CRC64 || check == XZAMD_CHECK_CRC32) {
+		e = xzk_crc_blocks(B->d_in + B->in_off, n, (uint32_t)block_size, (uint32_t)nb, CRC_STRIP,
+				check == XZAMD_CHECK_CRC32, (uint64_t *)c->strip_crc.p, (uint64_t *)c->block_crc.p, stb);
+		if (e) return fail(c, XZAMD_DEVICE_ERROR, "crc64 launch", e);
+		e = xzk_d2h(c->h_block_crc.p, c->block_crc.p, 8ull * nb, stb);
+		if (e) return fail(c, XZAMD_DEVICE_ERROR, "d2h crc", e);
+	} else if (check == XZAMD_CHECK_SHA256) {
+		e = B->sha_early ? xzk_stream_wait_event(stb, c->ev_sha)
+				: xzk_sha256_blocks(B->d_in + B->in_off, n, (uint32_t)block_size, (uint32_t)nb, (uint8_t *)c->block_crc.p, stb);
+		if (e) return fail(c, XZAMD_DEVICE_ERROR, "sha256 launch", e);
+		e = xzk_d2h(c->h_block_crc.p, c->block_crc.p, 32ull * nb, stb);
+		if (e) return fail(c, XZAMD_DEVICE_ERROR, "d2h sha256", e);
+	}
+	xzk_event_record(ev[EV_CRC], stb);
+	e = two ? xzk_d2h(c->h_chunks.p, c->chunks.p, (uint64_t)B->nch * sizeof(xzamd_chunk), stb)
+			: xzk_d2h(c->h_span_bytes.p, c->span_bytes.p, 4ull * B->nout, stb);
+	if (!e) e = xzk_d2h((uint8_t *)c->h_err[par].p + 512, c->errw2.p, 512, stb);
+	if (e) return fail(c, XZAMD_DEVICE_ERROR, "d2h sizes", e);
+	return XZAMD_OK;
+}
+
 /* Second half of a batch's back end: wait for the sizes, lay the Blocks out (the ordered output queue of the
  * reference, outqueue.c) and gather them into the Stream. */
 static int back_finish(xzamd_ctx *c, job_env *J, batch_run *B)
@@ -1235,6 +1293,13 @@ int xzamd_encode_device_(xzamd_ctx *c,
 	int rc = XZAMD_OK;
 	batch_run prev;
 	memset(&prev, 0, sizeof(prev));
+	back_args BA;
+	memset(&BA, 0, sizeof(BA));
+	/* Where the back end of a batch that has another batch behind it starts: behind that batch's structure build, beside its
+	 * finder (the default since the end of round 6: the sorts of the build and the coder's walks slow each other down more
+	 * than the finder and the walks do -- 4 GiB: 7.14 -> 6.99 s, same Stream); XZAMD_BACK_BESIDE_BUILD=1: right behind its
+	 * own front end, beside the next build (rounds 4 - 6) */
+	const int back_after_build = getenv("XZAMD_BACK_BESIDE_BUILD") == NULL;
 	uint64_t batch_index = 0;
 	progress_set(c, 0, 0, 0);
 	xzk_event_record(c->ev_total[0], st);
@@ -1373,6 +1438,13 @@ int xzamd_encode_device_(xzamd_ctx *c,
 		rc = launch_chains(c, opt, enc_in, &g, block_size, hb, hmask, hbits, st);
 		if (rc != XZAMD_OK) goto done;
 		xzk_event_record(ev[EV_CHAINS], st);
+		if (BA.valid) {
+			/* the previous batch's back end starts here, behind this batch's structure build */
+			int e_ = BA.stb != st ? xzk_stream_wait_event(BA.stb, ev[EV_CHAINS]) : 0;
+			if (e_) { rc = fail(c, XZAMD_DEVICE_ERROR, "stream wait", e_); goto done; }
+			rc = back_enqueue(c, &BA);
+			if (rc != XZAMD_OK) goto done;
+		}
 		xzamd_span_args a;
 		memset(&a, 0, sizeof(a));
 		a.in = enc_in;
@@ -1543,39 +1615,15 @@ int xzamd_encode_device_(xzamd_ctx *c,
 			if (rc != XZAMD_OK) goto done;
 		}
 		{
-			void *stb = J.stb;
-			int e = 0;
-			if (stb != st) e = xzk_stream_wait_event(stb, ev[EV_FRONT]);
-			xzk_event_record(ev[EV_BACK0], stb);
-			if (!e) e = xzk_memset(c->errw2.p, 0, 512, stb);
-			if (!e && two) {
-				xzamd_span_args a2 = a;
-				a2.err = (uint32_t *)c->errw2.p;
-				a2.cb_bnd = (uint32_t *)c->cb_bnd[1].p; a2.cb_log = (uint32_t *)c->cb_log[1].p; a2.cb_hdr = (uint32_t *)c->cb_hdr[1].p;
-				a2.cb_start = (uint16_t *)c->cb_start[1].p; a2.cb_carry = (uint32_t *)c->cb_carry[1].p;
-				e = xzk_encode_syms(&a2, (uint32_t)nb, stb);
+			BA.valid = 1;
+			BA.a = a; BA.nb = nb; BA.in_off = in_off; BA.block_size = block_size; BA.n = n; BA.nch = nch; BA.nout = nout;
+			BA.par = par; BA.two = two; BA.check = check; BA.sha_early = sha_early; BA.d_in = d_in; BA.st = st; BA.stb = J.stb;
+			BA.ev = ev;
+			/* (back_after_build: a batch that has another one behind it leaves its back end to that batch's iteration) */
+			if (!(back_after_build && pipelined && b0 + nb < total_blocks)) {
+				rc = back_enqueue(c, &BA);
+				if (rc != XZAMD_OK) goto done;
 			}
-			xzk_event_record(ev[EV_CODE], stb);
-			if (e) { rc = fail(c, XZAMD_DEVICE_ERROR, "encode_syms launch", e); goto done; }
-			/* Block checks */
-			if (check == XZAMD_CHECK_CRC64 || check == XZAMD_CHECK_CRC32) {
-				e = xzk_crc_blocks(d_in + in_off, n, (uint32_t)block_size, (uint32_t)nb, CRC_STRIP,
-						check == XZAMD_CHECK_CRC32, (uint64_t *)c->strip_crc.p, (uint64_t *)c->block_crc.p, stb);
-				if (e) { rc = fail(c, XZAMD_DEVICE_ERROR, "crc64 launch", e); goto done; }
-				e = xzk_d2h(c->h_block_crc.p, c->block_crc.p, 8ull * nb, stb);
-				if (e) { rc = fail(c, XZAMD_DEVICE_ERROR, "d2h crc", e); goto done; }
-			} else if (check == XZAMD_CHECK_SHA256) {
-				e = sha_early ? xzk_stream_wait_event(stb, c->ev_sha)
-						: xzk_sha256_blocks(d_in + in_off, n, (uint32_t)block_size, (uint32_t)nb, (uint8_t *)c->block_crc.p, stb);
-				if (e) { rc = fail(c, XZAMD_DEVICE_ERROR, "sha256 launch", e); goto done; }
-				e = xzk_d2h(c->h_block_crc.p, c->block_crc.p, 32ull * nb, stb);
-				if (e) { rc = fail(c, XZAMD_DEVICE_ERROR, "d2h sha256", e); goto done; }
-			}
-			xzk_event_record(ev[EV_CRC], stb);
-			e = two ? xzk_d2h(c->h_chunks.p, c->chunks.p, (uint64_t)nch * sizeof(xzamd_chunk), stb)
-					: xzk_d2h(c->h_span_bytes.p, c->span_bytes.p, 4ull * nout, stb);
-			if (!e) e = xzk_d2h((uint8_t *)c->h_err[par].p + 512, c->errw2.p, 512, stb);
-			if (e) { rc = fail(c, XZAMD_DEVICE_ERROR, "d2h sizes", e); goto done; }
 		}
 		progress_set(c, c->prog_done, n64, par);     /* every stage event of this batch has been recorded */
 		if (pipelined) {
@@ -1594,6 +1642,10 @@ retry_smaller:
 		 * release every per-batch device buffer and let the smaller geometry allocate afresh. */
 		if (c->pend.active)
 			(void)pend_complete(c);          /* (its result is the deferred call's) */
+		if (BA.valid) {                       /* (the earlier batch's back end has not been enqueued yet) */
+			rc = back_enqueue(c, &BA);
+			if (rc != XZAMD_OK) goto done;
+		}
 		if (prev.active) {
 			rc = back_finish_own(c, &J, &prev);
 			if (rc != XZAMD_OK) goto done;
